@@ -1,0 +1,269 @@
+// giql_amd/csrc/aux_kernels.hip.h -- SEMI / ANTI existence, per-row COUNT and
+// NEAREST k=1 on top of the sorted linearised arrays.
+//
+//   EXISTS b: b.start < a.end AND b.end > a.start
+//        <=>  max{ b.end : b.start < a.end } > a.start
+// so one prefix-max over B (sorted by start) plus one binary search per A row
+// decides SEMI / ANTI with no pair materialisation -- exact for every row,
+// including zero-length / inverted ones (no start<end assumption is used).
+#pragma once
+
+#include "dev_common.hip.h"
+#include "join_kernels.hip.h"
+
+namespace giql {
+
+// ------------------------------------------------------ inclusive prefix max
+constexpr int PM_NT = 256;
+constexpr int PM_ITEMS = 16;
+constexpr int PM_TILE = PM_NT * PM_ITEMS;
+
+__device__ __forceinline__ u32 umax(u32 a, u32 b) { return a > b ? a : b; }
+
+__device__ __forceinline__ u32 wave_incl_scan_max(u32 v) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    u32 t = __shfl_up(v, d, WAVE);
+    if ((int)lane_id() >= d) v = umax(v, t);
+  }
+  return v;
+}
+
+// Exclusive running max across the block's threads (identity 0); total = max.
+template <int NT>
+__device__ __forceinline__ u32 block_excl_scan_max(u32 v, u32* lds, u32& total) {
+  constexpr int NW = NT / WAVE;
+  const u32 incl = wave_incl_scan_max(v);
+  if (lane_id() == WAVE - 1) lds[wave_id()] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const u32 t = lds[w];
+      lds[w] = run;
+      run = umax(run, t);
+    }
+    lds[NW] = run;
+  }
+  __syncthreads();
+  const u32 base = lds[wave_id()];
+  total = lds[NW];
+  u32 prev = __shfl_up(incl, 1, WAVE);
+  if (lane_id() == 0) prev = 0;
+  __syncthreads();
+  return umax(base, prev);
+}
+
+__global__ __launch_bounds__(PM_NT) void k_pmax_reduce(const u32* __restrict__ in, u32 n,
+                                                        u32* __restrict__ bmax) {
+  __shared__ u32 lds[PM_NT / WAVE];
+  const u32 base = blockIdx.x * PM_TILE + threadIdx.x * PM_ITEMS;
+  u32 m = 0;
+#pragma unroll
+  for (int k = 0; k < PM_ITEMS; k++)
+    if (base + k < n) m = umax(m, in[base + k]);
+  m = wave_reduce_max_u32(m);
+  if (lane_id() == 0) lds[wave_id()] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 t = 0;
+#pragma unroll
+    for (int w = 0; w < PM_NT / WAVE; w++) t = umax(t, lds[w]);
+    bmax[blockIdx.x] = t;
+  }
+}
+
+// Single block: bmax[i] <- max(bmax[0..i))  (exclusive running max)
+__global__ __launch_bounds__(1024) void k_pmax_spine(u32* __restrict__ bmax, u32 nb) {
+  __shared__ u32 lds[1024 / WAVE + 1];
+  __shared__ u32 carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (u32 base = 0; base < nb; base += 1024) {
+    const u32 i = base + threadIdx.x;
+    const u32 v = i < nb ? bmax[i] : 0u;
+    u32 total;
+    const u32 ex = block_excl_scan_max<1024>(v, lds, total);
+    const u32 carry = carry_s;
+    if (i < nb) bmax[i] = umax(carry, ex);
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = umax(carry, total);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(PM_NT) void k_pmax_down(const u32* __restrict__ in, u32 n,
+                                                      const u32* __restrict__ bmax,
+                                                      u32* __restrict__ out) {
+  __shared__ u32 lds[PM_NT / WAVE + 1];
+  const u32 base = blockIdx.x * PM_TILE + threadIdx.x * PM_ITEMS;
+  u32 x[PM_ITEMS];
+  u32 m = 0;
+#pragma unroll
+  for (int k = 0; k < PM_ITEMS; k++) {
+    x[k] = (base + k < n) ? in[base + k] : 0u;
+    m = umax(m, x[k]);
+  }
+  u32 total;
+  u32 run = umax(bmax[blockIdx.x], block_excl_scan_max<PM_NT>(m, lds, total));
+#pragma unroll
+  for (int k = 0; k < PM_ITEMS; k++) {
+    run = umax(run, x[k]);
+    if (base + k < n) out[base + k] = run;
+  }
+}
+
+// ------------------------------------------------------------- SEMI / ANTI
+// flag[i] = 1 when A row i qualifies (SEMI: has an overlapping B row; ANTI: has
+// none).  B is sorted by linearised start with ALL its rows (no sentinels).
+__global__ __launch_bounds__(256) void k_semi_flags(SideView a, int n_chrom,
+                                                     const i64* __restrict__ chrom_base,
+                                                     const u32* __restrict__ b_keys,
+                                                     const u32* __restrict__ b_pmax, u32 n_b,
+                                                     int anti, u32* __restrict__ flag) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int c = a.chrom[i];
+  bool hit = false;
+  if (c >= 0 && c < n_chrom && n_b > 0) {
+    const i64 base = chrom_base[c];
+    const u32 qs = (u32)(base + (i64)a.start[i] + a.start_off);
+    const u32 qe = (u32)(base + (i64)a.end[i] + a.end_off);
+    const u32 j = lower_bound_u32(b_keys, 0, n_b, qe);  // rows with b.start < a.end
+    hit = j > 0 && b_pmax[j - 1] > qs;
+  }
+  flag[i] = (hit != (anti != 0)) ? 1u : 0u;
+}
+
+// rows_out[off[i]] = i for flagged rows (ascending row ids).
+__global__ __launch_bounds__(256) void k_compact(const u32* __restrict__ flag,
+                                                  const u64* __restrict__ off, u32 n,
+                                                  int32_t* __restrict__ rows_out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i]) rows_out[off[i]] = (int32_t)i;
+}
+
+// ------------------------------------------------------------------- COUNT
+// Regular rows: count(a) = #{b.start < a.end} - #{b.end <= a.start} over the
+// regular B rows (two sorted arrays, no candidate is touched); irregular rows on
+// either side are settled by the literal predicate.
+__global__ __launch_bounds__(256) void k_count_rows(
+    SideView a, SideView b, int n_chrom, const i64* __restrict__ chrom_base,
+    const u32* __restrict__ b_keys_sorted, const u32* __restrict__ b_ends_sorted, u32 n_b_total,
+    const u32* __restrict__ irr_b_list, const DevMeta* __restrict__ meta,
+    i64* __restrict__ counts_out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int c = a.chrom[i];
+  const i64 as = (i64)a.start[i] + a.start_off, ae = (i64)a.end[i] + a.end_off;
+  i64 cnt = 0;
+  if (ae > as && c >= 0 && c < n_chrom) {
+    const u32 n_reg = n_b_total - meta->irr_b;
+    const i64 base = chrom_base[c];
+    const u32 qs = (u32)(base + as), qe = (u32)(base + ae);
+    const u32 below = lower_bound_u32(b_keys_sorted, 0, n_reg, qe);  // b.start < a.end
+    const u32 done = upper_bound_u32(b_ends_sorted, 0, n_reg, qs);   // b.end <= a.start
+    cnt = (i64)below - (i64)done;
+    const u32 m = meta->irr_b;
+    for (u32 k = 0; k < m; k++) {
+      const u32 r = irr_b_list[k];
+      cnt += literal_overlap(c, as, ae, b.chrom[r], (i64)b.start[r] + b.start_off,
+                             (i64)b.end[r] + b.end_off);
+    }
+  } else {
+    cnt = -1;  // irregular A row: settled by k_count_irregular
+  }
+  counts_out[i] = cnt;
+}
+
+// One block per irregular A row: literal predicate against every B row.
+__global__ __launch_bounds__(256) void k_count_irregular(SideView a, SideView b,
+                                                          const u32* __restrict__ irr_a_list,
+                                                          i64* __restrict__ counts_out) {
+  __shared__ u64 lds[256 / WAVE];
+  const u32 r = irr_a_list[blockIdx.x];
+  const int ac = a.chrom[r];
+  const i64 as = (i64)a.start[r] + a.start_off, ae = (i64)a.end[r] + a.end_off;
+  u64 c = 0;
+  for (u32 j = threadIdx.x; j < b.n; j += 256)
+    c += literal_overlap(ac, as, ae, b.chrom[j], (i64)b.start[j] + b.start_off,
+                         (i64)b.end[j] + b.end_off);
+  c = wave_reduce_sum(c);
+  if (lane_id() == 0) lds[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 t = 0;
+#pragma unroll
+    for (int w = 0; w < 256 / WAVE; w++) t += lds[w];
+    counts_out[r] = (i64)t;
+  }
+}
+
+// ----------------------------------------------------------------- NEAREST
+// B sorted by (linearised start, end); b_pmax = inclusive prefix max of ends.
+// chrom_first[c] = linearised offset of chromosome c (n_chrom + 1 entries).
+// Distance CASE of _distance.py:67-87; order ABS(d), start, end (nearest.py:392).
+__global__ __launch_bounds__(256) void k_nearest(
+    SideView a, int n_chrom, const i64* __restrict__ chrom_base, const u32* __restrict__ chrom_first,
+    const u32* __restrict__ b_keys, const u32* __restrict__ b_ends, const u32* __restrict__ b_pmax,
+    const u32* __restrict__ b_rids, u32 n_b, int is_signed, i64 max_distance,
+    int32_t* __restrict__ idx_out, i64* __restrict__ dist_out, DevMeta* __restrict__ meta) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int c = a.chrom[i];
+  int32_t best = -1;
+  i64 best_d = 0;
+  if (c >= 0 && c < n_chrom && n_b > 0) {
+    const i64 as = (i64)a.start[i] + a.start_off, ae = (i64)a.end[i] + a.end_off;
+    if (ae < as) meta->status = -1;  // inverted row: NEAREST needs start <= end
+    const i64 base = chrom_base[c];
+    const u32 qs = (u32)(base + as), qe = (u32)(base + ae);
+    const u32 blo = lower_bound_u32(b_keys, 0, n_b, chrom_first[c]);
+    const u32 bhi = lower_bound_u32(b_keys, blo, n_b, chrom_first[c + 1]);
+    if (bhi > blo) {
+      const u32 hi = lower_bound_u32(b_keys, blo, bhi, qe);
+      u32 j = U32_MAX;
+      if (hi > blo && b_pmax[hi - 1] > qs) {
+        // overlap: first row in (start,end) order whose end exceeds a.start
+        j = upper_bound_u32(b_pmax, blo, hi, qs);
+        best_d = 0;
+      } else {
+        i64 up_d = 0, dn_d = 0;
+        u32 up = U32_MAX, dn = U32_MAX;
+        if (hi > blo) {
+          const u32 m = b_pmax[hi - 1];  // nearest upstream end (<= a.start)
+          up = lower_bound_u32(b_pmax, blo, hi, m);
+          up_d = (i64)qs - (i64)m + 1;
+        }
+        if (hi < bhi) {
+          dn = hi;
+          dn_d = (i64)b_keys[hi] - (i64)qe + 1;
+        }
+        if (up != U32_MAX && (dn == U32_MAX || up_d <= dn_d)) {
+          j = up;
+          best_d = is_signed ? -up_d : up_d;
+        } else if (dn != U32_MAX) {
+          j = dn;
+          best_d = dn_d;
+        }
+      }
+      if (j != U32_MAX) {
+        const i64 ad = best_d < 0 ? -best_d : best_d;
+        if (max_distance < 0 || ad <= max_distance) best = (int32_t)b_rids[j];
+      }
+    }
+  }
+  idx_out[i] = best;
+  dist_out[i] = best < 0 ? 0 : best_d;
+  (void)b_ends;
+}
+
+// NEAREST needs start <= end on the B side too.
+__global__ __launch_bounds__(256) void k_check_not_inverted(SideView s, DevMeta* __restrict__ meta) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n) return;
+  if ((i64)s.end[i] + s.end_off < (i64)s.start[i] + s.start_off) meta->status = -1;
+}
+
+}  // namespace giql

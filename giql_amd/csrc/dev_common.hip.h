@@ -1,0 +1,144 @@
+// giql_amd/csrc/dev_common.hip.h -- device helpers shared by every kernel.
+// gfx950 (MI355X) only: 64-wide wavefronts are assumed throughout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace giql {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int64_t i64;
+
+constexpr int WAVE = 64;
+constexpr u32 U32_MAX = 0xFFFFFFFFu;
+
+// Device-side bookkeeping shared by the kernels of one call.  A pinned host
+// mirror is copied back once per call (the only host sync of a join).
+struct DevMeta {
+  u64 total_span;   // linearised coordinate span (sum of per-chrom spans)
+  u64 n_out;        // regular-path output count (pairs), written by the scan
+  u64 n_out_irr;    // irregular-path output count
+  u32 sentinel;     // key given to irregular rows: sorts after every real key
+  u32 irr_a;        // rows of A with canonical end <= start
+  u32 irr_b;
+  int status;       // 0 ok, else a GIQL_ERR_* code
+  u32 aux0, aux1;   // per-operator scratch (e.g. compaction counter)
+};
+
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T v) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    T t = __shfl_up(v, d, WAVE);
+    if ((int)lane_id() >= d) v += t;
+  }
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_sum(T v) {
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WAVE);
+  return v;
+}
+
+__device__ __forceinline__ u32 wave_reduce_max_u32(u32 v) {
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) {
+    u32 t = __shfl_xor(v, d, WAVE);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+// Exclusive scan over the NT threads of a block.  `lds` holds NT/64 + 1 items.
+// Returns the exclusive prefix of v; `total` receives the block sum.
+template <typename T, int NT>
+__device__ __forceinline__ T block_excl_scan(T v, T* lds, T& total) {
+  constexpr int NW = NT / WAVE;
+  T incl = wave_incl_scan(v);
+  if (lane_id() == WAVE - 1) lds[wave_id()] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T run = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      T t = lds[w];
+      lds[w] = run;
+      run += t;
+    }
+    lds[NW] = run;
+  }
+  __syncthreads();
+  T base = lds[wave_id()];
+  total = lds[NW];
+  __syncthreads();  // lds may be reused by the caller
+  return base + incl - v;
+}
+
+// first index in [lo, hi) with v[idx] >= x   (v ascending)
+__device__ __forceinline__ u32 lower_bound_u32(const u32* __restrict__ v, u32 lo, u32 hi, u32 x) {
+  while (lo < hi) {
+    u32 mid = lo + ((hi - lo) >> 1);
+    if (v[mid] < x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// first index in [lo, hi) with v[idx] > x   (v ascending)
+__device__ __forceinline__ u32 upper_bound_u32(const u32* __restrict__ v, u32 lo, u32 hi, u32 x) {
+  while (lo < hi) {
+    u32 mid = lo + ((hi - lo) >> 1);
+    if (v[mid] <= x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ u64 upper_bound_u64(const u64* __restrict__ v, u64 lo, u64 hi, u64 x) {
+  while (lo < hi) {
+    u64 mid = lo + ((hi - lo) >> 1);
+    if (v[mid] <= x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// Cooperative lower_bound by one full wave: 64-ary search, every lane returns
+// the same result.  ~log64(n) rounds instead of log2(n) dependent loads.
+__device__ __forceinline__ u32 wave_lower_bound_u32(const u32* __restrict__ v, u32 lo, u32 hi, u32 x) {
+  const u32 lane = lane_id();
+  while (hi - lo > (u32)WAVE) {
+    const u32 len = hi - lo;
+    const u32 step = (len + WAVE - 1) / WAVE;  // >= 2
+    const u64 pos64 = (u64)lo + (u64)lane * step;
+    const bool in = pos64 < hi;
+    const u32 val = in ? v[(u32)pos64] : U32_MAX;
+    const u64 m = __ballot(in && val < x);  // prefix-true because v is sorted
+    const u32 k = __popcll(m);              // probes strictly below x
+    // answer lies in (probe[k-1], probe[k]]
+    const u32 nlo = k == 0 ? lo : lo + (k - 1) * step + 1;
+    u64 nhi64 = (u64)lo + (u64)k * step;
+    if (k == WAVE || nhi64 > hi) nhi64 = hi;
+    lo = nlo;
+    hi = (u32)nhi64;
+  }
+  const u32 pos = lo + lane;
+  const bool below = pos < hi && v[pos] < x;
+  return lo + __popcll(__ballot(below));
+}
+
+}  // namespace giql

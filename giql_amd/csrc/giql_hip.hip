@@ -1,0 +1,963 @@
+// giql_amd/csrc/giql_hip.hip -- C ABI of libgiql_hip.so (see include/giql_hip.h).
+//
+// Host-side orchestration only: arena carving, kernel launches on the caller's
+// stream, one pinned-memory readback per join (the output size).  All arithmetic
+// is in the *.hip.h kernels.  gfx950 only; there is no CPU fallback: without a
+// HIP device every entry point fails with GIQL_ERR_HIP.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/giql_hip.h"
+#include "aux_kernels.hip.h"
+#include "dev_common.hip.h"
+#include "join_kernels.hip.h"
+#include "radix_sort.hip.h"
+#include "scan.hip.h"
+
+using namespace giql;
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return set_err(GIQL_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                     __FILE__, __LINE__);                                                 \
+  } while (0)
+
+#define GIQL_TRY(expr)      \
+  do {                      \
+    int _rc = (expr);       \
+    if (_rc != GIQL_OK) return _rc; \
+  } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+// ----------------------------------------------------------------- context
+struct SortBufs {
+  u32* key[2];
+  u32* end[2];
+  u32* rid[2];
+};
+
+struct giql_hip_ctx {
+  int device = 0;
+  char* arena = nullptr;
+  size_t arena_cap = 0;
+  DevMeta* d_meta = nullptr;
+  DevMeta* h_meta = nullptr;  // pinned
+  u32* part = nullptr;        // fill partition (grown on demand)
+  size_t part_cap = 0;
+  u64* d_scratch64 = nullptr;  // small device scratch (checksum)
+
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  struct Span {
+    int phase;
+    hipEvent_t a, b;
+  };
+  std::vector<Span> spans;
+  size_t ev_used = 0;
+  giql_hip_stats stats;
+
+  // state kept between inner_plan and inner_fill
+  bool planned = false;
+  giql_side side_a, side_b;
+  u32 n_a = 0, n_b = 0;
+  int n_chrom = 0;
+  u64 n_reg = 0, n_irr = 0;
+  u64* off = nullptr;
+  u32* lo = nullptr;
+  u32* rid_a_sorted = nullptr;
+  u32* rid_b_sorted = nullptr;
+  u32* irr_a_list = nullptr;
+  u32* irr_b_list = nullptr;
+  u64* irr_off = nullptr;
+};
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t n) {
+    off = align_up(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+static int ensure_arena(giql_hip_ctx* ctx, size_t bytes, hipStream_t stream) {
+  if (bytes <= ctx->arena_cap) return GIQL_OK;
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (ctx->arena) HIP_TRY(hipFree(ctx->arena));
+  ctx->arena = nullptr;
+  ctx->arena_cap = 0;
+  ctx->planned = false;
+  const size_t want = align_up(bytes + bytes / 8, (size_t)1 << 20);
+  hipError_t e = hipMalloc((void**)&ctx->arena, want);
+  if (e != hipSuccess)
+    return set_err(GIQL_ERR_NOMEM, "hipMalloc(%zu bytes) for the workspace failed: %s", want,
+                   hipGetErrorString(e));
+  ctx->arena_cap = want;
+  return GIQL_OK;
+}
+
+// ---------------------------------------------------------------- profiling
+struct Phase {
+  giql_hip_ctx* ctx;
+  hipStream_t stream;
+  int phase;
+  hipEvent_t a = nullptr, b = nullptr;
+  Phase(giql_hip_ctx* c, hipStream_t s, int ph, int launches = 1) : ctx(c), stream(s), phase(ph) {
+    ctx->stats.phase_launches[ph] += launches;
+    if (!ctx->profiling) return;
+    while (ctx->ev_used + 2 > ctx->ev_pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      ctx->ev_pool.push_back(e);
+    }
+    a = ctx->ev_pool[ctx->ev_used++];
+    b = ctx->ev_pool[ctx->ev_used++];
+    (void)hipEventRecord(a, stream);
+  }
+  ~Phase() {
+    if (!a) return;
+    (void)hipEventRecord(b, stream);
+    ctx->spans.push_back({phase, a, b});
+  }
+};
+
+static void reset_stats(giql_hip_ctx* ctx) {
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  ctx->spans.clear();
+  ctx->ev_used = 0;
+}
+
+// Call only after the stream has been synchronised.
+static void collect_spans(giql_hip_ctx* ctx) {
+  if (!ctx->profiling) return;
+  for (auto& s : ctx->spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) ctx->stats.phase_ms[s.phase] += ms;
+  }
+  ctx->spans.clear();
+  ctx->ev_used = 0;
+  float t = 0.f;
+  for (int i = 0; i < GIQL_PH_N; i++) t += ctx->stats.phase_ms[i];
+  ctx->stats.total_ms = t;
+  ctx->stats.profiled = 1;
+}
+
+// ------------------------------------------------------------ small helpers
+static int check_side(const giql_side* s, const char* name) {
+  if (!s) return set_err(GIQL_ERR_INVALID, "side %s is NULL", name);
+  if (s->n < 0 || s->n > 0x7FFFFFF0ll)
+    return set_err(GIQL_ERR_INVALID, "side %s: n=%lld outside [0, 2^31-16]", name, (long long)s->n);
+  if (s->n > 0 && (!s->chrom || !s->start || !s->end))
+    return set_err(GIQL_ERR_INVALID, "side %s: NULL column buffer", name);
+  if (s->start_off < -1 || s->start_off > 0 || s->end_off < -1 || s->end_off > 1)
+    return set_err(GIQL_ERR_INVALID, "side %s: canonical offsets (%d,%d) outside {0,-1}x{+1,0,-1}",
+                   name, s->start_off, s->end_off);
+  return GIQL_OK;
+}
+
+static SideView view_of(const giql_side& s) {
+  SideView v;
+  v.chrom = s.chrom;
+  v.start = s.start;
+  v.end = s.end;
+  v.n = (u32)s.n;
+  v.start_off = s.start_off;
+  v.end_off = s.end_off;
+  return v;
+}
+
+static int post_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return set_err(GIQL_ERR_HIP, "kernel launch failed in %s: %s", what, hipGetErrorString(e));
+  return GIQL_OK;
+}
+
+// exclusive scan of u32 counts; TOut in {u32,u64}; in-place allowed for u32.
+template <typename TOut>
+static int run_scan(giql_hip_ctx* ctx, hipStream_t st, int phase, const u32* in, u64 n, TOut* out,
+                    u64* bsums, u64* total_out) {
+  if (n == 0) {
+    if (total_out) HIP_TRY(hipMemsetAsync(total_out, 0, sizeof(u64), st));
+    return GIQL_OK;
+  }
+  const u32 nb = cdiv(n, SCAN_TILE);
+  Phase ph(ctx, st, phase, 3);
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_NT), 0, st, in, n, bsums);
+  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, bsums, nb, total_out);
+  hipLaunchKernelGGL((k_scan_down<TOut>), dim3(nb), dim3(SCAN_NT), 0, st, in, n, bsums, out);
+  return post_launch("scan");
+}
+
+// Spans + linearised keys for both sides.
+struct LinBufs {
+  int* gmin;
+  int* gmax;
+  i64* chrom_base;
+  u32* chrom_first;
+};
+
+static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, const giql_side& b,
+                     int n_chrom, const LinBufs& lb) {
+  Phase ph(ctx, st, GIQL_PH_SPAN, 4);
+  hipLaunchKernelGGL(k_init_minmax, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st, lb.gmin,
+                     lb.gmax, n_chrom, ctx->d_meta);
+  const size_t lds = n_chrom <= MM_LDS_CHROMS ? (size_t)n_chrom * 2 * sizeof(int) : 0;
+  const giql_side* sides[2] = {&a, &b};
+  for (int k = 0; k < 2; k++) {
+    const giql_side& s = *sides[k];
+    if (s.n == 0) continue;
+    u32 grid = cdiv((u64)s.n, (u64)MM_NT * MM_ITEMS);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_chrom_minmax, dim3(grid), dim3(MM_NT), lds, st, s.chrom, s.start, s.end,
+                       (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta);
+  }
+  int omin = a.start_off, omax = a.start_off;
+  const int offs[3] = {a.end_off, b.start_off, b.end_off};
+  for (int k = 0; k < 3; k++) {
+    if (offs[k] < omin) omin = offs[k];
+    if (offs[k] > omax) omax = offs[k];
+  }
+  hipLaunchKernelGGL(k_chrom_offsets, dim3(1), dim3(256), 0, st, lb.gmin, lb.gmax, n_chrom, omin,
+                     omax, lb.chrom_base, lb.chrom_first, ctx->d_meta);
+  return post_launch("spans");
+}
+
+static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, int n_chrom,
+                         const LinBufs& lb, u32* keys, u32* ends, u32* irr_list, int which,
+                         int keep_irregular) {
+  if (s.n == 0) return GIQL_OK;
+  Phase ph(ctx, st, GIQL_PH_LINEARIZE);
+  u32 grid = cdiv((u64)s.n, LIN_NT);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_linearize, dim3(grid), dim3(LIN_NT), 0, st, s.chrom, s.start, s.end,
+                     (u32)s.n, s.start_off, s.end_off, n_chrom, lb.chrom_base, keys, ends, irr_list,
+                     ctx->d_meta, which, keep_irregular);
+  return post_launch("linearize");
+}
+
+// Stable LSD radix sort; input in buffer 0, result in buffer 0 (4 passes).
+// rids: identity on the first pass.  Payload-less when bufs.end[0] == nullptr.
+static int run_sort(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n, u32* tile_hist,
+                    u64* bsums) {
+  if (n == 0) return GIQL_OK;
+  const u32 n_tiles = cdiv(n, RS_TILE);
+  for (int pass = 0; pass < 4; pass++) {
+    const int src = pass & 1, dst = src ^ 1;
+    const int shift = pass * 8;
+    {
+      Phase ph(ctx, st, GIQL_PH_SORT_HIST);
+      hipLaunchKernelGGL(k_radix_hist, dim3(n_tiles), dim3(RS_NT), 0, st, sb.key[src], n, shift,
+                         n_tiles, tile_hist);
+    }
+    GIQL_TRY(run_scan<u32>(ctx, st, GIQL_PH_SORT_SCAN, tile_hist, (u64)n_tiles * RS_BINS, tile_hist,
+                           bsums, nullptr));
+    {
+      Phase ph(ctx, st, GIQL_PH_SORT_SCATTER);
+      hipLaunchKernelGGL(k_radix_scatter, dim3(n_tiles), dim3(RS_NT), 0, st, sb.key[src],
+                         sb.end[src], pass == 0 ? (const u32*)nullptr : sb.rid[src], sb.key[dst],
+                         sb.end[dst], sb.rid[dst], n, shift, n_tiles, tile_hist);
+    }
+  }
+  return post_launch("radix sort");
+}
+
+static int run_pmax(giql_hip_ctx* ctx, hipStream_t st, const u32* in, u32 n, u32* out, u32* bmax) {
+  if (n == 0) return GIQL_OK;
+  const u32 nb = cdiv(n, PM_TILE);
+  Phase ph(ctx, st, GIQL_PH_AUX, 3);
+  hipLaunchKernelGGL(k_pmax_reduce, dim3(nb), dim3(PM_NT), 0, st, in, n, bmax);
+  hipLaunchKernelGGL(k_pmax_spine, dim3(1), dim3(1024), 0, st, bmax, nb);
+  hipLaunchKernelGGL(k_pmax_down, dim3(nb), dim3(PM_NT), 0, st, in, n, bmax, out);
+  return post_launch("prefix max");
+}
+
+static int read_meta(giql_hip_ctx* ctx, hipStream_t st) {
+  HIP_TRY(hipMemcpyAsync(ctx->h_meta, ctx->d_meta, sizeof(DevMeta), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const int status = ctx->h_meta->status;
+  if (status == GIQL_ERR_CHROM)
+    return set_err(GIQL_ERR_CHROM, "a chrom id is outside [0, n_chrom)");
+  if (status == GIQL_ERR_SPAN)
+    return set_err(GIQL_ERR_SPAN,
+                   "linearised coordinate span %llu does not fit 32 bits; shard the chromosomes "
+                   "into groups (giql_amd.shard) and join each group",
+                   (unsigned long long)ctx->h_meta->total_span);
+  if (status != 0) return set_err(status, "device reported status %d", status);
+  return GIQL_OK;
+}
+
+static void common_sizes(Carver& c, int n_chrom, LinBufs& lb) {
+  lb.gmin = c.take<int>((size_t)n_chrom);
+  lb.gmax = c.take<int>((size_t)n_chrom);
+  lb.chrom_base = c.take<i64>((size_t)n_chrom);
+  lb.chrom_first = c.take<u32>((size_t)n_chrom + 1);
+}
+
+static void sort_sizes(Carver& c, size_t n, SortBufs& sb, bool payload) {
+  for (int k = 0; k < 2; k++) {
+    sb.key[k] = c.take<u32>(n);
+    sb.end[k] = payload ? c.take<u32>(n) : nullptr;
+    sb.rid[k] = c.take<u32>(n);
+  }
+}
+
+// ================================================================= C ABI
+extern "C" {
+
+int giql_hip_abi_version(void) { return GIQL_HIP_ABI_VERSION; }
+
+const char* giql_hip_last_error(void) { return g_err; }
+
+int giql_hip_device_count(int* n_devices) {
+  if (!n_devices) return set_err(GIQL_ERR_INVALID, "n_devices is NULL");
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  *n_devices = n;
+  return GIQL_OK;
+}
+
+int giql_hip_create(int device, giql_hip_ctx** out) {
+  if (!out) return set_err(GIQL_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n)
+    return set_err(GIQL_ERR_INVALID, "device %d not in [0,%d)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  giql_hip_ctx* ctx = new (std::nothrow) giql_hip_ctx();
+  if (!ctx) return set_err(GIQL_ERR_NOMEM, "out of host memory");
+  ctx->device = device;
+  memset(&ctx->stats, 0, sizeof(ctx->stats));
+  hipError_t e = hipMalloc((void**)&ctx->d_meta, sizeof(DevMeta));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_meta, sizeof(DevMeta), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_scratch64, 64);
+  if (e != hipSuccess) {
+    giql_hip_destroy(ctx);
+    return set_err(GIQL_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e));
+  }
+  *out = ctx;
+  return GIQL_OK;
+}
+
+int giql_hip_destroy(giql_hip_ctx* ctx) {
+  if (!ctx) return GIQL_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->arena) (void)hipFree(ctx->arena);
+  if (ctx->part) (void)hipFree(ctx->part);
+  if (ctx->d_meta) (void)hipFree(ctx->d_meta);
+  if (ctx->d_scratch64) (void)hipFree(ctx->d_scratch64);
+  if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
+  delete ctx;
+  return GIQL_OK;
+}
+
+int giql_hip_reserve(giql_hip_ctx* ctx, int64_t bytes) {
+  if (!ctx || bytes < 0) return set_err(GIQL_ERR_INVALID, "bad ctx/bytes");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return ensure_arena(ctx, (size_t)bytes, nullptr);
+}
+
+int giql_hip_set_profiling(giql_hip_ctx* ctx, int enabled) {
+  if (!ctx) return set_err(GIQL_ERR_INVALID, "ctx is NULL");
+  ctx->profiling = enabled != 0;
+  return GIQL_OK;
+}
+
+int giql_hip_get_stats(giql_hip_ctx* ctx, giql_hip_stats* out) {
+  if (!ctx || !out) return set_err(GIQL_ERR_INVALID, "ctx/out is NULL");
+  if (ctx->profiling && !ctx->spans.empty()) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ctx->spans.back().b));
+    collect_spans(ctx);
+  }
+  ctx->stats.workspace_bytes = (int64_t)ctx->arena_cap;
+  *out = ctx->stats;
+  return GIQL_OK;
+}
+
+// ------------------------------------------------------------------ INNER
+int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
+                            int32_t n_chrom, void* stream, int64_t* n_pairs) {
+  if (!ctx || !n_pairs) return set_err(GIQL_ERR_INVALID, "ctx/n_pairs is NULL");
+  GIQL_TRY(check_side(a, "a"));
+  GIQL_TRY(check_side(b, "b"));
+  if (n_chrom < 0) return set_err(GIQL_ERR_INVALID, "n_chrom < 0");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  ctx->planned = false;
+  reset_stats(ctx);
+  ctx->stats.n_a = a->n;
+  ctx->stats.n_b = b->n;
+  ctx->side_a = *a;
+  ctx->side_b = *b;
+  ctx->n_a = (u32)a->n;
+  ctx->n_b = (u32)b->n;
+  ctx->n_chrom = n_chrom;
+  ctx->n_reg = ctx->n_irr = 0;
+  *n_pairs = 0;
+  if (a->n == 0 || b->n == 0 || n_chrom == 0) {  // empty result (tests :4173-4229)
+    ctx->planned = true;
+    return GIQL_OK;
+  }
+  const size_t na = (size_t)a->n, nb = (size_t)b->n, nq = na + nb;
+
+  // ---- carve the arena (dry run for the size, then for real)
+  LinBufs lb;
+  SortBufs sa, sbb;
+  u32 *tile_hist = nullptr, *cnt = nullptr, *irr_cnt = nullptr;
+  u64* bsums = nullptr;
+  const size_t n_tiles_max = cdiv(na > nb ? na : nb, RS_TILE);
+  const size_t scan_max = (nq > n_tiles_max * RS_BINS ? nq : n_tiles_max * RS_BINS);
+  auto carve = [&](char* base) {
+    Carver c{base};
+    common_sizes(c, n_chrom, lb);
+    sort_sizes(c, na, sa, true);
+    sort_sizes(c, nb, sbb, true);
+    tile_hist = c.take<u32>(n_tiles_max * RS_BINS);
+    bsums = c.take<u64>(cdiv(scan_max, SCAN_TILE) + 2);
+    cnt = c.take<u32>(nq);
+    ctx->lo = c.take<u32>(nq);
+    ctx->off = c.take<u64>(nq + 1);
+    ctx->irr_a_list = c.take<u32>(na);
+    ctx->irr_b_list = c.take<u32>(nb);
+    irr_cnt = cnt;  // reused after the regular scan
+    ctx->irr_off = c.take<u64>(nq + 1);
+    return c.off;
+  };
+  const size_t need = carve(nullptr);
+  GIQL_TRY(ensure_arena(ctx, need, st));
+  carve(ctx->arena);
+
+  GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
+  GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], ctx->irr_a_list, 0, 0));
+  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], ctx->irr_b_list, 1, 0));
+  GIQL_TRY(run_sort(ctx, st, sa, (u32)na, tile_hist, bsums));
+  GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
+  ctx->rid_a_sorted = sa.rid[0];
+  ctx->rid_b_sorted = sbb.rid[0];
+  {
+    Phase ph(ctx, st, GIQL_PH_COUNT, 2);
+    // class 1: queries = sorted B, points = sorted A starts, range [b.start, b.end)
+    hipLaunchKernelGGL(k_range_count, dim3(cdiv(nb, RC_TILE)), dim3(RC_NT), 0, st, sbb.key[0],
+                       sbb.end[0], (u32)nb, &ctx->d_meta->irr_b, sa.key[0], (u32)na,
+                       &ctx->d_meta->irr_a, 0u, ctx->lo, cnt);
+    // class 2: queries = sorted A, points = sorted B starts, range (a.start, a.end)
+    hipLaunchKernelGGL(k_range_count, dim3(cdiv(na, RC_TILE)), dim3(RC_NT), 0, st, sa.key[0],
+                       sa.end[0], (u32)na, &ctx->d_meta->irr_a, sbb.key[0], (u32)nb,
+                       &ctx->d_meta->irr_b, 1u, ctx->lo + nb, cnt + nb);
+    GIQL_TRY(post_launch("range count"));
+  }
+  GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt, nq, ctx->off, bsums, ctx->off + nq));
+  HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out, ctx->off + nq, sizeof(u64), hipMemcpyDeviceToDevice, st));
+  GIQL_TRY(read_meta(ctx, st));
+  ctx->n_reg = ctx->h_meta->n_out;
+  ctx->stats.n_irregular_a = ctx->h_meta->irr_a;
+  ctx->stats.n_irregular_b = ctx->h_meta->irr_b;
+  ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+
+  if (ctx->h_meta->irr_a + ctx->h_meta->irr_b > 0) {
+    {
+      Phase ph(ctx, st, GIQL_PH_IRREGULAR);
+      hipLaunchKernelGGL(k_irr_count, dim3(cdiv(nq, 256)), dim3(256), 0, st, view_of(*a), view_of(*b),
+                         ctx->irr_a_list, ctx->irr_b_list, ctx->d_meta, irr_cnt);
+      GIQL_TRY(post_launch("irregular count"));
+    }
+    GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_IRREGULAR, irr_cnt, nq, ctx->irr_off, bsums,
+                           ctx->irr_off + nq));
+    HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out_irr, ctx->irr_off + nq, sizeof(u64),
+                           hipMemcpyDeviceToDevice, st));
+    GIQL_TRY(read_meta(ctx, st));
+    ctx->n_irr = ctx->h_meta->n_out_irr;
+  }
+  collect_spans(ctx);
+  ctx->stats.n_out = (int64_t)(ctx->n_reg + ctx->n_irr);
+  *n_pairs = (int64_t)(ctx->n_reg + ctx->n_irr);
+  ctx->planned = true;
+  return GIQL_OK;
+}
+
+int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, int64_t capacity,
+                            void* stream) {
+  if (!ctx) return set_err(GIQL_ERR_INVALID, "ctx is NULL");
+  if (!ctx->planned) return set_err(GIQL_ERR_STATE, "inner_fill without a successful inner_plan");
+  const u64 total = ctx->n_reg + ctx->n_irr;
+  if (total == 0) return GIQL_OK;
+  if (!row_a || !row_b) return set_err(GIQL_ERR_INVALID, "row_a/row_b is NULL");
+  if (capacity < 0 || (u64)capacity < total)
+    return set_err(GIQL_ERR_CAPACITY, "capacity %lld < %llu pairs", (long long)capacity,
+                   (unsigned long long)total);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const u32 nq = ctx->n_a + ctx->n_b;
+  if (ctx->n_reg > 0) {
+    const u64 n_tiles64 = (ctx->n_reg + FILL_TILE - 1) / FILL_TILE;
+    if (n_tiles64 > 0x7FFFFFFFull) return set_err(GIQL_ERR_INVALID, "output too large");
+    const u32 n_tiles = (u32)n_tiles64;
+    if ((size_t)n_tiles + 1 > ctx->part_cap) {
+      HIP_TRY(hipStreamSynchronize(st));
+      if (ctx->part) HIP_TRY(hipFree(ctx->part));
+      ctx->part = nullptr;
+      ctx->part_cap = 0;
+      const size_t want = (size_t)n_tiles + 1 + n_tiles / 4;
+      HIP_TRY(hipMalloc((void**)&ctx->part, want * sizeof(u32)));
+      ctx->part_cap = want;
+    }
+    {
+      Phase ph(ctx, st, GIQL_PH_PARTITION);
+      hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)n_tiles + 1, 256)), dim3(256), 0, st, ctx->off,
+                         (u64)nq, ctx->n_reg, n_tiles, ctx->part);
+    }
+    {
+      Phase ph(ctx, st, GIQL_PH_FILL);
+      hipLaunchKernelGGL(k_fill, dim3(n_tiles), dim3(FILL_NT), 0, st, ctx->off, ctx->lo, ctx->n_b, nq,
+                         ctx->rid_a_sorted, ctx->rid_b_sorted, ctx->part, ctx->n_reg, row_a, row_b);
+    }
+    GIQL_TRY(post_launch("fill"));
+  }
+  if (ctx->n_irr > 0) {
+    Phase ph(ctx, st, GIQL_PH_IRREGULAR);
+    hipLaunchKernelGGL(k_irr_fill, dim3(cdiv(nq, 256)), dim3(256), 0, st, view_of(ctx->side_a),
+                       view_of(ctx->side_b), ctx->irr_a_list, ctx->irr_b_list, ctx->d_meta,
+                       ctx->irr_off, row_a + ctx->n_reg, row_b + ctx->n_reg);
+    GIQL_TRY(post_launch("irregular fill"));
+  }
+  return GIQL_OK;
+}
+
+// -------------------------------------------------------------- SEMI / ANTI
+int giql_hip_semi_anti_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
+                           int32_t n_chrom, int anti, int32_t* rows_out, int64_t* n_out,
+                           void* stream) {
+  if (!ctx || !n_out) return set_err(GIQL_ERR_INVALID, "ctx/n_out is NULL");
+  GIQL_TRY(check_side(a, "a"));
+  GIQL_TRY(check_side(b, "b"));
+  if (n_chrom < 0) return set_err(GIQL_ERR_INVALID, "n_chrom < 0");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  ctx->planned = false;
+  reset_stats(ctx);
+  ctx->stats.n_a = a->n;
+  ctx->stats.n_b = b->n;
+  *n_out = 0;
+  if (a->n == 0) return GIQL_OK;
+  if (!rows_out) return set_err(GIQL_ERR_INVALID, "rows_out is NULL");
+  const size_t na = (size_t)a->n, nb = (size_t)b->n;
+  const int nch = n_chrom > 0 ? n_chrom : 1;
+
+  LinBufs lb;
+  SortBufs sbb;
+  u32 *tile_hist = nullptr, *flag = nullptr, *pmax = nullptr, *bmax = nullptr, *dummy_irr = nullptr;
+  u64 *bsums = nullptr, *off = nullptr;
+  const size_t n_tiles = cdiv(nb ? nb : 1, RS_TILE);
+  const size_t scan_max = (na > n_tiles * RS_BINS ? na : n_tiles * RS_BINS);
+  auto carve = [&](char* base) {
+    Carver c{base};
+    common_sizes(c, nch, lb);
+    sort_sizes(c, nb ? nb : 1, sbb, true);
+    tile_hist = c.take<u32>(n_tiles * RS_BINS);
+    bsums = c.take<u64>(cdiv(scan_max, SCAN_TILE) + 2);
+    flag = c.take<u32>(na);
+    off = c.take<u64>(na + 1);
+    pmax = c.take<u32>(nb ? nb : 1);
+    bmax = c.take<u32>(cdiv(nb ? nb : 1, PM_TILE) + 1);
+    dummy_irr = c.take<u32>(16);
+    return c.off;
+  };
+  GIQL_TRY(ensure_arena(ctx, carve(nullptr), st));
+  carve(ctx->arena);
+
+  GIQL_TRY(run_spans(ctx, st, *a, *b, nch, lb));
+  if (nb > 0) {
+    GIQL_TRY(run_linearize(ctx, st, *b, nch, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1));
+    GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
+    GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
+  }
+  {
+    Phase ph(ctx, st, GIQL_PH_COUNT);
+    hipLaunchKernelGGL(k_semi_flags, dim3(cdiv(na, 256)), dim3(256), 0, st, view_of(*a), nch,
+                       lb.chrom_base, sbb.key[0], pmax, (u32)nb, anti, flag);
+    GIQL_TRY(post_launch("semi flags"));
+  }
+  GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, flag, na, off, bsums, off + na));
+  HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out, off + na, sizeof(u64), hipMemcpyDeviceToDevice, st));
+  {
+    Phase ph(ctx, st, GIQL_PH_FILL);
+    hipLaunchKernelGGL(k_compact, dim3(cdiv(na, 256)), dim3(256), 0, st, flag, off, (u32)na, rows_out);
+    GIQL_TRY(post_launch("compact"));
+  }
+  GIQL_TRY(read_meta(ctx, st));
+  collect_spans(ctx);
+  *n_out = (int64_t)ctx->h_meta->n_out;
+  ctx->stats.n_out = *n_out;
+  ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+  return GIQL_OK;
+}
+
+// ------------------------------------------------------------------- COUNT
+int giql_hip_count_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+                       int64_t* counts_out, void* stream) {
+  if (!ctx) return set_err(GIQL_ERR_INVALID, "ctx is NULL");
+  GIQL_TRY(check_side(a, "a"));
+  GIQL_TRY(check_side(b, "b"));
+  if (n_chrom < 0) return set_err(GIQL_ERR_INVALID, "n_chrom < 0");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  ctx->planned = false;
+  reset_stats(ctx);
+  ctx->stats.n_a = a->n;
+  ctx->stats.n_b = b->n;
+  if (a->n == 0) return GIQL_OK;
+  if (!counts_out) return set_err(GIQL_ERR_INVALID, "counts_out is NULL");
+  const size_t na = (size_t)a->n, nb = (size_t)b->n;
+  if (nb == 0 || n_chrom == 0) {
+    HIP_TRY(hipMemsetAsync(counts_out, 0, na * sizeof(int64_t), st));
+    return GIQL_OK;
+  }
+  LinBufs lb;
+  SortBufs sbb, sends;
+  u32 *tile_hist = nullptr, *irr_a_list = nullptr, *irr_b_list = nullptr;
+  u64* bsums = nullptr;
+  const size_t n_tiles = cdiv(nb, RS_TILE);
+  auto carve = [&](char* base) {
+    Carver c{base};
+    common_sizes(c, n_chrom, lb);
+    sort_sizes(c, nb, sbb, true);
+    sort_sizes(c, nb, sends, false);
+    tile_hist = c.take<u32>(n_tiles * RS_BINS);
+    bsums = c.take<u64>(cdiv(n_tiles * RS_BINS, SCAN_TILE) + 2);
+    irr_a_list = c.take<u32>(na);
+    irr_b_list = c.take<u32>(nb);
+    return c.off;
+  };
+  GIQL_TRY(ensure_arena(ctx, carve(nullptr), st));
+  carve(ctx->arena);
+
+  GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
+  // A is only linearised to collect its irregular rows (keys are not used)
+  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], irr_b_list, 1, 0));
+  HIP_TRY(hipMemcpyAsync(sends.key[0], sbb.end[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
+  GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
+  GIQL_TRY(run_sort(ctx, st, sends, (u32)nb, tile_hist, bsums));
+  {
+    // reuse sbb.key[1]/end[1] as scratch for A's (unused) keys
+    u32* scratch_k = nullptr;
+    u32* scratch_e = nullptr;
+    if (na <= nb) {
+      scratch_k = sbb.key[1];
+      scratch_e = sbb.end[1];
+      GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, scratch_k, scratch_e, irr_a_list, 0, 0));
+    } else {
+      // A larger than B: flag irregular rows without materialising keys
+      GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, nullptr, nullptr, irr_a_list, 0, 0));
+    }
+  }
+  {
+    Phase ph(ctx, st, GIQL_PH_COUNT);
+    hipLaunchKernelGGL(k_count_rows, dim3(cdiv(na, 256)), dim3(256), 0, st, view_of(*a), view_of(*b),
+                       n_chrom, lb.chrom_base, sbb.key[0], sends.key[0], (u32)nb, irr_b_list,
+                       ctx->d_meta, counts_out);
+    GIQL_TRY(post_launch("count rows"));
+  }
+  GIQL_TRY(read_meta(ctx, st));
+  ctx->stats.n_irregular_a = ctx->h_meta->irr_a;
+  ctx->stats.n_irregular_b = ctx->h_meta->irr_b;
+  if (ctx->h_meta->irr_a > 0) {
+    Phase ph(ctx, st, GIQL_PH_IRREGULAR);
+    hipLaunchKernelGGL(k_count_irregular, dim3(ctx->h_meta->irr_a), dim3(256), 0, st, view_of(*a),
+                       view_of(*b), irr_a_list, counts_out);
+    GIQL_TRY(post_launch("count irregular"));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  collect_spans(ctx);
+  ctx->stats.n_out = a->n;
+  ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+  return GIQL_OK;
+}
+
+// ----------------------------------------------------------------- NEAREST
+int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+                         int is_signed, int64_t max_distance, int32_t* idx_b_out, int64_t* dist_out,
+                         void* stream) {
+  if (!ctx) return set_err(GIQL_ERR_INVALID, "ctx is NULL");
+  GIQL_TRY(check_side(a, "a"));
+  GIQL_TRY(check_side(b, "b"));
+  if (n_chrom < 0) return set_err(GIQL_ERR_INVALID, "n_chrom < 0");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  ctx->planned = false;
+  reset_stats(ctx);
+  ctx->stats.n_a = a->n;
+  ctx->stats.n_b = b->n;
+  if (a->n == 0) return GIQL_OK;
+  if (!idx_b_out || !dist_out) return set_err(GIQL_ERR_INVALID, "idx_b_out/dist_out is NULL");
+  const size_t na = (size_t)a->n, nb = (size_t)b->n;
+  if (nb == 0 || n_chrom == 0) {
+    HIP_TRY(hipMemsetAsync(idx_b_out, 0xFF, na * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(dist_out, 0, na * sizeof(int64_t), st));
+    return GIQL_OK;
+  }
+  LinBufs lb;
+  SortBufs sbb;
+  u32 *tile_hist = nullptr, *pmax = nullptr, *bmax = nullptr, *dummy_irr = nullptr;
+  u64* bsums = nullptr;
+  const size_t n_tiles = cdiv(nb, RS_TILE);
+  auto carve = [&](char* base) {
+    Carver c{base};
+    common_sizes(c, n_chrom, lb);
+    sort_sizes(c, nb, sbb, true);
+    tile_hist = c.take<u32>(n_tiles * RS_BINS);
+    bsums = c.take<u64>(cdiv(n_tiles * RS_BINS, SCAN_TILE) + 2);
+    pmax = c.take<u32>(nb);
+    bmax = c.take<u32>(cdiv(nb, PM_TILE) + 1);
+    dummy_irr = c.take<u32>(16);
+    return c.off;
+  };
+  GIQL_TRY(ensure_arena(ctx, carve(nullptr), st));
+  carve(ctx->arena);
+
+  GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
+  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1));
+  {
+    Phase ph(ctx, st, GIQL_PH_AUX);
+    hipLaunchKernelGGL(k_check_not_inverted, dim3(cdiv(nb, 256)), dim3(256), 0, st, view_of(*b),
+                       ctx->d_meta);
+  }
+  // (start, end) lexicographic order = stable sort by end, then stable sort by start
+  {
+    SortBufs by_end = sbb;
+    for (int k = 0; k < 2; k++) {
+      by_end.key[k] = sbb.end[k];
+      by_end.end[k] = sbb.key[k];
+    }
+    GIQL_TRY(run_sort(ctx, st, by_end, (u32)nb, tile_hist, bsums));
+  }
+  {
+    // second sort must carry the row ids produced by the first one: run the
+    // passes by hand with rids_in set on pass 0 as well
+    const u32 n = (u32)nb;
+    const u32 nt = cdiv(n, RS_TILE);
+    for (int pass = 0; pass < 4; pass++) {
+      const int src = pass & 1, dst = src ^ 1;
+      {
+        Phase ph(ctx, st, GIQL_PH_SORT_HIST);
+        hipLaunchKernelGGL(k_radix_hist, dim3(nt), dim3(RS_NT), 0, st, sbb.key[src], n, pass * 8, nt,
+                           tile_hist);
+      }
+      GIQL_TRY(run_scan<u32>(ctx, st, GIQL_PH_SORT_SCAN, tile_hist, (u64)nt * RS_BINS, tile_hist,
+                             bsums, nullptr));
+      {
+        Phase ph(ctx, st, GIQL_PH_SORT_SCATTER);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nt), dim3(RS_NT), 0, st, sbb.key[src], sbb.end[src],
+                           (const u32*)sbb.rid[src], sbb.key[dst], sbb.end[dst], sbb.rid[dst], n,
+                           pass * 8, nt, tile_hist);
+      }
+    }
+    GIQL_TRY(post_launch("nearest sort"));
+  }
+  GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
+  {
+    Phase ph(ctx, st, GIQL_PH_COUNT);
+    hipLaunchKernelGGL(k_nearest, dim3(cdiv(na, 256)), dim3(256), 0, st, view_of(*a), n_chrom,
+                       lb.chrom_base, lb.chrom_first, sbb.key[0], sbb.end[0], pmax, sbb.rid[0], (u32)nb,
+                       is_signed, (i64)max_distance, idx_b_out, dist_out, ctx->d_meta);
+    GIQL_TRY(post_launch("nearest"));
+  }
+  GIQL_TRY(read_meta(ctx, st));
+  collect_spans(ctx);
+  ctx->stats.n_out = a->n;
+  ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+  return GIQL_OK;
+}
+
+// ---------------------------------------------------------------- checksum
+int giql_hip_pairs_checksum_dev(giql_hip_ctx* ctx, const int32_t* row_a, const int32_t* row_b,
+                                int64_t n, void* stream, uint64_t* out) {
+  if (!ctx || !out || n < 0) return set_err(GIQL_ERR_INVALID, "bad arguments");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(ctx->d_scratch64, 0, sizeof(u64), st));
+  if (n > 0) {
+    u32 grid = cdiv((u64)n, 256 * 8);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_pairs_checksum, dim3(grid), dim3(256), 0, st, row_a, row_b, (u64)n,
+                       ctx->d_scratch64);
+    GIQL_TRY(post_launch("checksum"));
+  }
+  u64 h = 0;
+  HIP_TRY(hipMemcpyAsync(&h, ctx->d_scratch64, sizeof(u64), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *out = h;
+  return GIQL_OK;
+}
+
+// ----------------------------------------------------- host-buffer variants
+struct DevSide {
+  giql_side s;
+  int32_t* buf = nullptr;
+  ~DevSide() {
+    if (buf) (void)hipFree(buf);
+  }
+};
+
+static int upload_side(const giql_side* h, DevSide& d) {
+  d.s = *h;
+  if (h->n == 0) {
+    d.s.chrom = d.s.start = d.s.end = nullptr;
+    return GIQL_OK;
+  }
+  const size_t n = (size_t)h->n;
+  HIP_TRY(hipMalloc((void**)&d.buf, 3 * n * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(d.buf, h->chrom, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d.buf + n, h->start, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d.buf + 2 * n, h->end, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  d.s.chrom = d.buf;
+  d.s.start = d.buf + n;
+  d.s.end = d.buf + 2 * n;
+  return GIQL_OK;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+                   int64_t* n_pairs, int32_t** row_a, int32_t** row_b) {
+  if (!ctx || !n_pairs || !row_a || !row_b) return set_err(GIQL_ERR_INVALID, "NULL argument");
+  GIQL_TRY(check_side(a, "a"));
+  GIQL_TRY(check_side(b, "b"));
+  HIP_TRY(hipSetDevice(ctx->device));
+  *row_a = *row_b = nullptr;
+  DevSide da, db;
+  GIQL_TRY(upload_side(a, da));
+  GIQL_TRY(upload_side(b, db));
+  int64_t n = 0;
+  GIQL_TRY(giql_hip_inner_plan_dev(ctx, &da.s, &db.s, n_chrom, nullptr, &n));
+  *n_pairs = n;
+  int32_t* ha = (int32_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+  int32_t* hb = (int32_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+  if (!ha || !hb) {
+    free(ha);
+    free(hb);
+    return set_err(GIQL_ERR_NOMEM, "out of host memory for %lld pairs", (long long)n);
+  }
+  if (n > 0) {
+    DevBuf out;
+    hipError_t e = hipMalloc(&out.p, 2 * (size_t)n * sizeof(int32_t));
+    int rc = GIQL_OK;
+    if (e != hipSuccess) rc = set_err(GIQL_ERR_NOMEM, "hipMalloc for %lld pairs failed", (long long)n);
+    int32_t* d_a = (int32_t*)out.p;
+    int32_t* d_b = d_a + n;
+    if (rc == GIQL_OK) rc = giql_hip_inner_fill_dev(ctx, d_a, d_b, n, nullptr);
+    if (rc == GIQL_OK && hipMemcpy(ha, d_a, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+      rc = set_err(GIQL_ERR_HIP, "D2H copy of row_a failed");
+    if (rc == GIQL_OK && hipMemcpy(hb, d_b, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+      rc = set_err(GIQL_ERR_HIP, "D2H copy of row_b failed");
+    if (rc != GIQL_OK) {
+      free(ha);
+      free(hb);
+      return rc;
+    }
+  }
+  *row_a = ha;
+  *row_b = hb;
+  return GIQL_OK;
+}
+
+int giql_hip_semi_anti(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+                       int anti, int64_t* n_out, int32_t** rows_a) {
+  if (!ctx || !n_out || !rows_a) return set_err(GIQL_ERR_INVALID, "NULL argument");
+  GIQL_TRY(check_side(a, "a"));
+  GIQL_TRY(check_side(b, "b"));
+  HIP_TRY(hipSetDevice(ctx->device));
+  *rows_a = nullptr;
+  DevSide da, db;
+  GIQL_TRY(upload_side(a, da));
+  GIQL_TRY(upload_side(b, db));
+  DevBuf out;
+  const size_t na = (size_t)a->n;
+  HIP_TRY(hipMalloc(&out.p, (na ? na : 1) * sizeof(int32_t)));
+  int64_t n = 0;
+  GIQL_TRY(giql_hip_semi_anti_dev(ctx, &da.s, &db.s, n_chrom, anti, (int32_t*)out.p, &n, nullptr));
+  int32_t* h = (int32_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+  if (!h) return set_err(GIQL_ERR_NOMEM, "out of host memory");
+  if (n > 0 && hipMemcpy(h, out.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+    free(h);
+    return set_err(GIQL_ERR_HIP, "D2H copy failed");
+  }
+  *n_out = n;
+  *rows_a = h;
+  return GIQL_OK;
+}
+
+int giql_hip_count(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+                   int64_t* counts_out) {
+  if (!ctx) return set_err(GIQL_ERR_INVALID, "NULL argument");
+  GIQL_TRY(check_side(a, "a"));
+  GIQL_TRY(check_side(b, "b"));
+  if (a->n == 0) return GIQL_OK;
+  if (!counts_out) return set_err(GIQL_ERR_INVALID, "counts_out is NULL");
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevSide da, db;
+  GIQL_TRY(upload_side(a, da));
+  GIQL_TRY(upload_side(b, db));
+  DevBuf out;
+  HIP_TRY(hipMalloc(&out.p, (size_t)a->n * sizeof(int64_t)));
+  GIQL_TRY(giql_hip_count_dev(ctx, &da.s, &db.s, n_chrom, (int64_t*)out.p, nullptr));
+  HIP_TRY(hipMemcpy(counts_out, out.p, (size_t)a->n * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return GIQL_OK;
+}
+
+int giql_hip_nearest(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+                     int is_signed, int64_t max_distance, int32_t* idx_b_out, int64_t* dist_out) {
+  if (!ctx) return set_err(GIQL_ERR_INVALID, "NULL argument");
+  GIQL_TRY(check_side(a, "a"));
+  GIQL_TRY(check_side(b, "b"));
+  if (a->n == 0) return GIQL_OK;
+  if (!idx_b_out || !dist_out) return set_err(GIQL_ERR_INVALID, "output is NULL");
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevSide da, db;
+  GIQL_TRY(upload_side(a, da));
+  GIQL_TRY(upload_side(b, db));
+  DevBuf oi, od;
+  HIP_TRY(hipMalloc(&oi.p, (size_t)a->n * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&od.p, (size_t)a->n * sizeof(int64_t)));
+  GIQL_TRY(giql_hip_nearest_dev(ctx, &da.s, &db.s, n_chrom, is_signed, max_distance,
+                                (int32_t*)oi.p, (int64_t*)od.p, nullptr));
+  HIP_TRY(hipMemcpy(idx_b_out, oi.p, (size_t)a->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(dist_out, od.p, (size_t)a->n * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return GIQL_OK;
+}
+
+void giql_hip_free_host(void* p) { free(p); }
+
+}  // extern "C"

@@ -1,0 +1,487 @@
+// giql_amd/csrc/join_kernels.hip.h -- the interval-overlap join proper.
+//
+// Coordinates are linearised: key = chrom_base[chrom] + canonical coordinate, so
+// one flat u32 axis holds every chromosome back to back and the per-chromosome
+// partition of the reference (intersects_duckdb.py:1317-1330) is implicit: an
+// interval never reaches the next chromosome's range.
+//
+// With both sides sorted by linearised start, the overlap set
+//   a.start < b.end AND a.end > b.start          (intersects.py:149-154)
+// of well-formed rows (start < end) is the DISJOINT union of two range queries:
+//   class 1:  a.start in [b.start, b.end)   -- query b over sorted A starts
+//   class 2:  b.start in (a.start, a.end)   -- query a over sorted B starts
+// Every enumerated candidate is a match: no predicate test, no wasted reads.
+// Rows with end <= start ("irregular": zero-length / inverted) do not satisfy
+// that identity; they get a sentinel key (sorted past every real row) and go
+// through the literal-predicate kernels at the bottom of this file.
+#pragma once
+
+#include <limits.h>
+
+#include "dev_common.hip.h"
+
+namespace giql {
+
+// ------------------------------------------------------------------ spans
+__global__ void k_init_minmax(int* __restrict__ gmin, int* __restrict__ gmax, int n_chrom,
+                              DevMeta* __restrict__ meta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_chrom) {
+    gmin[i] = INT_MAX;
+    gmax[i] = INT_MIN;
+  }
+  if (i == 0) {
+    meta->total_span = 0;
+    meta->n_out = 0;
+    meta->n_out_irr = 0;
+    meta->sentinel = U32_MAX;
+    meta->irr_a = 0;
+    meta->irr_b = 0;
+    meta->status = 0;
+    meta->aux0 = 0;
+    meta->aux1 = 0;
+  }
+}
+
+constexpr int MM_NT = 256;
+constexpr int MM_ITEMS = 8;
+constexpr int MM_LDS_CHROMS = 4096;
+
+// Per-chromosome min/max of the raw coordinates (both columns).  LDS-privatised
+// atomics; a per-thread run cache keeps chromosome-sorted input (the common BED
+// case) from serialising on one LDS address.
+__global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ chrom,
+                                                         const int* __restrict__ start,
+                                                         const int* __restrict__ end, i64 n,
+                                                         int n_chrom, int* __restrict__ gmin,
+                                                         int* __restrict__ gmax,
+                                                         DevMeta* __restrict__ meta) {
+  extern __shared__ int mm_lds[];
+  const bool use_lds = n_chrom <= MM_LDS_CHROMS;
+  int* lmin = use_lds ? mm_lds : gmin;
+  int* lmax = use_lds ? mm_lds + n_chrom : gmax;
+  if (use_lds) {
+    for (int c = threadIdx.x; c < n_chrom; c += MM_NT) {
+      lmin[c] = INT_MAX;
+      lmax[c] = INT_MIN;
+    }
+    __syncthreads();
+  }
+  int cur = -1, mn = INT_MAX, mx = INT_MIN;
+  bool bad = false;
+  const i64 stride = (i64)gridDim.x * MM_NT;
+  for (i64 i = (i64)blockIdx.x * MM_NT + threadIdx.x; i < n; i += stride) {
+    const int c = chrom[i];
+    const int s = start[i], e = end[i];
+    if (c < 0 || c >= n_chrom) {
+      bad = true;
+      continue;
+    }
+    if (c != cur) {
+      if (cur >= 0) {
+        atomicMin(&lmin[cur], mn);
+        atomicMax(&lmax[cur], mx);
+      }
+      cur = c;
+      mn = INT_MAX;
+      mx = INT_MIN;
+    }
+    const int lo = s < e ? s : e, hi = s < e ? e : s;
+    mn = lo < mn ? lo : mn;
+    mx = hi > mx ? hi : mx;
+  }
+  if (cur >= 0) {
+    atomicMin(&lmin[cur], mn);
+    atomicMax(&lmax[cur], mx);
+  }
+  if (bad) meta->status = -4;  // GIQL_ERR_CHROM
+  if (use_lds) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < n_chrom; c += MM_NT) {
+      if (lmin[c] <= lmax[c]) {
+        atomicMin(&gmin[c], lmin[c]);
+        atomicMax(&gmax[c], lmax[c]);
+      }
+    }
+  }
+}
+
+// Single block: chrom_base[c] = (exclusive prefix of spans) - (lowest canonical
+// coordinate of c), so key = chrom_base[c] + canonical coordinate.
+__global__ __launch_bounds__(256) void k_chrom_offsets(const int* __restrict__ gmin,
+                                                        const int* __restrict__ gmax, int n_chrom,
+                                                        int off_min, int off_max,
+                                                        i64* __restrict__ chrom_base,
+                                                        u32* __restrict__ chrom_first,
+                                                        DevMeta* __restrict__ meta) {
+  __shared__ u64 lds[256 / WAVE + 1];
+  __shared__ u64 carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_chrom; base += 256) {
+    const int c = base + threadIdx.x;
+    i64 lo = 0;
+    u64 span = 0;
+    if (c < n_chrom && gmin[c] <= gmax[c]) {
+      lo = (i64)gmin[c] + off_min;
+      span = (u64)((i64)gmax[c] + off_max - lo + 1);
+    }
+    u64 total;
+    const u64 ex = block_excl_scan<u64, 256>(span, lds, total);
+    const u64 carry = carry_s;
+    if (c < n_chrom) {
+      chrom_base[c] = (i64)(carry + ex) - lo;
+      const u64 f = carry + ex;
+      chrom_first[c] = f > 0xFFFFFFFFull ? U32_MAX : (u32)f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const u64 total = carry_s;
+    meta->total_span = total;
+    chrom_first[n_chrom] = total > 0xFFFFFFFFull ? U32_MAX : (u32)total;
+    if (total > 0xFFFFFFFFull) {
+      meta->status = -5;  // GIQL_ERR_SPAN
+      meta->sentinel = U32_MAX;
+    } else {
+      meta->sentinel = (u32)total;  // one past the largest real key
+    }
+  }
+}
+
+// -------------------------------------------------------------- linearise
+constexpr int LIN_NT = 256;
+
+// keys[i] = linearised canonical start, ends[i] = linearised canonical end.
+// Irregular rows (canonical end <= start) get the sentinel key and are appended
+// to irr_list -- unless keep_irregular, where every row keeps its real key (the
+// prefix-max operators are exact for any row).  which = 0 for side A, 1 for B.
+// keys / ends may be NULL (only the irregular list is wanted).
+__global__ __launch_bounds__(LIN_NT) void k_linearize(
+    const int* __restrict__ chrom, const int* __restrict__ start, const int* __restrict__ end, u32 n,
+    int start_off, int end_off, int n_chrom, const i64* __restrict__ chrom_base,
+    u32* __restrict__ keys, u32* __restrict__ ends, u32* __restrict__ irr_list,
+    DevMeta* __restrict__ meta, int which, int keep_irregular) {
+  const u32 sentinel = meta->sentinel;
+  u32* irr_count = which ? &meta->irr_b : &meta->irr_a;
+  const u32 stride = gridDim.x * LIN_NT;
+  // every lane runs the same number of iterations so the ballots are full-wave
+  const u32 n_iter = (n + stride - 1) / stride;
+  u32 i = blockIdx.x * LIN_NT + threadIdx.x;
+  for (u32 it = 0; it < n_iter; it++, i += stride) {
+    const bool ok = i < n;
+    bool irr = false;
+    u32 k = sentinel, ke = sentinel;
+    if (ok) {
+      const i64 cs = (i64)start[i] + start_off;
+      const i64 ce = (i64)end[i] + end_off;
+      const int c = chrom[i];
+      const bool c_ok = c >= 0 && c < n_chrom;  // bad ids were flagged by k_chrom_minmax
+      irr = c_ok && !keep_irregular && ce <= cs;
+      if (c_ok && !irr) {
+        const i64 b = chrom_base[c];
+        k = (u32)(b + cs);
+        ke = (u32)(b + ce);
+      }
+      if (keys) {
+        keys[i] = k;
+        ends[i] = ke;
+      }
+    }
+    const u64 m = __ballot(irr);
+    if (m) {
+      u32 base = 0;
+      if (lane_id() == 0) base = atomicAdd(irr_count, (u32)__popcll(m));
+      base = __shfl(base, 0, WAVE);
+      if (irr) irr_list[base + (u32)__popcll(m & lanemask_lt())] = i;
+    }
+  }
+}
+
+// ------------------------------------------------------------- range count
+constexpr int RC_NT = 256;
+constexpr int RC_ITEMS = 4;
+constexpr int RC_TILE = RC_NT * RC_ITEMS;  // 1024 queries per block
+constexpr int RC_LDS_CAP = 8192;           // staged S keys (32 KB)
+
+// For the sorted queries of one block, count the points of the sorted set S in
+// [qs + lo_off, qe).  lo_off = 0 is class 1 (closed low end), 1 is class 2.
+// Writes lo (first matching index in S) and cnt.  Rows past the regular prefix
+// (sentinel keys) get cnt = 0.  The block's S window is located with two
+// cooperative 64-ary searches, staged through LDS when it fits, and searched
+// per lane there (the "LDS tile + per-lane binary search" of the north star).
+__global__ __launch_bounds__(RC_NT) void k_range_count(
+    const u32* __restrict__ qs, const u32* __restrict__ qe, u32 nq_total,
+    const u32* __restrict__ irr_q, const u32* __restrict__ ss, u32 ns_total,
+    const u32* __restrict__ irr_s, u32 lo_off, u32* __restrict__ lo_out, u32* __restrict__ cnt_out) {
+  __shared__ u32 s_tile[RC_LDS_CAP];
+  __shared__ u32 s_red[RC_NT / WAVE];
+  __shared__ u32 s_bounds[2];
+
+  const u32 nq = nq_total - *irr_q;
+  const u32 ns = ns_total - *irr_s;
+  const u32 q0 = blockIdx.x * RC_TILE;
+  const u32 tid = threadIdx.x;
+
+  u32 s[RC_ITEMS], e[RC_ITEMS];
+  u32 emax = 0;
+#pragma unroll
+  for (int i = 0; i < RC_ITEMS; i++) {
+    const u32 q = q0 + i * RC_NT + tid;
+    const bool ok = q < nq;
+    s[i] = ok ? qs[q] : U32_MAX;
+    e[i] = ok ? qe[q] : 0u;
+    emax = e[i] > emax ? e[i] : emax;
+  }
+  if (q0 >= nq || ns == 0) {  // block-uniform
+#pragma unroll
+    for (int i = 0; i < RC_ITEMS; i++) {
+      const u32 q = q0 + i * RC_NT + tid;
+      if (q < nq_total) {
+        lo_out[q] = 0;
+        cnt_out[q] = 0;
+      }
+    }
+    return;
+  }
+  emax = wave_reduce_max_u32(emax);
+  if (lane_id() == 0) s_red[wave_id()] = emax;
+  __syncthreads();
+  if (wave_id() == 0) {
+    u32 m = s_red[0];
+#pragma unroll
+    for (int k = 1; k < RC_NT / WAVE; k++) m = s_red[k] > m ? s_red[k] : m;
+    const u32 smin = qs[q0] + lo_off;  // queries are sorted: first is smallest
+    const u32 w_lo = wave_lower_bound_u32(ss, 0, ns, smin);
+    const u32 w_hi = wave_lower_bound_u32(ss, w_lo, ns, m);
+    if (lane_id() == 0) {
+      s_bounds[0] = w_lo;
+      s_bounds[1] = w_hi;
+    }
+  }
+  __syncthreads();
+  const u32 w_lo = s_bounds[0], w_hi = s_bounds[1];
+  const u32 w_len = w_hi - w_lo;
+  const bool staged = w_len <= (u32)RC_LDS_CAP;
+  if (staged) {
+    for (u32 k = tid; k < w_len; k += RC_NT) s_tile[k] = ss[w_lo + k];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < RC_ITEMS; i++) {
+    const u32 q = q0 + i * RC_NT + tid;
+    if (q >= nq_total) continue;
+    u32 lo = 0, cnt = 0;
+    if (q < nq) {
+      u32 hi;
+      if (staged) {
+        lo = lower_bound_u32(s_tile, 0, w_len, s[i] + lo_off);
+        hi = lower_bound_u32(s_tile, lo, w_len, e[i]);
+        lo += w_lo;
+        hi += w_lo;
+      } else {
+        lo = lower_bound_u32(ss, w_lo, w_hi, s[i] + lo_off);
+        hi = lower_bound_u32(ss, lo, w_hi, e[i]);
+      }
+      cnt = hi - lo;
+    }
+    lo_out[q] = lo;
+    cnt_out[q] = cnt;
+  }
+}
+
+// --------------------------------------------------------------- partition
+constexpr int FILL_NT = 256;
+constexpr int FILL_ITEMS = 16;
+constexpr int FILL_TILE = FILL_NT * FILL_ITEMS;  // 4096 output pairs per block
+constexpr int FILL_QCAP = 4096;                  // staged query offsets
+
+// part[t] = last query q with off[q] <= t * FILL_TILE  (merge-path split of the
+// output among blocks: every block materialises exactly FILL_TILE pairs).
+__global__ void k_partition(const u64* __restrict__ off, u64 nq, u64 n_out, u32 n_tiles,
+                            u32* __restrict__ part) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > n_tiles) return;
+  if (t == n_tiles) {
+    part[t] = nq > 0 ? (u32)(nq - 1) : 0u;
+    return;
+  }
+  const u64 p = (u64)t * FILL_TILE;
+  (void)n_out;
+  part[t] = (u32)(upper_bound_u64(off, 0, nq + 1, p) - 1);
+}
+
+// -------------------------------------------------------------------- fill
+// Queries are the concatenation [class-1 queries = sorted B | class-2 queries =
+// sorted A]; off[] is their exclusive output offset, lo[] the first matching
+// index in the other side's sorted array.  Each thread materialises pairs for
+// output positions tile_start + i*256 + tid: coalesced 4-byte stores to row_a /
+// row_b, (mostly) coalesced rid reads.
+__global__ __launch_bounds__(FILL_NT) void k_fill(
+    const u64* __restrict__ off, const u32* __restrict__ lo, u32 nq_b, u32 nq_total,
+    const u32* __restrict__ rid_a_sorted, const u32* __restrict__ rid_b_sorted,
+    const u32* __restrict__ part, u64 n_out, int32_t* __restrict__ row_a,
+    int32_t* __restrict__ row_b) {
+  __shared__ u32 s_rel[FILL_QCAP + 1];
+  const u32 tid = threadIdx.x;
+  const u64 tile_start = (u64)blockIdx.x * FILL_TILE;
+  const u64 rem = n_out - tile_start;
+  const u32 tile_len = rem < (u64)FILL_TILE ? (u32)rem : (u32)FILL_TILE;
+  const u32 qf = part[blockIdx.x];
+  u32 ql = part[blockIdx.x + 1];
+  if (ql >= nq_total) ql = nq_total - 1;
+  const u32 nqt = ql - qf + 1;
+  const bool staged = nqt <= (u32)FILL_QCAP;
+  if (staged) {
+    // rel[k] = clamp(off[qf + k] - tile_start, 0 .. tile_len)
+    for (u32 k = tid; k < nqt; k += FILL_NT) {
+      const u64 o = off[qf + k];
+      u32 r = 0;
+      if (o > tile_start) {
+        const u64 d = o - tile_start;
+        r = d > (u64)tile_len ? tile_len : (u32)d;
+      }
+      s_rel[k] = r;
+    }
+    __syncthreads();
+  }
+#pragma unroll 4
+  for (int i = 0; i < FILL_ITEMS; i++) {
+    const u32 p_rel = i * FILL_NT + tid;
+    if (p_rel >= tile_len) break;
+    const u64 p = tile_start + p_rel;
+    u32 q;
+    if (staged) {
+      q = qf + upper_bound_u32(s_rel, 0, nqt, p_rel) - 1;
+    } else {
+      q = (u32)(upper_bound_u64(off, qf, (u64)ql + 1, p) - 1);
+    }
+    const u32 j = lo[q] + (u32)(p - off[q]);
+    int32_t ra, rb;
+    if (q < nq_b) {  // class 1: query is a B row, matches are A rows
+      rb = (int32_t)rid_b_sorted[q];
+      ra = (int32_t)rid_a_sorted[j];
+    } else {  // class 2: query is an A row, matches are B rows
+      ra = (int32_t)rid_a_sorted[q - nq_b];
+      rb = (int32_t)rid_b_sorted[j];
+    }
+    row_a[p] = ra;
+    row_b[p] = rb;
+  }
+}
+
+// ------------------------------------------------ irregular rows (literal)
+struct SideView {
+  const int* chrom;
+  const int* start;
+  const int* end;
+  u32 n;
+  int start_off, end_off;
+};
+
+__device__ __forceinline__ bool literal_overlap(int ac, i64 as, i64 ae, int bc, i64 bs, i64 be) {
+  return ac == bc && as < be && ae > bs;
+}
+
+// Pairs involving an irregular row, each counted once:
+//   part X: (irregular a) x (every b)          -- thread per B row
+//   part Y: (regular a)   x (irregular b)      -- thread per A row
+// cnt has n_b + n_a entries [X | Y].
+__global__ void k_irr_count(SideView a, SideView b, const u32* __restrict__ irr_a_list,
+                            const u32* __restrict__ irr_b_list, const DevMeta* __restrict__ meta,
+                            u32* __restrict__ cnt) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.n + b.n) return;
+  u32 c = 0;
+  if (t < b.n) {
+    const int bc = b.chrom[t];
+    const i64 bs = (i64)b.start[t] + b.start_off, be = (i64)b.end[t] + b.end_off;
+    const u32 m = meta->irr_a;
+    for (u32 k = 0; k < m; k++) {
+      const u32 r = irr_a_list[k];
+      c += literal_overlap(a.chrom[r], (i64)a.start[r] + a.start_off, (i64)a.end[r] + a.end_off, bc,
+                           bs, be);
+    }
+  } else {
+    const u32 i = t - b.n;
+    const int ac = a.chrom[i];
+    const i64 as = (i64)a.start[i] + a.start_off, ae = (i64)a.end[i] + a.end_off;
+    if (ae > as) {
+      const u32 m = meta->irr_b;
+      for (u32 k = 0; k < m; k++) {
+        const u32 r = irr_b_list[k];
+        c += literal_overlap(ac, as, ae, b.chrom[r], (i64)b.start[r] + b.start_off,
+                             (i64)b.end[r] + b.end_off);
+      }
+    }
+  }
+  cnt[t] = c;
+}
+
+__global__ void k_irr_fill(SideView a, SideView b, const u32* __restrict__ irr_a_list,
+                           const u32* __restrict__ irr_b_list, const DevMeta* __restrict__ meta,
+                           const u64* __restrict__ off, int32_t* __restrict__ row_a,
+                           int32_t* __restrict__ row_b) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.n + b.n) return;
+  u64 o = off[t];
+  if (t < b.n) {
+    const int bc = b.chrom[t];
+    const i64 bs = (i64)b.start[t] + b.start_off, be = (i64)b.end[t] + b.end_off;
+    const u32 m = meta->irr_a;
+    for (u32 k = 0; k < m; k++) {
+      const u32 r = irr_a_list[k];
+      if (literal_overlap(a.chrom[r], (i64)a.start[r] + a.start_off, (i64)a.end[r] + a.end_off, bc,
+                          bs, be)) {
+        row_a[o] = (int32_t)r;
+        row_b[o] = (int32_t)t;
+        o++;
+      }
+    }
+  } else {
+    const u32 i = t - b.n;
+    const int ac = a.chrom[i];
+    const i64 as = (i64)a.start[i] + a.start_off, ae = (i64)a.end[i] + a.end_off;
+    if (ae > as) {
+      const u32 m = meta->irr_b;
+      for (u32 k = 0; k < m; k++) {
+        const u32 r = irr_b_list[k];
+        if (literal_overlap(ac, as, ae, b.chrom[r], (i64)b.start[r] + b.start_off,
+                            (i64)b.end[r] + b.end_off)) {
+          row_a[o] = (int32_t)i;
+          row_b[o] = (int32_t)r;
+          o++;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- checksum
+__global__ __launch_bounds__(256) void k_pairs_checksum(const int32_t* __restrict__ row_a,
+                                                         const int32_t* __restrict__ row_b, u64 n,
+                                                         u64* __restrict__ out) {
+  __shared__ u64 lds[256 / WAVE];
+  u64 acc = 0;
+  const u64 stride = (u64)gridDim.x * 256;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    u64 x = ((u64)(u32)row_a[i] << 32) | (u64)(u32)row_b[i];
+    x *= 0x9E3779B97F4A7C15ull;
+    x ^= (x >> 32);
+    x *= 0xD6E8FEB86659FD93ull;
+    acc += x;
+  }
+  acc = wave_reduce_sum(acc);
+  if (lane_id() == 0) lds[wave_id()] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 t = 0;
+#pragma unroll
+    for (int w = 0; w < 256 / WAVE; w++) t += lds[w];
+    atomicAdd((unsigned long long*)out, (unsigned long long)t);
+  }
+}
+
+}  // namespace giql

@@ -1,0 +1,219 @@
+"""Device-resident engine: torch tensors in, torch tensors out, arithmetic in HIP.
+
+torch is used only as plumbing (device memory, the current stream); every result
+comes from ``libgiql_hip.so`` through the C ABI of ``include/giql_hip.h``.
+
+Reference interface mirrored (path:line under /root/reference/):
+the per-chromosome INNER / SEMI / ANTI plans of
+``src/giql/expanders/intersects_duckdb.py:1254-1330``, count_overlaps
+(``:806-854``) and NEAREST k=1 (``src/giql/expanders/nearest.py:336-397``), with
+each table's coordinate encoding applied as in ``src/giql/canonical.py:16-52``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+from . import _lib
+
+#: (coordinate_system, interval_type) -> (start_off, end_off)
+#: src/giql/canonical.py:16-52
+ENCODING_OFFSETS = {
+    ("0based", "half_open"): (0, 0),
+    ("0based", "closed"): (0, +1),
+    ("1based", "half_open"): (-1, -1),
+    ("1based", "closed"): (-1, 0),
+}
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+@dataclass
+class DeviceSide:
+    """One join side resident in HBM: int32 chrom ids / start / end tensors."""
+
+    chrom: "object"
+    start: "object"
+    end: "object"
+    start_off: int = 0
+    end_off: int = 0
+
+    def __post_init__(self) -> None:
+        torch = _torch()
+        for name in ("chrom", "start", "end"):
+            t = getattr(self, name)
+            if not isinstance(t, torch.Tensor) or t.dtype != torch.int32 or t.dim() != 1:
+                raise ValueError(f"{name} must be a 1-D torch.int32 tensor")
+            if not t.is_cuda:
+                raise ValueError(f"{name} must live on the GPU (cuda/hip device)")
+            if not t.is_contiguous():
+                raise ValueError(f"{name} must be contiguous")
+        if not (self.chrom.shape == self.start.shape == self.end.shape):
+            raise ValueError("chrom/start/end lengths differ")
+
+    @property
+    def n(self) -> int:
+        return int(self.chrom.shape[0])
+
+    @property
+    def device(self):
+        return self.chrom.device
+
+    @classmethod
+    def from_numpy(cls, chrom, start, end, encoding=("0based", "half_open"), device="cuda:0"):
+        import numpy as np
+
+        torch = _torch()
+        so, eo = ENCODING_OFFSETS[tuple(encoding)]
+
+        def up(x):
+            return torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(device)
+
+        return cls(up(chrom), up(start), up(end), so, eo)
+
+    def c_struct(self) -> _lib.CSide:
+        n = self.n
+        return _lib.CSide(
+            self.chrom.data_ptr() if n else None,
+            self.start.data_ptr() if n else None,
+            self.end.data_ptr() if n else None,
+            n, self.start_off, self.end_off)
+
+
+class HipEngine:
+    """One context (device arena + bookkeeping) on one GPU.  Not thread-safe."""
+
+    def __init__(self, device: int = 0, profiling: bool = False):
+        self._L = _lib.load()
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.GiqlHipUnavailable("no HIP device visible to torch; there is no CPU fallback")
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        h = ctypes.c_void_p()
+        _lib.check(self._L.giql_hip_create(self.device_index, ctypes.byref(h)))
+        self._h = h
+        self.set_profiling(profiling)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.giql_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------- utilities
+    def _stream(self):
+        torch = _torch()
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_profiling(self, enabled: bool) -> None:
+        _lib.check(self._L.giql_hip_set_profiling(self._h, int(bool(enabled))))
+
+    def reserve(self, nbytes: int) -> None:
+        _lib.check(self._L.giql_hip_reserve(self._h, int(nbytes)))
+
+    def stats(self) -> dict:
+        st = _lib.CStats()
+        _lib.check(self._L.giql_hip_get_stats(self._h, ctypes.byref(st)))
+        out = {k: int(getattr(st, k)) for k in
+               ("n_a", "n_b", "n_out", "n_irregular_a", "n_irregular_b", "workspace_bytes", "span",
+                "profiled")}
+        out["total_ms"] = float(st.total_ms)
+        out["phase_ms"] = {name: float(st.phase_ms[i]) for i, name in enumerate(_lib.PHASES)}
+        out["phase_launches"] = {name: int(st.phase_launches[i]) for i, name in enumerate(_lib.PHASES)}
+        return out
+
+    def _check_sides(self, a: DeviceSide, b: DeviceSide) -> None:
+        for s in (a, b):
+            if s.n and s.device != self.device:
+                raise ValueError(f"side lives on {s.device}, engine on {self.device}")
+
+    # ------------------------------------------------------------------ INNER
+    def inner_plan(self, a: DeviceSide, b: DeviceSide, n_chrom: int) -> int:
+        self._check_sides(a, b)
+        n = ctypes.c_int64(0)
+        ca, cb = a.c_struct(), b.c_struct()
+        _lib.check(self._L.giql_hip_inner_plan_dev(self._h, ca, cb, int(n_chrom), self._stream(),
+                                                   ctypes.byref(n)))
+        self._keepalive = (a, b)
+        return int(n.value)
+
+    def inner_fill(self, row_a, row_b) -> None:
+        cap = int(row_a.shape[0])
+        _lib.check(self._L.giql_hip_inner_fill_dev(
+            self._h, row_a.data_ptr() if cap else None, row_b.data_ptr() if cap else None, cap,
+            self._stream()))
+
+    def inner_join(self, a: DeviceSide, b: DeviceSide, n_chrom: int, out=None):
+        """All ``(row_a, row_b)`` with ``a INTERSECTS b``; two int32 device tensors."""
+        torch = _torch()
+        n = self.inner_plan(a, b, n_chrom)
+        if out is not None and out[0].shape[0] >= n:
+            row_a, row_b = out[0][:n], out[1][:n]
+        else:
+            row_a = torch.empty(n, dtype=torch.int32, device=self.device)
+            row_b = torch.empty(n, dtype=torch.int32, device=self.device)
+        self.inner_fill(row_a, row_b)
+        return row_a, row_b
+
+    # -------------------------------------------------------------- SEMI/ANTI
+    def semi_anti(self, a: DeviceSide, b: DeviceSide, n_chrom: int, anti: bool):
+        """Ascending A row ids with (SEMI) / without (ANTI) an overlapping B row."""
+        torch = _torch()
+        self._check_sides(a, b)
+        rows = torch.empty(a.n, dtype=torch.int32, device=self.device)
+        n = ctypes.c_int64(0)
+        _lib.check(self._L.giql_hip_semi_anti_dev(
+            self._h, a.c_struct(), b.c_struct(), int(n_chrom), int(bool(anti)),
+            rows.data_ptr() if a.n else None, ctypes.byref(n), self._stream()))
+        return rows[: int(n.value)]
+
+    def semi_join(self, a, b, n_chrom):
+        return self.semi_anti(a, b, n_chrom, False)
+
+    def anti_join(self, a, b, n_chrom):
+        return self.semi_anti(a, b, n_chrom, True)
+
+    # ------------------------------------------------------------------ COUNT
+    def count_overlaps(self, a: DeviceSide, b: DeviceSide, n_chrom: int):
+        """int64 tensor: number of overlapping B rows per A row (original order)."""
+        torch = _torch()
+        self._check_sides(a, b)
+        counts = torch.zeros(a.n, dtype=torch.int64, device=self.device)
+        _lib.check(self._L.giql_hip_count_dev(
+            self._h, a.c_struct(), b.c_struct(), int(n_chrom),
+            counts.data_ptr() if a.n else None, self._stream()))
+        return counts
+
+    # ---------------------------------------------------------------- NEAREST
+    def nearest(self, a: DeviceSide, b: DeviceSide, n_chrom: int, signed: bool = False,
+                max_distance=None):
+        """NEAREST k=1: ``(idx_b int32, distance int64)`` per A row; idx_b=-1 = none."""
+        torch = _torch()
+        self._check_sides(a, b)
+        idx = torch.full((a.n,), -1, dtype=torch.int32, device=self.device)
+        dist = torch.zeros(a.n, dtype=torch.int64, device=self.device)
+        md = -1 if max_distance is None else int(max_distance)
+        _lib.check(self._L.giql_hip_nearest_dev(
+            self._h, a.c_struct(), b.c_struct(), int(n_chrom), int(bool(signed)), md,
+            idx.data_ptr() if a.n else None, dist.data_ptr() if a.n else None, self._stream()))
+        return idx, dist
+
+    # --------------------------------------------------------------- checksum
+    def pairs_checksum(self, row_a, row_b) -> int:
+        h = ctypes.c_uint64(0)
+        n = int(row_a.shape[0])
+        _lib.check(self._L.giql_hip_pairs_checksum_dev(
+            self._h, row_a.data_ptr() if n else None, row_b.data_ptr() if n else None, n,
+            self._stream(), ctypes.byref(h)))
+        return int(h.value)

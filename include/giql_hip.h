@@ -1,0 +1,172 @@
+/*
+ * include/giql_hip.h -- C ABI of libgiql_hip.so, the MI355X (gfx950) execution
+ * backend for GIQL's column-to-column INTERSECTS range join (+ SEMI / ANTI,
+ * per-row COUNT and NEAREST k=1).
+ *
+ * This is the drop-in boundary.  In the reference the path ends with a SQL string
+ * handed to an engine; what the engine (DuckDB IE_JOIN) computes is what these
+ * entry points compute, on the same inputs:
+ *
+ *   reference interface replaced (path:line under /root/reference/)
+ *   ----------------------------------------------------------------
+ *   giql_hip_inner_*     per-chromosome INNER IEJoin plan + UNION ALL
+ *                        src/giql/expanders/intersects_duckdb.py:1283-1299,
+ *                        1317-1330, 1336-1400; _per_chrom.py:46-74; predicate
+ *                        src/giql/expanders/intersects.py:149-154
+ *   giql_hip_semi_anti_* SEMI / ANTI (WHERE [NOT] EXISTS) plan
+ *                        src/giql/expanders/intersects_duckdb.py:1254-1282,
+ *                        1321-1324
+ *   giql_hip_count_*     count_overlaps (COUNT per left row, zero-filled)
+ *                        src/giql/expanders/intersects_duckdb.py:432-548, 806-854
+ *   giql_hip_nearest_*   NEAREST k=1 (LATERAL top-k subquery + distance CASE)
+ *                        src/giql/expanders/nearest.py:255-397;
+ *                        src/giql/expanders/_distance.py:67-87
+ *   giql_side.start_off / end_off
+ *                        canonical_start / canonical_end
+ *                        src/giql/canonical.py:16-52
+ *
+ * Conventions
+ *   - C linkage, plain pointers and sizes, no C++ / torch types.
+ *   - Every entry returns an int status: 0 = ok, < 0 = error; the message is
+ *     available from giql_hip_last_error() (thread-local).
+ *   - Column buffers are BORROWED Arrow int32 data buffers (validity must be
+ *     all-valid, offset already applied); the library never writes or frees them.
+ *   - chrom is a dictionary id in [0, n_chrom) from a dictionary SHARED by both
+ *     sides (the reference compares VARCHAR values).
+ *   - "_dev" entry points take DEVICE pointers and a hipStream_t (as void*; NULL
+ *     = the default stream); results stay on the device.  The host-buffer entry
+ *     points stage H2D/D2H themselves and return malloc'ed host arrays that the
+ *     caller releases with giql_hip_free_host().
+ *   - Output order is unspecified (as upstream); pairs are a
+ *     multiset (bag semantics).
+ */
+#ifndef GIQL_HIP_H
+#define GIQL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GIQL_HIP_ABI_VERSION 1
+
+enum {
+  GIQL_OK = 0,
+  GIQL_ERR_INVALID = -1,   /* bad argument */
+  GIQL_ERR_HIP = -2,       /* HIP runtime failure */
+  GIQL_ERR_NOMEM = -3,     /* allocation failure */
+  GIQL_ERR_CHROM = -4,     /* chrom id outside [0, n_chrom) */
+  GIQL_ERR_SPAN = -5,      /* linearised coordinate space exceeds 32 bits */
+  GIQL_ERR_CAPACITY = -6,  /* caller-provided output too small */
+  GIQL_ERR_STATE = -7      /* fill without a successful plan */
+};
+
+typedef struct giql_hip_ctx giql_hip_ctx;
+
+/* One join side (reference: the (chrom,start,end) columns a ResolvedColumn
+ * names, src/giql/resolver.py:256-299, with its table's encoding). */
+typedef struct giql_side {
+  const int32_t* chrom;
+  const int32_t* start;
+  const int32_t* end;
+  int64_t n;
+  int32_t start_off; /* canonical start = start + start_off (0 or -1)       */
+  int32_t end_off;   /* canonical end   = end   + end_off   (+1, 0 or -1)   */
+} giql_side;
+
+/* Phase indices of giql_hip_stats.phase_ms (hipEvent-timed on the call's
+ * stream when profiling is enabled). */
+enum {
+  GIQL_PH_SPAN = 0,      /* per-chromosome min/max + offsets                */
+  GIQL_PH_LINEARIZE = 1, /* (chrom,start,end) -> 32-bit linear keys         */
+  GIQL_PH_SORT_HIST = 2, /* radix: per-tile digit histograms                */
+  GIQL_PH_SORT_SCAN = 3, /* radix: scan of tile histograms                  */
+  GIQL_PH_SORT_SCATTER = 4, /* radix: ranked scatter of (key,end,rid)       */
+  GIQL_PH_COUNT = 5,     /* per-row range bounds + counts                   */
+  GIQL_PH_SCAN = 6,      /* exclusive scan of counts -> output offsets      */
+  GIQL_PH_PARTITION = 7, /* output-tile -> row partition                    */
+  GIQL_PH_FILL = 8,      /* pair materialisation                            */
+  GIQL_PH_IRREGULAR = 9, /* literal-predicate path for end<=start rows      */
+  GIQL_PH_AUX = 10,      /* prefix-max / compaction / nearest kernels       */
+  GIQL_PH_N = 16
+};
+
+typedef struct giql_hip_stats {
+  int64_t n_a, n_b;
+  int64_t n_out;            /* pairs / rows produced by the last call       */
+  int64_t n_irregular_a;    /* rows with canonical end <= start             */
+  int64_t n_irregular_b;
+  int64_t workspace_bytes;  /* device arena size                            */
+  int64_t span;             /* linearised coordinate span                   */
+  float phase_ms[GIQL_PH_N];
+  int32_t phase_launches[GIQL_PH_N];
+  float total_ms;           /* sum of phase_ms                              */
+  int32_t profiled;         /* 1 if phase_ms are valid                      */
+  int32_t reserved;
+} giql_hip_stats;
+
+/* ---- library / context ------------------------------------------------- */
+int giql_hip_abi_version(void);
+const char* giql_hip_last_error(void);
+int giql_hip_device_count(int* n_devices);
+int giql_hip_create(int device, giql_hip_ctx** out);
+int giql_hip_destroy(giql_hip_ctx* ctx);
+/* Pre-size the device arena (bytes); optional, the arena grows on demand. */
+int giql_hip_reserve(giql_hip_ctx* ctx, int64_t bytes);
+int giql_hip_set_profiling(giql_hip_ctx* ctx, int enabled);
+int giql_hip_get_stats(giql_hip_ctx* ctx, giql_hip_stats* out);
+
+/* ---- device-resident entry points -------------------------------------- */
+/* INNER join in two calls so the caller owns the output:
+ *   plan: sort + count + scan; returns the exact number of pairs;
+ *   fill: writes row_a[i], row_b[i] for i < n_pairs (capacity >= n_pairs). */
+int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a,
+                            const giql_side* b, int32_t n_chrom, void* stream,
+                            int64_t* n_pairs);
+int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b,
+                            int64_t capacity, void* stream);
+
+/* SEMI (anti = 0) / ANTI (anti = 1): A row ids with / without an overlapping
+ * B row.  rows_out has capacity a->n; *n_out receives the count. */
+int giql_hip_semi_anti_dev(giql_hip_ctx* ctx, const giql_side* a,
+                           const giql_side* b, int32_t n_chrom, int anti,
+                           int32_t* rows_out, int64_t* n_out, void* stream);
+
+/* Overlap count per A row (counts_out[a->n], original row order). */
+int giql_hip_count_dev(giql_hip_ctx* ctx, const giql_side* a,
+                       const giql_side* b, int32_t n_chrom,
+                       int64_t* counts_out, void* stream);
+
+/* NEAREST k=1.  idx_b_out[i] = nearest B row of A row i (-1: none on that
+ * chromosome / within max_distance), dist_out[i] = distance (signed when
+ * is_signed).  max_distance < 0 = unlimited.  Requires start <= end rows. */
+int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a,
+                         const giql_side* b, int32_t n_chrom, int is_signed,
+                         int64_t max_distance, int32_t* idx_b_out,
+                         int64_t* dist_out, void* stream);
+
+/* ---- host-buffer entry points (Arrow buffers in host memory) ------------ */
+int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
+                   int32_t n_chrom, int64_t* n_pairs, int32_t** row_a,
+                   int32_t** row_b);
+int giql_hip_semi_anti(giql_hip_ctx* ctx, const giql_side* a,
+                       const giql_side* b, int32_t n_chrom, int anti,
+                       int64_t* n_out, int32_t** rows_a);
+int giql_hip_count(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
+                   int32_t n_chrom, int64_t* counts_out /* host, a->n */);
+int giql_hip_nearest(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
+                     int32_t n_chrom, int is_signed, int64_t max_distance,
+                     int32_t* idx_b_out /* host */, int64_t* dist_out /* host */);
+void giql_hip_free_host(void* p);
+
+/* Order-independent 64-bit checksum of a device-resident pair multiset (same
+ * function as the oracle's, for full-size parity checks). */
+int giql_hip_pairs_checksum_dev(giql_hip_ctx* ctx, const int32_t* row_a,
+                                const int32_t* row_b, int64_t n, void* stream,
+                                uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIQL_HIP_H */

@@ -1,0 +1,299 @@
+"""Parity of the HIP path (through the C ABI) against the oracle -- needs a GPU.
+
+Bit-exact: every result is integer row indices / counts / distances.
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+import _golden as G
+from oracle import pyoracle as ora
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+KNOWN = G.load("known_answers.json")
+FUZZ = G.load("fuzz_sqlite.json")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from giql_amd.engine import HipEngine
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    e = HipEngine(0)
+    yield e
+    e.close()
+
+
+def dev(side: ora.Side):
+    from giql_amd.engine import DeviceSide
+
+    d = "cuda:0"
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.int32)).to(d)
+    return DeviceSide(t(side.chrom), t(side.start), t(side.end), side.start_off, side.end_off)
+
+
+def n_chrom_of(a, b):
+    m = -1
+    for s in (a, b):
+        if s.n:
+            m = max(m, int(s.chrom.max()))
+    return m + 1
+
+
+def gpu_inner(eng, a, b, n_chrom=None):
+    ra, rb = eng.inner_join(dev(a), dev(b), n_chrom if n_chrom is not None else n_chrom_of(a, b))
+    torch.cuda.synchronize()
+    return ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy())
+
+
+# ----------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("case", [c for c in KNOWN if c["kind"] == "inner"], ids=lambda c: c["name"])
+def test_inner_known_answers(eng, case):
+    a, b = G.sides_of(case)
+    got = G.rows_of_pairs(case, gpu_inner(eng, a, b))
+    want = sorted(tuple(r) for r in case["expected"])
+    if case["mode"] == "contains":
+        assert all(w in got for w in want)
+    else:
+        assert got == want
+
+
+@pytest.mark.parametrize("case", [c for c in KNOWN if c["kind"] in ("semi", "anti")],
+                         ids=lambda c: c["name"])
+def test_semi_anti_known_answers(eng, case):
+    a, b = G.sides_of(case)
+    rows = eng.semi_anti(dev(a), dev(b), n_chrom_of(a, b), case["kind"] == "anti").cpu().numpy()
+    assert G.rows_of_left(case, rows) == sorted(tuple(r) for r in case["expected"])
+
+
+@pytest.mark.parametrize("case", [c for c in KNOWN if c["kind"] == "nearest"], ids=lambda c: c["name"])
+def test_nearest_known_answers(eng, case):
+    a, b = G.sides_of(case)
+    idx, dist = eng.nearest(dev(a), dev(b), n_chrom_of(a, b), signed=case["signed"],
+                            max_distance=case["max_distance"])
+    with_d = len(case["expected"][0]) == 4
+    got = G.nearest_rows(case, idx.cpu().numpy(), dist.cpu().numpy(), with_d)
+    assert got == sorted(tuple(r) for r in case["expected"])
+
+
+@pytest.mark.parametrize("case", [c for c in FUZZ if c["kind"] == "join"], ids=lambda c: c["name"])
+def test_join_fuzz_vs_sqlite(eng, case):
+    a, b = G.sides_of(case)
+    nc = max(n_chrom_of(a, b), 1)
+    assert np.array_equal(gpu_inner(eng, a, b, nc), np.asarray(case["inner"], np.int64).reshape(-1, 2))
+    da, db = dev(a), dev(b)
+    assert np.array_equal(eng.count_overlaps(da, db, nc).cpu().numpy(), np.asarray(case["count"], np.int64))
+    assert np.array_equal(eng.semi_join(da, db, nc).cpu().numpy().astype(np.int64),
+                          np.asarray(case["semi"], np.int64))
+    assert np.array_equal(eng.anti_join(da, db, nc).cpu().numpy().astype(np.int64),
+                          np.asarray(case["anti"], np.int64))
+
+
+@pytest.mark.parametrize("case", [c for c in FUZZ if c["kind"] == "nearest"], ids=lambda c: c["name"])
+def test_nearest_fuzz_vs_sqlite(eng, case):
+    a, b = G.sides_of(case)
+    idx, dist = eng.nearest(dev(a), dev(b), max(n_chrom_of(a, b), 1), signed=case["signed"],
+                            max_distance=case["max_distance"])
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    for i, exp in enumerate(case["expected"]):
+        if not exp:
+            assert idx[i] == -1, i
+            continue
+        _rid, bs, be, d = exp[0]
+        j = int(idx[i])
+        assert j >= 0, i
+        assert (case["b"][j][1], case["b"][j][2], int(dist[i])) == (bs, be, d), i
+
+
+# --------------------------------------------------- seeded random vs oracle
+def rand_side(seed, n, n_chrom, max_start, max_len, min_len=1, enc=("0based", "half_open")):
+    r = np.random.default_rng(seed)
+    ch = r.integers(0, n_chrom, n).astype(np.int32)
+    st = r.integers(0, max_start, n).astype(np.int32)
+    ln = r.integers(min_len, max_len, n).astype(np.int32)
+    so, eo = ora.ENCODING_OFFSETS[enc]
+    return ora.Side(ch, st, st + ln, so, eo)
+
+
+@pytest.mark.parametrize("na,nb,nch,ms,ml", [
+    (1, 1, 1, 10, 5),
+    (63, 65, 2, 500, 60),
+    (4096, 4097, 3, 100_000, 300),         # exactly one / one+1 radix tiles
+    (5000, 300_000, 24, 2_000_000, 500),
+    (200_000, 150_000, 24, 50_000_000, 3000),
+    (30_000, 30_000, 1, 40_000, 2000),     # dense: ~1500 matches per row
+])
+def test_inner_random_vs_oracle(eng, na, nb, nch, ms, ml):
+    a = rand_side(100 + na, na, nch, ms, ml)
+    b = rand_side(200 + nb, nb, nch, ms, ml)
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    got = gpu_inner(eng, a, b, nch)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("enc_a", list(ora.ENCODING_OFFSETS))
+@pytest.mark.parametrize("enc_b", list(ora.ENCODING_OFFSETS))
+def test_inner_all_encoding_pairs(eng, enc_a, enc_b):
+    a = rand_side(1, 3000, 4, 20_000, 50, enc=enc_a)
+    b = rand_side(2, 3000, 4, 20_000, 50, enc=enc_b)
+    assert np.array_equal(gpu_inner(eng, a, b, 4), ora.sort_pairs(*ora.c_inner(a, b, "sweep")))
+
+
+def test_inner_with_irregular_rows(eng):
+    """Zero-length and inverted rows follow the literal predicate."""
+    a = rand_side(5, 4000, 3, 3000, 40, min_len=-15)
+    b = rand_side(6, 5000, 3, 3000, 40, min_len=-15)
+    want = ora.sort_pairs(*ora.c_inner(a, b, "brute"))
+    got = gpu_inner(eng, a, b, 3)
+    assert np.array_equal(got, want)
+    st = eng.stats()
+    assert st["n_irregular_a"] > 0 and st["n_irregular_b"] > 0
+    da, db = dev(a), dev(b)
+    assert np.array_equal(eng.count_overlaps(da, db, 3).cpu().numpy(), ora.c_count(a, b, "brute"))
+    assert np.array_equal(eng.semi_join(da, db, 3).cpu().numpy(), ora.c_semi_anti(a, b, False))
+    assert np.array_equal(eng.anti_join(da, db, 3).cpu().numpy(), ora.c_semi_anti(a, b, True))
+
+
+def test_duplicates_keep_multiplicity(eng):
+    ch = np.zeros(2000, np.int32)
+    a = ora.Side(ch, np.full(2000, 100, np.int32), np.full(2000, 200, np.int32))
+    b = ora.Side(ch[:1500], np.full(1500, 150, np.int32), np.full(1500, 250, np.int32))
+    got = gpu_inner(eng, a, b, 1)
+    assert got.shape[0] == 2000 * 1500
+    assert np.array_equal(got, ora.sort_pairs(*ora.c_inner(a, b, "sweep")))
+
+
+def test_empty_and_disjoint(eng):
+    e = ora.Side(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    a = rand_side(1, 100, 2, 1000, 50)
+    assert gpu_inner(eng, e, a, 2).shape[0] == 0
+    assert gpu_inner(eng, a, e, 2).shape[0] == 0
+    assert gpu_inner(eng, e, e, 0).shape[0] == 0
+    b = ora.Side(a.chrom + 2, a.start, a.end)  # disjoint chromosome sets
+    assert gpu_inner(eng, a, b, 4).shape[0] == 0
+    da, db, de = dev(a), dev(b), dev(e)
+    assert eng.semi_join(da, db, 4).shape[0] == 0
+    assert np.array_equal(eng.anti_join(da, db, 4).cpu().numpy(), np.arange(100))
+    assert np.array_equal(eng.anti_join(da, de, 2).cpu().numpy(), np.arange(100))  # B empty
+    assert eng.semi_join(de, da, 2).shape[0] == 0
+    assert int(eng.count_overlaps(da, de, 2).sum()) == 0
+    idx, _ = eng.nearest(da, db, 4)
+    assert bool((idx == -1).all())
+
+
+def test_extreme_coordinates(eng):
+    """INT32_MAX ends with a +1 canonical offset must not overflow."""
+    big = 2**31 - 1
+    a = ora.Side(np.zeros(3, np.int32), np.array([big - 10, 0, 5], np.int32),
+                 np.array([big, 10, big], np.int32), 0, 1)
+    b = ora.Side(np.zeros(3, np.int32), np.array([big - 1, 3, big], np.int32),
+                 np.array([big, 4, big], np.int32), 0, 1)
+    assert np.array_equal(gpu_inner(eng, a, b, 1), ora.sort_pairs(*ora.c_inner(a, b, "brute")))
+
+
+def test_bad_chrom_id_is_an_error(eng):
+    from giql_amd import _lib
+
+    a = rand_side(1, 100, 2, 1000, 50)
+    with pytest.raises(_lib.GiqlHipError) as ei:
+        eng.inner_join(dev(a), dev(a), 1)  # ids up to 1 but n_chrom = 1
+    assert ei.value.code == _lib.GIQL_ERR_CHROM
+
+
+def test_span_overflow_is_an_error(eng):
+    from giql_amd import _lib
+
+    ch = np.arange(4, dtype=np.int32)
+    a = ora.Side(ch, np.zeros(4, np.int32), np.full(4, 2**31 - 2, np.int32))
+    with pytest.raises(_lib.GiqlHipError) as ei:
+        eng.inner_join(dev(a), dev(a), 4)
+    assert ei.value.code == _lib.GIQL_ERR_SPAN
+
+
+@pytest.mark.parametrize("na,nb,nch", [(50_000, 400_000, 24), (300_000, 20_000, 5)])
+def test_semi_anti_count_random_vs_oracle(eng, na, nb, nch):
+    a = rand_side(31, na, nch, 30_000_000, 1500)
+    b = rand_side(32, nb, nch - 1, 30_000_000, 200)  # last chrom absent from B
+    da, db = dev(a), dev(b)
+    assert np.array_equal(eng.semi_join(da, db, nch).cpu().numpy(), ora.c_semi_anti(a, b, False))
+    assert np.array_equal(eng.anti_join(da, db, nch).cpu().numpy(), ora.c_semi_anti(a, b, True))
+    assert np.array_equal(eng.count_overlaps(da, db, nch).cpu().numpy(), ora.c_count(a, b, "sweep"))
+
+
+@pytest.mark.parametrize("signed,md", [(False, None), (True, None), (False, 500), (True, 2000)])
+def test_nearest_random_vs_oracle(eng, signed, md):
+    a = rand_side(41, 60_000, 6, 5_000_000, 800)
+    b = rand_side(42, 50_000, 5, 5_000_000, 800)
+    idx, dist = eng.nearest(dev(a), dev(b), 6, signed=signed, max_distance=md)
+    oi, od = ora.c_nearest_k1(a, b, signed=signed, max_distance=md, method="sweep")
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    assert np.array_equal(idx >= 0, oi >= 0)
+    assert np.array_equal(dist, od)
+    m = oi >= 0
+    assert np.array_equal(b.start[idx[m]], b.start[oi[m]]) and np.array_equal(b.end[idx[m]], b.end[oi[m]])
+
+
+def test_nearest_rejects_inverted_rows(eng):
+    from giql_amd import _lib
+
+    a = ora.Side(np.zeros(2, np.int32), np.array([10, 50], np.int32), np.array([20, 40], np.int32))
+    b = ora.Side(np.zeros(1, np.int32), np.array([5], np.int32), np.array([8], np.int32))
+    with pytest.raises(_lib.GiqlHipError):
+        eng.nearest(dev(a), dev(b), 1)
+
+
+# ---------------------------------------------- BASELINE configs (moderate size)
+def test_config2_1m_x_1m_single_chrom(eng):
+    from giql_amd import synth
+
+    a = ora.Side(*synth.make_single_chrom(1_000_000, 1, "peaks"))
+    b = ora.Side(*synth.make_single_chrom(1_000_000, 2, "peaks"))
+    ra, rb = eng.inner_join(dev(a), dev(b), 1)
+    wa, wb = ora.c_inner(a, b, "sweep")
+    assert ra.shape[0] == wa.shape[0] and ra.shape[0] > 8_000_000
+    assert eng.pairs_checksum(ra, rb) == ora.c_pairs_checksum(wa, wb)
+    assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), ora.sort_pairs(wa, wb))
+
+
+def test_host_buffer_entry_points(eng):
+    """The Arrow-host-buffer flavour of the C ABI (what a ctypes stub binds)."""
+    from giql_amd import _lib
+
+    L = _lib.load()
+    a = rand_side(51, 20_000, 4, 1_000_000, 900)
+    b = rand_side(52, 30_000, 4, 1_000_000, 300)
+
+    def cs(s):
+        return _lib.CSide(s.chrom.ctypes.data, s.start.ctypes.data, s.end.ctypes.data, s.n,
+                          s.start_off, s.end_off)
+
+    n = ctypes.c_int64(0)
+    pa, pb = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(L.giql_hip_inner(eng._h, cs(a), cs(b), 4, ctypes.byref(n), ctypes.byref(pa),
+                                ctypes.byref(pb)))
+    ra = np.ctypeslib.as_array(ctypes.cast(pa, ctypes.POINTER(ctypes.c_int32)), (n.value,)).copy()
+    rb = np.ctypeslib.as_array(ctypes.cast(pb, ctypes.POINTER(ctypes.c_int32)), (n.value,)).copy()
+    L.giql_hip_free_host(pa)
+    L.giql_hip_free_host(pb)
+    assert np.array_equal(ora.sort_pairs(ra, rb), ora.sort_pairs(*ora.c_inner(a, b, "sweep")))
+
+    cnt = np.zeros(a.n, np.int64)
+    _lib.check(L.giql_hip_count(eng._h, cs(a), cs(b), 4, cnt.ctypes.data))
+    assert np.array_equal(cnt, ora.c_count(a, b, "sweep"))
+
+    p = ctypes.c_void_p()
+    _lib.check(L.giql_hip_semi_anti(eng._h, cs(a), cs(b), 4, 1, ctypes.byref(n), ctypes.byref(p)))
+    rows = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_int32)), (max(n.value, 1),))[: n.value].copy()
+    L.giql_hip_free_host(p)
+    assert np.array_equal(rows, ora.c_semi_anti(a, b, True))
+
+    idx = np.zeros(a.n, np.int32)
+    dist = np.zeros(a.n, np.int64)
+    _lib.check(L.giql_hip_nearest(eng._h, cs(a), cs(b), 4, 0, -1, idx.ctypes.data, dist.ctypes.data))
+    assert np.array_equal(dist, ora.c_nearest_k1(a, b, method="sweep")[1])
