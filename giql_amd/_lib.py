@@ -93,6 +93,15 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One process, one HIP runtime: libgiql_hip.so needs libamdhip64.so.7, and so
+    # does torch (which bundles its own copy under the same soname).  Whichever
+    # is loaded first serves both, so import torch first when it is installed:
+    # device tensors handed to the C ABI then belong to the runtime that runs the
+    # kernels.  Without torch the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - torch-less deployment
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise GiqlHipUnavailable(

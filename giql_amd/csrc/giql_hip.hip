@@ -278,9 +278,15 @@ static int run_sort(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n, u32*
                            bsums, nullptr));
     {
       Phase ph(ctx, st, GIQL_PH_SORT_SCATTER);
-      hipLaunchKernelGGL(k_radix_scatter, dim3(n_tiles), dim3(RS_NT), 0, st, sb.key[src],
-                         sb.end[src], pass == 0 ? (const u32*)nullptr : sb.rid[src], sb.key[dst],
-                         sb.end[dst], sb.rid[dst], n, shift, n_tiles, tile_hist);
+      if (sb.end[0]) {
+        hipLaunchKernelGGL((k_radix_scatter<true>), dim3(n_tiles), dim3(RS_NT), 0, st, sb.key[src],
+                           sb.end[src], pass == 0 ? (const u32*)nullptr : sb.rid[src], sb.key[dst],
+                           sb.end[dst], sb.rid[dst], n, shift, n_tiles, tile_hist);
+      } else {
+        hipLaunchKernelGGL((k_radix_scatter<false>), dim3(n_tiles), dim3(RS_NT), 0, st, sb.key[src],
+                           (const u32*)nullptr, (const u32*)nullptr, sb.key[dst], (u32*)nullptr,
+                           (u32*)nullptr, n, shift, n_tiles, tile_hist);
+      }
     }
   }
   return post_launch("radix sort");
@@ -322,7 +328,7 @@ static void sort_sizes(Carver& c, size_t n, SortBufs& sb, bool payload) {
   for (int k = 0; k < 2; k++) {
     sb.key[k] = c.take<u32>(n);
     sb.end[k] = payload ? c.take<u32>(n) : nullptr;
-    sb.rid[k] = c.take<u32>(n);
+    sb.rid[k] = payload ? c.take<u32>(n) : nullptr;
   }
 }
 
@@ -774,7 +780,7 @@ int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side*
                              bsums, nullptr));
       {
         Phase ph(ctx, st, GIQL_PH_SORT_SCATTER);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nt), dim3(RS_NT), 0, st, sbb.key[src], sbb.end[src],
+        hipLaunchKernelGGL((k_radix_scatter<true>), dim3(nt), dim3(RS_NT), 0, st, sbb.key[src], sbb.end[src],
                            (const u32*)sbb.rid[src], sbb.key[dst], sbb.end[dst], sbb.rid[dst], n,
                            pass * 8, nt, tile_hist);
       }

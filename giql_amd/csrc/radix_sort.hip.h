@@ -37,13 +37,15 @@ __global__ __launch_bounds__(RS_NT) void k_radix_hist(const u32* __restrict__ ke
 }
 
 // rids_in == nullptr means "identity" (first pass: row id = index).
+// PAYLOAD = false sorts the keys alone (ends / rids pointers are ignored).
+template <bool PAYLOAD>
 __global__ __launch_bounds__(RS_NT) void k_radix_scatter(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
     int shift, u32 n_tiles, const u32* __restrict__ tile_offs) {
   __shared__ u32 s_key[RS_TILE];
-  __shared__ u32 s_end[RS_TILE];
-  __shared__ u32 s_rid[RS_TILE];
+  __shared__ u32 s_end[PAYLOAD ? RS_TILE : 1];
+  __shared__ u32 s_rid[PAYLOAD ? RS_TILE : 1];
   __shared__ u32 s_wcnt[RS_NW][RS_BINS];  // per-wave digit counters -> bases
   __shared__ u32 s_dstart[RS_BINS];       // first in-tile position of a digit
   __shared__ u32 s_goff[RS_BINS];         // global offset - in-tile start
@@ -71,8 +73,10 @@ __global__ __launch_bounds__(RS_NT) void k_radix_scatter(
     const bool ok = r < n_valid;
     const u32 g = tile_base + r;
     key[i] = ok ? keys_in[g] : U32_MAX;
-    end[i] = ok ? ends_in[g] : 0u;
-    rid[i] = ok ? (rids_in ? rids_in[g] : g) : 0u;
+    if (PAYLOAD) {
+      end[i] = ok ? ends_in[g] : 0u;
+      rid[i] = ok ? (rids_in ? rids_in[g] : g) : 0u;
+    }
   }
 
   // stable rank inside the wave: peers = lanes holding the same digit
@@ -125,8 +129,10 @@ __global__ __launch_bounds__(RS_NT) void k_radix_scatter(
       const u32 d = (key[i] >> shift) & 0xFFu;
       const u32 p = s_dstart[d] + s_wcnt[w][d] + rank[i];
       s_key[p] = key[i];
-      s_end[p] = end[i];
-      s_rid[p] = rid[i];
+      if (PAYLOAD) {
+        s_end[p] = end[i];
+        s_rid[p] = rid[i];
+      }
     }
   }
   __syncthreads();
@@ -139,8 +145,10 @@ __global__ __launch_bounds__(RS_NT) void k_radix_scatter(
       const u32 k = s_key[p];
       const u32 dst = s_goff[(k >> shift) & 0xFFu] + p;
       keys_out[dst] = k;
-      ends_out[dst] = s_end[p];
-      rids_out[dst] = s_rid[p];
+      if (PAYLOAD) {
+        ends_out[dst] = s_end[p];
+        rids_out[dst] = s_rid[p];
+      }
     }
   }
 }

@@ -362,7 +362,8 @@ int ora_inner_sweep(const ora_side* a, const ora_side* b, int n_threads,
   for (int64_t t = 0; t < nt; t++) {
     const int32_t c = tasks[t].chrom;
     const int64_t blo = ci.b_off[c], bhi = ci.b_off[c + 1];
-    pairvec* v = &out[t];
+    pairvec local = {0, 0, 0, 0}; /* thread-private: no false sharing on out[] */
+    pairvec* v = &local;
     for (int64_t k = tasks[t].lo; k < tasks[t].hi; k++) {
       const int32_t ra = ci.a_idx[k];
       const int64_t as = cs_of(a, ra), ae = ce_of(a, ra);
@@ -375,6 +376,7 @@ int ora_inner_sweep(const ora_side* a, const ora_side* b, int n_threads,
         }
       }
     }
+    out[t] = local;
   }
   int64_t total = 0;
   for (int64_t t = 0; t < nt; t++) total += out[t].n;
