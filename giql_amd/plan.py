@@ -1,0 +1,78 @@
+"""The ``dialect="hip"`` lowering target: a serialisable join plan.
+
+Where the reference's DuckDB override emits a verbatim SQL payload through
+``exp.Command`` (``src/giql/expanders/intersects_duckdb.py:1713``), the hip target
+emits this plan's string form; :func:`giql_amd.execute.execute` turns plan +
+Arrow tables into one C-ABI call.  sqlglot-free.
+"""
+
+from __future__ import annotations
+
+import json
+from dataclasses import asdict, dataclass, field
+
+PLAN_PREFIX = "GIQL-HIP-PLAN/1 "
+
+KINDS = ("INNER", "SEMI", "ANTI", "NEAREST")
+
+
+@dataclass(frozen=True)
+class PlanSide:
+    """One operand: the table's physical columns and its coordinate encoding
+    (what ``_build_sql`` reads from ``self.tables``, intersects_duckdb.py:1179-1188)."""
+
+    table: str
+    alias: str
+    chrom_col: str = "chrom"
+    start_col: str = "start"
+    end_col: str = "end"
+    coordinate_system: str = "0based"
+    interval_type: str = "half_open"
+
+    @property
+    def encoding(self) -> tuple[str, str]:
+        return (self.coordinate_system, self.interval_type)
+
+
+@dataclass(frozen=True)
+class Projection:
+    side: str      # "l", "r" or "distance" (NEAREST's computed column)
+    column: str
+    name: str      # output column name
+
+
+@dataclass(frozen=True)
+class JoinPlan:
+    kind: str
+    left: PlanSide
+    right: PlanSide
+    projection: tuple[Projection, ...] = field(default_factory=tuple)
+    distinct: bool = False
+    # NEAREST only (src/giql/expanders/nearest.py:240-252)
+    k: int = 1
+    max_distance: int | None = None
+    signed: bool = False
+
+    def __post_init__(self) -> None:
+        if self.kind not in KINDS:
+            raise ValueError(f"unknown plan kind {self.kind!r}")
+
+    def to_string(self) -> str:
+        d = asdict(self)
+        d["projection"] = [asdict(p) for p in self.projection]
+        return PLAN_PREFIX + json.dumps(d, sort_keys=True, separators=(",", ":"))
+
+    @classmethod
+    def from_string(cls, text: str) -> "JoinPlan":
+        if not isinstance(text, str) or not text.startswith(PLAN_PREFIX):
+            raise ValueError("not a GIQL hip plan string")
+        d = json.loads(text[len(PLAN_PREFIX):])
+        return cls(
+            kind=d["kind"], left=PlanSide(**d["left"]), right=PlanSide(**d["right"]),
+            projection=tuple(Projection(**p) for p in d["projection"]),
+            distinct=d.get("distinct", False), k=d.get("k", 1),
+            max_distance=d.get("max_distance"), signed=d.get("signed", False))
+
+
+def is_plan_string(text) -> bool:
+    return isinstance(text, str) and text.startswith(PLAN_PREFIX)

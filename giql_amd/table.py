@@ -1,0 +1,76 @@
+"""Table schema configuration -- same fields, defaults and validation as the
+reference's ``giql.Table`` (``src/giql/table.py:16-136``,
+``src/giql/constants.py:7-11``), so a user's ``tables=[...]`` argument carries over
+unchanged.  sqlglot-free.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Literal
+
+DEFAULT_CHROM_COL = "chrom"
+DEFAULT_START_COL = "start"
+DEFAULT_END_COL = "end"
+DEFAULT_STRAND_COL = "strand"
+DEFAULT_GENOMIC_COL = "interval"
+
+
+@dataclass
+class Table:
+    """Genomic table configuration (mirror of ``giql.table.Table``)."""
+
+    name: str
+    genomic_col: str = DEFAULT_GENOMIC_COL
+    chrom_col: str = DEFAULT_CHROM_COL
+    start_col: str = DEFAULT_START_COL
+    end_col: str = DEFAULT_END_COL
+    strand_col: str | None = DEFAULT_STRAND_COL
+    coordinate_system: Literal["0based", "1based"] = "0based"
+    interval_type: Literal["half_open", "closed"] = "half_open"
+
+    def __post_init__(self) -> None:
+        if self.coordinate_system not in ("0based", "1based"):
+            raise ValueError(
+                f"coordinate_system must be '0based' or '1based', "
+                f"got {self.coordinate_system!r}")
+        if self.interval_type not in ("half_open", "closed"):
+            raise ValueError(
+                f"interval_type must be 'half_open' or 'closed', "
+                f"got {self.interval_type!r}")
+
+    @property
+    def encoding(self) -> tuple[str, str]:
+        return (self.coordinate_system, self.interval_type)
+
+
+class Tables:
+    """Container for Table configurations (mirror of ``giql.table.Tables``)."""
+
+    def __init__(self) -> None:
+        self._tables: dict[str, Table] = {}
+
+    def register(self, name: str, table: Table) -> None:
+        self._tables[name] = table
+
+    def get(self, name: str) -> Table | None:
+        return self._tables.get(name)
+
+    def __contains__(self, name: str) -> bool:
+        return name in self._tables
+
+    def __iter__(self):
+        return iter(self._tables.values())
+
+
+def build_tables(tables) -> Tables:
+    """``transpile()``'s ``tables`` argument -> Tables (``src/giql/transpile.py:217-242``)."""
+    container = Tables()
+    for item in tables or []:
+        if isinstance(item, str):
+            container.register(item, Table(item))
+        elif isinstance(item, Table) or (hasattr(item, "name") and hasattr(item, "chrom_col")):
+            container.register(item.name, item)  # a real giql.Table works too
+        else:
+            raise ValueError(f"tables entries must be str or Table, got {type(item).__name__}")
+    return container

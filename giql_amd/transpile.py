@@ -1,0 +1,515 @@
+"""``transpile(giql, tables, dialect="hip")`` -- host-side mirror of the reference's
+``giql.transpile`` (``src/giql/transpile.py:55-214``) for the one path this
+backend executes: the column-to-column INTERSECTS join (INNER / SEMI / ANTI) and
+the correlated NEAREST k=1 join.
+
+The reference parses with sqlglot, which is not installable here, so this module
+carries a small hand-written parser for exactly the query shapes the reference's
+IEJoin override engages on (the whitelist of
+``IntersectsDuckDBIEJoinTransformer.transform_to_sql``,
+``src/giql/expanders/intersects_duckdb.py:618-804``).  Same call signature, same
+``Table`` argument, same error convention:
+
+* user mistakes (unqualified / unknown-alias columns, right-side columns under
+  SEMI / ANTI)                                    -> ``ValueError``
+  (``_UnqualifiedProjectionError`` -> ``ValueError``, intersects_duckdb.py:803-804);
+* valid GIQL the hip path does not execute (stars, outer joins, self-joins, extra
+  predicates, aggregates, 3+ tables, ...)         -> :class:`HipDeclined`
+  (a ``ValueError``): the reference *declines* such shapes to the naive predicate
+  (intersects_duckdb.py:1715); without sqlglot there is no naive emitter to fall
+  back to, so the caller is told to use ``giql.transpile`` for that query.
+
+When the real ``giql`` package is importable, :mod:`giql_amd.plugin` registers the
+same lowering through giql's own ``@register(HipTarget, Intersects)`` hook instead.
+
+For ``dialect=None`` only the literal-range predicate of BASELINE config 1
+(``WHERE interval INTERSECTS 'chr1:1000-2000'``) is emitted, with the reference's
+exact text (``tests/expanders/test_intersects.py:83-85``).
+"""
+
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass
+
+from .plan import JoinPlan, PlanSide, Projection
+from .table import Table, Tables, build_tables
+
+
+class HipDeclined(ValueError):
+    """Valid GIQL that the hip dialect does not execute (reference: decline)."""
+
+
+# ------------------------------------------------------------------- tokens
+_TOKEN = re.compile(
+    r"""\s*(?:
+        (?P<str>'(?:[^']|'')*')
+      | (?P<qid>"(?:[^"]|"")*")
+      | (?P<num>\d+)
+      | (?P<assign>:=)
+      | (?P<id>[A-Za-z_][A-Za-z_0-9]*)
+      | (?P<punct>[(),.*;=<>+\-/])
+    )""",
+    re.X,
+)
+
+_KEYWORDS = {
+    "SELECT", "DISTINCT", "FROM", "JOIN", "INNER", "CROSS", "SEMI", "ANTI", "LEFT", "RIGHT",
+    "FULL", "OUTER", "NATURAL", "ON", "USING", "WHERE", "AND", "OR", "NOT", "AS", "INTERSECTS",
+    "CONTAINS", "WITHIN", "GROUP", "ORDER", "BY", "HAVING", "LIMIT", "OFFSET", "LATERAL",
+    "NEAREST", "WITH", "UNION", "ANY", "ALL", "EXISTS", "TRUE", "FALSE",
+}
+
+
+@dataclass
+class Tok:
+    kind: str   # kw / id / qid / str / num / punct / assign / end
+    text: str   # keyword upper-cased; identifiers verbatim (quotes stripped)
+    quoted: bool = False
+
+
+def _tokenize(sql: str) -> list[Tok]:
+    out: list[Tok] = []
+    pos = 0
+    n = len(sql)
+    while pos < n:
+        m = _TOKEN.match(sql, pos)
+        if not m:
+            if sql[pos:].strip() == "":
+                break
+            raise ValueError(f"Parse error: unexpected character {sql[pos:].lstrip()[:1]!r}")
+        pos = m.end()
+        if m.group("str") is not None:
+            out.append(Tok("str", m.group("str")[1:-1].replace("''", "'")))
+        elif m.group("qid") is not None:
+            out.append(Tok("id", m.group("qid")[1:-1].replace('""', '"'), quoted=True))
+        elif m.group("num") is not None:
+            out.append(Tok("num", m.group("num")))
+        elif m.group("assign") is not None:
+            out.append(Tok("assign", ":="))
+        elif m.group("id") is not None:
+            t = m.group("id")
+            out.append(Tok("kw", t.upper()) if t.upper() in _KEYWORDS else Tok("id", t))
+        else:
+            out.append(Tok("punct", m.group("punct")))
+    out.append(Tok("end", ""))
+    return out
+
+
+def _norm(name: str, quoted: bool = False) -> str:
+    # unquoted identifiers are case-insensitive (intersects_duckdb.py:119-128)
+    return name if quoted else name.casefold()
+
+
+# ------------------------------------------------------------------- parser
+@dataclass
+class _ColRef:
+    table: str | None
+    table_quoted: bool
+    column: str
+    star: bool = False
+
+
+@dataclass
+class _TableRef:
+    name: str
+    alias: str
+    alias_quoted: bool
+
+
+class _Parser:
+    def __init__(self, sql: str):
+        self.toks = _tokenize(sql)
+        self.i = 0
+
+    # -- token helpers
+    def peek(self, k: int = 0) -> Tok:
+        return self.toks[min(self.i + k, len(self.toks) - 1)]
+
+    def next(self) -> Tok:
+        t = self.toks[self.i]
+        self.i = min(self.i + 1, len(self.toks) - 1)
+        return t
+
+    def at_kw(self, *kws: str) -> bool:
+        t = self.peek()
+        return t.kind == "kw" and t.text in kws
+
+    def at_punct(self, p: str) -> bool:
+        t = self.peek()
+        return t.kind == "punct" and t.text == p
+
+    def expect_kw(self, kw: str) -> None:
+        if not self.at_kw(kw):
+            raise ValueError(f"Parse error: expected {kw} near {self.peek().text!r}")
+        self.next()
+
+    def expect_punct(self, p: str) -> None:
+        if not self.at_punct(p):
+            raise ValueError(f"Parse error: expected {p!r} near {self.peek().text!r}")
+        self.next()
+
+    def ident(self) -> Tok:
+        t = self.peek()
+        if t.kind != "id":
+            raise ValueError(f"Parse error: expected an identifier near {t.text!r}")
+        return self.next()
+
+    # -- grammar pieces
+    def colref(self) -> _ColRef:
+        if self.at_punct("*"):
+            self.next()
+            return _ColRef(None, False, "*", star=True)
+        first = self.ident()
+        if self.at_punct("."):
+            self.next()
+            if self.at_punct("*"):
+                self.next()
+                return _ColRef(first.text, first.quoted, "*", star=True)
+            second = self.next()
+            if second.kind not in ("id", "kw"):
+                raise ValueError(f"Parse error: expected a column name near {second.text!r}")
+            # `a.start` / `a.end`: keywords are fine as column names after a dot
+            col = second.text if second.kind == "id" else second.text.lower()
+            return _ColRef(first.text, first.quoted, col)
+        return _ColRef(None, False, first.text)
+
+    def table_ref(self) -> _TableRef:
+        name = self.ident()
+        if self.at_punct("."):
+            raise HipDeclined("catalog/schema-qualified tables are not handled by dialect='hip'")
+        if self.at_punct("("):
+            raise HipDeclined("table functions as join operands are not handled by dialect='hip'")
+        alias, aq = name.text, name.quoted
+        if self.at_kw("AS"):
+            self.next()
+            a = self.ident()
+            alias, aq = a.text, a.quoted
+        elif self.peek().kind == "id":
+            a = self.next()
+            alias, aq = a.text, a.quoted
+        return _TableRef(name.text, alias, aq)
+
+
+_UNSUPPORTED_TAIL = ("GROUP", "ORDER", "HAVING", "LIMIT", "OFFSET", "UNION")
+
+
+def _decline(reason: str) -> HipDeclined:
+    return HipDeclined(
+        f"{reason}: this query shape is valid GIQL but is not executed by dialect='hip' "
+        "(the reference declines it to the naive overlap predicate); transpile it with "
+        "giql.transpile(...) for a SQL engine instead")
+
+
+def _table_side(ref: _TableRef, tables: Tables) -> PlanSide:
+    t = tables.get(ref.name)
+    if t is None:
+        # an unregistered table uses default column names, like the naive plan
+        # (intersects_duckdb.py:1179-1188)
+        t = Table(ref.name)
+    return PlanSide(table=ref.name, alias=_norm(ref.alias, ref.alias_quoted),
+                    chrom_col=t.chrom_col, start_col=t.start_col, end_col=t.end_col,
+                    coordinate_system=t.coordinate_system, interval_type=t.interval_type)
+
+
+def _genomic_col(name: str, tables: Tables) -> str:
+    t = tables.get(name)
+    return t.genomic_col if t is not None else "interval"
+
+
+def _parse_projection(p: _Parser) -> list[tuple[_ColRef, str | None]]:
+    items: list[tuple[_ColRef, str | None]] = []
+    while True:
+        if p.peek().kind == "kw" and not p.at_kw("FROM"):
+            raise _decline(f"projection starting with {p.peek().text}")
+        if p.peek().kind in ("num", "str") or p.at_punct("("):
+            raise _decline("expression in the SELECT list")
+        ref = p.colref()
+        if p.at_punct("("):
+            raise _decline("function call / aggregate in the SELECT list")
+        if p.peek().kind == "punct" and p.peek().text in "+-/*=<>":
+            raise _decline("expression in the SELECT list")
+        alias = None
+        if p.at_kw("AS"):
+            p.next()
+            alias = p.next().text
+        elif p.peek().kind == "id":
+            alias = p.next().text
+        items.append((ref, alias))
+        if p.at_punct(","):
+            p.next()
+            continue
+        break
+    return items
+
+
+def _resolve_projection(items, left: PlanSide, right: PlanSide, left_only: bool,
+                        distance_alias: str | None = None) -> tuple[Projection, ...]:
+    out = []
+    for ref, alias in items:
+        if ref.star:
+            # schema-less star enumeration would narrow the result (#202)
+            raise _decline("star projection")
+        if ref.table is None:
+            raise ValueError(
+                f"Unqualified column {ref.column!r} in the SELECT list: the hip join path has no "
+                "live schema to attribute it to a side; qualify it with a table alias")
+        q = _norm(ref.table, ref.table_quoted)
+        name = alias or ref.column
+        if q == left.alias:
+            out.append(Projection("l", ref.column, name))
+        elif q == right.alias:
+            if left_only:
+                raise ValueError(
+                    f"Column {ref.table}.{ref.column} references the right side of a SEMI/ANTI "
+                    "join, which is out of scope in the SELECT list")
+            if distance_alias is not None and ref.column == "distance":
+                out.append(Projection("distance", "distance", name))
+            else:
+                out.append(Projection("r", ref.column, name))
+        else:
+            raise ValueError(f"Unknown table qualifier {ref.table!r} in the SELECT list")
+    return tuple(out)
+
+
+def _parse_nearest(p: _Parser, tables: Tables, from_ref: _TableRef):
+    """``CROSS JOIN LATERAL NEAREST(target, reference := a.interval, k := 1, ...) b``
+    (src/giql/expanders/nearest.py:240-252, 336-397)."""
+    p.expect_kw("NEAREST")
+    p.expect_punct("(")
+    target = p.ident()
+    args: dict[str, object] = {}
+    while p.at_punct(","):
+        p.next()
+        key = p.next()
+        if p.peek().kind != "assign":
+            raise ValueError("Parse error: NEAREST arguments must be named (name := value)")
+        p.next()
+        kname = key.text.lower()
+        if kname == "reference":
+            args["reference"] = p.colref()
+        else:
+            v = p.next()
+            neg = False
+            if v.kind == "punct" and v.text == "-":
+                neg = True
+                v = p.next()
+            if v.kind == "num":
+                args[kname] = -int(v.text) if neg else int(v.text)
+            elif v.kind == "kw" and v.text in ("TRUE", "FALSE"):
+                args[kname] = v.text == "TRUE"
+            else:
+                raise ValueError(f"Parse error: bad value for NEAREST argument {key.text!r}")
+    p.expect_punct(")")
+    alias = target.text
+    aq = target.quoted
+    if p.at_kw("AS"):
+        p.next()
+        a = p.ident()
+        alias, aq = a.text, a.quoted
+    elif p.peek().kind == "id":
+        a = p.next()
+        alias, aq = a.text, a.quoted
+    ref = args.get("reference")
+    if not isinstance(ref, _ColRef) or ref.table is None:
+        raise _decline("NEAREST without a correlated column reference")
+    if _norm(ref.table, ref.table_quoted) != _norm(from_ref.alias, from_ref.alias_quoted):
+        raise ValueError(f"NEAREST reference {ref.table}.{ref.column} does not name the FROM table")
+    if ref.column != _genomic_col(from_ref.name, tables):
+        raise ValueError(f"{ref.table}.{ref.column} is not the genomic column of {from_ref.name}")
+    k = int(args.get("k", 1))
+    if k != 1:
+        raise _decline("NEAREST with k != 1")
+    if args.get("stranded"):
+        raise _decline("stranded NEAREST")
+    md = args.get("max_distance")
+    return _TableRef(target.text, alias, aq), (None if md is None else int(md)), bool(args.get("signed", False))
+
+
+def _literal_range_sql(p: _Parser, proj_text: str, from_ref: _TableRef, tables: Tables) -> str:
+    """BASELINE config 1: the generic literal-range predicate
+    (src/giql/expanders/intersects.py:85-107, 204-222)."""
+    col = p.colref()
+    p.expect_kw("INTERSECTS")
+    lit = p.next()
+    if lit.kind != "str":
+        raise _decline("non-literal right operand")
+    if p.peek().kind != "end" and not p.at_punct(";"):
+        raise _decline("extra clauses after the literal predicate")
+    m = re.match(r"^(?P<chr>[\w.]+):(?P<start>\d+)-(?P<end>\d+)$", lit.text.strip())
+    if not m:
+        raise _decline("literal range formats other than 'chr:start-end'")
+    start, end = int(m.group("start")), int(m.group("end"))
+    if start >= end:
+        raise ValueError(f"Start must be less than end: {start} >= {end}")
+    t = tables.get(from_ref.name) or Table(from_ref.name)
+    if col.column != t.genomic_col:
+        raise ValueError(f"{col.column!r} is not the genomic column of {from_ref.name}")
+    if t.encoding != ("0based", "half_open"):
+        raise _decline("literal predicate over a non-canonical table")
+    q = (col.table + ".") if col.table else ""
+    chrom = m.group("chr").replace("'", "''")
+    return (f"SELECT {proj_text} FROM {from_ref.name}"
+            + (f" AS {from_ref.alias}" if from_ref.alias != from_ref.name else "")
+            + f" WHERE ({q}\"{t.chrom_col}\" = '{chrom}' AND {q}\"{t.start_col}\" < {end} "
+            f"AND {q}\"{t.end_col}\" > {start})")
+
+
+def build_plan(giql: str, tables=None) -> JoinPlan:
+    """Parse *giql* and lower the INTERSECTS / NEAREST join to a :class:`JoinPlan`."""
+    plan = _lower(giql, tables, want_sql=False)
+    assert isinstance(plan, JoinPlan)
+    return plan
+
+
+def _lower(giql: str, tables, want_sql: bool):
+    tbls = tables if isinstance(tables, Tables) else build_tables(tables)
+    p = _Parser(giql)
+    if p.at_kw("WITH"):
+        raise _decline("top-level WITH")
+    p.expect_kw("SELECT")
+    distinct = False
+    if p.at_kw("DISTINCT"):
+        p.next()
+        if p.at_kw("ON"):
+            raise _decline("DISTINCT ON")
+        distinct = True
+    proj_start = p.i
+    if want_sql:
+        # literal form: keep the projection text verbatim
+        depth = 0
+        while not (p.at_kw("FROM") and depth == 0) and p.peek().kind != "end":
+            depth += p.at_punct("(") - p.at_punct(")")
+            p.next()
+        proj_text = _render(p.toks[proj_start:p.i])
+        items = None
+    else:
+        items = _parse_projection(p)
+        proj_text = ""
+    p.expect_kw("FROM")
+    from_ref = p.table_ref()
+
+    if want_sql:
+        p.expect_kw("WHERE")
+        return _literal_range_sql(p, ("DISTINCT " if distinct else "") + proj_text, from_ref, tbls)
+
+    # ---- the join
+    kind = "INNER"
+    nearest = None
+    join_ref = None
+    on_seen = False
+    if p.at_punct(","):
+        p.next()
+        join_ref = p.table_ref()
+    else:
+        if p.at_kw("NATURAL"):
+            raise _decline("NATURAL join")
+        if p.at_kw("LEFT", "RIGHT", "FULL"):
+            side = p.next().text
+            if p.at_kw("SEMI", "ANTI"):
+                kind = p.next().text
+            else:
+                raise _decline(f"{side} outer join")  # intersects_duckdb.py:661-662
+        elif p.at_kw("INNER", "CROSS", "SEMI", "ANTI"):
+            k = p.next().text
+            kind = "INNER" if k in ("INNER", "CROSS") else k
+        if not p.at_kw("JOIN"):
+            raise _decline("no join (a single-table predicate)")
+        p.next()
+        if p.at_kw("LATERAL"):
+            p.next()
+            join_ref, max_distance, signed = _parse_nearest(p, tbls, from_ref)
+            nearest = (max_distance, signed)
+            kind = "NEAREST"
+        else:
+            join_ref = p.table_ref()
+            if p.at_kw("USING"):
+                raise _decline("JOIN ... USING")
+            if p.at_kw("ON"):
+                p.next()
+                on_seen = True
+
+    left = _table_side(from_ref, tbls)
+    right = _table_side(join_ref, tbls)
+
+    if kind == "NEAREST":
+        if p.peek().kind != "end" and not p.at_punct(";"):
+            raise _decline("extra clauses after NEAREST")
+        if left.alias == right.alias:
+            raise _decline("same alias on both sides")
+        proj = _resolve_projection(items, left, right, False, distance_alias=right.alias)
+        return JoinPlan("NEAREST", left, right, proj, distinct, 1, nearest[0], nearest[1])
+
+    if not on_seen:
+        if kind in ("SEMI", "ANTI"):
+            raise _decline("SEMI/ANTI join with its INTERSECTS outside ON")  # #201
+        if not p.at_kw("WHERE"):
+            raise _decline("join without an INTERSECTS predicate")
+        p.next()
+    lhs = p.colref()
+    if not p.at_kw("INTERSECTS"):
+        raise _decline("join condition other than a single INTERSECTS")
+    p.next()
+    if p.peek().kind == "str":
+        raise _decline("literal-range INTERSECTS inside a join")
+    if p.at_kw("ANY", "ALL"):
+        raise _decline("INTERSECTS ANY/ALL")
+    rhs = p.colref()
+    if p.at_kw("AND", "OR"):
+        raise _decline("extra predicates beside the INTERSECTS")
+    if p.peek().kind == "kw" and p.peek().text in _UNSUPPORTED_TAIL + ("WHERE", "JOIN", "INNER",
+                                                                       "LEFT", "CROSS"):
+        raise _decline(f"{p.peek().text} clause")
+    if p.at_punct(","):
+        raise _decline("a third table")
+    if p.peek().kind != "end" and not p.at_punct(";"):
+        raise _decline(f"trailing input near {p.peek().text!r}")
+
+    for side_ref in (lhs, rhs):
+        if side_ref.table is None or side_ref.star:
+            raise _decline("INTERSECTS operand that is not a table-qualified column")
+    la, ra = _norm(lhs.table, lhs.table_quoted), _norm(rhs.table, rhs.table_quoted)
+    if left.alias == right.alias:
+        raise _decline("same alias on both sides")
+    if left.table == right.table:
+        raise _decline("self-join")
+    # FROM-side orientation swap (intersects_duckdb.py:359-410)
+    if la == left.alias and ra == right.alias:
+        l_col, r_col = lhs.column, rhs.column
+    elif ra == left.alias and la == right.alias:
+        l_col, r_col = rhs.column, lhs.column
+    else:
+        raise _decline("INTERSECTS operands that do not name the two joined tables")
+    if l_col != _genomic_col(left.table, tbls) or r_col != _genomic_col(right.table, tbls):
+        raise ValueError(
+            f"INTERSECTS operands must be the tables' genomic columns "
+            f"({_genomic_col(left.table, tbls)!r} / {_genomic_col(right.table, tbls)!r})")
+    proj = _resolve_projection(items, left, right, kind in ("SEMI", "ANTI"))
+    return JoinPlan(kind, left, right, proj, distinct)
+
+
+def _render(toks: list[Tok]) -> str:
+    out = ""
+    for t in toks:
+        text = f"'{t.text}'" if t.kind == "str" else (f'"{t.text}"' if t.quoted else t.text)
+        if out and not (text in (",", ".", ")") or out.endswith((".", "("))):
+            out += " "
+        out += text
+    return out
+
+
+def transpile(giql: str, tables=None, *, dialect: str | None = None) -> str:
+    """Mirror of ``giql.transpile`` for this backend's path.
+
+    ``dialect="hip"``: returns the plan string of the INTERSECTS / NEAREST join
+    (hand it to :func:`giql_amd.execute`).  ``dialect=None``: returns SQL for the
+    literal-range predicate (plumbing, BASELINE config 1).  Other dialects belong to
+    the reference package.
+    """
+    if dialect == "hip":
+        return build_plan(giql, tables).to_string()
+    if dialect is None:
+        return _lower(giql, tables, want_sql=True)
+    raise ValueError(
+        f"Unknown dialect: {dialect!r}. giql_amd serves 'hip' (and None for the literal-range "
+        "predicate); 'duckdb' / 'datafusion' are emitted by the giql package")
