@@ -446,6 +446,8 @@ def _lower(giql: str, tables, want_sql: bool):
         if not p.at_kw("WHERE"):
             raise _decline("join without an INTERSECTS predicate")
         p.next()
+    if p.peek().kind != "id":
+        raise _decline("join condition other than a single INTERSECTS")
     lhs = p.colref()
     if not p.at_kw("INTERSECTS"):
         raise _decline("join condition other than a single INTERSECTS")

@@ -1,0 +1,146 @@
+"""transpile(dialect="hip"): plan structure and the decline / raise matrix.
+
+Modelled on the reference's SQL-structure tests for the DuckDB IEJoin dialect
+(tests/test_duckdb_iejoin.py:145-3217, 6610-7365 of the reference): which shapes
+engage the path, which decline, which are user errors.  No GPU needed.
+"""
+
+import pytest
+
+from giql_amd.plan import JoinPlan, PlanSide, Projection, is_plan_string
+from giql_amd.table import Table
+from giql_amd.transpile import HipDeclined, build_plan, transpile
+
+Q_INNER = """
+    SELECT a.chrom AS a_chrom, a.start AS a_start, a.end AS a_end,
+           b.chrom AS b_chrom, b.start AS b_start, b.end AS b_end
+    FROM peaks a
+    JOIN genes b ON a.interval INTERSECTS b.interval
+"""
+
+
+def test_transpile_returns_a_plan_string_for_hip():
+    s = transpile(Q_INNER, tables=["peaks", "genes"], dialect="hip")
+    assert isinstance(s, str) and is_plan_string(s)
+    plan = JoinPlan.from_string(s)
+    assert plan.kind == "INNER"
+    assert (plan.left.table, plan.left.alias) == ("peaks", "a")
+    assert (plan.right.table, plan.right.alias) == ("genes", "b")
+    assert [p.name for p in plan.projection] == ["a_chrom", "a_start", "a_end", "b_chrom", "b_start", "b_end"]
+    assert [p.side for p in plan.projection] == ["l", "l", "l", "r", "r", "r"]
+    assert JoinPlan.from_string(plan.to_string()) == plan
+
+
+def test_literal_range_predicate_matches_reference_text():
+    # README.md:35-50 / tests/expanders/test_intersects.py:83-85 of the reference
+    sql = transpile("SELECT * FROM peaks WHERE interval INTERSECTS 'chr1:1000-2000'", tables=["peaks"])
+    assert sql == 'SELECT * FROM peaks WHERE ("chrom" = \'chr1\' AND "start" < 2000 AND "end" > 1000)'
+
+
+def test_custom_columns_and_encoding_reach_the_plan():
+    tables = [
+        Table("variants", genomic_col="position", chrom_col="chr", start_col="pos_start",
+              end_col="pos_end", strand_col=None, coordinate_system="1based", interval_type="closed"),
+        "genes",
+    ]
+    plan = build_plan(
+        "SELECT v.id, g.name FROM variants v JOIN genes g ON v.position INTERSECTS g.interval", tables)
+    assert plan.left == PlanSide("variants", "v", "chr", "pos_start", "pos_end", "1based", "closed")
+    assert plan.right.encoding == ("0based", "half_open")
+    assert plan.projection == (Projection("l", "id", "id"), Projection("r", "name", "name"))
+
+
+def test_unregistered_table_uses_default_columns():
+    plan = build_plan("SELECT a.start FROM x a JOIN y b ON a.interval INTERSECTS b.interval")
+    assert plan.left.chrom_col == "chrom" and plan.right.end_col == "end"
+
+
+@pytest.mark.parametrize("kw,kind", [("", "INNER"), ("INNER ", "INNER"), ("CROSS ", "INNER"),
+                                     ("SEMI ", "SEMI"), ("ANTI ", "ANTI"), ("LEFT SEMI ", "SEMI")])
+def test_join_kinds(kw, kind):
+    plan = build_plan(f"SELECT a.start FROM peaks a {kw}JOIN genes b ON a.interval INTERSECTS b.interval",
+                      ["peaks", "genes"])
+    assert plan.kind == kind
+
+
+def test_from_side_orientation_swap():
+    # left is always the FROM table, whichever operand the user wrote first
+    plan = build_plan("SELECT a.start, b.start FROM peaks a JOIN genes b ON b.interval INTERSECTS a.interval",
+                      ["peaks", "genes"])
+    assert plan.left.table == "peaks" and plan.right.table == "genes"
+
+
+def test_implicit_cross_join_in_where_engages():
+    plan = build_plan("SELECT a.start, b.start FROM peaks a, genes b WHERE a.interval INTERSECTS b.interval",
+                      ["peaks", "genes"])
+    assert plan.kind == "INNER"
+
+
+def test_case_insensitive_aliases():
+    plan = build_plan("SELECT A.start FROM peaks A JOIN genes B ON a.interval INTERSECTS b.interval",
+                      ["peaks", "genes"])
+    assert plan.left.alias == "a"
+
+
+@pytest.mark.parametrize("query", [
+    "SELECT * FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
+    "SELECT a.* FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
+    "SELECT a.start FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval",
+    "SELECT a.start FROM peaks a RIGHT JOIN genes b ON a.interval INTERSECTS b.interval",
+    "SELECT a.start FROM peaks a FULL OUTER JOIN genes b ON a.interval INTERSECTS b.interval",
+    "SELECT a.start FROM peaks a NATURAL JOIN genes b",
+    "SELECT a.start FROM peaks a JOIN peaks b ON a.interval INTERSECTS b.interval",
+    "SELECT a.start FROM peaks a JOIN genes a ON a.interval INTERSECTS a.interval",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score > 5",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval WHERE a.score > 5",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval ORDER BY a.start",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval LIMIT 5",
+    "SELECT COUNT(*) FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
+    "SELECT a.start + 1 FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
+    "SELECT a.start FROM peaks a JOIN genes b USING (chrom)",
+    "SELECT a.start FROM peaks a SEMI JOIN genes b ON TRUE WHERE a.interval INTERSECTS b.interval",
+    "SELECT a.start FROM peaks a, genes b, exons c WHERE a.interval INTERSECTS b.interval",
+    "WITH x AS (SELECT 1) SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS 'chr1:1-10'",
+    "SELECT a.start FROM peaks a CROSS JOIN LATERAL NEAREST(genes, reference := a.interval, k := 2) b",
+])
+def test_valid_but_unsupported_shapes_decline(query):
+    with pytest.raises(HipDeclined):
+        build_plan(query, ["peaks", "genes"])
+
+
+@pytest.mark.parametrize("query,match", [
+    ("SELECT start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval", "Unqualified"),
+    ("SELECT c.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval", "Unknown table"),
+    ("SELECT b.start FROM peaks a SEMI JOIN genes b ON a.interval INTERSECTS b.interval", "right side"),
+    ("SELECT b.start FROM peaks a ANTI JOIN genes b ON a.interval INTERSECTS b.interval", "right side"),
+    ("SELECT a.start FROM peaks a JOIN genes b ON a.start INTERSECTS b.interval", "genomic"),
+])
+def test_user_mistakes_raise_value_error(query, match):
+    with pytest.raises(ValueError, match=match) as ei:
+        build_plan(query, ["peaks", "genes"])
+    assert not isinstance(ei.value, HipDeclined)
+
+
+def test_nearest_plan():
+    plan = build_plan(
+        "SELECT a.start AS a_start, b.start AS b_start, b.distance AS d FROM peaks a "
+        "CROSS JOIN LATERAL NEAREST(genes, reference := a.interval, k := 1, max_distance := 100, "
+        "signed := true) b", ["peaks", "genes"])
+    assert plan.kind == "NEAREST" and plan.k == 1 and plan.max_distance == 100 and plan.signed
+    assert plan.projection[2] == Projection("distance", "distance", "d")
+
+
+def test_unknown_dialect_and_bad_table_config():
+    with pytest.raises(ValueError, match="Unknown dialect"):
+        transpile(Q_INNER, tables=["peaks", "genes"], dialect="postgres")
+    with pytest.raises(ValueError, match="coordinate_system"):
+        Table("x", coordinate_system="2based")
+    with pytest.raises(ValueError, match="interval_type"):
+        Table("x", interval_type="open")
+
+
+def test_plugin_module_is_import_guarded():
+    from giql_amd import plugin
+
+    assert plugin.HAVE_GIQL in (True, False)  # importing never raises without giql/sqlglot
