@@ -20,6 +20,7 @@ struct DevMeta {
   u64 total_span;   // linearised coordinate span (sum of per-chrom spans)
   u64 n_out;        // regular-path output count (pairs), written by the scan
   u64 n_out_irr;    // irregular-path output count
+  u64 n_out_c1;     // class-1 share of n_out (first outputs of the pair arrays)
   u32 sentinel;     // key given to irregular rows: sorts after every real key
   u32 irr_a;        // rows of A with canonical end <= start
   u32 irr_b;

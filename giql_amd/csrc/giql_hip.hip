@@ -16,6 +16,7 @@
 #include "aux_kernels.hip.h"
 #include "dev_common.hip.h"
 #include "join_kernels.hip.h"
+#include "onesweep.hip.h"
 #include "radix_sort.hip.h"
 #include "scan.hip.h"
 
@@ -46,6 +47,13 @@ static int set_err(int code, const char* fmt, ...) {
     if (_rc != GIQL_OK) return _rc; \
   } while (0)
 
+// tile shapes per class: class 1 = many queries with ~0.5 match each (B rows as
+// queries), class 2 = fewer queries with tens of matches each (A rows)
+constexpr int RC_ITEMS_C1 = 8;     // 2048 B-queries per count block
+constexpr int RC_ITEMS_C2 = 2;     // 512 A-queries per count block
+constexpr int FILL_ITEMS_C1 = 2;   // 512 outputs per fill block
+constexpr int FILL_ITEMS_C2 = 16;  // 4096 outputs per fill block
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 
@@ -66,6 +74,8 @@ struct giql_hip_ctx {
   size_t part_cap = 0;
   u64* d_scratch64 = nullptr;  // small device scratch (checksum)
 
+  bool classic_sort = false;  // GIQL_HIP_SORT=classic: three-launch radix passes
+
   // profiling
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -82,7 +92,7 @@ struct giql_hip_ctx {
   giql_side side_a, side_b;
   u32 n_a = 0, n_b = 0;
   int n_chrom = 0;
-  u64 n_reg = 0, n_irr = 0;
+  u64 n_reg = 0, n_irr = 0, n_c1 = 0;
   u64* off = nullptr;
   u32* lo = nullptr;
   u32* rid_a_sorted = nullptr;
@@ -247,17 +257,40 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
   return post_launch("spans");
 }
 
+// hist_partial / gbase non-NULL: also produce the onesweep digit offsets.
 static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, int n_chrom,
                          const LinBufs& lb, u32* keys, u32* ends, u32* irr_list, int which,
-                         int keep_irregular) {
+                         int keep_irregular, u32* hist_partial = nullptr, u32* gbase = nullptr) {
   if (s.n == 0) return GIQL_OK;
-  Phase ph(ctx, st, GIQL_PH_LINEARIZE);
+  Phase ph(ctx, st, GIQL_PH_LINEARIZE, hist_partial ? 2 : 1);
   u32 grid = cdiv((u64)s.n, LIN_NT);
-  if (grid > 8192) grid = 8192;
+  const u32 cap = hist_partial ? (u32)LIN_MAX_BLOCKS : 8192u;
+  if (grid > cap) grid = cap;
   hipLaunchKernelGGL(k_linearize, dim3(grid), dim3(LIN_NT), 0, st, s.chrom, s.start, s.end,
                      (u32)s.n, s.start_off, s.end_off, n_chrom, lb.chrom_base, keys, ends, irr_list,
-                     ctx->d_meta, which, keep_irregular);
+                     ctx->d_meta, which, keep_irregular, hist_partial);
+  if (hist_partial)
+    hipLaunchKernelGGL(k_digit_offsets, dim3(1), dim3(256), 0, st, hist_partial, grid, gbase);
   return post_launch("linearize");
+}
+
+// Onesweep LSD sort (4 passes, one launch each); input and result in buffer 0.
+// status: cdiv(n, OS_TILE) * 256 words; tickets: 4 words (zeroed here).
+static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
+                             const u32* gbase, u32* status, u32* tickets) {
+  if (n == 0) return GIQL_OK;
+  const u32 n_tiles = cdiv(n, OS_TILE);
+  HIP_TRY(hipMemsetAsync(tickets, 0, 4 * sizeof(u32), st));
+  for (int pass = 0; pass < 4; pass++) {
+    const int src = pass & 1, dst = src ^ 1;
+    HIP_TRY(hipMemsetAsync(status, 0, (size_t)n_tiles * OS_BINS * sizeof(u32), st));
+    Phase ph(ctx, st, GIQL_PH_SORT_SCATTER);
+    hipLaunchKernelGGL((k_onesweep<true>), dim3(n_tiles), dim3(OS_NT), 0, st, sb.key[src],
+                       sb.end[src], pass == 0 ? (const u32*)nullptr : sb.rid[src], sb.key[dst],
+                       sb.end[dst], sb.rid[dst], n, pass * 8, gbase + pass * OS_BINS, status,
+                       tickets + pass, ctx->d_meta);
+  }
+  return post_launch("onesweep sort");
 }
 
 // Stable LSD radix sort; input in buffer 0, result in buffer 0 (4 passes).
@@ -358,6 +391,10 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
   giql_hip_ctx* ctx = new (std::nothrow) giql_hip_ctx();
   if (!ctx) return set_err(GIQL_ERR_NOMEM, "out of host memory");
   ctx->device = device;
+  {
+    const char* e = getenv("GIQL_HIP_SORT");
+    ctx->classic_sort = e && strcmp(e, "classic") == 0;
+  }
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   hipError_t e = hipMalloc((void**)&ctx->d_meta, sizeof(DevMeta));
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_meta, sizeof(DevMeta), hipHostMallocDefault);
@@ -438,19 +475,36 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
   LinBufs lb;
   SortBufs sa, sbb;
   u32 *tile_hist = nullptr, *cnt = nullptr, *irr_cnt = nullptr;
+  u32 *hist_a = nullptr, *hist_b = nullptr, *gbase_a = nullptr, *gbase_b = nullptr;
+  u32 *os_status = nullptr, *os_tickets = nullptr, *wlo1 = nullptr, *wlo2 = nullptr;
   u64* bsums = nullptr;
-  const size_t n_tiles_max = cdiv(na > nb ? na : nb, RS_TILE);
+  const bool onesweep = !ctx->classic_sort && na <= OS_MAX_ROWS && nb <= OS_MAX_ROWS;
+  const size_t n_max = na > nb ? na : nb;
+  const size_t n_tiles_max = cdiv(n_max, RS_TILE);
   const size_t scan_max = (nq > n_tiles_max * RS_BINS ? nq : n_tiles_max * RS_BINS);
+  constexpr u32 TQ1 = RC_NT * RC_ITEMS_C1, TQ2 = RC_NT * RC_ITEMS_C2;
+  const u32 nt1 = cdiv(nb, TQ1), nt2 = cdiv(na, TQ2);
   auto carve = [&](char* base) {
     Carver c{base};
     common_sizes(c, n_chrom, lb);
     sort_sizes(c, na, sa, true);
     sort_sizes(c, nb, sbb, true);
-    tile_hist = c.take<u32>(n_tiles_max * RS_BINS);
+    if (onesweep) {
+      hist_a = c.take<u32>((size_t)LIN_MAX_BLOCKS * 1024);
+      hist_b = c.take<u32>((size_t)LIN_MAX_BLOCKS * 1024);
+      gbase_a = c.take<u32>(1024);
+      gbase_b = c.take<u32>(1024);
+      os_status = c.take<u32>((size_t)cdiv(n_max, OS_TILE) * OS_BINS);
+      os_tickets = c.take<u32>(8);
+    } else {
+      tile_hist = c.take<u32>(n_tiles_max * RS_BINS);
+    }
     bsums = c.take<u64>(cdiv(scan_max, SCAN_TILE) + 2);
     cnt = c.take<u32>(nq);
     ctx->lo = c.take<u32>(nq);
     ctx->off = c.take<u64>(nq + 1);
+    wlo1 = c.take<u32>((size_t)nt1 + 2);
+    wlo2 = c.take<u32>((size_t)nt2 + 2);
     ctx->irr_a_list = c.take<u32>(na);
     ctx->irr_b_list = c.take<u32>(nb);
     irr_cnt = cnt;  // reused after the regular scan
@@ -462,28 +516,42 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
   carve(ctx->arena);
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
-  GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], ctx->irr_a_list, 0, 0));
-  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], ctx->irr_b_list, 1, 0));
-  GIQL_TRY(run_sort(ctx, st, sa, (u32)na, tile_hist, bsums));
-  GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
+  GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], ctx->irr_a_list, 0, 0,
+                         hist_a, gbase_a));
+  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], ctx->irr_b_list, 1, 0,
+                         hist_b, gbase_b));
+  if (onesweep) {
+    GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, gbase_a, os_status, os_tickets));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, gbase_b, os_status, os_tickets + 4));
+  } else {
+    GIQL_TRY(run_sort(ctx, st, sa, (u32)na, tile_hist, bsums));
+    GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
+  }
   ctx->rid_a_sorted = sa.rid[0];
   ctx->rid_b_sorted = sbb.rid[0];
   {
-    Phase ph(ctx, st, GIQL_PH_COUNT, 2);
+    Phase ph(ctx, st, GIQL_PH_COUNT, 4);
+    const u32* irr_a = &ctx->d_meta->irr_a;
+    const u32* irr_b = &ctx->d_meta->irr_b;
     // class 1: queries = sorted B, points = sorted A starts, range [b.start, b.end)
-    hipLaunchKernelGGL(k_range_count, dim3(cdiv(nb, RC_TILE)), dim3(RC_NT), 0, st, sbb.key[0],
-                       sbb.end[0], (u32)nb, &ctx->d_meta->irr_b, sa.key[0], (u32)na,
-                       &ctx->d_meta->irr_a, 0u, ctx->lo, cnt);
+    hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)nt1 + 1, 256)), dim3(256), 0, st, sbb.key[0],
+                       (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, 0u, TQ1, nt1, wlo1);
+    hipLaunchKernelGGL((k_range_count<RC_ITEMS_C1>), dim3(nt1), dim3(RC_NT), 0, st, sbb.key[0],
+                       sbb.end[0], (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, 0u, wlo1, ctx->lo, cnt);
     // class 2: queries = sorted A, points = sorted B starts, range (a.start, a.end)
-    hipLaunchKernelGGL(k_range_count, dim3(cdiv(na, RC_TILE)), dim3(RC_NT), 0, st, sa.key[0],
-                       sa.end[0], (u32)na, &ctx->d_meta->irr_a, sbb.key[0], (u32)nb,
-                       &ctx->d_meta->irr_b, 1u, ctx->lo + nb, cnt + nb);
+    hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)nt2 + 1, 256)), dim3(256), 0, st, sa.key[0],
+                       (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, 1u, TQ2, nt2, wlo2);
+    hipLaunchKernelGGL((k_range_count<RC_ITEMS_C2>), dim3(nt2), dim3(RC_NT), 0, st, sa.key[0],
+                       sa.end[0], (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, 1u, wlo2,
+                       ctx->lo + nb, cnt + nb);
     GIQL_TRY(post_launch("range count"));
   }
   GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt, nq, ctx->off, bsums, ctx->off + nq));
   HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out, ctx->off + nq, sizeof(u64), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out_c1, ctx->off + nb, sizeof(u64), hipMemcpyDeviceToDevice, st));
   GIQL_TRY(read_meta(ctx, st));
   ctx->n_reg = ctx->h_meta->n_out;
+  ctx->n_c1 = ctx->h_meta->n_out_c1;
   ctx->stats.n_irregular_a = ctx->h_meta->irr_a;
   ctx->stats.n_irregular_b = ctx->h_meta->irr_b;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
@@ -523,27 +591,44 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
   hipStream_t st = (hipStream_t)stream;
   const u32 nq = ctx->n_a + ctx->n_b;
   if (ctx->n_reg > 0) {
-    const u64 n_tiles64 = (ctx->n_reg + FILL_TILE - 1) / FILL_TILE;
-    if (n_tiles64 > 0x7FFFFFFFull) return set_err(GIQL_ERR_INVALID, "output too large");
-    const u32 n_tiles = (u32)n_tiles64;
-    if ((size_t)n_tiles + 1 > ctx->part_cap) {
+    constexpr u32 T1 = FILL_NT * FILL_ITEMS_C1, T2 = FILL_NT * FILL_ITEMS_C2;
+    const u64 p1 = ctx->n_c1, p2 = ctx->n_reg - ctx->n_c1;
+    const u64 nt1_64 = (p1 + T1 - 1) / T1, nt2_64 = (p2 + T2 - 1) / T2;
+    if (nt1_64 + nt2_64 > 0x7FFFFFF0ull) return set_err(GIQL_ERR_INVALID, "output too large");
+    const u32 nt1 = (u32)nt1_64, nt2 = (u32)nt2_64;
+    const size_t part_need = (size_t)nt1 + nt2 + 2;
+    if (part_need > ctx->part_cap) {
       HIP_TRY(hipStreamSynchronize(st));
       if (ctx->part) HIP_TRY(hipFree(ctx->part));
       ctx->part = nullptr;
       ctx->part_cap = 0;
-      const size_t want = (size_t)n_tiles + 1 + n_tiles / 4;
+      const size_t want = part_need + part_need / 4;
       HIP_TRY(hipMalloc((void**)&ctx->part, want * sizeof(u32)));
       ctx->part_cap = want;
     }
+    u32* part1 = ctx->part;
+    u32* part2 = ctx->part + nt1 + 1;
     {
-      Phase ph(ctx, st, GIQL_PH_PARTITION);
-      hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)n_tiles + 1, 256)), dim3(256), 0, st, ctx->off,
-                         (u64)nq, ctx->n_reg, n_tiles, ctx->part);
+      Phase ph(ctx, st, GIQL_PH_PARTITION, 2);
+      if (nt1)
+        hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt1 + 1, 256)), dim3(256), 0, st, ctx->off,
+                           ctx->n_b, (u64)0, T1, nt1, part1);
+      if (nt2)
+        hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt2 + 1, 256)), dim3(256), 0, st,
+                           ctx->off + ctx->n_b, ctx->n_a, p1, T2, nt2, part2);
     }
     {
-      Phase ph(ctx, st, GIQL_PH_FILL);
-      hipLaunchKernelGGL(k_fill, dim3(n_tiles), dim3(FILL_NT), 0, st, ctx->off, ctx->lo, ctx->n_b, nq,
-                         ctx->rid_a_sorted, ctx->rid_b_sorted, ctx->part, ctx->n_reg, row_a, row_b);
+      Phase ph(ctx, st, GIQL_PH_FILL, 2);
+      // class 1: query = B row, matches = A rows
+      if (nt1)
+        hipLaunchKernelGGL((k_fill<FILL_ITEMS_C1>), dim3(nt1), dim3(FILL_NT), 0, st, ctx->off,
+                           ctx->lo, ctx->rid_b_sorted, ctx->n_b, ctx->rid_a_sorted, part1, (u64)0, p1,
+                           row_b, row_a);
+      // class 2: query = A row, matches = B rows
+      if (nt2)
+        hipLaunchKernelGGL((k_fill<FILL_ITEMS_C2>), dim3(nt2), dim3(FILL_NT), 0, st,
+                           ctx->off + ctx->n_b, ctx->lo + ctx->n_b, ctx->rid_a_sorted, ctx->n_a,
+                           ctx->rid_b_sorted, part2, p1, p2, row_a, row_b);
     }
     GIQL_TRY(post_launch("fill"));
   }

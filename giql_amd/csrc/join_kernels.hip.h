@@ -34,6 +34,7 @@ __global__ void k_init_minmax(int* __restrict__ gmin, int* __restrict__ gmax, in
     meta->total_span = 0;
     meta->n_out = 0;
     meta->n_out_irr = 0;
+    meta->n_out_c1 = 0;
     meta->sentinel = U32_MAX;
     meta->irr_a = 0;
     meta->irr_b = 0;
@@ -153,17 +154,26 @@ __global__ __launch_bounds__(256) void k_chrom_offsets(const int* __restrict__ g
 
 // -------------------------------------------------------------- linearise
 constexpr int LIN_NT = 256;
+constexpr int LIN_MAX_BLOCKS = 1024;  // partial histograms: [block][4][256]
 
 // keys[i] = linearised canonical start, ends[i] = linearised canonical end.
 // Irregular rows (canonical end <= start) get the sentinel key and are appended
 // to irr_list -- unless keep_irregular, where every row keeps its real key (the
 // prefix-max operators are exact for any row).  which = 0 for side A, 1 for B.
 // keys / ends may be NULL (only the irregular list is wanted).
+// hist_partial (optional): this block's 4 x 256 digit histogram of the keys it
+// produced, for the onesweep sort (no global atomics: k_digit_offsets sums them).
 __global__ __launch_bounds__(LIN_NT) void k_linearize(
     const int* __restrict__ chrom, const int* __restrict__ start, const int* __restrict__ end, u32 n,
     int start_off, int end_off, int n_chrom, const i64* __restrict__ chrom_base,
     u32* __restrict__ keys, u32* __restrict__ ends, u32* __restrict__ irr_list,
-    DevMeta* __restrict__ meta, int which, int keep_irregular) {
+    DevMeta* __restrict__ meta, int which, int keep_irregular, u32* __restrict__ hist_partial) {
+  __shared__ u32 s_hist[4 * 256];
+  if (hist_partial) {
+#pragma unroll
+    for (int k = threadIdx.x; k < 4 * 256; k += LIN_NT) s_hist[k] = 0;
+    __syncthreads();
+  }
   const u32 sentinel = meta->sentinel;
   u32* irr_count = which ? &meta->irr_b : &meta->irr_a;
   const u32 stride = gridDim.x * LIN_NT;
@@ -190,6 +200,22 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
         ends[i] = ke;
       }
     }
+    if (hist_partial) {
+      const u64 act = __ballot(ok);
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const u32 d = (k >> (8 * p)) & 0xFFu;
+        // chromosome-sorted input makes the high digits wave-uniform: one add
+        const u32 d0 = __shfl(d, __ffsll((long long)act) - 1, WAVE);
+        const u64 same = __ballot(ok && d == d0);
+        if (act != 0 && same == act) {
+          if (lane_id() == (u32)(__ffsll((long long)act) - 1))
+            atomicAdd(&s_hist[p * 256 + d0], (u32)__popcll(act));
+        } else if (ok) {
+          atomicAdd(&s_hist[p * 256 + d], 1u);
+        }
+      }
+    }
     const u64 m = __ballot(irr);
     if (m) {
       u32 base = 0;
@@ -198,93 +224,94 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
       if (irr) irr_list[base + (u32)__popcll(m & lanemask_lt())] = i;
     }
   }
+  if (hist_partial) {
+    __syncthreads();
+#pragma unroll
+    for (int k = threadIdx.x; k < 4 * 256; k += LIN_NT)
+      hist_partial[(size_t)blockIdx.x * 1024 + k] = s_hist[k];
+  }
+}
+
+// Single block: gbase[p][d] = exclusive scan over d of sum_b partial[b][p][d].
+__global__ __launch_bounds__(256) void k_digit_offsets(const u32* __restrict__ partial, u32 n_blocks,
+                                                        u32* __restrict__ gbase) {
+  __shared__ u32 lds[256 / WAVE + 1];
+  for (int p = 0; p < 4; p++) {
+    u32 c = 0;
+    for (u32 b = 0; b < n_blocks; b++) c += partial[(size_t)b * 1024 + p * 256 + threadIdx.x];
+    u32 total;
+    const u32 ex = block_excl_scan<u32, 256>(c, lds, total);
+    gbase[p * 256 + threadIdx.x] = ex;
+  }
 }
 
 // ------------------------------------------------------------- range count
 constexpr int RC_NT = 256;
-constexpr int RC_ITEMS = 4;
-constexpr int RC_TILE = RC_NT * RC_ITEMS;  // 1024 queries per block
-constexpr int RC_LDS_CAP = 8192;           // staged S keys (32 KB)
+constexpr int RC_LDS_CAP = 10240;  // staged S keys (40 KB)
+constexpr int RC_MARGIN = 1024;    // S entries staged past the next tile's window
+
+// w_lo[t] = first S index a query of tile t can match = lower_bound(S, first
+// query start + lo_off); w_lo[n_tiles] = |S|.  One thread per tile: the count
+// kernel then starts with its S window known (no serial per-block search).
+__global__ void k_count_partition(const u32* __restrict__ qs, u32 nq_total,
+                                  const u32* __restrict__ irr_q, const u32* __restrict__ ss,
+                                  u32 ns_total, const u32* __restrict__ irr_s, u32 lo_off, u32 tq,
+                                  u32 n_tiles, u32* __restrict__ w_lo) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > n_tiles) return;
+  const u32 nq = nq_total - *irr_q;
+  const u32 ns = ns_total - *irr_s;
+  const u64 q = (u64)t * tq;
+  w_lo[t] = (t < n_tiles && q < nq) ? lower_bound_u32(ss, 0, ns, qs[q] + lo_off) : ns;
+}
 
 // For the sorted queries of one block, count the points of the sorted set S in
 // [qs + lo_off, qe).  lo_off = 0 is class 1 (closed low end), 1 is class 2.
 // Writes lo (first matching index in S) and cnt.  Rows past the regular prefix
-// (sentinel keys) get cnt = 0.  The block's S window is located with two
-// cooperative 64-ary searches, staged through LDS when it fits, and searched
-// per lane there (the "LDS tile + per-lane binary search" of the north star).
+// (sentinel keys) get cnt = 0.  The block's S window [w_lo[t], w_lo[t+1] +
+// margin) is staged in LDS and searched per lane there (LDS tile + per-lane
+// binary search); a bound that falls past the staged part is finished in HBM.
+template <int ITEMS>
 __global__ __launch_bounds__(RC_NT) void k_range_count(
     const u32* __restrict__ qs, const u32* __restrict__ qe, u32 nq_total,
     const u32* __restrict__ irr_q, const u32* __restrict__ ss, u32 ns_total,
-    const u32* __restrict__ irr_s, u32 lo_off, u32* __restrict__ lo_out, u32* __restrict__ cnt_out) {
+    const u32* __restrict__ irr_s, u32 lo_off, const u32* __restrict__ w_lo_arr,
+    u32* __restrict__ lo_out, u32* __restrict__ cnt_out) {
+  constexpr u32 TQ = RC_NT * ITEMS;
   __shared__ u32 s_tile[RC_LDS_CAP];
-  __shared__ u32 s_red[RC_NT / WAVE];
-  __shared__ u32 s_bounds[2];
-
   const u32 nq = nq_total - *irr_q;
   const u32 ns = ns_total - *irr_s;
-  const u32 q0 = blockIdx.x * RC_TILE;
+  const u32 q0 = blockIdx.x * TQ;
   const u32 tid = threadIdx.x;
-
-  u32 s[RC_ITEMS], e[RC_ITEMS];
-  u32 emax = 0;
-#pragma unroll
-  for (int i = 0; i < RC_ITEMS; i++) {
-    const u32 q = q0 + i * RC_NT + tid;
-    const bool ok = q < nq;
-    s[i] = ok ? qs[q] : U32_MAX;
-    e[i] = ok ? qe[q] : 0u;
-    emax = e[i] > emax ? e[i] : emax;
+  const u32 w0 = w_lo_arr[blockIdx.x];
+  const u32 w1 = w_lo_arr[blockIdx.x + 1];
+  u32 len = (ns - w0);
+  {
+    const u64 want = (u64)(w1 - w0) + RC_MARGIN;
+    if (want < len) len = (u32)want;
+    if (len > (u32)RC_LDS_CAP) len = RC_LDS_CAP;
   }
-  if (q0 >= nq || ns == 0) {  // block-uniform
-#pragma unroll
-    for (int i = 0; i < RC_ITEMS; i++) {
-      const u32 q = q0 + i * RC_NT + tid;
-      if (q < nq_total) {
-        lo_out[q] = 0;
-        cnt_out[q] = 0;
-      }
-    }
-    return;
-  }
-  emax = wave_reduce_max_u32(emax);
-  if (lane_id() == 0) s_red[wave_id()] = emax;
+  for (u32 k = tid; k < len; k += RC_NT) s_tile[k] = ss[w0 + k];
   __syncthreads();
-  if (wave_id() == 0) {
-    u32 m = s_red[0];
+  const u32 last = len ? s_tile[len - 1] : 0u;
+  const u32 w_end = w0 + len;  // first S index that is NOT staged
 #pragma unroll
-    for (int k = 1; k < RC_NT / WAVE; k++) m = s_red[k] > m ? s_red[k] : m;
-    const u32 smin = qs[q0] + lo_off;  // queries are sorted: first is smallest
-    const u32 w_lo = wave_lower_bound_u32(ss, 0, ns, smin);
-    const u32 w_hi = wave_lower_bound_u32(ss, w_lo, ns, m);
-    if (lane_id() == 0) {
-      s_bounds[0] = w_lo;
-      s_bounds[1] = w_hi;
-    }
-  }
-  __syncthreads();
-  const u32 w_lo = s_bounds[0], w_hi = s_bounds[1];
-  const u32 w_len = w_hi - w_lo;
-  const bool staged = w_len <= (u32)RC_LDS_CAP;
-  if (staged) {
-    for (u32 k = tid; k < w_len; k += RC_NT) s_tile[k] = ss[w_lo + k];
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < RC_ITEMS; i++) {
+  for (int i = 0; i < ITEMS; i++) {
     const u32 q = q0 + i * RC_NT + tid;
     if (q >= nq_total) continue;
     u32 lo = 0, cnt = 0;
     if (q < nq) {
+      const u32 xs = qs[q] + lo_off, xe = qe[q];
+      // lower_bound(S, x) over [w0, ns): staged part first
+      if (len && last >= xs)
+        lo = w0 + lower_bound_u32(s_tile, 0, len, xs);
+      else
+        lo = lower_bound_u32(ss, w_end, ns, xs);
       u32 hi;
-      if (staged) {
-        lo = lower_bound_u32(s_tile, 0, w_len, s[i] + lo_off);
-        hi = lower_bound_u32(s_tile, lo, w_len, e[i]);
-        lo += w_lo;
-        hi += w_lo;
-      } else {
-        lo = lower_bound_u32(ss, w_lo, w_hi, s[i] + lo_off);
-        hi = lower_bound_u32(ss, lo, w_hi, e[i]);
-      }
+      if (lo < w_end && last >= xe)
+        hi = w0 + lower_bound_u32(s_tile, lo - w0, len, xe);
+      else
+        hi = lower_bound_u32(ss, lo > w_end ? lo : w_end, ns, xe);
       cnt = hi - lo;
     }
     lo_out[q] = lo;
@@ -294,48 +321,50 @@ __global__ __launch_bounds__(RC_NT) void k_range_count(
 
 // --------------------------------------------------------------- partition
 constexpr int FILL_NT = 256;
-constexpr int FILL_ITEMS = 16;
-constexpr int FILL_TILE = FILL_NT * FILL_ITEMS;  // 4096 output pairs per block
-constexpr int FILL_QCAP = 4096;                  // staged query offsets
+constexpr int FILL_QCAP = 2048;  // query records staged per output tile
 
-// part[t] = last query q with off[q] <= t * FILL_TILE  (merge-path split of the
-// output among blocks: every block materialises exactly FILL_TILE pairs).
-__global__ void k_partition(const u64* __restrict__ off, u64 nq, u64 n_out, u32 n_tiles,
-                            u32* __restrict__ part) {
+// Merge-path split of one class's output among blocks: every block materialises
+// exactly `tile` pairs.  part[t] = last query q (relative to q_base) whose
+// offset is <= out_base + t*tile;  part[n_tiles] = nq - 1.
+__global__ void k_partition(const u64* __restrict__ off, u32 nq, u64 out_base, u32 tile,
+                            u32 n_tiles, u32* __restrict__ part) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t > n_tiles) return;
   if (t == n_tiles) {
-    part[t] = nq > 0 ? (u32)(nq - 1) : 0u;
+    part[t] = nq > 0 ? nq - 1 : 0u;
     return;
   }
-  const u64 p = (u64)t * FILL_TILE;
-  (void)n_out;
-  part[t] = (u32)(upper_bound_u64(off, 0, nq + 1, p) - 1);
+  const u64 p = out_base + (u64)t * tile;
+  part[t] = (u32)(upper_bound_u64(off, 0, (u64)nq + 1, p) - 1);
 }
 
 // -------------------------------------------------------------------- fill
-// Queries are the concatenation [class-1 queries = sorted B | class-2 queries =
-// sorted A]; off[] is their exclusive output offset, lo[] the first matching
-// index in the other side's sorted array.  Each thread materialises pairs for
-// output positions tile_start + i*256 + tid: coalesced 4-byte stores to row_a /
-// row_b, (mostly) coalesced rid reads.
+// One class per launch.  off / lo / q_rid are that class's query arrays (already
+// offset to its first query), s_rid the other side's sorted row ids.  Outputs
+// [out_base, out_base + n_out) go to row_q (the query side's ids) and row_s.
+// Per tile the query records {relative offset, lo, rid} are staged in LDS, so an
+// output costs one LDS search + one gather of s_rid + two coalesced 4 B stores.
+template <int ITEMS>
 __global__ __launch_bounds__(FILL_NT) void k_fill(
-    const u64* __restrict__ off, const u32* __restrict__ lo, u32 nq_b, u32 nq_total,
-    const u32* __restrict__ rid_a_sorted, const u32* __restrict__ rid_b_sorted,
-    const u32* __restrict__ part, u64 n_out, int32_t* __restrict__ row_a,
-    int32_t* __restrict__ row_b) {
-  __shared__ u32 s_rel[FILL_QCAP + 1];
+    const u64* __restrict__ off, const u32* __restrict__ lo, const u32* __restrict__ q_rid, u32 nq,
+    const u32* __restrict__ s_rid, const u32* __restrict__ part, u64 out_base, u64 n_out,
+    int32_t* __restrict__ row_q, int32_t* __restrict__ row_s) {
+  constexpr u32 TILE = FILL_NT * ITEMS;
+  __shared__ u32 s_rel[FILL_QCAP];
+  __shared__ u32 s_lo[FILL_QCAP];
+  __shared__ u32 s_qrid[FILL_QCAP];
   const u32 tid = threadIdx.x;
-  const u64 tile_start = (u64)blockIdx.x * FILL_TILE;
-  const u64 rem = n_out - tile_start;
-  const u32 tile_len = rem < (u64)FILL_TILE ? (u32)rem : (u32)FILL_TILE;
+  const u64 tile_rel = (u64)blockIdx.x * TILE;  // relative to out_base
+  const u64 tile_start = out_base + tile_rel;
+  const u64 rem = n_out - tile_rel;
+  const u32 tile_len = rem < (u64)TILE ? (u32)rem : TILE;
   const u32 qf = part[blockIdx.x];
   u32 ql = part[blockIdx.x + 1];
-  if (ql >= nq_total) ql = nq_total - 1;
+  if (ql >= nq) ql = nq - 1;
   const u32 nqt = ql - qf + 1;
   const bool staged = nqt <= (u32)FILL_QCAP;
+  const u32 first_delta = (u32)(tile_start - off[qf]);  // < cnt[qf] < 2^32
   if (staged) {
-    // rel[k] = clamp(off[qf + k] - tile_start, 0 .. tile_len)
     for (u32 k = tid; k < nqt; k += FILL_NT) {
       const u64 o = off[qf + k];
       u32 r = 0;
@@ -344,31 +373,30 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
         r = d > (u64)tile_len ? tile_len : (u32)d;
       }
       s_rel[k] = r;
+      s_lo[k] = lo[qf + k];
+      s_qrid[k] = q_rid[qf + k];
     }
     __syncthreads();
   }
-#pragma unroll 4
-  for (int i = 0; i < FILL_ITEMS; i++) {
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
     const u32 p_rel = i * FILL_NT + tid;
-    if (p_rel >= tile_len) break;
-    const u64 p = tile_start + p_rel;
-    u32 q;
-    if (staged) {
-      q = qf + upper_bound_u32(s_rel, 0, nqt, p_rel) - 1;
-    } else {
-      q = (u32)(upper_bound_u64(off, qf, (u64)ql + 1, p) - 1);
+    if (p_rel < tile_len) {
+      u32 j, qr;
+      if (staged) {
+        const u32 k = upper_bound_u32(s_rel, 0, nqt, p_rel) - 1;
+        j = s_lo[k] + (k == 0 ? p_rel + first_delta : p_rel - s_rel[k]);
+        qr = s_qrid[k];
+      } else {
+        const u64 p = tile_start + p_rel;
+        const u32 q = (u32)(upper_bound_u64(off, qf, (u64)ql + 1, p) - 1);
+        j = lo[q] + (u32)(p - off[q]);
+        qr = q_rid[q];
+      }
+      const u64 o = tile_start + p_rel;
+      row_q[o] = (int32_t)qr;
+      row_s[o] = (int32_t)s_rid[j];
     }
-    const u32 j = lo[q] + (u32)(p - off[q]);
-    int32_t ra, rb;
-    if (q < nq_b) {  // class 1: query is a B row, matches are A rows
-      rb = (int32_t)rid_b_sorted[q];
-      ra = (int32_t)rid_a_sorted[j];
-    } else {  // class 2: query is an A row, matches are B rows
-      ra = (int32_t)rid_a_sorted[q - nq_b];
-      rb = (int32_t)rid_b_sorted[j];
-    }
-    row_a[p] = ra;
-    row_b[p] = rb;
   }
 }
 

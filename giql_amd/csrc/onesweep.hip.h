@@ -1,0 +1,215 @@
+// giql_amd/csrc/onesweep.hip.h -- single-pass-per-digit stable LSD radix sort
+// ("onesweep": global digit histograms up front, per-tile offsets by decoupled
+// look-back) of (key, end, rid) triples.
+//
+// Compared with the three-launch pass of radix_sort.hip.h this reads the keys
+// once per pass instead of twice and removes the tile-histogram scan:
+//   per pass:  read 12 B/row, write 12 B/row   (algorithmic: exactly that)
+// Tiles are 8192 rows (512 threads x 16) so a 256-bin scatter writes ~32-row
+// (128 B) runs per array; the three arrays are staged through ONE 32 KB LDS
+// buffer in turn, which keeps 2-3 blocks (16-24 waves) resident per CU.
+//
+// Inter-workgroup protocol (cdna_hip_programming.md G16, "granule" form): the
+// only cross-block data is one 32-bit status word per (tile, digit) holding
+// {flag:2, count:30}.  It is written by ONE relaxed agent-scope atomic store and
+// polled with relaxed agent-scope atomic loads (sc1: L1 is bypassed), so no
+// fence is needed and nothing depends on workgroup placement.  Tiles take their
+// index from an atomic ticket, so every predecessor of a tile is already
+// running: the look-back cannot deadlock.  Spins are bounded all the same.
+#pragma once
+
+#include "dev_common.hip.h"
+
+namespace giql {
+
+constexpr int OS_NT = 512;
+constexpr int OS_ITEMS = 16;
+constexpr int OS_TILE = OS_NT * OS_ITEMS;  // 8192
+constexpr int OS_BINS = 256;
+constexpr int OS_NW = OS_NT / WAVE;  // 8
+constexpr u32 OS_FLAG_AGG = 1u << 30;
+constexpr u32 OS_FLAG_PREFIX = 2u << 30;
+constexpr u32 OS_VALUE_MASK = (1u << 30) - 1u;
+constexpr u32 OS_MAX_ROWS = (1u << 30) - 1u;
+constexpr u32 OS_SPIN_LIMIT = 1u << 24;
+
+template <bool PAYLOAD>
+__global__ __launch_bounds__(OS_NT) void k_onesweep(
+    const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
+    u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
+    int shift, const u32* __restrict__ gbase, u32* __restrict__ status, u32* __restrict__ ticket,
+    DevMeta* __restrict__ meta) {
+  __shared__ u32 s_buf[OS_TILE];          // staging, reused for key / end / rid
+  __shared__ u32 s_wcnt[OS_NW][OS_BINS];  // per-wave digit counters -> bases
+  __shared__ u32 s_dstart[OS_BINS];
+  __shared__ u32 s_goff[OS_BINS];
+  __shared__ u32 s_scan[OS_BINS / WAVE + 1];
+  __shared__ u32 s_tile;
+
+  const u32 tid = threadIdx.x;
+  const u32 lane = lane_id();
+  const u32 w = wave_id();
+
+  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+  for (int k = tid; k < OS_NW * OS_BINS; k += OS_NT) (&s_wcnt[0][0])[k] = 0;
+  __syncthreads();
+  const u32 tile = s_tile;
+  const u32 tile_base = tile * OS_TILE;
+  if (tile_base >= n) return;  // block-uniform (cannot happen: grid = n_tiles)
+  const u32 n_valid = (n - tile_base) < (u32)OS_TILE ? (n - tile_base) : (u32)OS_TILE;
+
+  // wave-striped: item i of lane l of wave w is row w*1024 + i*64 + l
+  u32 key[OS_ITEMS], end[OS_ITEMS], rid[OS_ITEMS];
+  const u32 wbase = w * (OS_ITEMS * WAVE);
+#pragma unroll
+  for (int i = 0; i < OS_ITEMS; i++) {
+    const u32 r = wbase + i * WAVE + lane;
+    const bool ok = r < n_valid;
+    const u32 g = tile_base + r;
+    key[i] = ok ? keys_in[g] : U32_MAX;
+    if (PAYLOAD) {
+      end[i] = ok ? ends_in[g] : 0u;
+      rid[i] = ok ? (rids_in ? rids_in[g] : g) : 0u;
+    }
+  }
+
+  // stable rank inside the wave (peers = lanes with the same digit)
+  u32 rank[OS_ITEMS];
+  {
+    volatile u32* wcnt = s_wcnt[w];
+    const u64 lt = lanemask_lt();
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      const bool ok = r < n_valid;
+      const u32 d = (key[i] >> shift) & 0xFFu;
+      u64 peers = __ballot(ok);
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        const bool bit = (d >> b) & 1u;
+        const u64 m = __ballot(bit);
+        peers &= bit ? m : ~m;
+      }
+      if (ok) {
+        const u32 pre = wcnt[d];
+        rank[i] = pre + (u32)__popcll(peers & lt);
+        if ((peers & lt) == 0) wcnt[d] = pre + (u32)__popcll(peers);
+      } else {
+        rank[i] = 0;
+      }
+    }
+  }
+  __syncthreads();
+
+  // threads 0..255 own one digit each: wave bases, tile digit starts, look-back
+  if (tid < OS_BINS) {
+    u32 run = 0;
+#pragma unroll
+    for (int k = 0; k < OS_NW; k++) {
+      const u32 c = s_wcnt[k][tid];
+      s_wcnt[k][tid] = run;
+      run += c;
+    }
+    const u32 count = run;
+    // exclusive scan of the 256 digit counts (4 waves)
+    const u32 incl = wave_incl_scan(count);
+    if (lane == WAVE - 1) s_scan[w] = incl;
+    // publish this tile's count before anything that could wait
+    u32* st = status + (size_t)tile * OS_BINS + tid;
+    u32 excl = 0;
+    if (tile == 0) {
+      __hip_atomic_store(st, OS_FLAG_PREFIX | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(st, OS_FLAG_AGG | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      u32 t = tile - 1;
+      u32 spins = 0;
+      while (true) {
+        const u32 v = __hip_atomic_load(status + (size_t)t * OS_BINS + tid, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+        const u32 f = v >> 30;
+        if (f == 0) {
+          if (++spins > OS_SPIN_LIMIT) {
+            meta->status = -2;  // GIQL_ERR_HIP: look-back timed out (never expected)
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        excl += v & OS_VALUE_MASK;
+        if (f == 2u || t == 0) break;
+        t--;
+      }
+      __hip_atomic_store(st, OS_FLAG_PREFIX | ((excl + count) & OS_VALUE_MASK), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_goff[tid] = gbase[tid] + excl;  // finished below once dstart is known
+    s_dstart[tid] = incl - count;     // wave-local exclusive; wave base added below
+  }
+  __syncthreads();
+  if (tid < OS_BINS) {
+    u32 wb = 0;
+#pragma unroll
+    for (int k = 0; k < OS_BINS / WAVE; k++)
+      if (k < (int)w) wb += s_scan[k];
+    const u32 dstart = s_dstart[tid] + wb;
+    s_dstart[tid] = dstart;
+    s_goff[tid] -= dstart;  // global dst = s_goff[d] + in-tile position
+  }
+  __syncthreads();
+
+  // in-tile sorted position of every item
+  u32 pos[OS_ITEMS];
+#pragma unroll
+  for (int i = 0; i < OS_ITEMS; i++) {
+    const u32 d = (key[i] >> shift) & 0xFFu;
+    pos[i] = s_dstart[d] + s_wcnt[w][d] + rank[i];
+  }
+
+  // round 1: keys through LDS; remember each output slot's global destination
+  u32 dst[OS_ITEMS];
+#pragma unroll
+  for (int i = 0; i < OS_ITEMS; i++) {
+    const u32 r = wbase + i * WAVE + lane;
+    if (r < n_valid) s_buf[pos[i]] = key[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < OS_ITEMS; i++) {
+    const u32 p = i * OS_NT + tid;
+    dst[i] = 0;
+    if (p < n_valid) {
+      const u32 k = s_buf[p];
+      dst[i] = s_goff[(k >> shift) & 0xFFu] + p;
+      keys_out[dst[i]] = k;
+    }
+  }
+  if (PAYLOAD) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      if (r < n_valid) s_buf[pos[i]] = end[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 p = i * OS_NT + tid;
+      if (p < n_valid) ends_out[dst[i]] = s_buf[p];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      if (r < n_valid) s_buf[pos[i]] = rid[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 p = i * OS_NT + tid;
+      if (p < n_valid) rids_out[dst[i]] = s_buf[p];
+    }
+  }
+}
+
+}  // namespace giql

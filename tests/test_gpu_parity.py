@@ -297,3 +297,30 @@ def test_host_buffer_entry_points(eng):
     dist = np.zeros(a.n, np.int64)
     _lib.check(L.giql_hip_nearest(eng._h, cs(a), cs(b), 4, 0, -1, idx.ctypes.data, dist.ctypes.data))
     assert np.array_equal(dist, ora.c_nearest_k1(a, b, method="sweep")[1])
+
+
+def test_classic_three_launch_sort_path(monkeypatch):
+    """GIQL_HIP_SORT=classic keeps the hist/scan/scatter radix passes usable."""
+    from giql_amd.engine import HipEngine
+
+    monkeypatch.setenv("GIQL_HIP_SORT", "classic")
+    e = HipEngine(0)
+    try:
+        a = rand_side(61, 70_000, 7, 9_000_000, 1200)
+        b = rand_side(62, 90_000, 7, 9_000_000, 400)
+        ra, rb = e.inner_join(dev(a), dev(b), 7)
+        got = ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy())
+        assert np.array_equal(got, ora.sort_pairs(*ora.c_inner(a, b, "sweep")))
+    finally:
+        e.close()
+
+
+def test_sorted_input_and_heavy_skew(eng):
+    """Chromosome/start-sorted input (BED-like) and one chromosome-spanning row."""
+    a = rand_side(71, 120_000, 5, 20_000_000, 900)
+    order = np.lexsort((a.start, a.chrom))
+    a = ora.Side(a.chrom[order], a.start[order], a.end[order])
+    b = rand_side(72, 150_000, 5, 20_000_000, 300)
+    b.start[0], b.end[0] = 0, 20_000_000  # overlaps every A row on its chromosome
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    assert np.array_equal(gpu_inner(eng, a, b, 5), want)
