@@ -79,6 +79,51 @@ def phase_bytes(phase: str, n_a: int, n_b: int, n_out: int) -> float:
     }[phase]
 
 
+def run_cpu_baseline(args, n_a, kind_a, seed_a, n_b, kind_b, seed_b):
+    """Time the oracle's OpenMP sort-merge port on a bounded sample of the workload.
+
+    A probe on four small chromosomes estimates the rate; the reported sample is
+    the largest prefix of chromosomes (by id) whose estimated time stays under
+    ~20 s -- the whole workload when the host is fast enough.
+    """
+    from giql_amd import synth
+    from oracle import pyoracle as ora
+
+    threads = ora.max_threads()
+
+    def run(chroms):
+        sa = synth.make_table(n_a, seed_a, kind_a, chroms=chroms)
+        sb = synth.make_table(n_b, seed_b, kind_b, chroms=chroms)
+        oa, ob = ora.Side(*sa), ora.Side(*sb)
+        t1 = time.perf_counter()
+        ra, _rb = ora.c_inner(oa, ob, "sweep", threads=threads)
+        return oa.n, ob.n, int(ra.shape[0]), time.perf_counter() - t1
+
+    probe = [int(c) for c in args.cpu_sample_chroms.split(",") if c != ""]
+    pa_, pb_, pp, pt = run(probe)
+    rows_total = synth.rows_per_chrom(n_a, seed_a) + synth.rows_per_chrom(n_b, seed_b)
+    rate = (pa_ + pb_) / max(pt, 1e-3)                    # rows/s on the probe
+    budget_rows = rate * 20.0
+    chroms, acc = [], 0
+    for c in range(len(rows_total)):
+        if acc + rows_total[c] > budget_rows and chroms:
+            break
+        chroms.append(c)
+        acc += int(rows_total[c])
+    sa_n, sb_n, sp, st_ = run(chroms)
+    whole = len(chroms) == len(rows_total)
+    return {
+        "value": round(sp / st_, 1),
+        "unit": "pairs/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": (("the whole workload" if whole else f"chromosome ids 0..{chroms[-1]} of the same workload")
+                   + f": {sa_n} x {sb_n} rows -> {sp} pairs in {st_:.2f} s "
+                   "(oracle OpenMP sort-merge port, not DuckDB: duckdb is not installed on the box)"),
+        "host_cpu_count": os.cpu_count(),
+    }
+
+
 def main() -> None:
     args = parse_args()
     import torch
@@ -120,12 +165,22 @@ def main() -> None:
     eng = HipEngine(local_rank)
     out_cap = 0
     out = None
-    count_t = torch.zeros(1, dtype=torch.int64, device=dev)
-    gathered = None
+    # shard-local row index -> global row id (ranks own disjoint chromosome sets;
+    # global ids are "rows of lower ranks first")
+    idmap_a = idmap_b = None
+    if distributed:
+        from giql_amd import distributed as D
+
+        sizes = torch.tensor([loc_na, loc_nb], dtype=torch.int64, device=dev)
+        all_sizes = torch.empty((world, 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(all_sizes.view(-1), sizes)
+        base = all_sizes[:rank].sum(0) if rank else torch.zeros(2, dtype=torch.int64, device=dev)
+        idmap_a = (torch.arange(loc_na, device=dev, dtype=torch.int64) + base[0]).to(torch.int32)
+        idmap_b = (torch.arange(loc_nb, device=dev, dtype=torch.int64) + base[1]).to(torch.int32)
 
     def step():
         """One pass of the hot path; returns this rank's pair count."""
-        nonlocal out, out_cap, gathered
+        nonlocal out, out_cap
         n = eng.inner_plan(a, b, n_chrom)
         if n > out_cap:
             out = None
@@ -133,19 +188,10 @@ def main() -> None:
             out = torch.empty((2, out_cap), dtype=torch.int32, device=dev)
         eng.inner_fill(out[0, :n], out[1, :n])
         if distributed and not args.no_gather:
-            # the path's one exchange step: counts, then the index pairs (padded)
-            count_t.fill_(n)
-            counts = torch.empty(world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(counts, count_t)
-            m = int(counts.max().item())
-            if out_cap < m:  # keep the send buffer at least as large as the pad
-                bigger = torch.empty((2, int(m * 1.05) + 1024), dtype=torch.int32, device=dev)
-                bigger[:, :n] = out[:, :n]
-                out, out_cap = bigger, bigger.shape[1]
-            send = out[:, :m].contiguous()
-            if gathered is None or gathered.shape[0] < world * 2 * m:
-                gathered = torch.empty(world * 2 * m, dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(gathered[: world * 2 * m], send.view(-1))
+            # the path's one exchange step: global ids, counts, then the padded pairs
+            ga = idmap_a[out[0, :n].long()]
+            gb = idmap_b[out[1, :n].long()]
+            D.gather_pairs(ga, gb)
         return n
 
     def sync_all():
@@ -216,26 +262,7 @@ def main() -> None:
 
         cpu_baseline = None
         if not args.no_cpu_baseline:
-            from oracle import pyoracle as ora
-
-            sample = [int(c) for c in args.cpu_sample_chroms.split(",") if c != ""]
-            sa = synth.make_table(n_a, seed_a, kind_a, chroms=sample)
-            sb = synth.make_table(n_b, seed_b, kind_b, chroms=sample)
-            threads = ora.max_threads()
-            oa, ob = ora.Side(*sa), ora.Side(*sb)
-            t1 = time.perf_counter()
-            ra, rb = ora.c_inner(oa, ob, "sweep", threads=threads)
-            cpu_s = time.perf_counter() - t1
-            cpu_baseline = {
-                "value": round(ra.shape[0] / cpu_s, 1),
-                "unit": "pairs/s",
-                "cores": threads,
-                "kind": "port",
-                "sample": (f"chromosome ids {sample} of the same workload: {oa.n} x {ob.n} rows -> "
-                           f"{ra.shape[0]} pairs in {cpu_s:.2f} s (oracle OpenMP sort-merge port, "
-                           "not DuckDB: duckdb is not installed on the box)"),
-                "host_cpu_count": os.cpu_count(),
-            }
+            cpu_baseline = run_cpu_baseline(args, n_a, kind_a, seed_a, n_b, kind_b, seed_b)
 
         value = n_pairs * args.steps / elapsed
         line = {
