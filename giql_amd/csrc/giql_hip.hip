@@ -49,9 +49,7 @@ static int set_err(int code, const char* fmt, ...) {
 
 // tile shapes per class: class 1 = many queries with ~0.5 match each (B rows as
 // queries), class 2 = fewer queries with tens of matches each (A rows)
-constexpr int RC_ITEMS_C1 = 8;     // 2048 B-queries per count block
 constexpr int RC_ITEMS_C2 = 2;     // 512 A-queries per count block
-constexpr int FILL_ITEMS_C1 = 2;   // 512 outputs per fill block
 constexpr int FILL_ITEMS_C2 = 16;  // 4096 outputs per fill block
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -62,6 +60,17 @@ struct SortBufs {
   u32* key[2];
   u32* end[2];
   u32* rid[2];
+};
+
+// Device pointers kept between inner_plan and inner_fill (all inside the arena).
+struct InnerState {
+  SortBufs sa, sb;   // sorted (key, end, rid) of A / B in buffer 0
+  u32 nt1 = 0, nt2 = 0;
+  u32* wlo1 = nullptr;   // class-1 S-window starts per block
+  u64* c1_base = nullptr;  // class-1 output base per block
+  u32* wlo2 = nullptr;
+  u32* lo2 = nullptr;    // class-2 first matching B index per A row
+  u64* off2 = nullptr;   // class-2 exclusive output offsets
 };
 
 struct giql_hip_ctx {
@@ -93,10 +102,7 @@ struct giql_hip_ctx {
   u32 n_a = 0, n_b = 0;
   int n_chrom = 0;
   u64 n_reg = 0, n_irr = 0, n_c1 = 0;
-  u64* off = nullptr;
-  u32* lo = nullptr;
-  u32* rid_a_sorted = nullptr;
-  u32* rid_b_sorted = nullptr;
+  InnerState inner;
   u32* irr_a_list = nullptr;
   u32* irr_b_list = nullptr;
   u64* irr_off = nullptr;
@@ -262,15 +268,17 @@ static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, 
                          const LinBufs& lb, u32* keys, u32* ends, u32* irr_list, int which,
                          int keep_irregular, u32* hist_partial = nullptr, u32* gbase = nullptr) {
   if (s.n == 0) return GIQL_OK;
+  if (hist_partial)
+    HIP_TRY(hipMemsetAsync(hist_partial, 0, (size_t)LIN_HIST_REPLICAS * 1024 * sizeof(u32), st));
   Phase ph(ctx, st, GIQL_PH_LINEARIZE, hist_partial ? 2 : 1);
   u32 grid = cdiv((u64)s.n, LIN_NT);
-  const u32 cap = hist_partial ? (u32)LIN_MAX_BLOCKS : 8192u;
-  if (grid > cap) grid = cap;
+  if (grid > (u32)LIN_MAX_BLOCKS) grid = LIN_MAX_BLOCKS;
   hipLaunchKernelGGL(k_linearize, dim3(grid), dim3(LIN_NT), 0, st, s.chrom, s.start, s.end,
                      (u32)s.n, s.start_off, s.end_off, n_chrom, lb.chrom_base, keys, ends, irr_list,
                      ctx->d_meta, which, keep_irregular, hist_partial);
   if (hist_partial)
-    hipLaunchKernelGGL(k_digit_offsets, dim3(1), dim3(256), 0, st, hist_partial, grid, gbase);
+    hipLaunchKernelGGL(k_digit_offsets, dim3(1), dim3(256), 0, st, hist_partial,
+                       (u32)LIN_HIST_REPLICAS, gbase);
   return post_launch("linearize");
 }
 
@@ -463,7 +471,7 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
   ctx->n_a = (u32)a->n;
   ctx->n_b = (u32)b->n;
   ctx->n_chrom = n_chrom;
-  ctx->n_reg = ctx->n_irr = 0;
+  ctx->n_reg = ctx->n_irr = ctx->n_c1 = 0;
   *n_pairs = 0;
   if (a->n == 0 || b->n == 0 || n_chrom == 0) {  // empty result (tests :4173-4229)
     ctx->planned = true;
@@ -473,25 +481,26 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
 
   // ---- carve the arena (dry run for the size, then for real)
   LinBufs lb;
-  SortBufs sa, sbb;
-  u32 *tile_hist = nullptr, *cnt = nullptr, *irr_cnt = nullptr;
+  InnerState& S = ctx->inner;
+  u32 *tile_hist = nullptr, *cnt2 = nullptr, *irr_cnt = nullptr;
   u32 *hist_a = nullptr, *hist_b = nullptr, *gbase_a = nullptr, *gbase_b = nullptr;
-  u32 *os_status = nullptr, *os_tickets = nullptr, *wlo1 = nullptr, *wlo2 = nullptr;
+  u32 *os_status = nullptr, *os_tickets = nullptr;
   u64* bsums = nullptr;
   const bool onesweep = !ctx->classic_sort && na <= OS_MAX_ROWS && nb <= OS_MAX_ROWS;
   const size_t n_max = na > nb ? na : nb;
   const size_t n_tiles_max = cdiv(n_max, RS_TILE);
   const size_t scan_max = (nq > n_tiles_max * RS_BINS ? nq : n_tiles_max * RS_BINS);
-  constexpr u32 TQ1 = RC_NT * RC_ITEMS_C1, TQ2 = RC_NT * RC_ITEMS_C2;
-  const u32 nt1 = cdiv(nb, TQ1), nt2 = cdiv(na, TQ2);
+  constexpr u32 TQ2 = RC_NT * RC_ITEMS_C2;
+  S.nt1 = cdiv(nb, C1_TQ);
+  S.nt2 = cdiv(na, TQ2);
   auto carve = [&](char* base) {
     Carver c{base};
     common_sizes(c, n_chrom, lb);
-    sort_sizes(c, na, sa, true);
-    sort_sizes(c, nb, sbb, true);
+    sort_sizes(c, na, S.sa, true);
+    sort_sizes(c, nb, S.sb, true);
     if (onesweep) {
-      hist_a = c.take<u32>((size_t)LIN_MAX_BLOCKS * 1024);
-      hist_b = c.take<u32>((size_t)LIN_MAX_BLOCKS * 1024);
+      hist_a = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
+      hist_b = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
       gbase_a = c.take<u32>(1024);
       gbase_b = c.take<u32>(1024);
       os_status = c.take<u32>((size_t)cdiv(n_max, OS_TILE) * OS_BINS);
@@ -500,20 +509,23 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
       tile_hist = c.take<u32>(n_tiles_max * RS_BINS);
     }
     bsums = c.take<u64>(cdiv(scan_max, SCAN_TILE) + 2);
-    cnt = c.take<u32>(nq);
-    ctx->lo = c.take<u32>(nq);
-    ctx->off = c.take<u64>(nq + 1);
-    wlo1 = c.take<u32>((size_t)nt1 + 2);
-    wlo2 = c.take<u32>((size_t)nt2 + 2);
+    S.wlo1 = c.take<u32>((size_t)S.nt1 + 2);
+    S.c1_base = c.take<u64>((size_t)S.nt1 + 2);
+    S.wlo2 = c.take<u32>((size_t)S.nt2 + 2);
+    cnt2 = c.take<u32>(na);
+    S.lo2 = c.take<u32>(na);
+    S.off2 = c.take<u64>(na + 1);
     ctx->irr_a_list = c.take<u32>(na);
     ctx->irr_b_list = c.take<u32>(nb);
-    irr_cnt = cnt;  // reused after the regular scan
+    irr_cnt = c.take<u32>(nq);
     ctx->irr_off = c.take<u64>(nq + 1);
     return c.off;
   };
   const size_t need = carve(nullptr);
   GIQL_TRY(ensure_arena(ctx, need, st));
   carve(ctx->arena);
+  SortBufs& sa = S.sa;
+  SortBufs& sbb = S.sb;
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
   GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], ctx->irr_a_list, 0, 0,
@@ -527,31 +539,36 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
     GIQL_TRY(run_sort(ctx, st, sa, (u32)na, tile_hist, bsums));
     GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
   }
-  ctx->rid_a_sorted = sa.rid[0];
-  ctx->rid_b_sorted = sbb.rid[0];
+  const u32* irr_a = &ctx->d_meta->irr_a;
+  const u32* irr_b = &ctx->d_meta->irr_b;
   {
     Phase ph(ctx, st, GIQL_PH_COUNT, 4);
-    const u32* irr_a = &ctx->d_meta->irr_a;
-    const u32* irr_b = &ctx->d_meta->irr_b;
-    // class 1: queries = sorted B, points = sorted A starts, range [b.start, b.end)
-    hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)nt1 + 1, 256)), dim3(256), 0, st, sbb.key[0],
-                       (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, 0u, TQ1, nt1, wlo1);
-    hipLaunchKernelGGL((k_range_count<RC_ITEMS_C1>), dim3(nt1), dim3(RC_NT), 0, st, sbb.key[0],
-                       sbb.end[0], (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, 0u, wlo1, ctx->lo, cnt);
+    // class 1: queries = sorted B, points = sorted A starts, range [b.start, b.end);
+    // only one total per block is kept (see k_c1_count)
+    hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt1 + 1, 256)), dim3(256), 0, st,
+                       sbb.key[0], (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, 0u, (u32)C1_TQ, S.nt1,
+                       S.wlo1);
+    hipLaunchKernelGGL(k_c1_count, dim3(S.nt1), dim3(RC_NT), 0, st, sbb.key[0], sbb.end[0], (u32)nb,
+                       irr_b, sa.key[0], (u32)na, irr_a, S.wlo1, S.c1_base);
     // class 2: queries = sorted A, points = sorted B starts, range (a.start, a.end)
-    hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)nt2 + 1, 256)), dim3(256), 0, st, sa.key[0],
-                       (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, 1u, TQ2, nt2, wlo2);
-    hipLaunchKernelGGL((k_range_count<RC_ITEMS_C2>), dim3(nt2), dim3(RC_NT), 0, st, sa.key[0],
-                       sa.end[0], (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, 1u, wlo2,
-                       ctx->lo + nb, cnt + nb);
+    hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt2 + 1, 256)), dim3(256), 0, st,
+                       sa.key[0], (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, 1u, TQ2, S.nt2, S.wlo2);
+    hipLaunchKernelGGL((k_range_count<RC_ITEMS_C2, RC_LDS_CAP>), dim3(S.nt2), dim3(RC_NT), 0, st,
+                       sa.key[0], sa.end[0], (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, 1u, S.wlo2,
+                       S.lo2, cnt2);
     GIQL_TRY(post_launch("range count"));
   }
-  GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt, nq, ctx->off, bsums, ctx->off + nq));
-  HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out, ctx->off + nq, sizeof(u64), hipMemcpyDeviceToDevice, st));
-  HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out_c1, ctx->off + nb, sizeof(u64), hipMemcpyDeviceToDevice, st));
+  {
+    Phase ph(ctx, st, GIQL_PH_SCAN);
+    // class-1 block totals -> block bases (one block, in place); total -> n_out_c1
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, S.c1_base, S.nt1,
+                       &ctx->d_meta->n_out_c1);
+  }
+  GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt2, na, S.off2, bsums, S.off2 + na));
+  HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out, S.off2 + na, sizeof(u64), hipMemcpyDeviceToDevice, st));
   GIQL_TRY(read_meta(ctx, st));
-  ctx->n_reg = ctx->h_meta->n_out;
   ctx->n_c1 = ctx->h_meta->n_out_c1;
+  ctx->n_reg = ctx->h_meta->n_out + ctx->n_c1;
   ctx->stats.n_irregular_a = ctx->h_meta->irr_a;
   ctx->stats.n_irregular_b = ctx->h_meta->irr_b;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
@@ -590,13 +607,17 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   const u32 nq = ctx->n_a + ctx->n_b;
-  if (ctx->n_reg > 0) {
-    constexpr u32 T1 = FILL_NT * FILL_ITEMS_C1, T2 = FILL_NT * FILL_ITEMS_C2;
-    const u64 p1 = ctx->n_c1, p2 = ctx->n_reg - ctx->n_c1;
-    const u64 nt1_64 = (p1 + T1 - 1) / T1, nt2_64 = (p2 + T2 - 1) / T2;
-    if (nt1_64 + nt2_64 > 0x7FFFFFF0ull) return set_err(GIQL_ERR_INVALID, "output too large");
-    const u32 nt1 = (u32)nt1_64, nt2 = (u32)nt2_64;
-    const size_t part_need = (size_t)nt1 + nt2 + 2;
+  InnerState& S = ctx->inner;
+  const u32* irr_a = &ctx->d_meta->irr_a;
+  const u32* irr_b = &ctx->d_meta->irr_b;
+  const u64 p1 = ctx->n_c1, p2 = ctx->n_reg - ctx->n_c1;
+  u32 nt2 = 0;
+  if (p2 > 0) {
+    constexpr u32 T2 = FILL_NT * FILL_ITEMS_C2;
+    const u64 nt2_64 = (p2 + T2 - 1) / T2;
+    if (nt2_64 > 0x7FFFFFF0ull) return set_err(GIQL_ERR_INVALID, "output too large");
+    nt2 = (u32)nt2_64;
+    const size_t part_need = (size_t)nt2 + 2;
     if (part_need > ctx->part_cap) {
       HIP_TRY(hipStreamSynchronize(st));
       if (ctx->part) HIP_TRY(hipFree(ctx->part));
@@ -606,30 +627,22 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
       HIP_TRY(hipMalloc((void**)&ctx->part, want * sizeof(u32)));
       ctx->part_cap = want;
     }
-    u32* part1 = ctx->part;
-    u32* part2 = ctx->part + nt1 + 1;
-    {
-      Phase ph(ctx, st, GIQL_PH_PARTITION, 2);
-      if (nt1)
-        hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt1 + 1, 256)), dim3(256), 0, st, ctx->off,
-                           ctx->n_b, (u64)0, T1, nt1, part1);
-      if (nt2)
-        hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt2 + 1, 256)), dim3(256), 0, st,
-                           ctx->off + ctx->n_b, ctx->n_a, p1, T2, nt2, part2);
-    }
-    {
-      Phase ph(ctx, st, GIQL_PH_FILL, 2);
-      // class 1: query = B row, matches = A rows
-      if (nt1)
-        hipLaunchKernelGGL((k_fill<FILL_ITEMS_C1>), dim3(nt1), dim3(FILL_NT), 0, st, ctx->off,
-                           ctx->lo, ctx->rid_b_sorted, ctx->n_b, ctx->rid_a_sorted, part1, (u64)0, p1,
-                           row_b, row_a);
-      // class 2: query = A row, matches = B rows
-      if (nt2)
-        hipLaunchKernelGGL((k_fill<FILL_ITEMS_C2>), dim3(nt2), dim3(FILL_NT), 0, st,
-                           ctx->off + ctx->n_b, ctx->lo + ctx->n_b, ctx->rid_a_sorted, ctx->n_a,
-                           ctx->rid_b_sorted, part2, p1, p2, row_a, row_b);
-    }
+    Phase ph(ctx, st, GIQL_PH_PARTITION);
+    hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt2 + 1, 256)), dim3(256), 0, st, S.off2, ctx->n_a,
+                       (u64)0, T2, nt2, ctx->part);
+  }
+  {
+    Phase ph(ctx, st, GIQL_PH_FILL, 2);
+    // class 1 -> outputs [0, p1): query = B row, matches = A rows
+    if (p1 > 0)
+      hipLaunchKernelGGL(k_c1_emit, dim3(S.nt1), dim3(RC_NT), 0, st, S.sb.key[0], S.sb.end[0],
+                         S.sb.rid[0], ctx->n_b, irr_b, S.sa.key[0], S.sa.rid[0], ctx->n_a, irr_a,
+                         S.wlo1, S.c1_base, (u64)0, row_b, row_a);
+    // class 2 -> outputs [p1, p1 + p2): query = A row, matches = B rows
+    if (p2 > 0)
+      hipLaunchKernelGGL((k_fill<FILL_ITEMS_C2>), dim3(nt2), dim3(FILL_NT), 0, st, S.off2, S.lo2,
+                         S.sa.rid[0], ctx->n_a, S.sb.rid[0], ctx->part, (u64)0, p2, row_a + p1,
+                         row_b + p1);
     GIQL_TRY(post_launch("fill"));
   }
   if (ctx->n_irr > 0) {

@@ -154,15 +154,17 @@ __global__ __launch_bounds__(256) void k_chrom_offsets(const int* __restrict__ g
 
 // -------------------------------------------------------------- linearise
 constexpr int LIN_NT = 256;
-constexpr int LIN_MAX_BLOCKS = 1024;  // partial histograms: [block][4][256]
+constexpr int LIN_MAX_BLOCKS = 8192;
+constexpr int LIN_HIST_REPLICAS = 64;  // ghist[replica][4][256], block b adds to b % 64
 
 // keys[i] = linearised canonical start, ends[i] = linearised canonical end.
 // Irregular rows (canonical end <= start) get the sentinel key and are appended
 // to irr_list -- unless keep_irregular, where every row keeps its real key (the
 // prefix-max operators are exact for any row).  which = 0 for side A, 1 for B.
 // keys / ends may be NULL (only the irregular list is wanted).
-// hist_partial (optional): this block's 4 x 256 digit histogram of the keys it
-// produced, for the onesweep sort (no global atomics: k_digit_offsets sums them).
+// hist_partial (optional): 64 replicas of the 4 x 256 digit histogram of the keys
+// (for the onesweep sort); each block adds its LDS histogram to one replica, so an
+// address sees at most grid/64 adds; k_digit_offsets sums the replicas.
 __global__ __launch_bounds__(LIN_NT) void k_linearize(
     const int* __restrict__ chrom, const int* __restrict__ start, const int* __restrict__ end, u32 n,
     int start_off, int end_off, int n_chrom, const i64* __restrict__ chrom_base,
@@ -226,18 +228,22 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
   }
   if (hist_partial) {
     __syncthreads();
+    u32* g = hist_partial + (size_t)(blockIdx.x % LIN_HIST_REPLICAS) * 1024;
 #pragma unroll
-    for (int k = threadIdx.x; k < 4 * 256; k += LIN_NT)
-      hist_partial[(size_t)blockIdx.x * 1024 + k] = s_hist[k];
+    for (int k = threadIdx.x; k < 4 * 256; k += LIN_NT) {
+      const u32 v = s_hist[k];
+      if (v) atomicAdd(&g[k], v);
+    }
   }
 }
 
-// Single block: gbase[p][d] = exclusive scan over d of sum_b partial[b][p][d].
+// Single block: gbase[p][d] = exclusive scan over d of sum_r replica[r][p][d].
 __global__ __launch_bounds__(256) void k_digit_offsets(const u32* __restrict__ partial, u32 n_blocks,
                                                         u32* __restrict__ gbase) {
   __shared__ u32 lds[256 / WAVE + 1];
   for (int p = 0; p < 4; p++) {
     u32 c = 0;
+#pragma unroll 8
     for (u32 b = 0; b < n_blocks; b++) c += partial[(size_t)b * 1024 + p * 256 + threadIdx.x];
     u32 total;
     const u32 ex = block_excl_scan<u32, 256>(c, lds, total);
@@ -265,57 +271,201 @@ __global__ void k_count_partition(const u32* __restrict__ qs, u32 nq_total,
   w_lo[t] = (t < n_tiles && q < nq) ? lower_bound_u32(ss, 0, ns, qs[q] + lo_off) : ns;
 }
 
+// Shared by the count / emit kernels: the block's S window [w0, w0 + len) staged
+// in LDS; lower_bound over [w0, ns) searches the staged part first and finishes
+// in HBM only when the bound falls past it.
+struct SWindow {
+  const u32* __restrict__ ss;
+  const u32* s_tile;
+  u32 w0, len, ns, last, w_end;
+  __device__ __forceinline__ void bounds(u32 xs, u32 xe, u32& lo, u32& hi) const {
+    if (len && last >= xs)
+      lo = w0 + lower_bound_u32(s_tile, 0, len, xs);
+    else
+      lo = lower_bound_u32(ss, w_end, ns, xs);
+    if (lo < w_end && last >= xe)
+      hi = w0 + lower_bound_u32(s_tile, lo - w0, len, xe);
+    else
+      hi = lower_bound_u32(ss, lo > w_end ? lo : w_end, ns, xe);
+  }
+};
+
+template <int CAP>
+__device__ __forceinline__ SWindow stage_window(const u32* __restrict__ ss, u32 ns, u32 w0, u32 w1,
+                                                u32* s_tile) {
+  u32 len = ns - w0;
+  const u64 want = (u64)(w1 - w0) + RC_MARGIN;
+  if (want < len) len = (u32)want;
+  if (len > (u32)CAP) len = CAP;
+  for (u32 k = threadIdx.x; k < len; k += RC_NT) s_tile[k] = ss[w0 + k];
+  __syncthreads();
+  SWindow w;
+  w.ss = ss;
+  w.s_tile = s_tile;
+  w.w0 = w0;
+  w.len = len;
+  w.ns = ns;
+  w.last = len ? s_tile[len - 1] : 0u;
+  w.w_end = w0 + len;
+  return w;
+}
+
 // For the sorted queries of one block, count the points of the sorted set S in
 // [qs + lo_off, qe).  lo_off = 0 is class 1 (closed low end), 1 is class 2.
 // Writes lo (first matching index in S) and cnt.  Rows past the regular prefix
 // (sentinel keys) get cnt = 0.  The block's S window [w_lo[t], w_lo[t+1] +
 // margin) is staged in LDS and searched per lane there (LDS tile + per-lane
 // binary search); a bound that falls past the staged part is finished in HBM.
-template <int ITEMS>
+template <int ITEMS, int CAP>
 __global__ __launch_bounds__(RC_NT) void k_range_count(
     const u32* __restrict__ qs, const u32* __restrict__ qe, u32 nq_total,
     const u32* __restrict__ irr_q, const u32* __restrict__ ss, u32 ns_total,
     const u32* __restrict__ irr_s, u32 lo_off, const u32* __restrict__ w_lo_arr,
     u32* __restrict__ lo_out, u32* __restrict__ cnt_out) {
   constexpr u32 TQ = RC_NT * ITEMS;
-  __shared__ u32 s_tile[RC_LDS_CAP];
+  __shared__ u32 s_tile[CAP];
   const u32 nq = nq_total - *irr_q;
   const u32 ns = ns_total - *irr_s;
   const u32 q0 = blockIdx.x * TQ;
   const u32 tid = threadIdx.x;
-  const u32 w0 = w_lo_arr[blockIdx.x];
-  const u32 w1 = w_lo_arr[blockIdx.x + 1];
-  u32 len = (ns - w0);
-  {
-    const u64 want = (u64)(w1 - w0) + RC_MARGIN;
-    if (want < len) len = (u32)want;
-    if (len > (u32)RC_LDS_CAP) len = RC_LDS_CAP;
+  u32 xs[ITEMS], xe[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    const u32 q = q0 + i * RC_NT + tid;
+    const bool ok = q < nq;
+    xs[i] = ok ? qs[q] + lo_off : U32_MAX;
+    xe[i] = ok ? qe[q] : U32_MAX;
   }
-  for (u32 k = tid; k < len; k += RC_NT) s_tile[k] = ss[w0 + k];
-  __syncthreads();
-  const u32 last = len ? s_tile[len - 1] : 0u;
-  const u32 w_end = w0 + len;  // first S index that is NOT staged
+  const SWindow w = stage_window<CAP>(ss, ns, w_lo_arr[blockIdx.x], w_lo_arr[blockIdx.x + 1], s_tile);
 #pragma unroll
   for (int i = 0; i < ITEMS; i++) {
     const u32 q = q0 + i * RC_NT + tid;
     if (q >= nq_total) continue;
-    u32 lo = 0, cnt = 0;
-    if (q < nq) {
-      const u32 xs = qs[q] + lo_off, xe = qe[q];
-      // lower_bound(S, x) over [w0, ns): staged part first
-      if (len && last >= xs)
-        lo = w0 + lower_bound_u32(s_tile, 0, len, xs);
-      else
-        lo = lower_bound_u32(ss, w_end, ns, xs);
-      u32 hi;
-      if (lo < w_end && last >= xe)
-        hi = w0 + lower_bound_u32(s_tile, lo - w0, len, xe);
-      else
-        hi = lower_bound_u32(ss, lo > w_end ? lo : w_end, ns, xe);
-      cnt = hi - lo;
-    }
+    u32 lo = 0, hi = 0;
+    if (q < nq) w.bounds(xs[i], xe[i], lo, hi);
     lo_out[q] = lo;
-    cnt_out[q] = cnt;
+    cnt_out[q] = hi - lo;
+  }
+}
+
+// ---- class 1 without per-row arrays -------------------------------------------
+// Class-1 queries are the B rows (the big side) and most of them match nothing,
+// so materialising (lo, cnt, offset) per row costs more HBM traffic than the pairs
+// they describe.  Instead: k_c1_count writes one total per block, a tiny scan
+// turns those into block bases, and k_c1_emit recomputes the bounds (an LDS search
+// over a ~200-entry window) and writes the pairs straight away.
+constexpr int C1_ITEMS = 8;
+constexpr int C1_TQ = RC_NT * C1_ITEMS;  // 2048 B rows per block
+constexpr int C1_CAP = 3072;             // staged A starts (12 KB)
+constexpr u32 C1_COOP = 16;              // matches per row above which a wave co-writes
+
+__global__ __launch_bounds__(RC_NT) void k_c1_count(
+    const u32* __restrict__ qs, const u32* __restrict__ qe, u32 nq_total,
+    const u32* __restrict__ irr_q, const u32* __restrict__ ss, u32 ns_total,
+    const u32* __restrict__ irr_s, const u32* __restrict__ w_lo_arr, u64* __restrict__ block_sum) {
+  __shared__ u32 s_tile[C1_CAP];
+  __shared__ u64 s_red[RC_NT / WAVE];
+  const u32 nq = nq_total - *irr_q;
+  const u32 ns = ns_total - *irr_s;
+  const u32 q0 = blockIdx.x * C1_TQ;
+  const u32 tid = threadIdx.x;
+  u32 xs[C1_ITEMS], xe[C1_ITEMS];
+#pragma unroll
+  for (int i = 0; i < C1_ITEMS; i++) {
+    const u32 q = q0 + i * RC_NT + tid;
+    const bool ok = q < nq;
+    xs[i] = ok ? qs[q] : U32_MAX;
+    xe[i] = ok ? qe[q] : U32_MAX;
+  }
+  const SWindow w = stage_window<C1_CAP>(ss, ns, w_lo_arr[blockIdx.x], w_lo_arr[blockIdx.x + 1], s_tile);
+  u64 total = 0;
+#pragma unroll
+  for (int i = 0; i < C1_ITEMS; i++) {
+    const u32 q = q0 + i * RC_NT + tid;
+    if (q < nq) {
+      u32 lo, hi;
+      w.bounds(xs[i], xe[i], lo, hi);
+      total += hi - lo;
+    }
+  }
+  total = wave_reduce_sum(total);
+  if (lane_id() == 0) s_red[wave_id()] = total;
+  __syncthreads();
+  if (tid == 0) {
+    u64 t = 0;
+#pragma unroll
+    for (int k = 0; k < RC_NT / WAVE; k++) t += s_red[k];
+    block_sum[blockIdx.x] = t;
+  }
+}
+
+// block_base[] = exclusive scan of block_sum.  Output slots of a block are given
+// out thread by thread (item order), so every slot is written exactly once; rows
+// with many matches are written cooperatively by their wave (coalesced).
+__global__ __launch_bounds__(RC_NT) void k_c1_emit(
+    const u32* __restrict__ qs, const u32* __restrict__ qe, const u32* __restrict__ q_rid,
+    u32 nq_total, const u32* __restrict__ irr_q, const u32* __restrict__ ss,
+    const u32* __restrict__ s_rid, u32 ns_total, const u32* __restrict__ irr_s,
+    const u32* __restrict__ w_lo_arr, const u64* __restrict__ block_base, u64 out_base,
+    int32_t* __restrict__ row_q, int32_t* __restrict__ row_s) {
+  __shared__ u32 s_tile[C1_CAP];
+  __shared__ u64 s_scan[RC_NT / WAVE + 1];
+  const u32 nq = nq_total - *irr_q;
+  const u32 ns = ns_total - *irr_s;
+  const u32 q0 = blockIdx.x * C1_TQ;
+  const u32 tid = threadIdx.x;
+  u32 xs[C1_ITEMS], xe[C1_ITEMS], rid[C1_ITEMS];
+#pragma unroll
+  for (int i = 0; i < C1_ITEMS; i++) {
+    const u32 q = q0 + i * RC_NT + tid;
+    const bool ok = q < nq;
+    xs[i] = ok ? qs[q] : U32_MAX;
+    xe[i] = ok ? qe[q] : U32_MAX;
+    rid[i] = ok ? q_rid[q] : 0u;
+  }
+  const SWindow w = stage_window<C1_CAP>(ss, ns, w_lo_arr[blockIdx.x], w_lo_arr[blockIdx.x + 1], s_tile);
+  u32 lo[C1_ITEMS], cnt[C1_ITEMS];
+  u64 mine = 0;
+#pragma unroll
+  for (int i = 0; i < C1_ITEMS; i++) {
+    const u32 q = q0 + i * RC_NT + tid;
+    lo[i] = 0;
+    cnt[i] = 0;
+    if (q < nq) {
+      u32 hi;
+      w.bounds(xs[i], xe[i], lo[i], hi);
+      cnt[i] = hi - lo[i];
+    }
+    mine += cnt[i];
+  }
+  u64 total;
+  u64 o = out_base + block_base[blockIdx.x] + block_excl_scan<u64, RC_NT>(mine, s_scan, total);
+  if (total == 0) return;  // block-uniform
+#pragma unroll
+  for (int i = 0; i < C1_ITEMS; i++) {
+    const u32 c = cnt[i];
+    const bool big = c > C1_COOP;
+    if (!big) {
+      for (u32 k = 0; k < c; k++) {
+        row_q[o + k] = (int32_t)rid[i];
+        row_s[o + k] = (int32_t)s_rid[lo[i] + k];
+      }
+    }
+    // rows with many matches: the whole wave writes them, 64 pairs per step
+    u64 m = __ballot(big);
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const u32 c2 = __shfl(c, src, WAVE);
+      const u32 lo2 = __shfl(lo[i], src, WAVE);
+      const u32 rid2 = __shfl(rid[i], src, WAVE);
+      const u64 o2 = __shfl(o, src, WAVE);
+      for (u32 k = lane_id(); k < c2; k += WAVE) {
+        row_q[o2 + k] = (int32_t)rid2;
+        row_s[o2 + k] = (int32_t)s_rid[lo2 + k];
+      }
+    }
+    o += c;
   }
 }
 

@@ -22,11 +22,11 @@
 
 namespace giql {
 
-constexpr int OS_NT = 512;
-constexpr int OS_ITEMS = 16;
-constexpr int OS_TILE = OS_NT * OS_ITEMS;  // 8192
+constexpr int OS_NT = 1024;  // 16 waves: half the per-wave serial work of 512 x 16
+constexpr int OS_ITEMS = 8;
+constexpr int OS_TILE = OS_NT * OS_ITEMS;  // 8192 rows per tile
 constexpr int OS_BINS = 256;
-constexpr int OS_NW = OS_NT / WAVE;  // 8
+constexpr int OS_NW = OS_NT / WAVE;  // 16
 constexpr u32 OS_FLAG_AGG = 1u << 30;
 constexpr u32 OS_FLAG_PREFIX = 2u << 30;
 constexpr u32 OS_VALUE_MASK = (1u << 30) - 1u;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(OS_NT) void k_onesweep(
   if (tile_base >= n) return;  // block-uniform (cannot happen: grid = n_tiles)
   const u32 n_valid = (n - tile_base) < (u32)OS_TILE ? (n - tile_base) : (u32)OS_TILE;
 
-  // wave-striped: item i of lane l of wave w is row w*1024 + i*64 + l
+  // wave-striped: item i of lane l of wave w is row w*(ITEMS*64) + i*64 + l
   u32 key[OS_ITEMS], end[OS_ITEMS], rid[OS_ITEMS];
   const u32 wbase = w * (OS_ITEMS * WAVE);
 #pragma unroll
