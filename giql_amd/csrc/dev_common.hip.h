@@ -58,6 +58,15 @@ __device__ __forceinline__ u32 wave_reduce_max_u32(u32 v) {
   return v;
 }
 
+__device__ __forceinline__ u32 wave_incl_scan_max_u32(u32 v) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const u32 t = __shfl_up(v, d, WAVE);
+    if ((int)lane_id() >= d) v = t > v ? t : v;
+  }
+  return v;
+}
+
 // Exclusive scan over the NT threads of a block.  `lds` holds NT/64 + 1 items.
 // Returns the exclusive prefix of v; `total` receives the block sum.
 template <typename T, int NT>
