@@ -584,7 +584,15 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
     if (p_w0 >= tile_len) return;  // wave-uniform; no barrier follows
     // last row whose outputs start at or before this wave's first output
     u32 k_cur = upper_bound_u32(s_rel, 0, nqt, p_w0) - 1;
-    for (u32 pc = p_w0; pc < p_w0 + PER_WAVE && pc < tile_len; pc += WAVE) {
+    constexpr int NWIN = PER_WAVE / WAVE;
+    u32 jj[NWIN], qr[NWIN];
+    // phase A (LDS only): which row does each of my NWIN outputs belong to
+#pragma unroll
+    for (int it = 0; it < NWIN; it++) {
+      const u32 pc = p_w0 + it * WAVE;
+      jj[it] = 0;
+      qr[it] = 0;
+      if (pc >= tile_len) continue;  // wave-uniform
       mark[lane] = 0;
       __builtin_amdgcn_wave_barrier();
       // rows k_cur+1, k_cur+2, ... that start inside [pc, pc + 64)
@@ -601,13 +609,25 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
       const u32 kd = wave_incl_scan_max_u32(mark[lane]);
       const u32 k = k_cur + kd;
       const u32 p_rel = pc + lane;
-      if (p_rel < tile_len) {
-        const u32 j = s_lo[k] + (k == 0 ? p_rel + first_delta : p_rel - s_rel[k]);
-        const u64 o = tile_start + p_rel;
-        row_q[o] = (int32_t)s_qrid[k];
-        row_s[o] = (int32_t)s_rid[j];
-      }
+      jj[it] = s_lo[k] + (k == 0 ? p_rel + first_delta : p_rel - s_rel[k]);
+      qr[it] = s_qrid[k];
       k_cur = __shfl(k, WAVE - 1, WAVE);
+    }
+    // phase B: all gathers in flight together, then the coalesced stores
+    u32 sr[NWIN];
+#pragma unroll
+    for (int it = 0; it < NWIN; it++) {
+      const u32 p_rel = p_w0 + it * WAVE + lane;
+      sr[it] = p_rel < tile_len ? s_rid[jj[it]] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < NWIN; it++) {
+      const u32 p_rel = p_w0 + it * WAVE + lane;
+      if (p_rel < tile_len) {
+        const u64 o = tile_start + p_rel;
+        row_q[o] = (int32_t)qr[it];
+        row_s[o] = (int32_t)sr[it];
+      }
     }
     return;
   }
