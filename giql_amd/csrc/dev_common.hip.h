@@ -32,15 +32,6 @@ __device__ __forceinline__ u32 lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-template <typename T>
-__device__ __forceinline__ T wave_incl_scan(T v) {
-#pragma unroll
-  for (int d = 1; d < WAVE; d <<= 1) {
-    T t = __shfl_up(v, d, WAVE);
-    if ((int)lane_id() >= d) v += t;
-  }
-  return v;
-}
 
 template <typename T>
 __device__ __forceinline__ T wave_reduce_sum(T v) {
@@ -58,13 +49,56 @@ __device__ __forceinline__ u32 wave_reduce_max_u32(u32 v) {
   return v;
 }
 
+// DPP controls (GCN wave64): shift right inside a 16-lane row, and the two
+// cross-row broadcasts that finish a 64-lane scan.  bound_ctrl = true makes lanes
+// with no source read 0, the identity of unsigned max and of +.
+#define GIQL_DPP_ROW_SHR(n) (0x110 + (n))
+#define GIQL_DPP_ROW_BCAST15 0x142
+#define GIQL_DPP_ROW_BCAST31 0x143
+
+// 64-lane inclusive max-scan in 6 VALU+DPP instructions (a __shfl_up scan costs
+// 6 dependent ds_bpermute round trips through the LDS crossbar).
 __device__ __forceinline__ u32 wave_incl_scan_max_u32(u32 v) {
+  u32 t;
+  t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, GIQL_DPP_ROW_SHR(1), 0xF, 0xF, true);
+  v = t > v ? t : v;
+  t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, GIQL_DPP_ROW_SHR(2), 0xF, 0xF, true);
+  v = t > v ? t : v;
+  t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, GIQL_DPP_ROW_SHR(4), 0xF, 0xF, true);
+  v = t > v ? t : v;
+  t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, GIQL_DPP_ROW_SHR(8), 0xF, 0xF, true);
+  v = t > v ? t : v;
+  // lane 15 of row r -> all lanes of row r+1 (rows 1 and 3), then lane 31 -> rows 2,3
+  t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, GIQL_DPP_ROW_BCAST15, 0xA, 0xF, false);
+  v = t > v ? t : v;
+  t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, GIQL_DPP_ROW_BCAST31, 0xC, 0xF, false);
+  v = t > v ? t : v;
+  return v;
+}
+
+// Same structure for + on u32.
+__device__ __forceinline__ u32 wave_incl_scan_add_u32(u32 v) {
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, GIQL_DPP_ROW_SHR(1), 0xF, 0xF, true);
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, GIQL_DPP_ROW_SHR(2), 0xF, 0xF, true);
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, GIQL_DPP_ROW_SHR(4), 0xF, 0xF, true);
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, GIQL_DPP_ROW_SHR(8), 0xF, 0xF, true);
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, GIQL_DPP_ROW_BCAST15, 0xA, 0xF, false);
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, GIQL_DPP_ROW_BCAST31, 0xC, 0xF, false);
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T v) {
 #pragma unroll
   for (int d = 1; d < WAVE; d <<= 1) {
-    const u32 t = __shfl_up(v, d, WAVE);
-    if ((int)lane_id() >= d) v = t > v ? t : v;
+    T t = __shfl_up(v, d, WAVE);
+    if ((int)lane_id() >= d) v += t;
   }
   return v;
+}
+template <>
+__device__ __forceinline__ u32 wave_incl_scan<u32>(u32 v) {
+  return wave_incl_scan_add_u32(v);
 }
 
 // Exclusive scan over the NT threads of a block.  `lds` holds NT/64 + 1 items.

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
       const u32 p_rel = pc + lane;
       jj[it] = s_lo[k] + (k == 0 ? p_rel + first_delta : p_rel - s_rel[k]);
       qr[it] = s_qrid[k];
-      k_cur = __shfl(k, WAVE - 1, WAVE);
+      k_cur = (u32)__builtin_amdgcn_readlane((int)k, WAVE - 1);
     }
     // phase B: all gathers in flight together, then the coalesced stores
     u32 sr[NWIN];
