@@ -297,7 +297,18 @@ __device__ __forceinline__ SWindow stage_window(const u32* __restrict__ ss, u32 
   const u64 want = (u64)(w1 - w0) + RC_MARGIN;
   if (want < len) len = (u32)want;
   if (len > (u32)CAP) len = CAP;
-  for (u32 k = threadIdx.x; k < len; k += RC_NT) s_tile[k] = ss[w0 + k];
+  // 4 independent loads in flight per thread (a plain loop waits for each load)
+  for (u32 k = threadIdx.x; k < len; k += 4 * RC_NT) {
+    const u32 k1 = k + RC_NT, k2 = k + 2 * RC_NT, k3 = k + 3 * RC_NT;
+    const u32 v0 = ss[w0 + k];
+    const u32 v1 = k1 < len ? ss[w0 + k1] : 0u;
+    const u32 v2 = k2 < len ? ss[w0 + k2] : 0u;
+    const u32 v3 = k3 < len ? ss[w0 + k3] : 0u;
+    s_tile[k] = v0;
+    if (k1 < len) s_tile[k1] = v1;
+    if (k2 < len) s_tile[k2] = v2;
+    if (k3 < len) s_tile[k3] = v3;
+  }
   __syncthreads();
   SWindow w;
   w.ss = ss;
@@ -483,12 +494,28 @@ __global__ __launch_bounds__(RC_NT) void k_c1_emit(
   u64 total;
   u64 o = out_base + block_base[blockIdx.x] + block_excl_scan<u64, RC_NT>(mine, s_scan, total);
   if (total == 0) return;  // block-uniform
+  // most rows match 0-2 points: fetch those ids for all rows first (16 gathers
+  // in flight) instead of one dependent gather per pair
+  u32 g0[C1_ITEMS], g1[C1_ITEMS];
+#pragma unroll
+  for (int i = 0; i < C1_ITEMS; i++) {
+    g0[i] = b.cnt[i] > 0 ? s_rid[b.lo[i]] : 0u;
+    g1[i] = b.cnt[i] > 1 ? s_rid[b.lo[i] + 1] : 0u;
+  }
 #pragma unroll
   for (int i = 0; i < C1_ITEMS; i++) {
     const u32 c = b.cnt[i];
     const bool big = c > C1_COOP;
     if (!big) {
-      for (u32 k = 0; k < c; k++) {
+      if (c > 0) {
+        row_q[o] = (int32_t)rid[i];
+        row_s[o] = (int32_t)g0[i];
+      }
+      if (c > 1) {
+        row_q[o + 1] = (int32_t)rid[i];
+        row_s[o + 1] = (int32_t)g1[i];
+      }
+      for (u32 k = 2; k < c; k++) {
         row_q[o + k] = (int32_t)rid[i];
         row_s[o + k] = (int32_t)s_rid[b.lo[i] + k];
       }
@@ -513,7 +540,7 @@ __global__ __launch_bounds__(RC_NT) void k_c1_emit(
 
 // --------------------------------------------------------------- partition
 constexpr int FILL_NT = 256;
-constexpr int FILL_QCAP = 2048;  // query records staged per output tile
+constexpr int FILL_QCAP = 1024;  // query records staged per output tile
 
 // Merge-path split of one class's output among blocks: every block materialises
 // exactly `tile` pairs.  part[t] = last query q (relative to q_base) whose
@@ -593,20 +620,60 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
       jj[it] = 0;
       qr[it] = 0;
       if (pc >= tile_len) continue;  // wave-uniform
-      mark[lane] = 0;
-      __builtin_amdgcn_wave_barrier();
-      // rows k_cur+1, k_cur+2, ... that start inside [pc, pc + 64)
-      u32 base = k_cur + 1;
-      while (true) {
-        const u32 kk = base + lane;
-        const bool in = kk < nqt && s_rel[kk] < pc + WAVE;
-        if (in) atomicMax((u32*)&mark[s_rel[kk] - pc], kk - k_cur);
-        const u64 m = __ballot(in);
-        if (m != ~0ull) break;  // fewer than 64 candidates qualified: done
-        base += WAVE;
+      // rows k_cur+1, k_cur+2, ... that start inside [pc, pc + 64).  Fast path: at
+      // most 64 of them and all at distinct positions -> OR their start bits into
+      // one 64-bit mask (DPP reduction), the row of output l is then
+      // popcount(mask & bits 0..l): no LDS round trip at all.
+      const u32 kk0 = k_cur + 1 + lane;
+      const u32 r0 = kk0 < nqt ? s_rel[kk0] : U32_MAX;
+      const bool in0 = r0 < pc + WAVE;
+      const u64 m0 = __ballot(in0);
+      const u32 rprev = (u32)__builtin_amdgcn_update_dpp((int)U32_MAX, (int)r0, GIQL_DPP_ROW_SHR(1), 0xF, 0xF, false);
+      // duplicate start positions (rows without matches) only matter between
+      // neighbouring lanes because rel is sorted; lane 0/16/32/48 compare across
+      // rows through a shuffle-free trick: treat a row boundary as "maybe dup"
+      const bool dup = in0 && (lane & 15u) != 0 && rprev == r0;
+      const bool edge = in0 && (lane & 15u) == 0 && lane != 0;  // checked below
+      u32 kd;
+      bool fast = (m0 != ~0ull) && (__ballot(dup) == 0);
+      if (fast && __ballot(edge) != 0) {
+        // verify the three row-boundary neighbours (lanes 15|16, 31|32, 47|48)
+        const u32 rl = __shfl_up(r0, 1, WAVE);
+        fast = __ballot(edge && rl == r0) == 0;
       }
-      __builtin_amdgcn_wave_barrier();
-      const u32 kd = wave_incl_scan_max_u32(mark[lane]);
+      if (fast) {
+        u64 bit = in0 ? (1ull << (r0 - pc)) : 0ull;
+        u32 blo = (u32)bit, bhi = (u32)(bit >> 32);
+#define GIQL_OR_STEP(ctrl, rm)                                                          \
+  blo |= (u32)__builtin_amdgcn_update_dpp(0, (int)blo, ctrl, rm, 0xF, false);          \
+  bhi |= (u32)__builtin_amdgcn_update_dpp(0, (int)bhi, ctrl, rm, 0xF, false);
+        GIQL_OR_STEP(GIQL_DPP_ROW_SHR(1), 0xF)
+        GIQL_OR_STEP(GIQL_DPP_ROW_SHR(2), 0xF)
+        GIQL_OR_STEP(GIQL_DPP_ROW_SHR(4), 0xF)
+        GIQL_OR_STEP(GIQL_DPP_ROW_SHR(8), 0xF)
+        GIQL_OR_STEP(GIQL_DPP_ROW_BCAST15, 0xA)
+        GIQL_OR_STEP(GIQL_DPP_ROW_BCAST31, 0xC)
+#undef GIQL_OR_STEP
+        const u32 mlo = (u32)__builtin_amdgcn_readlane((int)blo, WAVE - 1);
+        const u32 mhi = (u32)__builtin_amdgcn_readlane((int)bhi, WAVE - 1);
+        const u64 mask = ((u64)mhi << 32) | mlo;
+        const u64 upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+        kd = (u32)__popcll(mask & upto);
+      } else {
+        mark[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        u32 base = k_cur + 1;
+        while (true) {
+          const u32 kk = base + lane;
+          const bool in = kk < nqt && s_rel[kk] < pc + WAVE;
+          if (in) atomicMax((u32*)&mark[s_rel[kk] - pc], kk - k_cur);
+          const u64 m = __ballot(in);
+          if (m != ~0ull) break;  // fewer than 64 candidates qualified: done
+          base += WAVE;
+        }
+        __builtin_amdgcn_wave_barrier();
+        kd = wave_incl_scan_max_u32(mark[lane]);
+      }
       const u32 k = k_cur + kd;
       const u32 p_rel = pc + lane;
       jj[it] = s_lo[k] + (k == 0 ? p_rel + first_delta : p_rel - s_rel[k]);
