@@ -84,6 +84,7 @@ struct giql_hip_ctx {
   u64* d_scratch64 = nullptr;  // small device scratch (checksum)
 
   bool classic_sort = false;  // GIQL_HIP_SORT=classic: three-launch radix passes
+  int os_variant = 0;         // GIQL_HIP_OS_VARIANT: onesweep block shape (tuning)
 
   // profiling
   bool profiling = false;
@@ -283,20 +284,35 @@ static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, 
 }
 
 // Onesweep LSD sort (4 passes, one launch each); input and result in buffer 0.
-// status: cdiv(n, OS_TILE) * 256 words; tickets: 4 words (zeroed here).
+// status: cdiv(n, OS_MIN_TILE) * 256 words per pass (4 passes, zeroed here in one
+// memset); tickets: 4 words.
+template <int NT, int ITEMS>
+static void launch_onesweep(hipStream_t st, SortBufs& sb, int src, int dst, bool first, u32 n,
+                            int shift, const u32* gbase, u32* status, u32* ticket, DevMeta* meta) {
+  const u32 n_tiles = cdiv(n, NT * ITEMS);
+  hipLaunchKernelGGL((k_onesweep<true, NT, ITEMS>), dim3(n_tiles), dim3(NT), 0, st, sb.key[src],
+                     sb.end[src], first ? (const u32*)nullptr : sb.rid[src], sb.key[dst], sb.end[dst],
+                     sb.rid[dst], n, shift, gbase, status, ticket, meta);
+}
+
 static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
                              const u32* gbase, u32* status, u32* tickets) {
   if (n == 0) return GIQL_OK;
-  const u32 n_tiles = cdiv(n, OS_TILE);
+  const size_t per_pass = (size_t)cdiv(n, OS_MIN_TILE) * OS_BINS;
   HIP_TRY(hipMemsetAsync(tickets, 0, 4 * sizeof(u32), st));
+  HIP_TRY(hipMemsetAsync(status, 0, 4 * per_pass * sizeof(u32), st));
   for (int pass = 0; pass < 4; pass++) {
     const int src = pass & 1, dst = src ^ 1;
-    HIP_TRY(hipMemsetAsync(status, 0, (size_t)n_tiles * OS_BINS * sizeof(u32), st));
+    u32* stat = status + pass * per_pass;
     Phase ph(ctx, st, GIQL_PH_SORT_SCATTER);
-    hipLaunchKernelGGL((k_onesweep<true>), dim3(n_tiles), dim3(OS_NT), 0, st, sb.key[src],
-                       sb.end[src], pass == 0 ? (const u32*)nullptr : sb.rid[src], sb.key[dst],
-                       sb.end[dst], sb.rid[dst], n, pass * 8, gbase + pass * OS_BINS, status,
-                       tickets + pass, ctx->d_meta);
+    switch (ctx->os_variant) {
+      case 1: launch_onesweep<512, 8>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+      case 2: launch_onesweep<512, 16>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+      case 3: launch_onesweep<256, 16>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+      case 4: launch_onesweep<1024, 4>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+      case 5: launch_onesweep<1024, 12>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+      default: launch_onesweep<1024, 8>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+    }
   }
   return post_launch("onesweep sort");
 }
@@ -402,6 +418,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
   {
     const char* e = getenv("GIQL_HIP_SORT");
     ctx->classic_sort = e && strcmp(e, "classic") == 0;
+    const char* v = getenv("GIQL_HIP_OS_VARIANT");
+    ctx->os_variant = v ? atoi(v) : 0;
   }
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   hipError_t e = hipMalloc((void**)&ctx->d_meta, sizeof(DevMeta));
@@ -503,7 +521,7 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
       hist_b = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
       gbase_a = c.take<u32>(1024);
       gbase_b = c.take<u32>(1024);
-      os_status = c.take<u32>((size_t)cdiv(n_max, OS_TILE) * OS_BINS);
+      os_status = c.take<u32>(4 * (size_t)cdiv(n_max, OS_MIN_TILE) * OS_BINS);
       os_tickets = c.take<u32>(8);
     } else {
       tile_hist = c.take<u32>(n_tiles_max * RS_BINS);

@@ -22,23 +22,24 @@
 
 namespace giql {
 
-constexpr int OS_NT = 1024;  // 16 waves: half the per-wave serial work of 512 x 16
-constexpr int OS_ITEMS = 8;
-constexpr int OS_TILE = OS_NT * OS_ITEMS;  // 8192 rows per tile
 constexpr int OS_BINS = 256;
-constexpr int OS_NW = OS_NT / WAVE;  // 16
+constexpr int OS_MIN_TILE = 4096;  // smallest tile of any instantiated variant
 constexpr u32 OS_FLAG_AGG = 1u << 30;
 constexpr u32 OS_FLAG_PREFIX = 2u << 30;
 constexpr u32 OS_VALUE_MASK = (1u << 30) - 1u;
 constexpr u32 OS_MAX_ROWS = (1u << 30) - 1u;
 constexpr u32 OS_SPIN_LIMIT = 1u << 24;
 
-template <bool PAYLOAD>
+// OS_NT threads x OS_ITEMS rows per thread = one tile.  Default 1024 x 8: 16 waves
+// halve the per-wave serial work of 512 x 16 at the same 8192-row tile.
+template <bool PAYLOAD, int OS_NT, int OS_ITEMS>
 __global__ __launch_bounds__(OS_NT) void k_onesweep(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
     int shift, const u32* __restrict__ gbase, u32* __restrict__ status, u32* __restrict__ ticket,
     DevMeta* __restrict__ meta) {
+  constexpr int OS_TILE = OS_NT * OS_ITEMS;
+  constexpr int OS_NW = OS_NT / WAVE;
   __shared__ u32 s_buf[OS_TILE];          // staging, reused for key / end / rid
   __shared__ u32 s_wcnt[OS_NW][OS_BINS];  // per-wave digit counters -> bases
   __shared__ u32 s_dstart[OS_BINS];
