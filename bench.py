@@ -283,6 +283,7 @@ def main() -> None:
                 "n_a": tot_na, "n_b": tot_nb, "n_chrom": n_chrom, "pairs_per_step": n_pairs,
                 "parallelism": f"chrom-shard x{world}" + ("" if world == 1 or args.no_gather else " + rccl all-gather of pairs"),
                 "inputs": "resident in HBM before the timed region",
+                "join_form": st["join_form"],
             },
             "hbm_algorithmic_GBps": round((12.0 * (tot_na + tot_nb) + 8.0 * n_pairs) * args.steps / elapsed / 1e9, 1),
             "roofline": roofline,

@@ -26,6 +26,9 @@ struct DevMeta {
   u32 irr_b;
   int status;       // 0 ok, else a GIQL_ERR_* code
   u32 aux0, aux1;   // per-operator scratch (e.g. compaction counter)
+  // canonical length (end - start) range over the well-formed rows of each side;
+  // min == max means "uniform length" (fixed-length reads): see k_range_count
+  int len_min_a, len_max_a, len_min_b, len_max_b;
 };
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & (WAVE - 1); }

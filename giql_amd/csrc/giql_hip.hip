@@ -71,6 +71,9 @@ struct InnerState {
   u32* wlo2 = nullptr;
   u32* lo2 = nullptr;    // class-2 first matching B index per A row
   u64* off2 = nullptr;   // class-2 exclusive output offsets
+  // uniform-length form: 0 = general two-class join; 1 = B is uniform (queries =
+  // A rows); 2 = A is uniform (queries = B rows)
+  int uniform = 0;
 };
 
 struct giql_hip_ctx {
@@ -85,6 +88,7 @@ struct giql_hip_ctx {
 
   bool classic_sort = false;  // GIQL_HIP_SORT=classic: three-launch radix passes
   int os_variant = 0;         // GIQL_HIP_OS_VARIANT: onesweep block shape (tuning)
+  bool no_uniform = false;    // GIQL_HIP_NO_UNIFORM=1: always run the general two-class join
 
   // profiling
   bool profiling = false;
@@ -251,7 +255,7 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
     u32 grid = cdiv((u64)s.n, (u64)MM_NT * MM_ITEMS);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(k_chrom_minmax, dim3(grid), dim3(MM_NT), lds, st, s.chrom, s.start, s.end,
-                       (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta);
+                       (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k);
   }
   int omin = a.start_off, omax = a.start_off;
   const int offs[3] = {a.end_off, b.start_off, b.end_off};
@@ -290,9 +294,15 @@ template <int NT, int ITEMS>
 static void launch_onesweep(hipStream_t st, SortBufs& sb, int src, int dst, bool first, u32 n,
                             int shift, const u32* gbase, u32* status, u32* ticket, DevMeta* meta) {
   const u32 n_tiles = cdiv(n, NT * ITEMS);
-  hipLaunchKernelGGL((k_onesweep<true, NT, ITEMS>), dim3(n_tiles), dim3(NT), 0, st, sb.key[src],
-                     sb.end[src], first ? (const u32*)nullptr : sb.rid[src], sb.key[dst], sb.end[dst],
-                     sb.rid[dst], n, shift, gbase, status, ticket, meta);
+  const u32* rin = first ? (const u32*)nullptr : sb.rid[src];
+  if (sb.end[0])  // (key, end, rid)
+    hipLaunchKernelGGL((k_onesweep<2, NT, ITEMS>), dim3(n_tiles), dim3(NT), 0, st, sb.key[src],
+                       sb.end[src], rin, sb.key[dst], sb.end[dst], sb.rid[dst], n, shift, gbase, status,
+                       ticket, meta);
+  else  // (key, rid): the uniform-length side carries no end
+    hipLaunchKernelGGL((k_onesweep<1, NT, ITEMS>), dim3(n_tiles), dim3(NT), 0, st, sb.key[src],
+                       (const u32*)nullptr, rin, sb.key[dst], (u32*)nullptr, sb.rid[dst], n, shift, gbase,
+                       status, ticket, meta);
 }
 
 static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
@@ -420,6 +430,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->classic_sort = e && strcmp(e, "classic") == 0;
     const char* v = getenv("GIQL_HIP_OS_VARIANT");
     ctx->os_variant = v ? atoi(v) : 0;
+    const char* u = getenv("GIQL_HIP_NO_UNIFORM");
+    ctx->no_uniform = u && atoi(u) != 0;
   }
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   hipError_t e = hipMalloc((void**)&ctx->d_meta, sizeof(DevMeta));
@@ -529,10 +541,11 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
     bsums = c.take<u64>(cdiv(scan_max, SCAN_TILE) + 2);
     S.wlo1 = c.take<u32>((size_t)S.nt1 + 2);
     S.c1_base = c.take<u64>((size_t)S.nt1 + 2);
-    S.wlo2 = c.take<u32>((size_t)S.nt2 + 2);
-    cnt2 = c.take<u32>(na);
-    S.lo2 = c.take<u32>(na);
-    S.off2 = c.take<u64>(na + 1);
+    const size_t nq2 = ctx->no_uniform ? na : n_max;  // the uniform form may query the other side
+    S.wlo2 = c.take<u32>((size_t)cdiv(nq2, TQ2) + 2);
+    cnt2 = c.take<u32>(nq2);
+    S.lo2 = c.take<u32>(nq2);
+    S.off2 = c.take<u64>(nq2 + 1);
     ctx->irr_a_list = c.take<u32>(na);
     ctx->irr_b_list = c.take<u32>(nb);
     irr_cnt = c.take<u32>(nq);
@@ -546,6 +559,65 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
   SortBufs& sbb = S.sb;
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
+  // Uniform-length side?  (fixed-length reads: min == max over well-formed rows).
+  // One 100-byte readback; it also surfaces chrom / span errors before the sort.
+  S.uniform = 0;
+  i64 uni_len = 0;
+  if (onesweep && !ctx->no_uniform) {
+    GIQL_TRY(read_meta(ctx, st));
+    const DevMeta& m = *ctx->h_meta;
+    const bool ub = m.len_min_b == m.len_max_b && m.len_max_b > 0;
+    const bool ua = m.len_min_a == m.len_max_a && m.len_max_a > 0;
+    // sort the uniform side without its end; prefer the larger side when both are
+    if (ub && (!ua || nb >= na)) {
+      S.uniform = 1;
+      uni_len = m.len_max_b;
+    } else if (ua) {
+      S.uniform = 2;
+      uni_len = m.len_max_a;
+    }
+  }
+  const u32* irr_a = &ctx->d_meta->irr_a;
+  const u32* irr_b = &ctx->d_meta->irr_b;
+  if (S.uniform) {
+    // ---- uniform-length form: queries Q (full rows) against points U (starts only)
+    const bool q_is_a = S.uniform == 1;
+    const giql_side& qs_ = q_is_a ? *a : *b;
+    const giql_side& us_ = q_is_a ? *b : *a;
+    SortBufs& sq = q_is_a ? sa : sbb;
+    SortBufs& su = q_is_a ? sbb : sa;
+    const size_t nqr = q_is_a ? na : nb, nu = q_is_a ? nb : na;
+    su.end[0] = su.end[1] = nullptr;  // the uniform side carries (key, rid) only
+    GIQL_TRY(run_linearize(ctx, st, qs_, n_chrom, lb, sq.key[0], sq.end[0],
+                           q_is_a ? ctx->irr_a_list : ctx->irr_b_list, q_is_a ? 0 : 1, 0,
+                           q_is_a ? hist_a : hist_b, q_is_a ? gbase_a : gbase_b));
+    GIQL_TRY(run_linearize(ctx, st, us_, n_chrom, lb, su.key[0], nullptr,
+                           q_is_a ? ctx->irr_b_list : ctx->irr_a_list, q_is_a ? 1 : 0, 0,
+                           q_is_a ? hist_b : hist_a, q_is_a ? gbase_b : gbase_a));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sq, (u32)nqr, q_is_a ? gbase_a : gbase_b, os_status, os_tickets));
+    GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, os_status,
+                               os_tickets + 4));
+    constexpr u32 TQ = RC_NT * RC_ITEMS_C2;
+    S.nt2 = cdiv(nqr, TQ);
+    {
+      Phase ph(ctx, st, GIQL_PH_COUNT, 2);
+      const u32* irr_q = q_is_a ? irr_a : irr_b;
+      const u32* irr_u = q_is_a ? irr_b : irr_a;
+      const i64 lo_off = 1 - uni_len;  // u.start in [q.start - L + 1, q.end)
+      hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt2 + 1, 256)), dim3(256), 0, st,
+                         sq.key[0], (u32)nqr, irr_q, su.key[0], (u32)nu, irr_u, lo_off, TQ, S.nt2,
+                         S.wlo2);
+      hipLaunchKernelGGL((k_range_count<RC_ITEMS_C2, RC_LDS_CAP>), dim3(S.nt2), dim3(RC_NT), 0, st,
+                         sq.key[0], sq.end[0], (u32)nqr, irr_q, su.key[0], (u32)nu, irr_u, lo_off,
+                         S.wlo2, S.lo2, cnt2);
+      GIQL_TRY(post_launch("range count (uniform)"));
+    }
+    GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt2, nqr, S.off2, bsums, S.off2 + nqr));
+    HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out, S.off2 + nqr, sizeof(u64), hipMemcpyDeviceToDevice, st));
+    GIQL_TRY(read_meta(ctx, st));
+    ctx->n_c1 = 0;
+    ctx->n_reg = ctx->h_meta->n_out;
+  } else {
   GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], ctx->irr_a_list, 0, 0,
                          hist_a, gbase_a));
   GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], ctx->irr_b_list, 1, 0,
@@ -557,22 +629,20 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
     GIQL_TRY(run_sort(ctx, st, sa, (u32)na, tile_hist, bsums));
     GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
   }
-  const u32* irr_a = &ctx->d_meta->irr_a;
-  const u32* irr_b = &ctx->d_meta->irr_b;
   {
     Phase ph(ctx, st, GIQL_PH_COUNT, 4);
     // class 1: queries = sorted B, points = sorted A starts, range [b.start, b.end);
     // only one total per block is kept (see k_c1_count)
     hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt1 + 1, 256)), dim3(256), 0, st,
-                       sbb.key[0], (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, 0u, (u32)C1_TQ, S.nt1,
+                       sbb.key[0], (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, (i64)0, (u32)C1_TQ, S.nt1,
                        S.wlo1);
     hipLaunchKernelGGL(k_c1_count, dim3(S.nt1), dim3(RC_NT), 0, st, sbb.key[0], sbb.end[0], (u32)nb,
                        irr_b, sa.key[0], (u32)na, irr_a, S.wlo1, S.c1_base);
     // class 2: queries = sorted A, points = sorted B starts, range (a.start, a.end)
     hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt2 + 1, 256)), dim3(256), 0, st,
-                       sa.key[0], (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, 1u, TQ2, S.nt2, S.wlo2);
+                       sa.key[0], (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, (i64)1, TQ2, S.nt2, S.wlo2);
     hipLaunchKernelGGL((k_range_count<RC_ITEMS_C2, RC_LDS_CAP>), dim3(S.nt2), dim3(RC_NT), 0, st,
-                       sa.key[0], sa.end[0], (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, 1u, S.wlo2,
+                       sa.key[0], sa.end[0], (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, (i64)1, S.wlo2,
                        S.lo2, cnt2);
     GIQL_TRY(post_launch("range count"));
   }
@@ -587,6 +657,7 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
   GIQL_TRY(read_meta(ctx, st));
   ctx->n_c1 = ctx->h_meta->n_out_c1;
   ctx->n_reg = ctx->h_meta->n_out + ctx->n_c1;
+  }
   ctx->stats.n_irregular_a = ctx->h_meta->irr_a;
   ctx->stats.n_irregular_b = ctx->h_meta->irr_b;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
@@ -606,6 +677,7 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
     ctx->n_irr = ctx->h_meta->n_out_irr;
   }
   collect_spans(ctx);
+  ctx->stats.reserved = S.uniform;  // which form ran: 0 general, 1 B uniform, 2 A uniform
   ctx->stats.n_out = (int64_t)(ctx->n_reg + ctx->n_irr);
   *n_pairs = (int64_t)(ctx->n_reg + ctx->n_irr);
   ctx->planned = true;
@@ -629,6 +701,10 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
   const u32* irr_a = &ctx->d_meta->irr_a;
   const u32* irr_b = &ctx->d_meta->irr_b;
   const u64 p1 = ctx->n_c1, p2 = ctx->n_reg - ctx->n_c1;
+  // who plays "query" in the range-fill: A rows (general class 2, or B uniform),
+  // or B rows (A uniform)
+  const bool q_is_a = S.uniform != 2;
+  const u32 nq2 = q_is_a ? ctx->n_a : ctx->n_b;
   u32 nt2 = 0;
   if (p2 > 0) {
     constexpr u32 T2 = FILL_NT * FILL_ITEMS_C2;
@@ -646,7 +722,7 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
       ctx->part_cap = want;
     }
     Phase ph(ctx, st, GIQL_PH_PARTITION);
-    hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt2 + 1, 256)), dim3(256), 0, st, S.off2, ctx->n_a,
+    hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt2 + 1, 256)), dim3(256), 0, st, S.off2, nq2,
                        (u64)0, T2, nt2, ctx->part);
   }
   {
@@ -656,11 +732,15 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
       hipLaunchKernelGGL(k_c1_emit, dim3(S.nt1), dim3(RC_NT), 0, st, S.sb.key[0], S.sb.end[0],
                          S.sb.rid[0], ctx->n_b, irr_b, S.sa.key[0], S.sa.rid[0], ctx->n_a, irr_a,
                          S.wlo1, S.c1_base, (u64)0, row_b, row_a);
-    // class 2 -> outputs [p1, p1 + p2): query = A row, matches = B rows
-    if (p2 > 0)
-      hipLaunchKernelGGL((k_fill<FILL_ITEMS_C2>), dim3(nt2), dim3(FILL_NT), 0, st, S.off2, S.lo2,
-                         S.sa.rid[0], ctx->n_a, S.sb.rid[0], ctx->part, (u64)0, p2, row_a + p1,
-                         row_b + p1);
+    // range fill -> outputs [p1, p1 + p2)
+    if (p2 > 0) {
+      const u32* qrid = q_is_a ? S.sa.rid[0] : S.sb.rid[0];
+      const u32* srid = q_is_a ? S.sb.rid[0] : S.sa.rid[0];
+      int32_t* rq = (q_is_a ? row_a : row_b) + p1;
+      int32_t* rs = (q_is_a ? row_b : row_a) + p1;
+      hipLaunchKernelGGL((k_fill<FILL_ITEMS_C2>), dim3(nt2), dim3(FILL_NT), 0, st, S.off2, S.lo2, qrid,
+                         nq2, srid, ctx->part, (u64)0, p2, rq, rs);
+    }
     GIQL_TRY(post_launch("fill"));
   }
   if (ctx->n_irr > 0) {

@@ -41,6 +41,10 @@ __global__ void k_init_minmax(int* __restrict__ gmin, int* __restrict__ gmax, in
     meta->status = 0;
     meta->aux0 = 0;
     meta->aux1 = 0;
+    meta->len_min_a = INT_MAX;
+    meta->len_max_a = 0;
+    meta->len_min_b = INT_MAX;
+    meta->len_max_b = 0;
   }
 }
 
@@ -56,7 +60,8 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
                                                          const int* __restrict__ end, i64 n,
                                                          int n_chrom, int* __restrict__ gmin,
                                                          int* __restrict__ gmax,
-                                                         DevMeta* __restrict__ meta) {
+                                                         DevMeta* __restrict__ meta, int len_bias,
+                                                         int which) {
   extern __shared__ int mm_lds[];
   const bool use_lds = n_chrom <= MM_LDS_CHROMS;
   int* lmin = use_lds ? mm_lds : gmin;
@@ -69,11 +74,17 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
     __syncthreads();
   }
   int cur = -1, mn = INT_MAX, mx = INT_MIN;
+  i64 lmn = INT_MAX, lmx = 0;  // canonical length range of well-formed rows
   bool bad = false;
   const i64 stride = (i64)gridDim.x * MM_NT;
   for (i64 i = (i64)blockIdx.x * MM_NT + threadIdx.x; i < n; i += stride) {
     const int c = chrom[i];
     const int s = start[i], e = end[i];
+    const i64 len = (i64)e - (i64)s + len_bias;
+    if (len > 0) {
+      lmn = len < lmn ? len : lmn;
+      lmx = len > lmx ? len : lmx;
+    }
     if (c < 0 || c >= n_chrom) {
       bad = true;
       continue;
@@ -96,6 +107,20 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
     atomicMax(&lmax[cur], mx);
   }
   if (bad) meta->status = -4;  // GIQL_ERR_CHROM
+  {
+    // wave-reduce the length range, one pair of atomics per wave
+    int a = (int)(lmn > INT_MAX ? INT_MAX : lmn), b = (int)(lmx > INT_MAX ? INT_MAX : lmx);
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+      const int ta = __shfl_xor(a, d, WAVE), tb = __shfl_xor(b, d, WAVE);
+      a = ta < a ? ta : a;
+      b = tb > b ? tb : b;
+    }
+    if (lane_id() == 0) {
+      atomicMin(which ? &meta->len_min_b : &meta->len_min_a, a);
+      atomicMax(which ? &meta->len_max_b : &meta->len_max_a, b);
+    }
+  }
   if (use_lds) {
     __syncthreads();
     for (int c = threadIdx.x; c < n_chrom; c += MM_NT) {
@@ -197,10 +222,8 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
         k = (u32)(b + cs);
         ke = (u32)(b + ce);
       }
-      if (keys) {
-        keys[i] = k;
-        ends[i] = ke;
-      }
+      if (keys) keys[i] = k;
+      if (ends) ends[i] = ke;
     }
     if (hist_partial) {
       const u64 act = __ballot(ok);
@@ -256,19 +279,25 @@ constexpr int RC_NT = 256;
 constexpr int RC_LDS_CAP = 10240;  // staged S keys (40 KB)
 constexpr int RC_MARGIN = 1024;    // S entries staged past the next tile's window
 
+// query start + signed offset, clamped to the u32 key axis
+__device__ __forceinline__ u32 shift_key(u32 k, i64 off) {
+  const i64 v = (i64)k + off;
+  return v < 0 ? 0u : (v > (i64)U32_MAX ? U32_MAX : (u32)v);
+}
+
 // w_lo[t] = first S index a query of tile t can match = lower_bound(S, first
 // query start + lo_off); w_lo[n_tiles] = |S|.  One thread per tile: the count
 // kernel then starts with its S window known (no serial per-block search).
 __global__ void k_count_partition(const u32* __restrict__ qs, u32 nq_total,
                                   const u32* __restrict__ irr_q, const u32* __restrict__ ss,
-                                  u32 ns_total, const u32* __restrict__ irr_s, u32 lo_off, u32 tq,
+                                  u32 ns_total, const u32* __restrict__ irr_s, i64 lo_off, u32 tq,
                                   u32 n_tiles, u32* __restrict__ w_lo) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t > n_tiles) return;
   const u32 nq = nq_total - *irr_q;
   const u32 ns = ns_total - *irr_s;
   const u64 q = (u64)t * tq;
-  w_lo[t] = (t < n_tiles && q < nq) ? lower_bound_u32(ss, 0, ns, qs[q] + lo_off) : ns;
+  w_lo[t] = (t < n_tiles && q < nq) ? lower_bound_u32(ss, 0, ns, shift_key(qs[q], lo_off)) : ns;
 }
 
 // Shared by the count / emit kernels: the block's S window [w0, w0 + len) staged
@@ -322,7 +351,11 @@ __device__ __forceinline__ SWindow stage_window(const u32* __restrict__ ss, u32 
 }
 
 // For the sorted queries of one block, count the points of the sorted set S in
-// [qs + lo_off, qe).  lo_off = 0 is class 1 (closed low end), 1 is class 2.
+// [qs + lo_off, qe).  lo_off = 0 is class 1 (closed low end), 1 is class 2, and
+// 1 - L is the uniform-length form: when every S row has length L,
+//   overlap  <=>  s.start < q.end AND s.start + L > q.start
+//            <=>  s.start in [q.start - L + 1, q.end)
+// -- ONE range per query row, no class split and no `end` on the S side.
 // Writes lo (first matching index in S) and cnt.  Rows past the regular prefix
 // (sentinel keys) get cnt = 0.  The block's S window [w_lo[t], w_lo[t+1] +
 // margin) is staged in LDS and searched per lane there (LDS tile + per-lane
@@ -331,7 +364,7 @@ template <int ITEMS, int CAP>
 __global__ __launch_bounds__(RC_NT) void k_range_count(
     const u32* __restrict__ qs, const u32* __restrict__ qe, u32 nq_total,
     const u32* __restrict__ irr_q, const u32* __restrict__ ss, u32 ns_total,
-    const u32* __restrict__ irr_s, u32 lo_off, const u32* __restrict__ w_lo_arr,
+    const u32* __restrict__ irr_s, i64 lo_off, const u32* __restrict__ w_lo_arr,
     u32* __restrict__ lo_out, u32* __restrict__ cnt_out) {
   constexpr u32 TQ = RC_NT * ITEMS;
   __shared__ u32 s_tile[CAP];
@@ -344,7 +377,7 @@ __global__ __launch_bounds__(RC_NT) void k_range_count(
   for (int i = 0; i < ITEMS; i++) {
     const u32 q = q0 + i * RC_NT + tid;
     const bool ok = q < nq;
-    xs[i] = ok ? qs[q] + lo_off : U32_MAX;
+    xs[i] = ok ? shift_key(qs[q], lo_off) : U32_MAX;
     xe[i] = ok ? qe[q] : U32_MAX;
   }
   const SWindow w = stage_window<CAP>(ss, ns, w_lo_arr[blockIdx.x], w_lo_arr[blockIdx.x + 1], s_tile);

@@ -32,7 +32,8 @@ constexpr u32 OS_SPIN_LIMIT = 1u << 24;
 
 // OS_NT threads x OS_ITEMS rows per thread = one tile.  Default 1024 x 8: 16 waves
 // halve the per-wave serial work of 512 x 16 at the same 8192-row tile.
-template <bool PAYLOAD, int OS_NT, int OS_ITEMS>
+// PAYLOAD: 0 = keys only, 1 = (key, rid), 2 = (key, end, rid).
+template <int PAYLOAD, int OS_NT, int OS_ITEMS>
 __global__ __launch_bounds__(OS_NT) void k_onesweep(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
@@ -69,10 +70,8 @@ __global__ __launch_bounds__(OS_NT) void k_onesweep(
     const bool ok = r < n_valid;
     const u32 g = tile_base + r;
     key[i] = ok ? keys_in[g] : U32_MAX;
-    if (PAYLOAD) {
-      end[i] = ok ? ends_in[g] : 0u;
-      rid[i] = ok ? (rids_in ? rids_in[g] : g) : 0u;
-    }
+    if (PAYLOAD == 2) end[i] = ok ? ends_in[g] : 0u;
+    if (PAYLOAD >= 1) rid[i] = ok ? (rids_in ? rids_in[g] : g) : 0u;
   }
 
   // stable rank inside the wave (peers = lanes with the same digit)
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(OS_NT) void k_onesweep(
       keys_out[dst[i]] = k;
     }
   }
-  if (PAYLOAD) {
+  if (PAYLOAD == 2) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
@@ -198,6 +197,8 @@ __global__ __launch_bounds__(OS_NT) void k_onesweep(
       const u32 p = i * OS_NT + tid;
       if (p < n_valid) ends_out[dst[i]] = s_buf[p];
     }
+  }
+  if (PAYLOAD >= 1) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {

@@ -103,7 +103,8 @@ typedef struct giql_hip_stats {
   int32_t phase_launches[GIQL_PH_N];
   float total_ms;           /* sum of phase_ms                              */
   int32_t profiled;         /* 1 if phase_ms are valid                      */
-  int32_t reserved;
+  int32_t reserved;         /* INNER: 0 = general two-class join, 1 / 2 = uniform-
+                               length form with B / A as the fixed-length side */
 } giql_hip_stats;
 
 /* ---- library / context ------------------------------------------------- */

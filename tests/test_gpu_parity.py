@@ -324,3 +324,61 @@ def test_sorted_input_and_heavy_skew(eng):
     b.start[0], b.end[0] = 0, 20_000_000  # overlaps every A row on its chromosome
     want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
     assert np.array_equal(gpu_inner(eng, a, b, 5), want)
+
+
+# ------------------------------------------- uniform-length form (fixed-length reads)
+def uniform_side(seed, n, n_chrom, max_start, length):
+    r = np.random.default_rng(seed)
+    ch = r.integers(0, n_chrom, n).astype(np.int32)
+    st = r.integers(0, max_start, n).astype(np.int32)
+    return ora.Side(ch, st, st + np.int32(length))
+
+
+@pytest.mark.parametrize("which", ["b", "a", "both"])
+def test_uniform_length_form(eng, which):
+    a = uniform_side(81, 40_000, 6, 3_000_000, 75) if which in ("a", "both") else rand_side(81, 40_000, 6, 3_000_000, 900)
+    b = uniform_side(82, 300_000, 6, 3_000_000, 150) if which in ("b", "both") else rand_side(82, 300_000, 6, 3_000_000, 900)
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    assert np.array_equal(gpu_inner(eng, a, b, 6), want)
+    form = eng.stats()["join_form"]
+    assert form == {"b": "uniform_b", "a": "uniform_a", "both": "uniform_b"}[which]
+
+
+def test_uniform_length_with_irregular_rows_and_encodings(eng):
+    """Zero-length / inverted rows go through the literal path; the canonical
+    offsets change the uniform length (closed intervals are one longer)."""
+    a = rand_side(83, 9000, 3, 40_000, 60, min_len=-5, enc=("1based", "closed"))
+    b = uniform_side(84, 20_000, 3, 40_000, 30)
+    b.end_off = 1  # 0-based closed: canonical length 31
+    bad = np.random.default_rng(1).integers(0, b.n, 50)
+    b.end[bad] = b.start[bad] - 3  # inverted rows on the uniform side
+    want = ora.sort_pairs(*ora.c_inner(a, b, "brute"))
+    assert np.array_equal(gpu_inner(eng, a, b, 3), want)
+    st = eng.stats()
+    assert st["join_form"] == "uniform_b" and st["n_irregular_b"] > 0 and st["n_irregular_a"] > 0
+
+
+def test_uniform_form_can_be_disabled(monkeypatch):
+    from giql_amd.engine import HipEngine
+
+    monkeypatch.setenv("GIQL_HIP_NO_UNIFORM", "1")
+    e = HipEngine(0)
+    try:
+        a = rand_side(85, 30_000, 4, 2_000_000, 700)
+        b = uniform_side(86, 120_000, 4, 2_000_000, 150)
+        ra, rb = e.inner_join(dev(a), dev(b), 4)
+        assert e.stats()["join_form"] == "general"
+        assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()),
+                              ora.sort_pairs(*ora.c_inner(a, b, "sweep")))
+    finally:
+        e.close()
+
+
+def test_uniform_length_at_chromosome_edges(eng):
+    """q.start - L + 1 reaches below a chromosome's first key: no leak across chroms."""
+    a = ora.Side(np.array([0, 1, 1, 2], np.int32), np.array([0, 0, 5, 0], np.int32),
+                 np.array([10, 3, 9, 1000], np.int32))
+    b = ora.Side(np.array([0, 0, 1, 1, 2], np.int32), np.array([0, 990, 0, 2, 0], np.int32),
+                 np.array([100, 1090, 100, 102, 100], np.int32))
+    assert np.array_equal(gpu_inner(eng, a, b, 3), ora.sort_pairs(*ora.c_inner(a, b, "brute")))
+    assert eng.stats()["join_form"] == "uniform_b"
