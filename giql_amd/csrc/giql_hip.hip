@@ -305,6 +305,18 @@ static void launch_onesweep(hipStream_t st, SortBufs& sb, int src, int dst, bool
                        status, ticket, meta);
 }
 
+// (key, rid) rows need 2/3 of the registers: a 12-row-per-thread tile (12288 rows,
+// 192-byte runs) still fits two 1024-thread blocks per CU.
+static void launch_onesweep_kr(hipStream_t st, SortBufs& sb, int src, int dst, bool first, u32 n,
+                               int shift, const u32* gbase, u32* status, u32* ticket, DevMeta* meta) {
+  constexpr int NT = 1024, ITEMS = 12;
+  const u32 n_tiles = cdiv(n, NT * ITEMS);
+  const u32* rin = first ? (const u32*)nullptr : sb.rid[src];
+  hipLaunchKernelGGL((k_onesweep<1, NT, ITEMS>), dim3(n_tiles), dim3(NT), 0, st, sb.key[src],
+                     (const u32*)nullptr, rin, sb.key[dst], (u32*)nullptr, sb.rid[dst], n, shift, gbase,
+                     status, ticket, meta);
+}
+
 static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
                              const u32* gbase, u32* status, u32* tickets) {
   if (n == 0) return GIQL_OK;
@@ -315,6 +327,11 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
     const int src = pass & 1, dst = src ^ 1;
     u32* stat = status + pass * per_pass;
     Phase ph(ctx, st, GIQL_PH_SORT_SCATTER);
+    if (!sb.end[0] && ctx->os_variant == 0) {
+      launch_onesweep_kr(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat,
+                         tickets + pass, ctx->d_meta);
+      continue;
+    }
     switch (ctx->os_variant) {
       case 1: launch_onesweep<512, 8>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
       case 2: launch_onesweep<512, 16>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;

@@ -74,14 +74,22 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
     __syncthreads();
   }
   int cur = -1, mn = INT_MAX, mx = INT_MIN;
-  i64 lmn = INT_MAX, lmx = 0;  // canonical length range of well-formed rows
+  int lmn = INT_MAX, lmx = 0;  // canonical length range of well-formed rows
   bool bad = false;
   const i64 stride = (i64)gridDim.x * MM_NT;
   for (i64 i = (i64)blockIdx.x * MM_NT + threadIdx.x; i < n; i += stride) {
     const int c = chrom[i];
     const int s = start[i], e = end[i];
-    const i64 len = (i64)e - (i64)s + len_bias;
-    if (len > 0) {
+    // canonical length, saturated to int range; rows with len <= 0 are irregular
+    if (e > s) {
+      const u32 d = (u32)e - (u32)s;  // exact for e > s
+      const int len = (int)(d > 0x7FFFFFF0u ? 0x7FFFFFF0u : d) + len_bias;
+      if (len > 0) {
+        lmn = len < lmn ? len : lmn;
+        lmx = len > lmx ? len : lmx;
+      }
+    } else if (e - s + len_bias > 0) {  // e in {s, s-1} with a positive offset
+      const int len = e - s + len_bias;
       lmn = len < lmn ? len : lmn;
       lmx = len > lmx ? len : lmx;
     }
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
   if (bad) meta->status = -4;  // GIQL_ERR_CHROM
   {
     // wave-reduce the length range, one pair of atomics per wave
-    int a = (int)(lmn > INT_MAX ? INT_MAX : lmn), b = (int)(lmx > INT_MAX ? INT_MAX : lmx);
+    int a = lmn, b = lmx;
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) {
       const int ta = __shfl_xor(a, d, WAVE), tb = __shfl_xor(b, d, WAVE);

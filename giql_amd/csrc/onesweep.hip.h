@@ -34,7 +34,7 @@ constexpr u32 OS_SPIN_LIMIT = 1u << 24;
 // halve the per-wave serial work of 512 x 16 at the same 8192-row tile.
 // PAYLOAD: 0 = keys only, 1 = (key, rid), 2 = (key, end, rid).
 template <int PAYLOAD, int OS_NT, int OS_ITEMS>
-__global__ __launch_bounds__(OS_NT) void k_onesweep(
+__global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD < 2 || OS_ITEMS <= 8)) ? 8 : 1) void k_onesweep(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
     int shift, const u32* __restrict__ gbase, u32* __restrict__ status, u32* __restrict__ ticket,
