@@ -240,6 +240,7 @@ struct LinBufs {
   int* gmax;
   i64* chrom_base;
   u32* chrom_first;
+  int* len_part;  // [2 sides][MM_MAX_BLOCKS][min,max]
 };
 
 static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, const giql_side& b,
@@ -249,13 +250,16 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
                      lb.gmax, n_chrom, ctx->d_meta);
   const size_t lds = n_chrom <= MM_LDS_CHROMS ? (size_t)n_chrom * 2 * sizeof(int) : 0;
   const giql_side* sides[2] = {&a, &b};
+  int nblk[2] = {0, 0};
   for (int k = 0; k < 2; k++) {
     const giql_side& s = *sides[k];
     if (s.n == 0) continue;
     u32 grid = cdiv((u64)s.n, (u64)MM_NT * MM_ITEMS);
-    if (grid > 2048) grid = 2048;
+    if (grid > (u32)MM_MAX_BLOCKS) grid = MM_MAX_BLOCKS;
+    nblk[k] = (int)grid;
     hipLaunchKernelGGL(k_chrom_minmax, dim3(grid), dim3(MM_NT), lds, st, s.chrom, s.start, s.end,
-                       (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k);
+                       (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
+                       lb.len_part);
   }
   int omin = a.start_off, omax = a.start_off;
   const int offs[3] = {a.end_off, b.start_off, b.end_off};
@@ -264,7 +268,7 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
     if (offs[k] > omax) omax = offs[k];
   }
   hipLaunchKernelGGL(k_chrom_offsets, dim3(1), dim3(256), 0, st, lb.gmin, lb.gmax, n_chrom, omin,
-                     omax, lb.chrom_base, lb.chrom_first, ctx->d_meta);
+                     omax, lb.chrom_base, lb.chrom_first, ctx->d_meta, lb.len_part, nblk[0], nblk[1]);
   return post_launch("spans");
 }
 
@@ -406,6 +410,7 @@ static void common_sizes(Carver& c, int n_chrom, LinBufs& lb) {
   lb.gmax = c.take<int>((size_t)n_chrom);
   lb.chrom_base = c.take<i64>((size_t)n_chrom);
   lb.chrom_first = c.take<u32>((size_t)n_chrom + 1);
+  lb.len_part = c.take<int>((size_t)2 * MM_MAX_BLOCKS * 2);
 }
 
 static void sort_sizes(Carver& c, size_t n, SortBufs& sb, bool payload) {

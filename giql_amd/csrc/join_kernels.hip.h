@@ -51,6 +51,7 @@ __global__ void k_init_minmax(int* __restrict__ gmin, int* __restrict__ gmax, in
 constexpr int MM_NT = 256;
 constexpr int MM_ITEMS = 8;
 constexpr int MM_LDS_CHROMS = 4096;
+constexpr int MM_MAX_BLOCKS = 2048;  // grid cap; len_part holds 2 sides x blocks x {min,max}
 
 // Per-chromosome min/max of the raw coordinates (both columns).  LDS-privatised
 // atomics; a per-thread run cache keeps chromosome-sorted input (the common BED
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
                                                          int n_chrom, int* __restrict__ gmin,
                                                          int* __restrict__ gmax,
                                                          DevMeta* __restrict__ meta, int len_bias,
-                                                         int which) {
+                                                         int which, int* __restrict__ len_part) {
   extern __shared__ int mm_lds[];
   const bool use_lds = n_chrom <= MM_LDS_CHROMS;
   int* lmin = use_lds ? mm_lds : gmin;
@@ -77,38 +78,52 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
   int lmn = INT_MAX, lmx = 0;  // canonical length range of well-formed rows
   bool bad = false;
   const i64 stride = (i64)gridDim.x * MM_NT;
-  for (i64 i = (i64)blockIdx.x * MM_NT + threadIdx.x; i < n; i += stride) {
-    const int c = chrom[i];
-    const int s = start[i], e = end[i];
-    // canonical length, saturated to int range; rows with len <= 0 are irregular
-    if (e > s) {
-      const u32 d = (u32)e - (u32)s;  // exact for e > s
-      const int len = (int)(d > 0x7FFFFFF0u ? 0x7FFFFFF0u : d) + len_bias;
-      if (len > 0) {
+  for (i64 i0 = (i64)blockIdx.x * MM_NT + threadIdx.x; i0 < n; i0 += 4 * stride) {
+    int cv[4], sv[4], ev[4];
+    bool okv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {  // 12 loads in flight per thread
+      const i64 i = i0 + u * stride;
+      okv[u] = i < n;
+      cv[u] = okv[u] ? chrom[i] : 0;
+      sv[u] = okv[u] ? start[i] : 0;
+      ev[u] = okv[u] ? end[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (!okv[u]) continue;
+      const int c = cv[u];
+      const int s = sv[u], e = ev[u];
+      // canonical length, saturated to int range; rows with len <= 0 are irregular
+      if (e > s) {
+        const u32 d = (u32)e - (u32)s;  // exact for e > s
+        const int len = (int)(d > 0x7FFFFFF0u ? 0x7FFFFFF0u : d) + len_bias;
+        if (len > 0) {
+          lmn = len < lmn ? len : lmn;
+          lmx = len > lmx ? len : lmx;
+        }
+      } else if (e - s + len_bias > 0) {  // e in {s, s-1} with a positive offset
+        const int len = e - s + len_bias;
         lmn = len < lmn ? len : lmn;
         lmx = len > lmx ? len : lmx;
       }
-    } else if (e - s + len_bias > 0) {  // e in {s, s-1} with a positive offset
-      const int len = e - s + len_bias;
-      lmn = len < lmn ? len : lmn;
-      lmx = len > lmx ? len : lmx;
-    }
-    if (c < 0 || c >= n_chrom) {
-      bad = true;
-      continue;
-    }
-    if (c != cur) {
-      if (cur >= 0) {
-        atomicMin(&lmin[cur], mn);
-        atomicMax(&lmax[cur], mx);
+      if (c < 0 || c >= n_chrom) {
+        bad = true;
+        continue;
       }
-      cur = c;
-      mn = INT_MAX;
-      mx = INT_MIN;
+      if (c != cur) {
+        if (cur >= 0) {
+          atomicMin(&lmin[cur], mn);
+          atomicMax(&lmax[cur], mx);
+        }
+        cur = c;
+        mn = INT_MAX;
+        mx = INT_MIN;
+      }
+      const int lo = s < e ? s : e, hi = s < e ? e : s;
+      mn = lo < mn ? lo : mn;
+      mx = hi > mx ? hi : mx;
     }
-    const int lo = s < e ? s : e, hi = s < e ? e : s;
-    mn = lo < mn ? lo : mn;
-    mx = hi > mx ? hi : mx;
   }
   if (cur >= 0) {
     atomicMin(&lmin[cur], mn);
@@ -116,7 +131,9 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
   }
   if (bad) meta->status = -4;  // GIQL_ERR_CHROM
   {
-    // wave-reduce the length range, one pair of atomics per wave
+    // block-reduce the length range into this block's slot (no global atomics:
+    // thousands of waves hitting two addresses serialise for ~0.2 ms)
+    __shared__ int s_len[2][MM_NT / WAVE];
     int a = lmn, b = lmx;
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) {
@@ -125,8 +142,18 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
       b = tb > b ? tb : b;
     }
     if (lane_id() == 0) {
-      atomicMin(which ? &meta->len_min_b : &meta->len_min_a, a);
-      atomicMax(which ? &meta->len_max_b : &meta->len_max_a, b);
+      s_len[0][wave_id()] = a;
+      s_len[1][wave_id()] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 1; k < MM_NT / WAVE; k++) {
+        a = s_len[0][k] < a ? s_len[0][k] : a;
+        b = s_len[1][k] > b ? s_len[1][k] : b;
+      }
+      len_part[(which * MM_MAX_BLOCKS + blockIdx.x) * 2 + 0] = a;
+      len_part[(which * MM_MAX_BLOCKS + blockIdx.x) * 2 + 1] = b;
     }
   }
   if (use_lds) {
@@ -147,10 +174,39 @@ __global__ __launch_bounds__(256) void k_chrom_offsets(const int* __restrict__ g
                                                         int off_min, int off_max,
                                                         i64* __restrict__ chrom_base,
                                                         u32* __restrict__ chrom_first,
-                                                        DevMeta* __restrict__ meta) {
+                                                        DevMeta* __restrict__ meta,
+                                                        const int* __restrict__ len_part, int nblk_a,
+                                                        int nblk_b) {
   __shared__ u64 lds[256 / WAVE + 1];
   __shared__ u64 carry_s;
   if (threadIdx.x == 0) carry_s = 0;
+  // canonical length range per side from the min/max kernels' block partials
+  if (threadIdx.x < 2 * WAVE) {
+    const int which = threadIdx.x / WAVE;  // wave 0 -> side A, wave 1 -> side B
+    const int nblk = which ? nblk_b : nblk_a;
+    int a = INT_MAX, b = 0;
+    for (int k = lane_id(); k < nblk; k += WAVE) {
+      const int ta = len_part[(which * MM_MAX_BLOCKS + k) * 2 + 0];
+      const int tb = len_part[(which * MM_MAX_BLOCKS + k) * 2 + 1];
+      a = ta < a ? ta : a;
+      b = tb > b ? tb : b;
+    }
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+      const int ta = __shfl_xor(a, d, WAVE), tb = __shfl_xor(b, d, WAVE);
+      a = ta < a ? ta : a;
+      b = tb > b ? tb : b;
+    }
+    if (lane_id() == 0) {
+      if (which) {
+        meta->len_min_b = a;
+        meta->len_max_b = b;
+      } else {
+        meta->len_min_a = a;
+        meta->len_max_a = b;
+      }
+    }
+  }
   __syncthreads();
   for (int base = 0; base < n_chrom; base += 256) {
     const int c = base + threadIdx.x;
@@ -214,47 +270,65 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
   const u32 stride = gridDim.x * LIN_NT;
   // every lane runs the same number of iterations so the ballots are full-wave
   const u32 n_iter = (n + stride - 1) / stride;
-  u32 i = blockIdx.x * LIN_NT + threadIdx.x;
-  for (u32 it = 0; it < n_iter; it++, i += stride) {
-    const bool ok = i < n;
-    bool irr = false;
-    u32 k = sentinel, ke = sentinel;
-    if (ok) {
-      const i64 cs = (i64)start[i] + start_off;
-      const i64 ce = (i64)end[i] + end_off;
-      const int c = chrom[i];
-      const bool c_ok = c >= 0 && c < n_chrom;  // bad ids were flagged by k_chrom_minmax
-      irr = c_ok && !keep_irregular && ce <= cs;
-      if (c_ok && !irr) {
-        const i64 b = chrom_base[c];
-        k = (u32)(b + cs);
-        ke = (u32)(b + ce);
-      }
-      if (keys) keys[i] = k;
-      if (ends) ends[i] = ke;
-    }
-    if (hist_partial) {
-      const u64 act = __ballot(ok);
+  constexpr int UNROLL = 4;  // rows in flight per thread (a 1-row loop is latency-bound)
+  const u32 i0 = blockIdx.x * LIN_NT + threadIdx.x;
+  for (u32 it0 = 0; it0 < n_iter; it0 += UNROLL) {
+    u32 idx[UNROLL];
+    bool okv[UNROLL];
+    int cv[UNROLL], sv[UNROLL], ev[UNROLL];
 #pragma unroll
-      for (int p = 0; p < 4; p++) {
-        const u32 d = (k >> (8 * p)) & 0xFFu;
-        // chromosome-sorted input makes the high digits wave-uniform: one add
-        const u32 d0 = __shfl(d, __ffsll((long long)act) - 1, WAVE);
-        const u64 same = __ballot(ok && d == d0);
-        if (act != 0 && same == act) {
-          if (lane_id() == (u32)(__ffsll((long long)act) - 1))
-            atomicAdd(&s_hist[p * 256 + d0], (u32)__popcll(act));
-        } else if (ok) {
-          atomicAdd(&s_hist[p * 256 + d], 1u);
+    for (int u = 0; u < UNROLL; u++) {
+      const u64 i64_ = (u64)i0 + (u64)(it0 + u) * stride;
+      okv[u] = (it0 + u) < n_iter && i64_ < n;
+      idx[u] = (u32)i64_;
+      cv[u] = okv[u] ? chrom[idx[u]] : 0;
+      sv[u] = okv[u] ? start[idx[u]] : 0;
+      ev[u] = okv[u] ? end[idx[u]] : 1;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      if (it0 + u >= n_iter) break;  // wave-uniform
+      const bool ok = okv[u];
+      const u32 i = idx[u];
+      bool irr = false;
+      u32 k = sentinel, ke = sentinel;
+      if (ok) {
+        const i64 cs = (i64)sv[u] + start_off;
+        const i64 ce = (i64)ev[u] + end_off;
+        const int c = cv[u];
+        const bool c_ok = c >= 0 && c < n_chrom;  // bad ids were flagged by k_chrom_minmax
+        irr = c_ok && !keep_irregular && ce <= cs;
+        if (c_ok && !irr) {
+          const i64 b = chrom_base[c];
+          k = (u32)(b + cs);
+          ke = (u32)(b + ce);
+        }
+        if (keys) keys[i] = k;
+        if (ends) ends[i] = ke;
+      }
+      if (hist_partial) {
+        const u64 act = __ballot(ok);
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const u32 d = (k >> (8 * p)) & 0xFFu;
+          // chromosome-sorted input makes the high digits wave-uniform: one add
+          const u32 d0 = __shfl(d, __ffsll((long long)act) - 1, WAVE);
+          const u64 same = __ballot(ok && d == d0);
+          if (act != 0 && same == act) {
+            if (lane_id() == (u32)(__ffsll((long long)act) - 1))
+              atomicAdd(&s_hist[p * 256 + d0], (u32)__popcll(act));
+          } else if (ok) {
+            atomicAdd(&s_hist[p * 256 + d], 1u);
+          }
         }
       }
-    }
-    const u64 m = __ballot(irr);
-    if (m) {
-      u32 base = 0;
-      if (lane_id() == 0) base = atomicAdd(irr_count, (u32)__popcll(m));
-      base = __shfl(base, 0, WAVE);
-      if (irr) irr_list[base + (u32)__popcll(m & lanemask_lt())] = i;
+      const u64 m = __ballot(irr);
+      if (m) {
+        u32 base = 0;
+        if (lane_id() == 0) base = atomicAdd(irr_count, (u32)__popcll(m));
+        base = __shfl(base, 0, WAVE);
+        if (irr) irr_list[base + (u32)__popcll(m & lanemask_lt())] = i;
+      }
     }
   }
   if (hist_partial) {
