@@ -52,6 +52,9 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-gather", action="store_true",
                    help="N>1: skip the final RCCL gather of the pairs (compute-only scaling)")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="N>1 exchange backend; 'gloo' is a rehearsal mode for boxes with fewer "
+                        "GPUs than ranks (ranks share GPUs, pairs are exchanged through host memory)")
     p.add_argument("--cpu-sample-chroms", default="18,19,20,21",
                    help="chromosome ids of the bounded cpu_baseline sample")
     return p.parse_args()
@@ -139,11 +142,16 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the exchange happens
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     n_a, kind_a, seed_a, n_b, kind_b, seed_b = WORKLOADS[args.workload]
     n_chrom = len(synth.HG38_LENGTHS)
@@ -162,7 +170,7 @@ def main() -> None:
     b = DeviceSide.from_numpy(bc, bs, be, device=dev)
     loc_na, loc_nb = a.n, b.n
 
-    eng = HipEngine(local_rank)
+    eng = HipEngine(dev_index)
     out_cap = 0
     out = None
     # shard-local row index -> global row id (ranks own disjoint chromosome sets;
@@ -171,10 +179,10 @@ def main() -> None:
     if distributed:
         from giql_amd import distributed as D
 
-        sizes = torch.tensor([loc_na, loc_nb], dtype=torch.int64, device=dev)
-        all_sizes = torch.empty((world, 2), dtype=torch.int64, device=dev)
+        sizes = torch.tensor([loc_na, loc_nb], dtype=torch.int64, device=xdev)
+        all_sizes = torch.empty((world, 2), dtype=torch.int64, device=xdev)
         dist.all_gather_into_tensor(all_sizes.view(-1), sizes)
-        base = all_sizes[:rank].sum(0) if rank else torch.zeros(2, dtype=torch.int64, device=dev)
+        base = (all_sizes[:rank].sum(0) if rank else torch.zeros(2, dtype=torch.int64)).to(dev)
         idmap_a = (torch.arange(loc_na, device=dev, dtype=torch.int64) + base[0]).to(torch.int32)
         idmap_b = (torch.arange(loc_nb, device=dev, dtype=torch.int64) + base[1]).to(torch.int32)
 
@@ -191,7 +199,7 @@ def main() -> None:
             # the path's one exchange step: global ids, counts, then the padded pairs
             ga = idmap_a[out[0, :n].long()]
             gb = idmap_b[out[1, :n].long()]
-            D.gather_pairs(ga, gb)
+            D.gather_pairs(ga.to(xdev), gb.to(xdev))
         return n
 
     def sync_all():
@@ -221,8 +229,8 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     eng.set_profiling(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([n_local, loc_na, loc_nb], dtype=torch.int64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
+    tot = torch.tensor([n_local, loc_na, loc_nb], dtype=torch.int64, device=xdev)
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -281,7 +289,9 @@ def main() -> None:
             "config": {
                 "workload": args.workload,
                 "n_a": tot_na, "n_b": tot_nb, "n_chrom": n_chrom, "pairs_per_step": n_pairs,
-                "parallelism": f"chrom-shard x{world}" + ("" if world == 1 or args.no_gather else " + rccl all-gather of pairs"),
+                "parallelism": f"chrom-shard x{world}" + ("" if world == 1 or args.no_gather else
+                                                            (" + rccl all-gather of pairs" if args.backend == "nccl"
+                                                             else " + gloo (rehearsal) all-gather of pairs")),
                 "inputs": "resident in HBM before the timed region",
                 "join_form": st["join_form"],
             },
