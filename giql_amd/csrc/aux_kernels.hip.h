@@ -115,25 +115,26 @@ __global__ __launch_bounds__(PM_NT) void k_pmax_down(const u32* __restrict__ in,
 }
 
 // ------------------------------------------------------------- SEMI / ANTI
-// flag[i] = 1 when A row i qualifies (SEMI: has an overlapping B row; ANTI: has
+// Queries are the A rows SORTED by linearised start (coherent binary searches:
+// neighbouring lanes walk the same path), results are scattered back by row id.
+// flag[rid] = 1 when the A row qualifies (SEMI: has an overlapping B row; ANTI: has
 // none).  B is sorted by linearised start with ALL its rows (no sentinels).
-__global__ __launch_bounds__(256) void k_semi_flags(SideView a, int n_chrom,
-                                                     const i64* __restrict__ chrom_base,
+__global__ __launch_bounds__(256) void k_semi_flags(const u32* __restrict__ a_keys,
+                                                     const u32* __restrict__ a_ends,
+                                                     const u32* __restrict__ a_rids, u32 n_a,
+                                                     const DevMeta* __restrict__ meta,
                                                      const u32* __restrict__ b_keys,
                                                      const u32* __restrict__ b_pmax, u32 n_b,
                                                      int anti, u32* __restrict__ flag) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  const int c = a.chrom[i];
+  if (i >= n_a) return;
+  const u32 qs = a_keys[i], qe = a_ends[i];
   bool hit = false;
-  if (c >= 0 && c < n_chrom && n_b > 0) {
-    const i64 base = chrom_base[c];
-    const u32 qs = (u32)(base + (i64)a.start[i] + a.start_off);
-    const u32 qe = (u32)(base + (i64)a.end[i] + a.end_off);
+  if (n_b > 0 && qs < meta->sentinel) {          // rows with a bad chrom id carry the sentinel
     const u32 j = lower_bound_u32(b_keys, 0, n_b, qe);  // rows with b.start < a.end
     hit = j > 0 && b_pmax[j - 1] > qs;
   }
-  flag[i] = (hit != (anti != 0)) ? 1u : 0u;
+  flag[a_rids[i]] = (hit != (anti != 0)) ? 1u : 0u;
 }
 
 // rows_out[off[i]] = i for flagged rows (ascending row ids).
@@ -147,34 +148,31 @@ __global__ __launch_bounds__(256) void k_compact(const u32* __restrict__ flag,
 // ------------------------------------------------------------------- COUNT
 // Regular rows: count(a) = #{b.start < a.end} - #{b.end <= a.start} over the
 // regular B rows (two sorted arrays, no candidate is touched); irregular rows on
-// either side are settled by the literal predicate.
+// either side are settled by the literal predicate.  A rows come sorted by start
+// (regular prefix only; the irregular tail is settled by k_count_irregular).
 __global__ __launch_bounds__(256) void k_count_rows(
-    SideView a, SideView b, int n_chrom, const i64* __restrict__ chrom_base,
-    const u32* __restrict__ b_keys_sorted, const u32* __restrict__ b_ends_sorted, u32 n_b_total,
-    const u32* __restrict__ irr_b_list, const DevMeta* __restrict__ meta,
-    i64* __restrict__ counts_out) {
+    const u32* __restrict__ a_keys, const u32* __restrict__ a_ends, const u32* __restrict__ a_rids,
+    u32 n_a_total, SideView a, SideView b, const u32* __restrict__ b_keys_sorted,
+    const u32* __restrict__ b_ends_sorted, u32 n_b_total, const u32* __restrict__ irr_b_list,
+    const DevMeta* __restrict__ meta, i64* __restrict__ counts_out) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  const int c = a.chrom[i];
-  const i64 as = (i64)a.start[i] + a.start_off, ae = (i64)a.end[i] + a.end_off;
-  i64 cnt = 0;
-  if (ae > as && c >= 0 && c < n_chrom) {
-    const u32 n_reg = n_b_total - meta->irr_b;
-    const i64 base = chrom_base[c];
-    const u32 qs = (u32)(base + as), qe = (u32)(base + ae);
-    const u32 below = lower_bound_u32(b_keys_sorted, 0, n_reg, qe);  // b.start < a.end
-    const u32 done = upper_bound_u32(b_ends_sorted, 0, n_reg, qs);   // b.end <= a.start
-    cnt = (i64)below - (i64)done;
-    const u32 m = meta->irr_b;
+  if (i >= n_a_total - meta->irr_a) return;
+  const u32 n_reg = n_b_total - meta->irr_b;
+  const u32 qs = a_keys[i], qe = a_ends[i], r = a_rids[i];
+  const u32 below = lower_bound_u32(b_keys_sorted, 0, n_reg, qe);  // b.start < a.end
+  const u32 done = upper_bound_u32(b_ends_sorted, 0, n_reg, qs);   // b.end <= a.start
+  i64 cnt = (i64)below - (i64)done;
+  const u32 m = meta->irr_b;
+  if (m) {  // rare: literal predicate against the irregular B rows
+    const int ac = a.chrom[r];
+    const i64 as = (i64)a.start[r] + a.start_off, ae = (i64)a.end[r] + a.end_off;
     for (u32 k = 0; k < m; k++) {
-      const u32 r = irr_b_list[k];
-      cnt += literal_overlap(c, as, ae, b.chrom[r], (i64)b.start[r] + b.start_off,
-                             (i64)b.end[r] + b.end_off);
+      const u32 rb = irr_b_list[k];
+      cnt += literal_overlap(ac, as, ae, b.chrom[rb], (i64)b.start[rb] + b.start_off,
+                             (i64)b.end[rb] + b.end_off);
     }
-  } else {
-    cnt = -1;  // irregular A row: settled by k_count_irregular
   }
-  counts_out[i] = cnt;
+  counts_out[r] = cnt;
 }
 
 // One block per irregular A row: literal predicate against every B row.
@@ -201,26 +199,33 @@ __global__ __launch_bounds__(256) void k_count_irregular(SideView a, SideView b,
 }
 
 // ----------------------------------------------------------------- NEAREST
+// chrom_lo[c] = first index of chromosome c in the start-sorted B keys.
+__global__ void k_chrom_bounds(const u32* __restrict__ chrom_first, int n_chrom,
+                               const u32* __restrict__ b_keys, u32 n_b, u32* __restrict__ chrom_lo) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c <= n_chrom) chrom_lo[c] = lower_bound_u32(b_keys, 0, n_b, chrom_first[c]);
+}
+
 // B sorted by (linearised start, end); b_pmax = inclusive prefix max of ends.
-// chrom_first[c] = linearised offset of chromosome c (n_chrom + 1 entries).
+// A rows come sorted by start; results are scattered back by row id.
 // Distance CASE of _distance.py:67-87; order ABS(d), start, end (nearest.py:392).
 __global__ __launch_bounds__(256) void k_nearest(
-    SideView a, int n_chrom, const i64* __restrict__ chrom_base, const u32* __restrict__ chrom_first,
-    const u32* __restrict__ b_keys, const u32* __restrict__ b_ends, const u32* __restrict__ b_pmax,
-    const u32* __restrict__ b_rids, u32 n_b, int is_signed, i64 max_distance,
-    int32_t* __restrict__ idx_out, i64* __restrict__ dist_out, DevMeta* __restrict__ meta) {
+    const u32* __restrict__ a_keys, const u32* __restrict__ a_ends, const u32* __restrict__ a_rids,
+    u32 n_a, int n_chrom, const u32* __restrict__ chrom_first, const u32* __restrict__ chrom_lo,
+    const u32* __restrict__ b_keys, const u32* __restrict__ b_pmax, const u32* __restrict__ b_rids,
+    u32 n_b, int is_signed, i64 max_distance, int32_t* __restrict__ idx_out,
+    i64* __restrict__ dist_out, DevMeta* __restrict__ meta) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
-  const int c = a.chrom[i];
+  if (i >= n_a) return;
+  const u32 qs = a_keys[i], qe = a_ends[i], r = a_rids[i];
   int32_t best = -1;
   i64 best_d = 0;
-  if (c >= 0 && c < n_chrom && n_b > 0) {
-    const i64 as = (i64)a.start[i] + a.start_off, ae = (i64)a.end[i] + a.end_off;
-    if (ae < as) meta->status = -1;  // inverted row: NEAREST needs start <= end
-    const i64 base = chrom_base[c];
-    const u32 qs = (u32)(base + as), qe = (u32)(base + ae);
-    const u32 blo = lower_bound_u32(b_keys, 0, n_b, chrom_first[c]);
-    const u32 bhi = lower_bound_u32(b_keys, blo, n_b, chrom_first[c + 1]);
+  if (n_b > 0 && qs < meta->sentinel) {
+    if (qe < qs) meta->status = -1;  // inverted row: NEAREST needs start <= end
+    // chromosome of the row = last c with chrom_first[c] <= key
+    const u32 c = upper_bound_u32(chrom_first, 0, (u32)n_chrom + 1, qs) - 1;
+    const u32 blo = chrom_lo[c];
+    const u32 bhi = chrom_lo[c + 1];
     if (bhi > blo) {
       const u32 hi = lower_bound_u32(b_keys, blo, bhi, qe);
       u32 j = U32_MAX;
@@ -254,9 +259,8 @@ __global__ __launch_bounds__(256) void k_nearest(
       }
     }
   }
-  idx_out[i] = best;
-  dist_out[i] = best < 0 ? 0 : best_d;
-  (void)b_ends;
+  idx_out[r] = best;
+  dist_out[r] = best < 0 ? 0 : best_d;
 }
 
 // NEAREST needs start <= end on the B side too.

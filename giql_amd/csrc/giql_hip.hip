@@ -275,54 +275,63 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
 // hist_partial / gbase non-NULL: also produce the onesweep digit offsets.
 static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, int n_chrom,
                          const LinBufs& lb, u32* keys, u32* ends, u32* irr_list, int which,
-                         int keep_irregular, u32* hist_partial = nullptr, u32* gbase = nullptr) {
+                         int keep_irregular, u32* hist_partial = nullptr, u32* gbase = nullptr,
+                         u32* hist_end = nullptr, u32* gbase_end = nullptr) {
   if (s.n == 0) return GIQL_OK;
   if (hist_partial)
     HIP_TRY(hipMemsetAsync(hist_partial, 0, (size_t)LIN_HIST_REPLICAS * 1024 * sizeof(u32), st));
+  if (hist_end)
+    HIP_TRY(hipMemsetAsync(hist_end, 0, (size_t)LIN_HIST_REPLICAS * 1024 * sizeof(u32), st));
   Phase ph(ctx, st, GIQL_PH_LINEARIZE, hist_partial ? 2 : 1);
   u32 grid = cdiv((u64)s.n, LIN_NT);
   if (grid > (u32)LIN_MAX_BLOCKS) grid = LIN_MAX_BLOCKS;
   hipLaunchKernelGGL(k_linearize, dim3(grid), dim3(LIN_NT), 0, st, s.chrom, s.start, s.end,
                      (u32)s.n, s.start_off, s.end_off, n_chrom, lb.chrom_base, keys, ends, irr_list,
-                     ctx->d_meta, which, keep_irregular, hist_partial);
+                     ctx->d_meta, which, keep_irregular, hist_partial, hist_end);
   if (hist_partial)
     hipLaunchKernelGGL(k_digit_offsets, dim3(1), dim3(256), 0, st, hist_partial,
                        (u32)LIN_HIST_REPLICAS, gbase);
+  if (hist_end)
+    hipLaunchKernelGGL(k_digit_offsets, dim3(1), dim3(256), 0, st, hist_end, (u32)LIN_HIST_REPLICAS,
+                       gbase_end);
   return post_launch("linearize");
 }
 
 // Onesweep LSD sort (4 passes, one launch each); input and result in buffer 0.
 // status: cdiv(n, OS_MIN_TILE) * 256 words per pass (4 passes, zeroed here in one
 // memset); tickets: 4 words.
+// Payload of a sort = which of end / rid buffers the SortBufs carries.
 template <int NT, int ITEMS>
 static void launch_onesweep(hipStream_t st, SortBufs& sb, int src, int dst, bool first, u32 n,
                             int shift, const u32* gbase, u32* status, u32* ticket, DevMeta* meta) {
   const u32 n_tiles = cdiv(n, NT * ITEMS);
-  const u32* rin = first ? (const u32*)nullptr : sb.rid[src];
-  if (sb.end[0])  // (key, end, rid)
-    hipLaunchKernelGGL((k_onesweep<2, NT, ITEMS>), dim3(n_tiles), dim3(NT), 0, st, sb.key[src],
-                       sb.end[src], rin, sb.key[dst], sb.end[dst], sb.rid[dst], n, shift, gbase, status,
-                       ticket, meta);
-  else  // (key, rid): the uniform-length side carries no end
-    hipLaunchKernelGGL((k_onesweep<1, NT, ITEMS>), dim3(n_tiles), dim3(NT), 0, st, sb.key[src],
-                       (const u32*)nullptr, rin, sb.key[dst], (u32*)nullptr, sb.rid[dst], n, shift, gbase,
-                       status, ticket, meta);
+  const u32* rin = (first || !sb.rid[0]) ? (const u32*)nullptr : sb.rid[src];
+  const int mode = (sb.rid[0] ? 1 : 0) | (sb.end[0] ? 2 : 0);
+#define GIQL_OS_LAUNCH(M)                                                                            \
+  hipLaunchKernelGGL((k_onesweep<M, NT, ITEMS>), dim3(n_tiles), dim3(NT), 0, st, sb.key[src],       \
+                     sb.end[0] ? sb.end[src] : (const u32*)nullptr, rin, sb.key[dst],                 \
+                     sb.end[0] ? sb.end[dst] : (u32*)nullptr, sb.rid[0] ? sb.rid[dst] : (u32*)nullptr, \
+                     n, shift, gbase, status, ticket, meta)
+  switch (mode) {
+    case 0: GIQL_OS_LAUNCH(0); break;
+    case 1: GIQL_OS_LAUNCH(1); break;
+    case 2: GIQL_OS_LAUNCH(2); break;
+    default: GIQL_OS_LAUNCH(3); break;
+  }
+#undef GIQL_OS_LAUNCH
 }
 
-// (key, rid) rows need 2/3 of the registers: a 12-row-per-thread tile (12288 rows,
-// 192-byte runs) still fits two 1024-thread blocks per CU.
-static void launch_onesweep_kr(hipStream_t st, SortBufs& sb, int src, int dst, bool first, u32 n,
-                               int shift, const u32* gbase, u32* status, u32* ticket, DevMeta* meta) {
-  constexpr int NT = 1024, ITEMS = 12;
-  const u32 n_tiles = cdiv(n, NT * ITEMS);
-  const u32* rin = first ? (const u32*)nullptr : sb.rid[src];
-  hipLaunchKernelGGL((k_onesweep<1, NT, ITEMS>), dim3(n_tiles), dim3(NT), 0, st, sb.key[src],
-                     (const u32*)nullptr, rin, sb.key[dst], (u32*)nullptr, sb.rid[dst], n, shift, gbase,
-                     status, ticket, meta);
+// one- and two-array rows need fewer registers: a 12-row-per-thread tile (12288
+// rows, 192-byte runs) still fits two 1024-thread blocks per CU.
+static void launch_onesweep_small(hipStream_t st, SortBufs& sb, int src, int dst, bool first, u32 n,
+                                  int shift, const u32* gbase, u32* status, u32* ticket,
+                                  DevMeta* meta) {
+  launch_onesweep<1024, 12>(st, sb, src, dst, first, n, shift, gbase, status, ticket, meta);
 }
 
+// keep_rids: the rid buffer already holds row ids (second sort of a two-key sort).
 static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
-                             const u32* gbase, u32* status, u32* tickets) {
+                             const u32* gbase, u32* status, u32* tickets, bool keep_rids = false) {
   if (n == 0) return GIQL_OK;
   const size_t per_pass = (size_t)cdiv(n, OS_MIN_TILE) * OS_BINS;
   HIP_TRY(hipMemsetAsync(tickets, 0, 4 * sizeof(u32), st));
@@ -331,18 +340,18 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
     const int src = pass & 1, dst = src ^ 1;
     u32* stat = status + pass * per_pass;
     Phase ph(ctx, st, GIQL_PH_SORT_SCATTER);
-    if (!sb.end[0] && ctx->os_variant == 0) {
-      launch_onesweep_kr(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat,
-                         tickets + pass, ctx->d_meta);
+    if (!(sb.end[0] && sb.rid[0]) && ctx->os_variant == 0) {
+      launch_onesweep_small(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat,
+                            tickets + pass, ctx->d_meta);
       continue;
     }
     switch (ctx->os_variant) {
-      case 1: launch_onesweep<512, 8>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
-      case 2: launch_onesweep<512, 16>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
-      case 3: launch_onesweep<256, 16>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
-      case 4: launch_onesweep<1024, 4>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
-      case 5: launch_onesweep<1024, 12>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
-      default: launch_onesweep<1024, 8>(st, sb, src, dst, pass == 0, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+      case 1: launch_onesweep<512, 8>(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+      case 2: launch_onesweep<512, 16>(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+      case 3: launch_onesweep<256, 16>(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+      case 4: launch_onesweep<1024, 4>(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+      case 5: launch_onesweep<1024, 12>(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+      default: launch_onesweep<1024, 8>(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
     }
   }
   return post_launch("onesweep sort");
@@ -775,6 +784,22 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
   return GIQL_OK;
 }
 
+// Scratch shared by the single-output operators: histogram replicas, digit bases,
+// onesweep status words and tickets for one side at a time.
+struct OsScratch {
+  u32 *hist = nullptr, *gbase = nullptr, *hist_e = nullptr, *gbase_e = nullptr;
+  u32 *status = nullptr, *tickets = nullptr;
+};
+
+static void os_scratch_sizes(Carver& c, size_t n_max, OsScratch& o) {
+  o.hist = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
+  o.hist_e = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
+  o.gbase = c.take<u32>(1024);
+  o.gbase_e = c.take<u32>(1024);
+  o.status = c.take<u32>(4 * (size_t)cdiv(n_max ? n_max : 1, OS_MIN_TILE) * OS_BINS);
+  o.tickets = c.take<u32>(8);
+}
+
 // -------------------------------------------------------------- SEMI / ANTI
 int giql_hip_semi_anti_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
                            int32_t n_chrom, int anti, int32_t* rows_out, int64_t* n_out,
@@ -793,20 +818,25 @@ int giql_hip_semi_anti_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   if (a->n == 0) return GIQL_OK;
   if (!rows_out) return set_err(GIQL_ERR_INVALID, "rows_out is NULL");
   const size_t na = (size_t)a->n, nb = (size_t)b->n;
+  if (na > OS_MAX_ROWS || nb > OS_MAX_ROWS) return set_err(GIQL_ERR_INVALID, "side larger than 2^30 rows");
   const int nch = n_chrom > 0 ? n_chrom : 1;
 
   LinBufs lb;
-  SortBufs sbb;
-  u32 *tile_hist = nullptr, *flag = nullptr, *pmax = nullptr, *bmax = nullptr, *dummy_irr = nullptr;
+  SortBufs sa, sbb;
+  OsScratch os;
+  u32 *flag = nullptr, *pmax = nullptr, *bmax = nullptr, *dummy_irr = nullptr;
   u64 *bsums = nullptr, *off = nullptr;
-  const size_t n_tiles = cdiv(nb ? nb : 1, RS_TILE);
-  const size_t scan_max = (na > n_tiles * RS_BINS ? na : n_tiles * RS_BINS);
   auto carve = [&](char* base) {
     Carver c{base};
     common_sizes(c, nch, lb);
-    sort_sizes(c, nb ? nb : 1, sbb, true);
-    tile_hist = c.take<u32>(n_tiles * RS_BINS);
-    bsums = c.take<u64>(cdiv(scan_max, SCAN_TILE) + 2);
+    sort_sizes(c, na, sa, true);
+    for (int k = 0; k < 2; k++) {  // B: (key, end), no row ids
+      sbb.key[k] = c.take<u32>(nb ? nb : 1);
+      sbb.end[k] = c.take<u32>(nb ? nb : 1);
+      sbb.rid[k] = nullptr;
+    }
+    os_scratch_sizes(c, na > nb ? na : nb, os);
+    bsums = c.take<u64>(cdiv(na, SCAN_TILE) + 2);
     flag = c.take<u32>(na);
     off = c.take<u64>(na + 1);
     pmax = c.take<u32>(nb ? nb : 1);
@@ -819,14 +849,18 @@ int giql_hip_semi_anti_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, nch, lb));
   if (nb > 0) {
-    GIQL_TRY(run_linearize(ctx, st, *b, nch, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1));
-    GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
+    // every B row keeps its real key: the prefix-max test is exact for any row
+    GIQL_TRY(run_linearize(ctx, st, *b, nch, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist,
+                           os.gbase));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, os.tickets));
     GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
   }
+  GIQL_TRY(run_linearize(ctx, st, *a, nch, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist, os.gbase));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, os.tickets + 4));
   {
     Phase ph(ctx, st, GIQL_PH_COUNT);
-    hipLaunchKernelGGL(k_semi_flags, dim3(cdiv(na, 256)), dim3(256), 0, st, view_of(*a), nch,
-                       lb.chrom_base, sbb.key[0], pmax, (u32)nb, anti, flag);
+    hipLaunchKernelGGL(k_semi_flags, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0],
+                       sa.rid[0], (u32)na, ctx->d_meta, sbb.key[0], pmax, (u32)nb, anti, flag);
     GIQL_TRY(post_launch("semi flags"));
   }
   GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, flag, na, off, bsums, off + na));
@@ -860,22 +894,26 @@ int giql_hip_count_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b
   if (a->n == 0) return GIQL_OK;
   if (!counts_out) return set_err(GIQL_ERR_INVALID, "counts_out is NULL");
   const size_t na = (size_t)a->n, nb = (size_t)b->n;
+  if (na > OS_MAX_ROWS || nb > OS_MAX_ROWS) return set_err(GIQL_ERR_INVALID, "side larger than 2^30 rows");
   if (nb == 0 || n_chrom == 0) {
     HIP_TRY(hipMemsetAsync(counts_out, 0, na * sizeof(int64_t), st));
     return GIQL_OK;
   }
   LinBufs lb;
-  SortBufs sbb, sends;
-  u32 *tile_hist = nullptr, *irr_a_list = nullptr, *irr_b_list = nullptr;
-  u64* bsums = nullptr;
-  const size_t n_tiles = cdiv(nb, RS_TILE);
+  SortBufs sa, sstart, send;
+  OsScratch os;
+  u32 *irr_a_list = nullptr, *irr_b_list = nullptr;
   auto carve = [&](char* base) {
     Carver c{base};
     common_sizes(c, n_chrom, lb);
-    sort_sizes(c, nb, sbb, true);
-    sort_sizes(c, nb, sends, false);
-    tile_hist = c.take<u32>(n_tiles * RS_BINS);
-    bsums = c.take<u64>(cdiv(n_tiles * RS_BINS, SCAN_TILE) + 2);
+    sort_sizes(c, na, sa, true);
+    for (int k = 0; k < 2; k++) {  // two keys-only sorts of B: starts and ends
+      sstart.key[k] = c.take<u32>(nb);
+      sstart.end[k] = sstart.rid[k] = nullptr;
+      send.key[k] = c.take<u32>(nb);
+      send.end[k] = send.rid[k] = nullptr;
+    }
+    os_scratch_sizes(c, na > nb ? na : nb, os);
     irr_a_list = c.take<u32>(na);
     irr_b_list = c.take<u32>(nb);
     return c.off;
@@ -884,29 +922,18 @@ int giql_hip_count_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b
   carve(ctx->arena);
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
-  // A is only linearised to collect its irregular rows (keys are not used)
-  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], irr_b_list, 1, 0));
-  HIP_TRY(hipMemcpyAsync(sends.key[0], sbb.end[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
-  GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
-  GIQL_TRY(run_sort(ctx, st, sends, (u32)nb, tile_hist, bsums));
-  {
-    // reuse sbb.key[1]/end[1] as scratch for A's (unused) keys
-    u32* scratch_k = nullptr;
-    u32* scratch_e = nullptr;
-    if (na <= nb) {
-      scratch_k = sbb.key[1];
-      scratch_e = sbb.end[1];
-      GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, scratch_k, scratch_e, irr_a_list, 0, 0));
-    } else {
-      // A larger than B: flag irregular rows without materialising keys
-      GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, nullptr, nullptr, irr_a_list, 0, 0));
-    }
-  }
+  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sstart.key[0], send.key[0], irr_b_list, 1, 0,
+                         os.hist, os.gbase, os.hist_e, os.gbase_e));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sstart, (u32)nb, os.gbase, os.status, os.tickets));
+  GIQL_TRY(run_sort_onesweep(ctx, st, send, (u32)nb, os.gbase_e, os.status, os.tickets + 4));
+  GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], irr_a_list, 0, 0, os.hist,
+                         os.gbase));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, os.tickets));
   {
     Phase ph(ctx, st, GIQL_PH_COUNT);
-    hipLaunchKernelGGL(k_count_rows, dim3(cdiv(na, 256)), dim3(256), 0, st, view_of(*a), view_of(*b),
-                       n_chrom, lb.chrom_base, sbb.key[0], sends.key[0], (u32)nb, irr_b_list,
-                       ctx->d_meta, counts_out);
+    hipLaunchKernelGGL(k_count_rows, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0],
+                       sa.rid[0], (u32)na, view_of(*a), view_of(*b), sstart.key[0], send.key[0], (u32)nb,
+                       irr_b_list, ctx->d_meta, counts_out);
     GIQL_TRY(post_launch("count rows"));
   }
   GIQL_TRY(read_meta(ctx, st));
@@ -942,24 +969,25 @@ int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side*
   if (a->n == 0) return GIQL_OK;
   if (!idx_b_out || !dist_out) return set_err(GIQL_ERR_INVALID, "idx_b_out/dist_out is NULL");
   const size_t na = (size_t)a->n, nb = (size_t)b->n;
+  if (na > OS_MAX_ROWS || nb > OS_MAX_ROWS) return set_err(GIQL_ERR_INVALID, "side larger than 2^30 rows");
   if (nb == 0 || n_chrom == 0) {
     HIP_TRY(hipMemsetAsync(idx_b_out, 0xFF, na * sizeof(int32_t), st));
     HIP_TRY(hipMemsetAsync(dist_out, 0, na * sizeof(int64_t), st));
     return GIQL_OK;
   }
   LinBufs lb;
-  SortBufs sbb;
-  u32 *tile_hist = nullptr, *pmax = nullptr, *bmax = nullptr, *dummy_irr = nullptr;
-  u64* bsums = nullptr;
-  const size_t n_tiles = cdiv(nb, RS_TILE);
+  SortBufs sa, sbb;
+  OsScratch os;
+  u32 *pmax = nullptr, *bmax = nullptr, *dummy_irr = nullptr, *chrom_lo = nullptr;
   auto carve = [&](char* base) {
     Carver c{base};
     common_sizes(c, n_chrom, lb);
+    sort_sizes(c, na, sa, true);
     sort_sizes(c, nb, sbb, true);
-    tile_hist = c.take<u32>(n_tiles * RS_BINS);
-    bsums = c.take<u64>(cdiv(n_tiles * RS_BINS, SCAN_TILE) + 2);
+    os_scratch_sizes(c, na > nb ? na : nb, os);
     pmax = c.take<u32>(nb);
     bmax = c.take<u32>(cdiv(nb, PM_TILE) + 1);
+    chrom_lo = c.take<u32>((size_t)n_chrom + 2);
     dummy_irr = c.take<u32>(16);
     return c.off;
   };
@@ -967,7 +995,8 @@ int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side*
   carve(ctx->arena);
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
-  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1));
+  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist,
+                         os.gbase, os.hist_e, os.gbase_e));
   {
     Phase ph(ctx, st, GIQL_PH_AUX);
     hipLaunchKernelGGL(k_check_not_inverted, dim3(cdiv(nb, 256)), dim3(256), 0, st, view_of(*b),
@@ -980,36 +1009,19 @@ int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side*
       by_end.key[k] = sbb.end[k];
       by_end.end[k] = sbb.key[k];
     }
-    GIQL_TRY(run_sort(ctx, st, by_end, (u32)nb, tile_hist, bsums));
+    GIQL_TRY(run_sort_onesweep(ctx, st, by_end, (u32)nb, os.gbase_e, os.status, os.tickets));
   }
-  {
-    // second sort must carry the row ids produced by the first one: run the
-    // passes by hand with rids_in set on pass 0 as well
-    const u32 n = (u32)nb;
-    const u32 nt = cdiv(n, RS_TILE);
-    for (int pass = 0; pass < 4; pass++) {
-      const int src = pass & 1, dst = src ^ 1;
-      {
-        Phase ph(ctx, st, GIQL_PH_SORT_HIST);
-        hipLaunchKernelGGL(k_radix_hist, dim3(nt), dim3(RS_NT), 0, st, sbb.key[src], n, pass * 8, nt,
-                           tile_hist);
-      }
-      GIQL_TRY(run_scan<u32>(ctx, st, GIQL_PH_SORT_SCAN, tile_hist, (u64)nt * RS_BINS, tile_hist,
-                             bsums, nullptr));
-      {
-        Phase ph(ctx, st, GIQL_PH_SORT_SCATTER);
-        hipLaunchKernelGGL((k_radix_scatter<true>), dim3(nt), dim3(RS_NT), 0, st, sbb.key[src], sbb.end[src],
-                           (const u32*)sbb.rid[src], sbb.key[dst], sbb.end[dst], sbb.rid[dst], n,
-                           pass * 8, nt, tile_hist);
-      }
-    }
-    GIQL_TRY(post_launch("nearest sort"));
-  }
+  GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, os.tickets + 4, /*keep_rids=*/true));
   GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
+  GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist,
+                         os.gbase));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, os.tickets));
   {
-    Phase ph(ctx, st, GIQL_PH_COUNT);
-    hipLaunchKernelGGL(k_nearest, dim3(cdiv(na, 256)), dim3(256), 0, st, view_of(*a), n_chrom,
-                       lb.chrom_base, lb.chrom_first, sbb.key[0], sbb.end[0], pmax, sbb.rid[0], (u32)nb,
+    Phase ph(ctx, st, GIQL_PH_COUNT, 2);
+    hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st,
+                       lb.chrom_first, n_chrom, sbb.key[0], (u32)nb, chrom_lo);
+    hipLaunchKernelGGL(k_nearest, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0], sa.rid[0],
+                       (u32)na, n_chrom, lb.chrom_first, chrom_lo, sbb.key[0], pmax, sbb.rid[0], (u32)nb,
                        is_signed, (i64)max_distance, idx_b_out, dist_out, ctx->d_meta);
     GIQL_TRY(post_launch("nearest"));
   }

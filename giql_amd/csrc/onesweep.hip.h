@@ -32,9 +32,10 @@ constexpr u32 OS_SPIN_LIMIT = 1u << 24;
 
 // OS_NT threads x OS_ITEMS rows per thread = one tile.  Default 1024 x 8: 16 waves
 // halve the per-wave serial work of 512 x 16 at the same 8192-row tile.
-// PAYLOAD: 0 = keys only, 1 = (key, rid), 2 = (key, end, rid).
+// PAYLOAD bit 0: carry rid, bit 1: carry end.  0 = keys only, 1 = (key, rid),
+// 2 = (key, end), 3 = (key, end, rid).
 template <int PAYLOAD, int OS_NT, int OS_ITEMS>
-__global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD < 2 || OS_ITEMS <= 8)) ? 8 : 1) void k_onesweep(
+__global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS <= 8)) ? 8 : 1) void k_onesweep(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
     int shift, const u32* __restrict__ gbase, u32* __restrict__ status, u32* __restrict__ ticket,
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD < 2 || OS_ITEMS <
     const bool ok = r < n_valid;
     const u32 g = tile_base + r;
     key[i] = ok ? keys_in[g] : U32_MAX;
-    if (PAYLOAD == 2) end[i] = ok ? ends_in[g] : 0u;
-    if (PAYLOAD >= 1) rid[i] = ok ? (rids_in ? rids_in[g] : g) : 0u;
+    if (PAYLOAD & 2) end[i] = ok ? ends_in[g] : 0u;
+    if (PAYLOAD & 1) rid[i] = ok ? (rids_in ? rids_in[g] : g) : 0u;
   }
 
   // stable rank inside the wave (peers = lanes with the same digit)
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD < 2 || OS_ITEMS <
       keys_out[dst[i]] = k;
     }
   }
-  if (PAYLOAD == 2) {
+  if (PAYLOAD & 2) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD < 2 || OS_ITEMS <
       if (p < n_valid) ends_out[dst[i]] = s_buf[p];
     }
   }
-  if (PAYLOAD >= 1) {
+  if (PAYLOAD & 1) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {

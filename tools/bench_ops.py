@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Secondary benchmark: the other BASELINE.json configs on one GPU.
+
+cfg2  1M x 1M INNER, single chromosome (sparse G=248,956,422 and dense G=10,000,000)
+cfg3  SEMI and ANTI, 1M peaks x 10M reads, 24 chromosomes (+ COUNT on the same input)
+cfg5  NEAREST k=1, 10M x 10M peaks, 24 chromosomes
+Prints one JSON line per case: ms per call (median of --reps after --warmup), rows/s,
+and the hipEvent phase breakdown.  Inputs are resident in HBM before timing.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    import torch
+
+    from giql_amd import synth
+    from giql_amd.engine import DeviceSide, HipEngine
+
+    eng = HipEngine(0)
+    dev = "cuda:0"
+
+    def side(cols):
+        return DeviceSide.from_numpy(*cols, device=dev)
+
+    def run(name, fn, units, unit_name):
+        if args.only and args.only not in name:
+            return
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        eng.set_profiling(True)
+        times, phases = [], {}
+        for _ in range(args.reps):
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+            for k, v in eng.stats()["phase_ms"].items():
+                phases[k] = phases.get(k, 0.0) + v / args.reps
+        eng.set_profiling(False)
+        ms = statistics.median(times)
+        n_out = int(out) if not hasattr(out, "shape") else int(out.shape[0])
+        print(json.dumps({"case": name, "ms": round(ms, 3), "n_out": n_out,
+                          unit_name + "_per_s": round(units / (ms * 1e-3), 1),
+                          "join_form": eng.stats().get("join_form"),
+                          "phase_ms": {k: round(v, 3) for k, v in phases.items() if v > 0}}), flush=True)
+
+    # ---- cfg 2
+    for tag, g in (("sparse", 248_956_422), ("dense", 10_000_000)):
+        a = side(synth.make_single_chrom(1_000_000, 1, "peaks", g))
+        b = side(synth.make_single_chrom(1_000_000, 2, "peaks", g))
+        n = eng.inner_plan(a, b, 1)
+        out = torch.empty((2, n), dtype=torch.int32, device=dev)
+
+        def inner():
+            m = eng.inner_plan(a, b, 1)
+            eng.inner_fill(out[0, :m], out[1, :m])
+            return m
+
+        run(f"cfg2_inner_1Mx1M_{tag}", inner, n, "pairs")
+        del out
+    # ---- cfg 3
+    a = side(synth.make_table(1_000_000, 3, "peaks"))
+    b = side(synth.make_table(10_000_000, 4, "reads"))
+    run("cfg3_semi_1Mx10M", lambda: eng.semi_join(a, b, 24), 11_000_000, "input_rows")
+    run("cfg3_anti_1Mx10M", lambda: eng.anti_join(a, b, 24), 11_000_000, "input_rows")
+    run("cfg3_count_1Mx10M", lambda: eng.count_overlaps(a, b, 24), 11_000_000, "input_rows")
+    # ---- cfg 5
+    a = side(synth.make_table(10_000_000, 7, "peaks"))
+    b = side(synth.make_table(10_000_000, 8, "peaks"))
+    run("cfg5_nearest_10Mx10M", lambda: eng.nearest(a, b, 24)[0], 20_000_000, "input_rows")
+    run("cfg5_count_10Mx10M", lambda: eng.count_overlaps(a, b, 24), 20_000_000, "input_rows")
+    run("cfg5_semi_10Mx10M", lambda: eng.semi_join(a, b, 24), 20_000_000, "input_rows")
+
+
+if __name__ == "__main__":
+    main()
