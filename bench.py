@@ -60,23 +60,42 @@ def parse_args():
     return p.parse_args()
 
 
-def phase_bytes(phase: str, n_a: int, n_b: int, n_out: int) -> float:
+def phase_bytes(phase: str, n_a: int, n_b: int, n_out: int, form: str = "general") -> float:
     """Algorithmic (minimal) HBM bytes moved by ALL launches of one phase per step.
 
-    DESIGN.md §kernels states each figure: read every input once, write every
-    output once, nothing else.
+    DESIGN.md §3 states each figure: read every input of the kernel once, write
+    every output once, nothing else.  In the uniform-length forms the fixed-length
+    side is sorted as (key, rid) -- 8 B/row -- and there is no class-1 stage.
     """
     n = n_a + n_b
+    if form == "uniform_b":
+        n_q, n_u = n_a, n_b
+    elif form == "uniform_a":
+        n_q, n_u = n_b, n_a
+    else:
+        n_q = n_u = 0
+    if form == "general":
+        sort = 24.0 * n * 4                      # 4 passes x (read + write key,end,rid)
+        lin = 12.0 * n + 8.0 * n                 # read 3 cols, write key + end
+        count = (8.0 * n_b + 4.0 * n_a) + (8.0 * n_a + 4.0 * n_b + 8.0 * n_a)
+        scan = 12.0 * n_a
+        fill = 8.0 * n_out + 12.0 * n_b + 4.0 * n_a + 16.0 * n_a + 4.0 * n_b
+    else:
+        sort = (24.0 * n_q + 16.0 * n_u) * 4     # the uniform side carries (key, rid)
+        lin = 12.0 * n + 8.0 * n_q + 4.0 * n_u
+        count = 8.0 * n_q + 4.0 * n_u + 8.0 * n_q
+        scan = 12.0 * n_q
+        fill = 8.0 * n_out + 16.0 * n_q + 4.0 * n_u
     return {
-        "span": 8.0 * n,                  # chrom + (start|end) once
-        "linearize": 12.0 * n + 8.0 * n,  # read 3 cols, write key + end
-        "sort_hist": 4.0 * n * 4,         # 4 passes x key
+        "span": 12.0 * n,       # chrom, start, end once
+        "linearize": lin,
+        "sort_hist": 4.0 * n * 4,
         "sort_scan": 0.0,
-        "sort_scatter": 24.0 * n * 4,     # 4 passes x (read + write key,end,rid)
-        "count": 8.0 * n + 8.0 * n,       # read (start,end) of each query, write lo + cnt
-        "scan": 4.0 * n + 8.0 * n,        # read cnt, write u64 offset
+        "sort_scatter": sort,
+        "count": count,
+        "scan": scan,
         "partition": 0.0,
-        "fill": 8.0 * n_out + 4.0 * n,    # write (row_a,row_b); read each rid once
+        "fill": fill,
         "irregular": 0.0,
         "aux": 0.0,
     }[phase]
@@ -244,7 +263,7 @@ def main() -> None:
         dom = max(per_step_ms, key=lambda k: per_step_ms[k])
         dom_ms = per_step_ms[dom]
         dom_launches = max(per_step_launches[dom], 1)
-        dom_bytes = phase_bytes(dom, loc_na, loc_nb, n_local)
+        dom_bytes = phase_bytes(dom, loc_na, loc_nb, n_local, st["join_form"])
         achieved = (dom_bytes / dom_launches) / (dom_ms / dom_launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         join_bytes = 12.0 * (loc_na + loc_nb) + 8.0 * n_local
         device_ms = sum(per_step_ms.values())

@@ -285,9 +285,14 @@ static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, 
   Phase ph(ctx, st, GIQL_PH_LINEARIZE, hist_partial ? 2 : 1);
   u32 grid = cdiv((u64)s.n, LIN_NT);
   if (grid > (u32)LIN_MAX_BLOCKS) grid = LIN_MAX_BLOCKS;
-  hipLaunchKernelGGL(k_linearize, dim3(grid), dim3(LIN_NT), 0, st, s.chrom, s.start, s.end,
-                     (u32)s.n, s.start_off, s.end_off, n_chrom, lb.chrom_base, keys, ends, irr_list,
-                     ctx->d_meta, which, keep_irregular, hist_partial, hist_end);
+  if (hist_end)
+    hipLaunchKernelGGL((k_linearize<true>), dim3(grid), dim3(LIN_NT), 0, st, s.chrom, s.start, s.end,
+                       (u32)s.n, s.start_off, s.end_off, n_chrom, lb.chrom_base, keys, ends, irr_list,
+                       ctx->d_meta, which, keep_irregular, hist_partial, hist_end);
+  else
+    hipLaunchKernelGGL((k_linearize<false>), dim3(grid), dim3(LIN_NT), 0, st, s.chrom, s.start, s.end,
+                       (u32)s.n, s.start_off, s.end_off, n_chrom, lb.chrom_base, keys, ends, irr_list,
+                       ctx->d_meta, which, keep_irregular, hist_partial, (u32*)nullptr);
   if (hist_partial)
     hipLaunchKernelGGL(k_digit_offsets, dim3(1), dim3(256), 0, st, hist_partial,
                        (u32)LIN_HIST_REPLICAS, gbase);

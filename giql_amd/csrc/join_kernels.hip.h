@@ -254,6 +254,7 @@ constexpr int LIN_HIST_REPLICAS = 64;  // ghist[replica][4][256], block b adds t
 // hist_partial (optional): 64 replicas of the 4 x 256 digit histogram of the keys
 // (for the onesweep sort); each block adds its LDS histogram to one replica, so an
 // address sees at most grid/64 adds; k_digit_offsets sums the replicas.
+template <bool END_HIST>
 __global__ __launch_bounds__(LIN_NT) void k_linearize(
     const int* __restrict__ chrom, const int* __restrict__ start, const int* __restrict__ end, u32 n,
     int start_off, int end_off, int n_chrom, const i64* __restrict__ chrom_base,
@@ -261,12 +262,12 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
     DevMeta* __restrict__ meta, int which, int keep_irregular, u32* __restrict__ hist_partial,
     u32* __restrict__ hist_partial_end) {
   __shared__ u32 s_hist[4 * 256];
-  __shared__ u32 s_hist_e[4 * 256];  // same histogram over the END keys (sorts by end)
+  __shared__ u32 s_hist_e[END_HIST ? 4 * 256 : 1];  // same histogram over the END keys
   if (hist_partial) {
 #pragma unroll
     for (int k = threadIdx.x; k < 4 * 256; k += LIN_NT) {
       s_hist[k] = 0;
-      s_hist_e[k] = 0;
+      if (END_HIST) s_hist_e[k] = 0;
     }
     __syncthreads();
   }
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
           } else if (ok) {
             atomicAdd(&s_hist[p * 256 + d], 1u);
           }
-          if (hist_partial_end && ok) atomicAdd(&s_hist_e[p * 256 + ((ke >> (8 * p)) & 0xFFu)], 1u);
+          if (END_HIST && ok) atomicAdd(&s_hist_e[p * 256 + ((ke >> (8 * p)) & 0xFFu)], 1u);
         }
       }
       const u64 m = __ballot(irr);
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
     for (int k = threadIdx.x; k < 4 * 256; k += LIN_NT) {
       const u32 v = s_hist[k];
       if (v) atomicAdd(&g[k], v);
-      if (hist_partial_end) {
+      if (END_HIST) {
         const u32 ve = s_hist_e[k];
         if (ve) atomicAdd(&hist_partial_end[(size_t)(blockIdx.x % LIN_HIST_REPLICAS) * 1024 + k], ve);
       }

@@ -382,3 +382,62 @@ def test_uniform_length_at_chromosome_edges(eng):
                  np.array([100, 1090, 100, 102, 100], np.int32))
     assert np.array_equal(gpu_inner(eng, a, b, 3), ora.sort_pairs(*ora.c_inner(a, b, "brute")))
     assert eng.stats()["join_form"] == "uniform_b"
+
+
+# ------------------------------------------- BASELINE full size (cfg 4), properties
+def test_config4_full_size_properties(eng):
+    """10M x 100M, 24 chromosomes: too large to sort-compare pair by pair in a
+    test, so check size-independent properties of the full result on the GPU:
+    every pair satisfies the literal predicate, no pair is repeated, the count
+    equals the sum of per-row counts from the independent two-sorted-arrays COUNT
+    kernel, per-chromosome pair counts equal the oracle's on two sampled
+    chromosomes, and the uniform and general forms agree (multiset checksum)."""
+    from giql_amd import synth
+    from giql_amd.engine import DeviceSide, HipEngine
+    import os
+
+    ac, as_, ae = synth.make_table(10_000_000, 5, "peaks")
+    bc, bs, be = synth.make_table(100_000_000, 6, "reads")
+    a = DeviceSide.from_numpy(ac, as_, ae)
+    b = DeviceSide.from_numpy(bc, bs, be)
+    ra, rb = eng.inner_join(a, b, 24)
+    n = int(ra.shape[0])
+    assert eng.stats()["join_form"] == "uniform_b"
+    assert 3.9e8 < n < 4.2e8
+    la, lb_ = ra.long(), rb.long()
+    # 1. predicate holds for every emitted pair
+    ok = (a.chrom[la] == b.chrom[lb_]) & (a.start[la] < b.end[lb_]) & (a.end[la] > b.start[lb_])
+    assert bool(ok.all())
+    del ok
+    # 2. completeness: total == sum of COUNT (independent kernels), per-row too
+    counts = eng.count_overlaps(a, b, 24)
+    assert int(counts.sum()) == n
+    per_row = torch.bincount(la, minlength=a.n)
+    assert torch.equal(per_row, counts)
+    del per_row, counts
+    # 3. no repeated pair (rows are distinct, so pairs must be)
+    packed = (la << 32) | lb_
+    assert int(torch.unique(packed).shape[0]) == n
+    del packed
+    # 4. two sampled chromosomes against the oracle (full pair set)
+    for c in (20, 23):
+        ma, mb = ac == c, bc == c
+        oa, ob = ora.Side(ac[ma], as_[ma], ae[ma]), ora.Side(bc[mb], bs[mb], be[mb])
+        wa, wb = ora.c_inner(oa, ob, "sweep")
+        ia, ib = np.nonzero(ma)[0], np.nonzero(mb)[0]
+        sel = (a.chrom[la] == c)
+        got = ora.sort_pairs(ra[sel].cpu().numpy(), rb[sel].cpu().numpy())
+        want = ora.sort_pairs(ia[wa], ib[wb])
+        assert np.array_equal(got, want), c
+    # 5. the general two-class form returns the same multiset
+    chk = eng.pairs_checksum(ra, rb)
+    del ra, rb, la, lb_
+    os.environ["GIQL_HIP_NO_UNIFORM"] = "1"
+    try:
+        e2 = HipEngine(0)
+        ga, gb = e2.inner_join(a, b, 24)
+        assert e2.stats()["join_form"] == "general"
+        assert int(ga.shape[0]) == n and e2.pairs_checksum(ga, gb) == chk
+        e2.close()
+    finally:
+        del os.environ["GIQL_HIP_NO_UNIFORM"]
