@@ -101,6 +101,18 @@ def phase_bytes(phase: str, n_a: int, n_b: int, n_out: int, form: str = "general
     }[phase]
 
 
+def pmc_traffic(workload: str, form: str, phase: str, launches: int):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/pmc_traffic.json; rocprofv3 cannot run inside the timed process).
+    None when no counter run exists for this workload / join form."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        return round(t[workload][form][phase] / max(launches, 1))
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def run_cpu_baseline(args, n_a, kind_a, seed_a, n_b, kind_b, seed_b):
     """Time the oracle's OpenMP sort-merge port on a bounded sample of the workload.
 
@@ -277,7 +289,7 @@ def main() -> None:
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic(args.workload, st["join_form"], dom, dom_launches),
             "whole_join": {
                 "algorithmic_bytes": join_bytes,
                 "device_ms": round(device_ms, 3),
