@@ -317,11 +317,13 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
 #pragma unroll
         for (int p = 0; p < 4; p++) {
           const u32 d = (k >> (8 * p)) & 0xFFu;
-          // chromosome-sorted input makes the high digits wave-uniform: one add
-          const u32 d0 = __shfl(d, __ffsll((long long)act) - 1, WAVE);
+          // chromosome-sorted input makes the high digits wave-uniform: one add.
+          // Valid lanes are a prefix of the wave (row index grows with the lane),
+          // so lane 0 is valid whenever any lane is: readfirstlane, no LDS shuffle.
+          const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
           const u64 same = __ballot(ok && d == d0);
           if (act != 0 && same == act) {
-            if (lane_id() == (u32)(__ffsll((long long)act) - 1))
+            if (lane_id() == 0)
               atomicAdd(&s_hist[p * 256 + d0], (u32)__popcll(act));
           } else if (ok) {
             atomicAdd(&s_hist[p * 256 + d], 1u);
@@ -738,13 +740,14 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
     // last row whose outputs start at or before this wave's first output
     u32 k_cur = upper_bound_u32(s_rel, 0, nqt, p_w0) - 1;
     constexpr int NWIN = PER_WAVE / WAVE;
-    u32 jj[NWIN], qr[NWIN];
-    // phase A (LDS only): which row does each of my NWIN outputs belong to
+    u32 jj[NWIN], qr[NWIN], sr[NWIN];
+    // phase A: which row does each of my NWIN outputs belong to (LDS + DPP only)
 #pragma unroll
     for (int it = 0; it < NWIN; it++) {
       const u32 pc = p_w0 + it * WAVE;
       jj[it] = 0;
       qr[it] = 0;
+      sr[it] = 0;
       if (pc >= tile_len) continue;  // wave-uniform
       // rows k_cur+1, k_cur+2, ... that start inside [pc, pc + 64).  Fast path: at
       // most 64 of them and all at distinct positions -> OR their start bits into
@@ -804,15 +807,12 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
       const u32 p_rel = pc + lane;
       jj[it] = s_lo[k] + (k == 0 ? p_rel + first_delta : p_rel - s_rel[k]);
       qr[it] = s_qrid[k];
+      // the gather is issued now and only waited for at the stores below, so it
+      // flies under the LDS chain of the following windows
+      sr[it] = p_rel < tile_len ? s_rid[jj[it]] : 0u;
       k_cur = (u32)__builtin_amdgcn_readlane((int)k, WAVE - 1);
     }
-    // phase B: all gathers in flight together, then the coalesced stores
-    u32 sr[NWIN];
-#pragma unroll
-    for (int it = 0; it < NWIN; it++) {
-      const u32 p_rel = p_w0 + it * WAVE + lane;
-      sr[it] = p_rel < tile_len ? s_rid[jj[it]] : 0u;
-    }
+    // phase B: the coalesced stores
 #pragma unroll
     for (int it = 0; it < NWIN; it++) {
       const u32 p_rel = p_w0 + it * WAVE + lane;
