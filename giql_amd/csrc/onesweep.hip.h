@@ -32,73 +32,79 @@ constexpr u32 OS_SPIN_LIMIT = 1u << 24;
 
 // OS_NT threads x OS_ITEMS rows per thread = one tile.  Default 1024 x 8: 16 waves
 // halve the per-wave serial work of 512 x 16 at the same 8192-row tile.
+// Stable in-wave rank of one item by its 8-bit digit.  For every digit bit b the
+// wave ballots the bit (m) and each lane ORs into `mis` the lanes whose bit differs
+// from its own: mis |= m ^ (mybit ? ~0 : 0).  peers = active & ~mis are the lanes
+// holding the same digit.  Shaped so hipcc emits, per bit, v_bfe_i32 + v_cmp +
+// 2 x v_xor + (OR folded three-way): ~5 VALU instead of the ~11 it produces for the
+// naive `peers &= bit ? m : ~m`.
+__device__ __forceinline__ void wave_match8(u32 d, u64 active, u32& below, u32& total) {
+  u32 mis_lo = 0, mis_hi = 0;
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    const int s = __builtin_amdgcn_sbfe((int)d, b, 1);  // 0 or -1
+    const u64 m = __ballot(s != 0);
+    mis_lo |= (u32)m ^ (u32)s;
+    mis_hi |= (u32)(m >> 32) ^ (u32)s;
+  }
+  const u32 p_lo = (u32)active & ~mis_lo;
+  const u32 p_hi = (u32)(active >> 32) & ~mis_hi;
+  // lanes below me in the peer set: mbcnt counts mask bits of lower lanes directly
+  below = __builtin_amdgcn_mbcnt_hi(p_hi, __builtin_amdgcn_mbcnt_lo(p_lo, 0u));
+  total = (u32)__popc(p_lo) + (u32)__popc(p_hi);
+}
+
 // PAYLOAD bit 0: carry rid, bit 1: carry end.  0 = keys only, 1 = (key, rid),
 // 2 = (key, end), 3 = (key, end, rid).
-template <int PAYLOAD, int OS_NT, int OS_ITEMS>
-__global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS <= 8)) ? 8 : 1) void k_onesweep(
+// FULL = every row of the tile is valid (all tiles but the last): no per-item
+// bounds predicates.
+template <int PAYLOAD, int OS_NT, int OS_ITEMS, bool FULL>
+__device__ __forceinline__ void onesweep_tile(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
-    u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
-    int shift, const u32* __restrict__ gbase, u32* __restrict__ status, u32* __restrict__ ticket,
-    DevMeta* __restrict__ meta) {
-  constexpr int OS_TILE = OS_NT * OS_ITEMS;
+    u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n_valid,
+    u32 tile, u32 tile_base, int shift, const u32* __restrict__ gbase, u32* __restrict__ status,
+    DevMeta* __restrict__ meta, u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff,
+    u32* s_scan) {
   constexpr int OS_NW = OS_NT / WAVE;
-  __shared__ u32 s_buf[OS_TILE];          // staging, reused for key / end / rid
-  __shared__ u32 s_wcnt[OS_NW][OS_BINS];  // per-wave digit counters -> bases
-  __shared__ u32 s_dstart[OS_BINS];
-  __shared__ u32 s_goff[OS_BINS];
-  __shared__ u32 s_scan[OS_BINS / WAVE + 1];
-  __shared__ u32 s_tile;
-
   const u32 tid = threadIdx.x;
   const u32 lane = lane_id();
   const u32 w = wave_id();
 
-  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-#pragma unroll
-  for (int k = tid; k < OS_NW * OS_BINS; k += OS_NT) (&s_wcnt[0][0])[k] = 0;
-  __syncthreads();
-  const u32 tile = s_tile;
-  const u32 tile_base = tile * OS_TILE;
-  if (tile_base >= n) return;  // block-uniform (cannot happen: grid = n_tiles)
-  const u32 n_valid = (n - tile_base) < (u32)OS_TILE ? (n - tile_base) : (u32)OS_TILE;
-
   // wave-striped: item i of lane l of wave w is row w*(ITEMS*64) + i*64 + l
   u32 key[OS_ITEMS], end[OS_ITEMS], rid[OS_ITEMS];
   const u32 wbase = w * (OS_ITEMS * WAVE);
+  const u32* kin = keys_in + tile_base;  // block-uniform bases: 32-bit lane offsets
+  const u32* ein = (PAYLOAD & 2) ? ends_in + tile_base : nullptr;
+  const u32* rin = ((PAYLOAD & 1) && rids_in) ? rids_in + tile_base : nullptr;
 #pragma unroll
   for (int i = 0; i < OS_ITEMS; i++) {
     const u32 r = wbase + i * WAVE + lane;
-    const bool ok = r < n_valid;
-    const u32 g = tile_base + r;
-    key[i] = ok ? keys_in[g] : U32_MAX;
-    if (PAYLOAD & 2) end[i] = ok ? ends_in[g] : 0u;
-    if (PAYLOAD & 1) rid[i] = ok ? (rids_in ? rids_in[g] : g) : 0u;
+    const bool ok = FULL || r < n_valid;
+    key[i] = ok ? kin[r] : U32_MAX;
+    if (PAYLOAD & 2) end[i] = ok ? ein[r] : 0u;
+    if (PAYLOAD & 1) rid[i] = ok ? (rin ? rin[r] : tile_base + r) : 0u;
   }
 
   // stable rank inside the wave (peers = lanes with the same digit)
   u32 rank[OS_ITEMS];
   {
-    volatile u32* wcnt = s_wcnt[w];
-    const u64 lt = lanemask_lt();
+    u32* wcnt = s_wcnt[w];
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 r = wbase + i * WAVE + lane;
-      const bool ok = r < n_valid;
+      const bool ok = FULL || r < n_valid;
       const u32 d = (key[i] >> shift) & 0xFFu;
-      u64 peers = __ballot(ok);
-#pragma unroll
-      for (int b = 0; b < 8; b++) {
-        const bool bit = (d >> b) & 1u;
-        const u64 m = __ballot(bit);
-        peers &= bit ? m : ~m;
-      }
+      const u64 active = FULL ? ~0ull : __ballot(ok);
+      u32 below, total;
+      wave_match8(d, active, below, total);
+      rank[i] = 0;
       if (ok) {
         const u32 pre = wcnt[d];
-        rank[i] = pre + (u32)__popcll(peers & lt);
-        if ((peers & lt) == 0) wcnt[d] = pre + (u32)__popcll(peers);
-      } else {
-        rank[i] = 0;
+        rank[i] = pre + below;
+        // every peer has read `pre` (one wave, in-order LDS) before the leader adds
+        if (below == 0) wcnt[d] = pre + total;
       }
+      asm volatile("" ::: "memory");  // keep the LDS accesses of item i before item i+1
     }
   }
   __syncthreads();
@@ -172,14 +178,14 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
 #pragma unroll
   for (int i = 0; i < OS_ITEMS; i++) {
     const u32 r = wbase + i * WAVE + lane;
-    if (r < n_valid) s_buf[pos[i]] = key[i];
+    if (FULL || r < n_valid) s_buf[pos[i]] = key[i];
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < OS_ITEMS; i++) {
     const u32 p = i * OS_NT + tid;
     dst[i] = 0;
-    if (p < n_valid) {
+    if (FULL || p < n_valid) {
       const u32 k = s_buf[p];
       dst[i] = s_goff[(k >> shift) & 0xFFu] + p;
       keys_out[dst[i]] = k;
@@ -190,13 +196,13 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 r = wbase + i * WAVE + lane;
-      if (r < n_valid) s_buf[pos[i]] = end[i];
+      if (FULL || r < n_valid) s_buf[pos[i]] = end[i];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 p = i * OS_NT + tid;
-      if (p < n_valid) ends_out[dst[i]] = s_buf[p];
+      if (FULL || p < n_valid) ends_out[dst[i]] = s_buf[p];
     }
   }
   if (PAYLOAD & 1) {
@@ -204,15 +210,51 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 r = wbase + i * WAVE + lane;
-      if (r < n_valid) s_buf[pos[i]] = rid[i];
+      if (FULL || r < n_valid) s_buf[pos[i]] = rid[i];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 p = i * OS_NT + tid;
-      if (p < n_valid) rids_out[dst[i]] = s_buf[p];
+      if (FULL || p < n_valid) rids_out[dst[i]] = s_buf[p];
     }
   }
+}
+
+// OS_NT threads x OS_ITEMS rows per thread = one tile.  Default 1024 x 8: 16 waves
+// halve the per-wave serial work of 512 x 16 at the same 8192-row tile.
+template <int PAYLOAD, int OS_NT, int OS_ITEMS>
+__global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS <= 8)) ? 8 : 1) void k_onesweep(
+    const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
+    u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
+    int shift, const u32* __restrict__ gbase, u32* __restrict__ status, u32* __restrict__ ticket,
+    DevMeta* __restrict__ meta) {
+  constexpr int OS_TILE = OS_NT * OS_ITEMS;
+  constexpr int OS_NW = OS_NT / WAVE;
+  __shared__ u32 s_buf[OS_TILE];          // staging, reused for key / end / rid
+  __shared__ u32 s_wcnt[OS_NW][OS_BINS];  // per-wave digit counters -> bases
+  __shared__ u32 s_dstart[OS_BINS];
+  __shared__ u32 s_goff[OS_BINS];
+  __shared__ u32 s_scan[OS_BINS / WAVE + 1];
+  __shared__ u32 s_tile;
+
+  const u32 tid = threadIdx.x;
+  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+  for (int k = tid; k < OS_NW * OS_BINS; k += OS_NT) (&s_wcnt[0][0])[k] = 0;
+  __syncthreads();
+  const u32 tile = s_tile;
+  const u32 tile_base = tile * OS_TILE;
+  if (tile_base >= n) return;  // block-uniform (cannot happen: grid = n_tiles)
+  const u32 n_valid = (n - tile_base) < (u32)OS_TILE ? (n - tile_base) : (u32)OS_TILE;
+  if (n_valid == (u32)OS_TILE)
+    onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, true>(keys_in, ends_in, rids_in, keys_out, ends_out,
+                                                  rids_out, n_valid, tile, tile_base, shift, gbase,
+                                                  status, meta, s_buf, s_wcnt, s_dstart, s_goff, s_scan);
+  else
+    onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, false>(keys_in, ends_in, rids_in, keys_out, ends_out,
+                                                   rids_out, n_valid, tile, tile_base, shift, gbase,
+                                                   status, meta, s_buf, s_wcnt, s_dstart, s_goff, s_scan);
 }
 
 }  // namespace giql
