@@ -30,8 +30,6 @@ constexpr u32 OS_VALUE_MASK = (1u << 30) - 1u;
 constexpr u32 OS_MAX_ROWS = (1u << 30) - 1u;
 constexpr u32 OS_SPIN_LIMIT = 1u << 24;
 
-// OS_NT threads x OS_ITEMS rows per thread = one tile.  Default 1024 x 8: 16 waves
-// halve the per-wave serial work of 512 x 16 at the same 8192-row tile.
 // Stable in-wave rank of one item by its 8-bit digit.  For every digit bit b the
 // wave ballots the bit (m) and each lane ORs into `mis` the lanes whose bit differs
 // from its own: mis |= m ^ (mybit ? ~0 : 0).  peers = active & ~mis are the lanes
@@ -71,7 +69,9 @@ __device__ __forceinline__ void onesweep_tile(
   const u32 w = wave_id();
 
   // wave-striped: item i of lane l of wave w is row w*(ITEMS*64) + i*64 + l
-  u32 key[OS_ITEMS], end[OS_ITEMS], rid[OS_ITEMS];
+  // Only the keys are live during the ranking; each payload array is loaded one
+  // phase before its staging round (64-VGPR budget = two 1024-thread blocks / CU).
+  u32 key[OS_ITEMS];
   const u32 wbase = w * (OS_ITEMS * WAVE);
   const u32* kin = keys_in + tile_base;  // block-uniform bases: 32-bit lane offsets
   const u32* ein = (PAYLOAD & 2) ? ends_in + tile_base : nullptr;
@@ -81,8 +81,6 @@ __device__ __forceinline__ void onesweep_tile(
     const u32 r = wbase + i * WAVE + lane;
     const bool ok = FULL || r < n_valid;
     key[i] = ok ? kin[r] : U32_MAX;
-    if (PAYLOAD & 2) end[i] = ok ? ein[r] : 0u;
-    if (PAYLOAD & 1) rid[i] = ok ? (rin ? rin[r] : tile_base + r) : 0u;
   }
 
   // stable rank inside the wave (peers = lanes with the same digit)
@@ -104,7 +102,6 @@ __device__ __forceinline__ void onesweep_tile(
         // every peer has read `pre` (one wave, in-order LDS) before the leader adds
         if (below == 0) wcnt[d] = pre + total;
       }
-      asm volatile("" ::: "memory");  // keep the LDS accesses of item i before item i+1
     }
   }
   __syncthreads();
@@ -173,6 +170,22 @@ __device__ __forceinline__ void onesweep_tile(
     pos[i] = s_dstart[d] + s_wcnt[w][d] + rank[i];
   }
 
+  // first payload array: issue its loads now, they fly under the key round
+  u32 pay[OS_ITEMS];
+  if (PAYLOAD & 2) {
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      pay[i] = (FULL || r < n_valid) ? ein[r] : 0u;
+    }
+  } else if (PAYLOAD & 1) {
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      pay[i] = (FULL || r < n_valid) ? (rin ? rin[r] : tile_base + r) : 0u;
+    }
+  }
+
   // round 1: keys through LDS; remember each output slot's global destination
   u32 dst[OS_ITEMS];
 #pragma unroll
@@ -191,12 +204,19 @@ __device__ __forceinline__ void onesweep_tile(
       keys_out[dst[i]] = k;
     }
   }
-  if (PAYLOAD & 2) {
+  if (PAYLOAD == 3) {
+    // second payload array (rid) loaded while the end round runs
+    u32 pay2[OS_ITEMS];
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      pay2[i] = (FULL || r < n_valid) ? (rin ? rin[r] : tile_base + r) : 0u;
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 r = wbase + i * WAVE + lane;
-      if (FULL || r < n_valid) s_buf[pos[i]] = end[i];
+      if (FULL || r < n_valid) s_buf[pos[i]] = pay[i];
     }
     __syncthreads();
 #pragma unroll
@@ -204,19 +224,31 @@ __device__ __forceinline__ void onesweep_tile(
       const u32 p = i * OS_NT + tid;
       if (FULL || p < n_valid) ends_out[dst[i]] = s_buf[p];
     }
-  }
-  if (PAYLOAD & 1) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 r = wbase + i * WAVE + lane;
-      if (FULL || r < n_valid) s_buf[pos[i]] = rid[i];
+      if (FULL || r < n_valid) s_buf[pos[i]] = pay2[i];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 p = i * OS_NT + tid;
       if (FULL || p < n_valid) rids_out[dst[i]] = s_buf[p];
+    }
+  } else if (PAYLOAD != 0) {
+    u32* out = (PAYLOAD & 2) ? ends_out : rids_out;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      if (FULL || r < n_valid) s_buf[pos[i]] = pay[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 p = i * OS_NT + tid;
+      if (FULL || p < n_valid) out[dst[i]] = s_buf[p];
     }
   }
 }
