@@ -345,7 +345,7 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
     const int src = pass & 1, dst = src ^ 1;
     u32* stat = status + pass * per_pass;
     Phase ph(ctx, st, GIQL_PH_SORT_SCATTER);
-    if (!(sb.end[0] && sb.rid[0]) && ctx->os_variant == 0) {
+    if (!(sb.end[0] && sb.rid[0]) && ctx->os_variant == 7) {  // 12-row tiles spill: tuning only
       launch_onesweep_small(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat,
                             tickets + pass, ctx->d_meta);
       continue;

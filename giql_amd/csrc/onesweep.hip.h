@@ -126,23 +126,43 @@ __device__ __forceinline__ void onesweep_tile(
       __hip_atomic_store(st, OS_FLAG_PREFIX | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       __hip_atomic_store(st, OS_FLAG_AGG | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      u32 t = tile - 1;
+      // look back: the four nearest predecessors are polled together (four
+      // independent loads in flight), so the common 1-3 tile walk is ONE round trip
+      u32 t = tile;  // predecessors t-1, t-2, ...
       u32 spins = 0;
-      while (true) {
-        const u32 v = __hip_atomic_load(status + (size_t)t * OS_BINS + tid, __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_AGENT);
-        const u32 f = v >> 30;
-        if (f == 0) {
+      bool done = false;
+      while (!done) {
+        u32 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const u32 tj = t > (u32)j ? t - 1 - j : 0u;  // clamped; tile 0 always holds a PREFIX
+          v[j] = __hip_atomic_load(status + (size_t)tj * OS_BINS + tid, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // consume in order while the words are ready
+        int used = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (done || used != j) continue;
+          if (t <= (u32)j) {  // ran past tile 0 (its PREFIX ended the walk already)
+            done = true;
+            continue;
+          }
+          const u32 f = v[j] >> 30;
+          if (f == 0) continue;  // not published yet: re-poll from here
+          excl += v[j] & OS_VALUE_MASK;
+          used = j + 1;
+          if (f == 2u) done = true;
+        }
+        t -= (u32)used;
+        if (!done && used == 0) {
           if (++spins > OS_SPIN_LIMIT) {
             meta->status = -2;  // GIQL_ERR_HIP: look-back timed out (never expected)
             break;
           }
           __builtin_amdgcn_s_sleep(1);
-          continue;
         }
-        excl += v & OS_VALUE_MASK;
-        if (f == 2u || t == 0) break;
-        t--;
+        if (t == 0) done = true;
       }
       __hip_atomic_store(st, OS_FLAG_PREFIX | ((excl + count) & OS_VALUE_MASK), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
