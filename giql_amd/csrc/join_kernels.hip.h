@@ -686,31 +686,123 @@ __global__ void k_partition(const u64* __restrict__ off, u32 nq, u64 out_base, u
 }
 
 // -------------------------------------------------------------------- fill
-// Class 2, one 4096-pair tile per block.  off / lo / q_rid are the query arrays,
-// s_rid the other side's sorted row ids.  Outputs [out_base, out_base + n_out) go
-// to row_q (the query side's ids) and row_s.
+// One 4096-pair tile per block.  off / lo / q_rid are the query arrays, s_rid the
+// other side's sorted row ids.  Outputs [out_base, out_base + n_out) go to row_q
+// (the query side's ids) and row_s.
 //
 // The tile's query records {relative offset, lo, rid} are staged in LDS.  Each
-// wave owns TILE/4 consecutive outputs and walks them 64 at a time: the
-// rows that START inside the current 64-output window drop a marker at their
-// start position (LDS max), a wave inclusive max-scan turns the markers into
-// "which row does output p belong to" -- a merge of the two sorted sequences by
-// ballot/scan, ~0.5 instruction per pair instead of a binary search per pair.
+// wave owns TILE/4 consecutive outputs and walks them 64 at a time: the rows that
+// START inside the current 64-output window set the bit of their start position
+// in a 64-bit mask (DPP OR-reduction); the row of output l is then the popcount of
+// the mask bits 0..l -- a merge of the two sorted sequences by ballot/scan, well
+// under one instruction per pair, instead of a binary search per pair.
 // Per pair: one gather of s_rid (coalesced inside a row) + two coalesced stores.
+
+// Slow path of one window (more than 63 rows start in it, or rows without matches
+// share a start position): markers through LDS + max-scan.  Out of line: rare.
+__device__ __noinline__ u32 fill_window_slow(const u32* s_rel, u32* mark, u32 nqt, u32 k_cur,
+                                             u32 pc) {
+  const u32 lane = lane_id();
+  mark[lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+  u32 base = k_cur + 1;
+  while (true) {
+    const u32 kk = base + lane;
+    const bool in = kk < nqt && s_rel[kk] < pc + WAVE;
+    if (in) atomicMax(&mark[s_rel[kk] - pc], kk - k_cur);
+    if (__ballot(in) != ~0ull) break;  // fewer than 64 candidates qualified: done
+    base += WAVE;
+  }
+  __builtin_amdgcn_wave_barrier();
+  return wave_incl_scan_max_u32(mark[lane]);
+}
+
+template <int ITEMS, bool FULL>
+__device__ __forceinline__ void fill_wave(const u32* s_rel, const int* s_rel0, const u32* s_lo,
+                                          const u32* s_qrid, u32* mark, u32 nqt, u32 tile_len,
+                                          u64 tile_start, const u32* __restrict__ s_rid,
+                                          int32_t* __restrict__ row_q, int32_t* __restrict__ row_s) {
+  constexpr u32 TILE = FILL_NT * ITEMS;
+  constexpr u32 PER_WAVE = TILE / (FILL_NT / WAVE);
+  constexpr int NWIN = PER_WAVE / WAVE;
+  const u32 lane = lane_id();
+  const u32 p_w0 = wave_id() * PER_WAVE;
+  if (!FULL && p_w0 >= tile_len) return;  // wave-uniform
+  // last row whose outputs start at or before this wave's first output (row 0 of
+  // the tile starts at or before the tile, so the search is over rows 1..)
+  u32 k_cur = upper_bound_u32(s_rel, 1, nqt, p_w0) - 1;
+  u32 qr[NWIN], sr[NWIN];
+  int32_t* rq = row_q + tile_start;
+  int32_t* rs = row_s + tile_start;
+#pragma unroll
+  for (int it = 0; it < NWIN; it++) {
+    const u32 pc = p_w0 + it * WAVE;
+    qr[it] = 0;
+    sr[it] = 0;
+    if (!FULL && pc >= tile_len) continue;  // wave-uniform
+    // candidates: rows k_cur+1 .. k_cur+64; in-window ones have rel in [pc, pc+64)
+    const u32 kk0 = k_cur + 1 + lane;
+    const u32 r0 = kk0 < nqt ? s_rel[kk0] : U32_MAX;
+    const bool in0 = r0 < pc + WAVE;
+    const u64 m0 = __ballot(in0);
+    // rows without matches share their successor's start: sorted, so compare with
+    // the previous lane (wave_shr:1 crosses the 16-lane rows on gfx9)
+    const u32 rprev = (u32)__builtin_amdgcn_update_dpp((int)(pc - 1u), (int)r0, 0x138, 0xF, 0xF, false);
+    const u64 mdup = __ballot(in0 && rprev == r0);
+    u32 kd;
+    if (m0 != ~0ull && mdup == 0) {  // wave-uniform fast path
+      const u64 bit = in0 ? (1ull << (r0 - pc)) : 0ull;
+      u32 blo = (u32)bit, bhi = (u32)(bit >> 32);
+#define GIQL_OR_STEP(ctrl, rm)                                                  \
+  blo |= (u32)__builtin_amdgcn_update_dpp(0, (int)blo, ctrl, rm, 0xF, false);  \
+  bhi |= (u32)__builtin_amdgcn_update_dpp(0, (int)bhi, ctrl, rm, 0xF, false);
+      GIQL_OR_STEP(GIQL_DPP_ROW_SHR(1), 0xF)
+      GIQL_OR_STEP(GIQL_DPP_ROW_SHR(2), 0xF)
+      GIQL_OR_STEP(GIQL_DPP_ROW_SHR(4), 0xF)
+      GIQL_OR_STEP(GIQL_DPP_ROW_SHR(8), 0xF)
+      GIQL_OR_STEP(GIQL_DPP_ROW_BCAST15, 0xA)
+      GIQL_OR_STEP(GIQL_DPP_ROW_BCAST31, 0xC)
+#undef GIQL_OR_STEP
+      const u32 mlo = (u32)__builtin_amdgcn_readlane((int)blo, WAVE - 1);
+      const u32 mhi = (u32)__builtin_amdgcn_readlane((int)bhi, WAVE - 1);
+      // rows starting at positions <= my lane: mbcnt counts mask bits BELOW the
+      // lane, so add my own position's bit
+      kd = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) +
+           (u32)((lane < 32 ? (mlo >> lane) : (mhi >> (lane - 32))) & 1u);
+    } else {
+      kd = fill_window_slow(s_rel, mark, nqt, k_cur, pc);
+    }
+    const u32 k = k_cur + kd;
+    const u32 p_rel = pc + lane;
+    // rel of row 0 is stored signed (-(tile_start - off[first row])): one formula
+    const u32 j = s_lo[k] + (u32)((int)p_rel - s_rel0[k]);
+    qr[it] = s_qrid[k];
+    // issued now, waited for at the stores: flies under the following windows
+    if (FULL || p_rel < tile_len) sr[it] = s_rid[j];
+    k_cur = (u32)__builtin_amdgcn_readlane((int)k, WAVE - 1);
+  }
+#pragma unroll
+  for (int it = 0; it < NWIN; it++) {
+    const u32 p_rel = p_w0 + it * WAVE + lane;
+    if (FULL || p_rel < tile_len) {
+      rq[p_rel] = (int32_t)qr[it];
+      rs[p_rel] = (int32_t)sr[it];
+    }
+  }
+}
+
 template <int ITEMS>
 __global__ __launch_bounds__(FILL_NT) void k_fill(
     const u64* __restrict__ off, const u32* __restrict__ lo, const u32* __restrict__ q_rid, u32 nq,
     const u32* __restrict__ s_rid, const u32* __restrict__ part, u64 out_base, u64 n_out,
     int32_t* __restrict__ row_q, int32_t* __restrict__ row_s) {
   constexpr u32 TILE = FILL_NT * ITEMS;
-  constexpr u32 PER_WAVE = TILE / (FILL_NT / WAVE);
-  __shared__ u32 s_rel[FILL_QCAP];
+  __shared__ u32 s_rel[FILL_QCAP];  // unsigned relative starts; [0] unused by searches
+  __shared__ int s_rel0[FILL_QCAP]; // same, signed, with the true (<= 0) value for row 0
   __shared__ u32 s_lo[FILL_QCAP];
   __shared__ u32 s_qrid[FILL_QCAP];
   __shared__ u32 s_mark[FILL_NT / WAVE][WAVE];
   const u32 tid = threadIdx.x;
-  const u32 lane = lane_id();
-  const u32 wv = wave_id();
   const u64 tile_rel = (u64)blockIdx.x * TILE;  // relative to out_base
   const u64 tile_start = out_base + tile_rel;
   const u64 rem = n_out - tile_rel;
@@ -719,8 +811,8 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
   u32 ql = part[blockIdx.x + 1];
   if (ql >= nq) ql = nq - 1;
   const u32 nqt = ql - qf + 1;
-  const bool staged = nqt <= (u32)FILL_QCAP;
-  const u32 first_delta = (u32)(tile_start - off[qf]);  // < cnt[qf] < 2^32
+  const u64 first_delta = tile_start - off[qf];
+  const bool staged = nqt <= (u32)FILL_QCAP && first_delta < 0x7FFFFFFFull;
   if (staged) {
     for (u32 k = tid; k < nqt; k += FILL_NT) {
       const u64 o = off[qf + k];
@@ -730,98 +822,17 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
         r = d > (u64)tile_len ? tile_len : (u32)d;
       }
       s_rel[k] = r;
+      s_rel0[k] = k == 0 ? -(int)(u32)first_delta : (int)r;
       s_lo[k] = lo[qf + k];
       s_qrid[k] = q_rid[qf + k];
     }
     __syncthreads();
-    volatile u32* mark = s_mark[wv];
-    const u32 p_w0 = wv * PER_WAVE;
-    if (p_w0 >= tile_len) return;  // wave-uniform; no barrier follows
-    // last row whose outputs start at or before this wave's first output
-    u32 k_cur = upper_bound_u32(s_rel, 0, nqt, p_w0) - 1;
-    constexpr int NWIN = PER_WAVE / WAVE;
-    u32 jj[NWIN], qr[NWIN], sr[NWIN];
-    // phase A: which row does each of my NWIN outputs belong to (LDS + DPP only)
-#pragma unroll
-    for (int it = 0; it < NWIN; it++) {
-      const u32 pc = p_w0 + it * WAVE;
-      jj[it] = 0;
-      qr[it] = 0;
-      sr[it] = 0;
-      if (pc >= tile_len) continue;  // wave-uniform
-      // rows k_cur+1, k_cur+2, ... that start inside [pc, pc + 64).  Fast path: at
-      // most 64 of them and all at distinct positions -> OR their start bits into
-      // one 64-bit mask (DPP reduction), the row of output l is then
-      // popcount(mask & bits 0..l): no LDS round trip at all.
-      const u32 kk0 = k_cur + 1 + lane;
-      const u32 r0 = kk0 < nqt ? s_rel[kk0] : U32_MAX;
-      const bool in0 = r0 < pc + WAVE;
-      const u64 m0 = __ballot(in0);
-      const u32 rprev = (u32)__builtin_amdgcn_update_dpp((int)U32_MAX, (int)r0, GIQL_DPP_ROW_SHR(1), 0xF, 0xF, false);
-      // duplicate start positions (rows without matches) only matter between
-      // neighbouring lanes because rel is sorted; lane 0/16/32/48 compare across
-      // rows through a shuffle-free trick: treat a row boundary as "maybe dup"
-      const bool dup = in0 && (lane & 15u) != 0 && rprev == r0;
-      const bool edge = in0 && (lane & 15u) == 0 && lane != 0;  // checked below
-      u32 kd;
-      bool fast = (m0 != ~0ull) && (__ballot(dup) == 0);
-      if (fast && __ballot(edge) != 0) {
-        // verify the three row-boundary neighbours (lanes 15|16, 31|32, 47|48)
-        const u32 rl = __shfl_up(r0, 1, WAVE);
-        fast = __ballot(edge && rl == r0) == 0;
-      }
-      if (fast) {
-        u64 bit = in0 ? (1ull << (r0 - pc)) : 0ull;
-        u32 blo = (u32)bit, bhi = (u32)(bit >> 32);
-#define GIQL_OR_STEP(ctrl, rm)                                                          \
-  blo |= (u32)__builtin_amdgcn_update_dpp(0, (int)blo, ctrl, rm, 0xF, false);          \
-  bhi |= (u32)__builtin_amdgcn_update_dpp(0, (int)bhi, ctrl, rm, 0xF, false);
-        GIQL_OR_STEP(GIQL_DPP_ROW_SHR(1), 0xF)
-        GIQL_OR_STEP(GIQL_DPP_ROW_SHR(2), 0xF)
-        GIQL_OR_STEP(GIQL_DPP_ROW_SHR(4), 0xF)
-        GIQL_OR_STEP(GIQL_DPP_ROW_SHR(8), 0xF)
-        GIQL_OR_STEP(GIQL_DPP_ROW_BCAST15, 0xA)
-        GIQL_OR_STEP(GIQL_DPP_ROW_BCAST31, 0xC)
-#undef GIQL_OR_STEP
-        const u32 mlo = (u32)__builtin_amdgcn_readlane((int)blo, WAVE - 1);
-        const u32 mhi = (u32)__builtin_amdgcn_readlane((int)bhi, WAVE - 1);
-        const u64 mask = ((u64)mhi << 32) | mlo;
-        const u64 upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-        kd = (u32)__popcll(mask & upto);
-      } else {
-        mark[lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-        u32 base = k_cur + 1;
-        while (true) {
-          const u32 kk = base + lane;
-          const bool in = kk < nqt && s_rel[kk] < pc + WAVE;
-          if (in) atomicMax((u32*)&mark[s_rel[kk] - pc], kk - k_cur);
-          const u64 m = __ballot(in);
-          if (m != ~0ull) break;  // fewer than 64 candidates qualified: done
-          base += WAVE;
-        }
-        __builtin_amdgcn_wave_barrier();
-        kd = wave_incl_scan_max_u32(mark[lane]);
-      }
-      const u32 k = k_cur + kd;
-      const u32 p_rel = pc + lane;
-      jj[it] = s_lo[k] + (k == 0 ? p_rel + first_delta : p_rel - s_rel[k]);
-      qr[it] = s_qrid[k];
-      // the gather is issued now and only waited for at the stores below, so it
-      // flies under the LDS chain of the following windows
-      sr[it] = p_rel < tile_len ? s_rid[jj[it]] : 0u;
-      k_cur = (u32)__builtin_amdgcn_readlane((int)k, WAVE - 1);
-    }
-    // phase B: the coalesced stores
-#pragma unroll
-    for (int it = 0; it < NWIN; it++) {
-      const u32 p_rel = p_w0 + it * WAVE + lane;
-      if (p_rel < tile_len) {
-        const u64 o = tile_start + p_rel;
-        row_q[o] = (int32_t)qr[it];
-        row_s[o] = (int32_t)sr[it];
-      }
-    }
+    if (tile_len == TILE)
+      fill_wave<ITEMS, true>(s_rel, s_rel0, s_lo, s_qrid, s_mark[wave_id()], nqt, tile_len,
+                             tile_start, s_rid, row_q, row_s);
+    else
+      fill_wave<ITEMS, false>(s_rel, s_rel0, s_lo, s_qrid, s_mark[wave_id()], nqt, tile_len,
+                              tile_start, s_rid, row_q, row_s);
     return;
   }
   // fallback (more rows than the LDS stage holds, e.g. long runs of empty rows):

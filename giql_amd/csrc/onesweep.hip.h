@@ -94,7 +94,13 @@ __device__ __forceinline__ void onesweep_tile(
       const u32 d = (key[i] >> shift) & 0xFFu;
       const u64 active = FULL ? ~0ull : __ballot(ok);
       u32 below, total;
+#if defined(GIQL_ABLATE) && GIQL_ABLATE == 2  // timing-only build: no ranking
+      below = lane;
+      total = 64;
+      (void)active;
+#else
       wave_match8(d, active, below, total);
+#endif
       rank[i] = 0;
       if (ok) {
         const u32 pre = wcnt[d];
@@ -122,6 +128,11 @@ __device__ __forceinline__ void onesweep_tile(
     // publish this tile's count before anything that could wait
     u32* st = status + (size_t)tile * OS_BINS + tid;
     u32 excl = 0;
+#if defined(GIQL_ABLATE) && GIQL_ABLATE == 1  // timing-only build: no look-back
+    if (true) {
+      excl = tile * 32;
+    } else
+#endif
     if (tile == 0) {
       __hip_atomic_store(st, OS_FLAG_PREFIX | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -190,6 +201,9 @@ __device__ __forceinline__ void onesweep_tile(
     pos[i] = s_dstart[d] + s_wcnt[w][d] + rank[i];
   }
 
+#if defined(GIQL_ABLATE) && GIQL_ABLATE == 3  // timing-only build: no staging / stores
+  if (key[0] != 0x12345u) return;
+#endif
   // first payload array: issue its loads now, they fly under the key round
   u32 pay[OS_ITEMS];
   if (PAYLOAD & 2) {

@@ -18,7 +18,10 @@ st = rng.integers(0, 240_000_000, n_b).astype(np.int32)
 cases["random"] = st
 cases["identical"] = np.full(n_b, 12345, np.int32)
 cases["sorted"] = np.sort(st)
+only = os.environ.get("GIQL_PROBE_CASES")
 for name, s in cases.items():
+    if only and name not in only.split(","):
+        continue
     b = DeviceSide.from_numpy(np.zeros(n_b, np.int32), s, s + np.int32(150))
     for _ in range(2):
         eng.semi_join(a, b, 1)   # sorts B as (key, end) + A; tiny A
