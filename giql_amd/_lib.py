@@ -31,7 +31,7 @@ SYMBOLS = [
     "giql_hip_abi_version", "giql_hip_last_error", "giql_hip_device_count",
     "giql_hip_create", "giql_hip_destroy", "giql_hip_reserve", "giql_hip_set_profiling",
     "giql_hip_get_stats", "giql_hip_inner_plan_dev", "giql_hip_inner_fill_dev",
-    "giql_hip_semi_anti_dev", "giql_hip_count_dev", "giql_hip_nearest_dev",
+    "giql_hip_semi_anti_dev", "giql_hip_count_dev", "giql_hip_nearest_dev", "giql_hip_chrom_spans_dev",
     "giql_hip_inner", "giql_hip_semi_anti", "giql_hip_count", "giql_hip_nearest",
     "giql_hip_free_host", "giql_hip_pairs_checksum_dev",
 ]
@@ -126,6 +126,7 @@ def load() -> ctypes.CDLL:
     L.giql_hip_semi_anti_dev.argtypes = [vp, P(CSide), P(CSide), i32, ctypes.c_int, vp, P(i64), vp]
     L.giql_hip_count_dev.argtypes = [vp, P(CSide), P(CSide), i32, vp, vp]
     L.giql_hip_nearest_dev.argtypes = [vp, P(CSide), P(CSide), i32, ctypes.c_int, i64, vp, vp, vp]
+    L.giql_hip_chrom_spans_dev.argtypes = [vp, P(CSide), P(CSide), i32, vp, vp]
     L.giql_hip_inner.argtypes = [vp, P(CSide), P(CSide), i32, P(i64), P(vp), P(vp)]
     L.giql_hip_semi_anti.argtypes = [vp, P(CSide), P(CSide), i32, ctypes.c_int, P(i64), P(vp)]
     L.giql_hip_count.argtypes = [vp, P(CSide), P(CSide), i32, vp]

@@ -1037,6 +1037,43 @@ int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side*
   return GIQL_OK;
 }
 
+// -------------------------------------------------------------------- spans
+int giql_hip_chrom_spans_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
+                             int32_t n_chrom, int64_t* spans_out, void* stream) {
+  if (!ctx || !spans_out) return set_err(GIQL_ERR_INVALID, "ctx/spans_out is NULL");
+  GIQL_TRY(check_side(a, "a"));
+  GIQL_TRY(check_side(b, "b"));
+  if (n_chrom <= 0) return set_err(GIQL_ERR_INVALID, "n_chrom <= 0");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  ctx->planned = false;
+  LinBufs lb;
+  auto carve = [&](char* base) {
+    Carver c{base};
+    common_sizes(c, n_chrom, lb);
+    return c.off;
+  };
+  GIQL_TRY(ensure_arena(ctx, carve(nullptr), st));
+  carve(ctx->arena);
+  GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
+  std::vector<int> mn((size_t)n_chrom), mx((size_t)n_chrom);
+  HIP_TRY(hipMemcpyAsync(mn.data(), lb.gmin, (size_t)n_chrom * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(mx.data(), lb.gmax, (size_t)n_chrom * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(ctx->h_meta, ctx->d_meta, sizeof(DevMeta), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (ctx->h_meta->status == GIQL_ERR_CHROM)
+    return set_err(GIQL_ERR_CHROM, "a chrom id is outside [0, n_chrom)");
+  int omin = a->start_off, omax = a->start_off;
+  const int offs[3] = {a->end_off, b->start_off, b->end_off};
+  for (int k = 0; k < 3; k++) {
+    if (offs[k] < omin) omin = offs[k];
+    if (offs[k] > omax) omax = offs[k];
+  }
+  for (int c = 0; c < n_chrom; c++)
+    spans_out[c] = mn[c] <= mx[c] ? ((int64_t)mx[c] + omax) - ((int64_t)mn[c] + omin) + 1 : 0;
+  return GIQL_OK;
+}
+
 // ---------------------------------------------------------------- checksum
 int giql_hip_pairs_checksum_dev(giql_hip_ctx* ctx, const int32_t* row_a, const int32_t* row_b,
                                 int64_t n, void* stream, uint64_t* out) {

@@ -158,7 +158,12 @@ class HipEngine:
     def inner_join(self, a: DeviceSide, b: DeviceSide, n_chrom: int, out=None):
         """All ``(row_a, row_b)`` with ``a INTERSECTS b``; two int32 device tensors."""
         torch = _torch()
-        n = self.inner_plan(a, b, n_chrom)
+        try:
+            n = self.inner_plan(a, b, n_chrom)
+        except _lib.GiqlHipError as exc:
+            if exc.code != _lib.GIQL_ERR_SPAN:
+                raise
+            return self._inner_by_groups(a, b, n_chrom)
         if out is not None and out[0].shape[0] >= n:
             row_a, row_b = out[0][:n], out[1][:n]
         else:
@@ -167,11 +172,75 @@ class HipEngine:
         self.inner_fill(row_a, row_b)
         return row_a, row_b
 
+    # ------------------------------------------------ genomes longer than 2^32
+    def chrom_spans(self, a: DeviceSide, b: DeviceSide, n_chrom: int):
+        """Per-chromosome coordinate span (host list of ints)."""
+        import numpy as np
+
+        self._check_sides(a, b)
+        spans = np.zeros(int(n_chrom), np.int64)
+        _lib.check(self._L.giql_hip_chrom_spans_dev(
+            self._h, a.c_struct(), b.c_struct(), int(n_chrom), spans.ctypes.data, self._stream()))
+        return spans.tolist()
+
+    def _groups(self, a: DeviceSide, b: DeviceSide, n_chrom: int):
+        """Yield ``(sub_a, rows_a, sub_b, rows_b)`` per 32-bit chromosome group.
+
+        The kernels place all chromosomes on one u32 axis; a genome whose spans sum
+        past 2^32 is joined group by group (chromosomes are independent units).
+        Row selection / id mapping here is data plumbing (torch indexing)."""
+        torch = _torch()
+        from .shard import span_groups
+
+        groups = span_groups(self.chrom_spans(a, b, n_chrom))
+        for g in groups:
+            lut = torch.zeros(int(n_chrom), dtype=torch.bool, device=self.device)
+            lut[torch.tensor(g, dtype=torch.long, device=self.device)] = True
+            ra = torch.nonzero(lut[a.chrom.long()], as_tuple=False).flatten()
+            rb = torch.nonzero(lut[b.chrom.long()], as_tuple=False).flatten()
+            sa = DeviceSide(a.chrom[ra].contiguous(), a.start[ra].contiguous(), a.end[ra].contiguous(),
+                            a.start_off, a.end_off)
+            sb = DeviceSide(b.chrom[rb].contiguous(), b.start[rb].contiguous(), b.end[rb].contiguous(),
+                            b.start_off, b.end_off)
+            yield sa, ra, sb, rb
+
+    def _inner_by_groups(self, a, b, n_chrom):
+        torch = _torch()
+        outs_a, outs_b = [], []
+        for sa, ra, sb, rb in self._groups(a, b, n_chrom):
+            n = self.inner_plan(sa, sb, n_chrom)
+            la = torch.empty(n, dtype=torch.int32, device=self.device)
+            lb = torch.empty(n, dtype=torch.int32, device=self.device)
+            self.inner_fill(la, lb)
+            outs_a.append(ra[la.long()].to(torch.int32))
+            outs_b.append(rb[lb.long()].to(torch.int32))
+        if not outs_a:
+            z = torch.empty(0, dtype=torch.int32, device=self.device)
+            return z, z.clone()
+        return torch.cat(outs_a), torch.cat(outs_b)
+
+    def _retry_by_groups(self, fn, a, b, n_chrom):
+        """Run ``fn(sub_a, sub_b)`` per group after a GIQL_ERR_SPAN."""
+        return [(ra, rb, fn(sa, sb)) for sa, ra, sb, rb in self._groups(a, b, n_chrom)]
+
     # -------------------------------------------------------------- SEMI/ANTI
     def semi_anti(self, a: DeviceSide, b: DeviceSide, n_chrom: int, anti: bool):
         """Ascending A row ids with (SEMI) / without (ANTI) an overlapping B row."""
         torch = _torch()
         self._check_sides(a, b)
+        try:
+            return self._semi_anti_once(a, b, n_chrom, anti)
+        except _lib.GiqlHipError as exc:
+            if exc.code != _lib.GIQL_ERR_SPAN:
+                raise
+        parts = [ra[rows.long()] for ra, _rb, rows in
+                 self._retry_by_groups(lambda sa, sb: self._semi_anti_once(sa, sb, n_chrom, anti), a, b, n_chrom)]
+        if not parts:
+            return torch.empty(0, dtype=torch.int32, device=self.device)
+        return torch.sort(torch.cat(parts)).values.to(torch.int32)
+
+    def _semi_anti_once(self, a: DeviceSide, b: DeviceSide, n_chrom: int, anti: bool):
+        torch = _torch()
         rows = torch.empty(a.n, dtype=torch.int32, device=self.device)
         n = ctypes.c_int64(0)
         _lib.check(self._L.giql_hip_semi_anti_dev(
@@ -190,6 +259,18 @@ class HipEngine:
         """int64 tensor: number of overlapping B rows per A row (original order)."""
         torch = _torch()
         self._check_sides(a, b)
+        try:
+            return self._count_once(a, b, n_chrom)
+        except _lib.GiqlHipError as exc:
+            if exc.code != _lib.GIQL_ERR_SPAN:
+                raise
+        counts = torch.zeros(a.n, dtype=torch.int64, device=self.device)
+        for ra, _rb, c in self._retry_by_groups(lambda sa, sb: self._count_once(sa, sb, n_chrom), a, b, n_chrom):
+            counts[ra] = c
+        return counts
+
+    def _count_once(self, a: DeviceSide, b: DeviceSide, n_chrom: int):
+        torch = _torch()
         counts = torch.zeros(a.n, dtype=torch.int64, device=self.device)
         _lib.check(self._L.giql_hip_count_dev(
             self._h, a.c_struct(), b.c_struct(), int(n_chrom),
@@ -202,6 +283,26 @@ class HipEngine:
         """NEAREST k=1: ``(idx_b int32, distance int64)`` per A row; idx_b=-1 = none."""
         torch = _torch()
         self._check_sides(a, b)
+        try:
+            return self._nearest_once(a, b, n_chrom, signed, max_distance)
+        except _lib.GiqlHipError as exc:
+            if exc.code != _lib.GIQL_ERR_SPAN:
+                raise
+        idx = torch.full((a.n,), -1, dtype=torch.int32, device=self.device)
+        dist = torch.zeros(a.n, dtype=torch.int64, device=self.device)
+        for ra, rb, (gi, gd) in self._retry_by_groups(
+                lambda sa, sb: self._nearest_once(sa, sb, n_chrom, signed, max_distance), a, b, n_chrom):
+            hit = gi >= 0
+            mapped = torch.full_like(gi, -1)
+            if rb.numel():
+                mapped[hit] = rb[gi[hit].long()].to(torch.int32)
+            idx[ra] = mapped
+            dist[ra] = gd
+        return idx, dist
+
+    def _nearest_once(self, a: DeviceSide, b: DeviceSide, n_chrom: int, signed: bool = False,
+                      max_distance=None):
+        torch = _torch()
         idx = torch.full((a.n,), -1, dtype=torch.int32, device=self.device)
         dist = torch.zeros(a.n, dtype=torch.int64, device=self.device)
         md = -1 if max_distance is None else int(max_distance)

@@ -147,6 +147,16 @@ int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a,
                          int64_t max_distance, int32_t* idx_b_out,
                          int64_t* dist_out, void* stream);
 
+/* Per-chromosome coordinate span (max - min + 1 over both sides' canonical
+ * coordinates, 0 for an absent chromosome) into the HOST array spans_out[n_chrom].
+ * The join entry points place all chromosomes on one 32-bit axis and return
+ * GIQL_ERR_SPAN when the spans sum past 2^32 - 1; callers then split the
+ * chromosomes into groups that fit (chromosomes are independent units of the
+ * join, src/giql/expanders/_per_chrom.py:3-9) and join group by group. */
+int giql_hip_chrom_spans_dev(giql_hip_ctx* ctx, const giql_side* a,
+                             const giql_side* b, int32_t n_chrom,
+                             int64_t* spans_out /* host */, void* stream);
+
 /* ---- host-buffer entry points (Arrow buffers in host memory) ------------ */
 int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
                    int32_t n_chrom, int64_t* n_pairs, int32_t** row_a,

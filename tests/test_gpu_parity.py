@@ -206,14 +206,49 @@ def test_bad_chrom_id_is_an_error(eng):
     assert ei.value.code == _lib.GIQL_ERR_CHROM
 
 
-def test_span_overflow_is_an_error(eng):
+def test_span_overflow_is_an_error_at_the_c_abi(eng):
     from giql_amd import _lib
 
     ch = np.arange(4, dtype=np.int32)
     a = ora.Side(ch, np.zeros(4, np.int32), np.full(4, 2**31 - 2, np.int32))
     with pytest.raises(_lib.GiqlHipError) as ei:
-        eng.inner_join(dev(a), dev(a), 4)
+        eng.inner_plan(dev(a), dev(a), 4)
     assert ei.value.code == _lib.GIQL_ERR_SPAN
+
+
+def test_genome_longer_than_32_bits_is_joined_by_chromosome_groups(eng):
+    """Spans summing past 2^32: the engine splits the chromosomes into groups that
+    fit the u32 axis and joins group by group -- same results as the oracle."""
+    r = np.random.default_rng(9)
+    n_chrom = 5
+
+    def side(n, max_len):
+        ch = r.integers(0, n_chrom, n).astype(np.int32)
+        st = r.integers(0, 2**31 - 5000, n).astype(np.int32)
+        st[: n // 2] = r.integers(0, 100_000, n // 2)            # a dense corner so rows overlap
+        ln = r.integers(1, max_len, n).astype(np.int32)
+        return ora.Side(ch, st, st + ln)
+
+    a, b = side(20_000, 3000), side(30_000, 800)
+    # make sure every chromosome reaches ~2^31 so the spans sum to ~1e10
+    a.start[:n_chrom] = 2**31 - 4000
+    a.end[:n_chrom] = 2**31 - 3000
+    a.chrom[:n_chrom] = np.arange(n_chrom)
+    da, db = dev(a), dev(b)
+    assert sum(eng.chrom_spans(da, db, n_chrom)) > 2**32
+    ra, rb = eng.inner_join(da, db, n_chrom)
+    got = ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy())
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    assert want.shape[0] > 1000 and np.array_equal(got, want)
+    assert np.array_equal(eng.semi_join(da, db, n_chrom).cpu().numpy(), ora.c_semi_anti(a, b, False))
+    assert np.array_equal(eng.anti_join(da, db, n_chrom).cpu().numpy(), ora.c_semi_anti(a, b, True))
+    assert np.array_equal(eng.count_overlaps(da, db, n_chrom).cpu().numpy(), ora.c_count(a, b, "sweep"))
+    idx, dist = eng.nearest(da, db, n_chrom)
+    oi, od = ora.c_nearest_k1(a, b, method="sweep")
+    idx = idx.cpu().numpy()
+    assert np.array_equal(dist.cpu().numpy(), od) and np.array_equal(idx >= 0, oi >= 0)
+    m = oi >= 0
+    assert np.array_equal(b.start[idx[m]], b.start[oi[m]]) and np.array_equal(b.end[idx[m]], b.end[oi[m]])
 
 
 @pytest.mark.parametrize("na,nb,nch", [(50_000, 400_000, 24), (300_000, 20_000, 5)])
