@@ -221,7 +221,9 @@ __global__ __launch_bounds__(256) void k_nearest(
   int32_t best = -1;
   i64 best_d = 0;
   if (n_b > 0 && qs < meta->sentinel) {
-    if (qe < qs) meta->status = -1;  // inverted row: NEAREST needs start <= end
+    // inverted row: NEAREST needs start <= end (never masks an earlier error, e.g. a
+    // span overflow that made these keys meaningless)
+    if (qe < qs && meta->status == 0) meta->status = -1;
     // chromosome of the row = last c with chrom_first[c] <= key
     const u32 c = upper_bound_u32(chrom_first, 0, (u32)n_chrom + 1, qs) - 1;
     const u32 blo = chrom_lo[c];
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void k_nearest(
 __global__ __launch_bounds__(256) void k_check_not_inverted(SideView s, DevMeta* __restrict__ meta) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= s.n) return;
-  if ((i64)s.end[i] + s.end_off < (i64)s.start[i] + s.start_off) meta->status = -1;
+  if ((i64)s.end[i] + s.end_off < (i64)s.start[i] + s.start_off && meta->status == 0) meta->status = -1;
 }
 
 }  // namespace giql
