@@ -217,20 +217,32 @@ def main() -> None:
         idmap_a = (torch.arange(loc_na, device=dev, dtype=torch.int64) + base[0]).to(torch.int32)
         idmap_b = (torch.arange(loc_nb, device=dev, dtype=torch.int64) + base[1]).to(torch.int32)
 
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if distributed else None
+    split_ms = [0.0, 0.0]  # [local join, exchange] summed over the timed steps
+
     def step():
         """One pass of the hot path; returns this rank's pair count."""
         nonlocal out, out_cap
+        if ev:
+            ev[0].record()
         n = eng.inner_plan(a, b, n_chrom)
         if n > out_cap:
             out = None
             out_cap = int(n * 1.05) + 1024
             out = torch.empty((2, out_cap), dtype=torch.int32, device=dev)
         eng.inner_fill(out[0, :n], out[1, :n])
+        if ev:
+            ev[1].record()
         if distributed and not args.no_gather:
             # the path's one exchange step: global ids, counts, then the padded pairs
             ga = idmap_a[out[0, :n].long()]
             gb = idmap_b[out[1, :n].long()]
             D.gather_pairs(ga.to(xdev), gb.to(xdev))
+        if ev:
+            ev[2].record()
+            ev[2].synchronize()
+            split_ms[0] += ev[0].elapsed_time(ev[1])
+            split_ms[1] += ev[1].elapsed_time(ev[2])
         return n
 
     def sync_all():
@@ -247,6 +259,7 @@ def main() -> None:
     phase_ms = {}
     phase_launches = {}
     sync_all()
+    split_ms[0] = split_ms[1] = 0.0
     t0 = time.perf_counter()
     n_local = 0
     for _ in range(args.steps):
@@ -331,6 +344,11 @@ def main() -> None:
             "cpu_baseline": cpu_baseline,
             "gen_seconds": round(gen_s, 1),
         }
+        if distributed:
+            # rank 0's view of where a step goes: its own shard's join vs the one
+            # exchange (global ids + all-gather of every rank's pairs)
+            line["rank0_local_join_ms"] = round(split_ms[0] / args.steps, 3)
+            line["rank0_exchange_ms"] = round(split_ms[1] / args.steps, 3)
         print(json.dumps(line), flush=True)
 
     if distributed:
