@@ -327,28 +327,6 @@ static void launch_onesweep(hipStream_t st, SortBufs& sb, int src, int dst, bool
 #undef GIQL_OS_LAUNCH
 }
 
-static void launch_onesweep_persist(hipStream_t st, SortBufs& sb, int src, int dst, bool first, u32 n,
-                                    int shift, const u32* gbase, u32* status, u32* ticket,
-                                    DevMeta* meta, int n_cu) {
-  constexpr int NT = 1024, ITEMS = 8;
-  u32 grid = cdiv(n, NT * ITEMS);
-  if (grid > (u32)(2 * n_cu)) grid = 2 * n_cu;
-  const u32* rin = (first || !sb.rid[0]) ? (const u32*)nullptr : sb.rid[src];
-  const int mode = (sb.rid[0] ? 1 : 0) | (sb.end[0] ? 2 : 0);
-#define GIQL_OSP_LAUNCH(M)                                                                          \
-  hipLaunchKernelGGL((k_onesweep_persist<M, NT, ITEMS>), dim3(grid), dim3(NT), 0, st, sb.key[src],  \
-                     sb.end[0] ? sb.end[src] : (const u32*)nullptr, rin, sb.key[dst],                \
-                     sb.end[0] ? sb.end[dst] : (u32*)nullptr, sb.rid[0] ? sb.rid[dst] : (u32*)nullptr, \
-                     n, shift, gbase, status, ticket, meta)
-  switch (mode) {
-    case 0: GIQL_OSP_LAUNCH(0); break;
-    case 1: GIQL_OSP_LAUNCH(1); break;
-    case 2: GIQL_OSP_LAUNCH(2); break;
-    default: GIQL_OSP_LAUNCH(3); break;
-  }
-#undef GIQL_OSP_LAUNCH
-}
-
 // one- and two-array rows need fewer registers: a 12-row-per-thread tile (12288
 // rows, 192-byte runs) still fits two 1024-thread blocks per CU.
 static void launch_onesweep_small(hipStream_t st, SortBufs& sb, int src, int dst, bool first, u32 n,
@@ -371,11 +349,6 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
     if (!(sb.end[0] && sb.rid[0]) && ctx->os_variant == 7) {  // 12-row tiles spill: tuning only
       launch_onesweep_small(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat,
                             tickets + pass, ctx->d_meta);
-      continue;
-    }
-    if (ctx->os_variant == 8) {
-      launch_onesweep_persist(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8,
-                              gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta, ctx->n_cu);
       continue;
     }
     switch (ctx->os_variant) {

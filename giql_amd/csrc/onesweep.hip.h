@@ -323,256 +323,4 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
                                                    status, meta, s_buf, s_wcnt, s_dstart, s_goff, s_scan);
 }
 
-// ---- persistent, software-pipelined variant ------------------------------------
-// grid = 2 blocks per CU; every block loops over tiles (atomic tickets, so the
-// look-back argument is unchanged).  While tile t is ranked / staged / stored, the
-// ticket and the KEY loads of the block's next tile are already in flight: the
-// ~3 us of ticket + HBM latency per tile overlap the ALU-bound ranking instead of
-// adding to it.  Bounds predicates are always on (only the last tile is partial).
-template <int PAYLOAD, int OS_NT, int OS_ITEMS>
-__global__ __launch_bounds__(OS_NT, OS_NT == 1024 ? 8 : 1) void k_onesweep_persist(
-    const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
-    u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
-    int shift, const u32* __restrict__ gbase, u32* __restrict__ status, u32* __restrict__ ticket,
-    DevMeta* __restrict__ meta) {
-  constexpr int OS_TILE = OS_NT * OS_ITEMS;
-  constexpr int OS_NW = OS_NT / WAVE;
-  __shared__ u32 s_buf[OS_TILE];
-  __shared__ u32 s_wcnt[OS_NW][OS_BINS];
-  __shared__ u32 s_dstart[OS_BINS];
-  __shared__ u32 s_goff[OS_BINS];
-  __shared__ u32 s_scan[OS_BINS / WAVE + 1];
-  __shared__ u32 s_next;
-
-  const u32 tid = threadIdx.x;
-  const u32 lane = lane_id();
-  const u32 w = wave_id();
-  const u32 wbase = w * (OS_ITEMS * WAVE);
-  const u32 n_tiles = (n + OS_TILE - 1) / OS_TILE;
-
-  if (tid == 0) s_next = atomicAdd(ticket, 1u);
-  __syncthreads();
-  u32 tile = s_next;
-  if (tile >= n_tiles) return;  // block-uniform
-  u32 key[OS_ITEMS];
-  {
-    const u32 tb = tile * OS_TILE;
-    const u32 nv = (n - tb) < (u32)OS_TILE ? (n - tb) : (u32)OS_TILE;
-#pragma unroll
-    for (int i = 0; i < OS_ITEMS; i++) {
-      const u32 r = wbase + i * WAVE + lane;
-      key[i] = r < nv ? keys_in[tb + r] : U32_MAX;
-    }
-  }
-  __syncthreads();  // everyone has read s_next
-
-  while (true) {
-    const u32 tile_base = tile * OS_TILE;
-    const u32 n_valid = (n - tile_base) < (u32)OS_TILE ? (n - tile_base) : (u32)OS_TILE;
-    // ---- prefetch: next ticket, counters zeroed, next tile's keys
-    if (tid == 0) s_next = atomicAdd(ticket, 1u);
-#pragma unroll
-    for (int k = tid; k < OS_NW * OS_BINS; k += OS_NT) (&s_wcnt[0][0])[k] = 0;
-    __syncthreads();
-    const u32 next = s_next;
-    const bool has_next = next < n_tiles;
-    u32 nkey[OS_ITEMS];
-    {
-      const u32 tb = has_next ? next * OS_TILE : 0u;
-      const u32 nv = has_next ? ((n - tb) < (u32)OS_TILE ? (n - tb) : (u32)OS_TILE) : 0u;
-#pragma unroll
-      for (int i = 0; i < OS_ITEMS; i++) {
-        const u32 r = wbase + i * WAVE + lane;
-        nkey[i] = r < nv ? keys_in[tb + r] : U32_MAX;
-      }
-    }
-
-    // ---- rank
-    u32 rank[OS_ITEMS];
-    {
-      u32* wcnt = s_wcnt[w];
-#pragma unroll
-      for (int i = 0; i < OS_ITEMS; i++) {
-        const u32 r = wbase + i * WAVE + lane;
-        const bool ok = r < n_valid;
-        const u32 d = (key[i] >> shift) & 0xFFu;
-        const u64 active = __ballot(ok);
-        u32 below, total;
-        wave_match8(d, active, below, total);
-        rank[i] = 0;
-        if (ok) {
-          const u32 pre = wcnt[d];
-          rank[i] = pre + below;
-          if (below == 0) wcnt[d] = pre + total;
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- digit totals, publish, look back
-    if (tid < OS_BINS) {
-      u32 run = 0;
-#pragma unroll
-      for (int k = 0; k < OS_NW; k++) {
-        const u32 c = s_wcnt[k][tid];
-        s_wcnt[k][tid] = run;
-        run += c;
-      }
-      const u32 count = run;
-      const u32 incl = wave_incl_scan(count);
-      if (lane == WAVE - 1) s_scan[w] = incl;
-      u32* st = status + (size_t)tile * OS_BINS + tid;
-      u32 excl = 0;
-      if (tile == 0) {
-        __hip_atomic_store(st, OS_FLAG_PREFIX | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        __hip_atomic_store(st, OS_FLAG_AGG | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        u32 t = tile;
-        u32 spins = 0;
-        bool done = false;
-        while (!done) {
-          u32 v[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const u32 tj = t > (u32)j ? t - 1 - j : 0u;
-            v[j] = __hip_atomic_load(status + (size_t)tj * OS_BINS + tid, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-          }
-          int used = 0;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (done || used != j) continue;
-            if (t <= (u32)j) {
-              done = true;
-              continue;
-            }
-            const u32 f = v[j] >> 30;
-            if (f == 0) continue;
-            excl += v[j] & OS_VALUE_MASK;
-            used = j + 1;
-            if (f == 2u) done = true;
-          }
-          t -= (u32)used;
-          if (!done && used == 0) {
-            if (++spins > OS_SPIN_LIMIT) {
-              meta->status = -2;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          if (t == 0) done = true;
-        }
-        __hip_atomic_store(st, OS_FLAG_PREFIX | ((excl + count) & OS_VALUE_MASK), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-      s_goff[tid] = gbase[tid] + excl;
-      s_dstart[tid] = incl - count;
-    }
-    __syncthreads();
-    if (tid < OS_BINS) {
-      u32 wb = 0;
-#pragma unroll
-      for (int k = 0; k < OS_BINS / WAVE; k++)
-        if (k < (int)w) wb += s_scan[k];
-      const u32 dstart = s_dstart[tid] + wb;
-      s_dstart[tid] = dstart;
-      s_goff[tid] -= dstart;
-    }
-    __syncthreads();
-
-    u32 pos[OS_ITEMS];
-#pragma unroll
-    for (int i = 0; i < OS_ITEMS; i++) {
-      const u32 d = (key[i] >> shift) & 0xFFu;
-      pos[i] = s_dstart[d] + s_wcnt[w][d] + rank[i];
-    }
-
-    // ---- payload loads (one phase ahead), staging rounds, stores
-    const u32* ein = (PAYLOAD & 2) ? ends_in + tile_base : nullptr;
-    const u32* rin = ((PAYLOAD & 1) && rids_in) ? rids_in + tile_base : nullptr;
-    u32 pay[OS_ITEMS];
-    if (PAYLOAD & 2) {
-#pragma unroll
-      for (int i = 0; i < OS_ITEMS; i++) {
-        const u32 r = wbase + i * WAVE + lane;
-        pay[i] = r < n_valid ? ein[r] : 0u;
-      }
-    } else if (PAYLOAD & 1) {
-#pragma unroll
-      for (int i = 0; i < OS_ITEMS; i++) {
-        const u32 r = wbase + i * WAVE + lane;
-        pay[i] = r < n_valid ? (rin ? rin[r] : tile_base + r) : 0u;
-      }
-    }
-    u32 dst[OS_ITEMS];
-#pragma unroll
-    for (int i = 0; i < OS_ITEMS; i++) {
-      const u32 r = wbase + i * WAVE + lane;
-      if (r < n_valid) s_buf[pos[i]] = key[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < OS_ITEMS; i++) {
-      const u32 p = i * OS_NT + tid;
-      dst[i] = 0;
-      if (p < n_valid) {
-        const u32 k = s_buf[p];
-        dst[i] = s_goff[(k >> shift) & 0xFFu] + p;
-        keys_out[dst[i]] = k;
-      }
-    }
-    if (PAYLOAD == 3) {
-      u32 pay2[OS_ITEMS];
-#pragma unroll
-      for (int i = 0; i < OS_ITEMS; i++) {
-        const u32 r = wbase + i * WAVE + lane;
-        pay2[i] = r < n_valid ? (rin ? rin[r] : tile_base + r) : 0u;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < OS_ITEMS; i++) {
-        const u32 r = wbase + i * WAVE + lane;
-        if (r < n_valid) s_buf[pos[i]] = pay[i];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < OS_ITEMS; i++) {
-        const u32 p = i * OS_NT + tid;
-        if (p < n_valid) ends_out[dst[i]] = s_buf[p];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < OS_ITEMS; i++) {
-        const u32 r = wbase + i * WAVE + lane;
-        if (r < n_valid) s_buf[pos[i]] = pay2[i];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < OS_ITEMS; i++) {
-        const u32 p = i * OS_NT + tid;
-        if (p < n_valid) rids_out[dst[i]] = s_buf[p];
-      }
-    } else if (PAYLOAD != 0) {
-      u32* out = (PAYLOAD & 2) ? ends_out : rids_out;
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < OS_ITEMS; i++) {
-        const u32 r = wbase + i * WAVE + lane;
-        if (r < n_valid) s_buf[pos[i]] = pay[i];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < OS_ITEMS; i++) {
-        const u32 p = i * OS_NT + tid;
-        if (p < n_valid) out[dst[i]] = s_buf[p];
-      }
-    }
-    if (!has_next) break;  // block-uniform
-    __syncthreads();       // s_buf / s_wcnt / s_next free for the next tile
-#pragma unroll
-    for (int i = 0; i < OS_ITEMS; i++) key[i] = nkey[i];
-    tile = next;
-  }
-}
-
 }  // namespace giql

@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {8: "persist 1024x8", 6: "1024x8-all", 0: "1024x8 default", 1: "512x8", 2: "512x16", 3: "256x16", 4: "1024x4", 5: "1024x12"}
+NAMES = {6: "1024x8-all", 0: "1024x8 default", 1: "512x8", 2: "512x16", 3: "256x16", 4: "1024x4", 5: "1024x12"}
 CHECK = r"""
 import numpy as np, sys
 sys.path.insert(0, %r)
