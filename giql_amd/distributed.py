@@ -18,7 +18,7 @@ from typing import Callable, Sequence
 
 import numpy as np
 
-from .shard import lpt_assign
+from .shard import assign_units, lpt_assign, plan_units
 
 
 def shard_rows(chrom: np.ndarray, assign: Sequence[int], rank: int) -> np.ndarray:
@@ -31,6 +31,44 @@ def plan_shards(chrom_a: np.ndarray, chrom_b: np.ndarray, n_chrom: int, world: i
     """LPT assignment of chromosomes to ranks by their row counts (A + B)."""
     w = np.bincount(chrom_a, minlength=n_chrom) + np.bincount(chrom_b, minlength=n_chrom)
     return lpt_assign(w.tolist(), world)
+
+
+def unit_rows(chrom_a: np.ndarray, chrom_b: np.ndarray, n_chrom: int, world: int, rank: int,
+              split_over: float = 1.0):
+    """This rank's (rows_a, rows_b) under the unit plan of :func:`giql_amd.shard.plan_units`.
+
+    Whole-chromosome units contribute all of the chromosome's rows on both sides.
+    A split chromosome contributes the rank's row-range slices of the split side
+    (slice j of k = the rows whose index within the chromosome falls in
+    ``[j*n/k, (j+1)*n/k)``) and ALL rows of the other side.  Row index arrays are
+    ascending; across ranks the split side's rows are disjoint, so every pair is
+    produced by exactly one rank.
+    """
+    chrom_a = np.asarray(chrom_a)
+    chrom_b = np.asarray(chrom_b)
+    na = np.bincount(chrom_a, minlength=n_chrom)
+    nb = np.bincount(chrom_b, minlength=n_chrom)
+    units = plan_units(na.tolist(), nb.tolist(), world, split_over)
+    owner = assign_units(units, world)
+    keep_a = np.zeros(chrom_a.shape[0], dtype=bool)
+    keep_b = np.zeros(chrom_b.shape[0], dtype=bool)
+    whole = np.zeros(n_chrom, dtype=bool)
+    for (c, j, k, side, _w), r in zip(units, owner):
+        if r != rank:
+            continue
+        if k == 1:
+            whole[c] = True
+            continue
+        split_chrom, other_keep, other_chrom = ((chrom_a, keep_b, chrom_b) if side == "a"
+                                                else (chrom_b, keep_a, chrom_a))
+        rows = np.nonzero(split_chrom == c)[0]
+        n = rows.shape[0]
+        sl = rows[(j * n) // k:((j + 1) * n) // k]
+        (keep_a if side == "a" else keep_b)[sl] = True
+        other_keep[other_chrom == c] = True
+    keep_a |= whole[chrom_a]
+    keep_b |= whole[chrom_b]
+    return np.nonzero(keep_a)[0], np.nonzero(keep_b)[0]
 
 
 def gather_pairs(row_a, row_b, group=None):
@@ -82,9 +120,9 @@ def sharded_inner_join(a, b, n_chrom: int, local_join: Callable, *, device=None,
     cb, sb, eb = (np.asarray(x) for x in b[:3])
     offs_a = tuple(a[3:5]) if len(a) >= 5 else (0, 0)
     offs_b = tuple(b[3:5]) if len(b) >= 5 else (0, 0)
-    assign = plan_shards(ca, cb, n_chrom, world)
-    ia = shard_rows(ca, assign, rank)
-    ib = shard_rows(cb, assign, rank)
+    # chromosome units, LPT-packed; a chromosome heavier than one rank's share is
+    # split by row ranges of its larger side (identical to plan_shards otherwise)
+    ia, ib = unit_rows(ca, cb, n_chrom, world, rank)
     la, lb = local_join(ca[ia], sa[ia], ea[ia], offs_a, cb[ib], sb[ib], eb[ib], offs_b, n_chrom)
     dev = la.device if device is None else torch.device(device)
     # local -> global row ids (the shard's id maps)

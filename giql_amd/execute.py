@@ -109,6 +109,33 @@ def _take(table, name: str, idx: np.ndarray):
     return np.asarray(col)[idx]
 
 
+def _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices):
+    """count_overlaps: COUNT(b.col) per distinct left key, zero-filled
+    (src/giql/expanders/intersects_duckdb.py:806-854; oracle semantics of
+    tests/test_duckdb_iejoin.py:66-81: a key held by k duplicate left rows counts
+    k times its overlaps)."""
+    import pyarrow as pa
+
+    cnt_proj = [p for p in plan.projection if p.side == "count"][0]
+    ccol = _column(rt, cnt_proj.column)
+    if hasattr(ccol, "null_count") and ccol.null_count:
+        # COUNT(col) skips NULLs; the kernels count rows
+        raise ValueError(f"COUNT({plan.right.alias}.{cnt_proj.column}) over a column with NULLs is not "
+                         "supported by dialect='hip'")
+    counts = eng.count_overlaps(a, b, n_chrom).cpu().numpy()
+    if return_indices:
+        return counts
+    keys = [p for p in plan.projection if p.side == "l"]
+    cols = {p.name: _column(lt, p.column) for p in keys}
+    cols[cnt_proj.name] = pa.array(counts, type=pa.int64())
+    tbl = pa.table({k: (v if isinstance(v, (pa.Array, pa.ChunkedArray)) else pa.array(v)) for k, v in cols.items()})
+    if tbl.num_rows == 0:
+        return tbl
+    out = tbl.group_by([p.name for p in keys], use_threads=False).aggregate([(cnt_proj.name, "sum")])
+    out = out.rename_columns([cnt_proj.name if c == cnt_proj.name + "_sum" else c for c in out.column_names])
+    return out.select([p.name for p in plan.projection])
+
+
 def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, return_indices=False):
     """Run *plan* (a :class:`JoinPlan`, its string form, or a GIQL query string)
     against ``tables`` (``{name: pyarrow.Table | dict of arrays}``).
@@ -133,6 +160,8 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
     a = _device_side(lt, plan.left, ia, eng)
     b = _device_side(rt, plan.right, ib, eng)
 
+    if plan.kind == "COUNT":
+        return _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices)
     if plan.kind == "INNER":
         ra, rb = eng.inner_join(a, b, n_chrom)
         ra, rb = ra.cpu().numpy(), rb.cpu().numpy()

@@ -13,7 +13,7 @@ from dataclasses import asdict, dataclass, field
 
 PLAN_PREFIX = "GIQL-HIP-PLAN/1 "
 
-KINDS = ("INNER", "SEMI", "ANTI", "NEAREST")
+KINDS = ("INNER", "SEMI", "ANTI", "NEAREST", "COUNT")
 
 
 @dataclass(frozen=True)
@@ -36,7 +36,7 @@ class PlanSide:
 
 @dataclass(frozen=True)
 class Projection:
-    side: str      # "l", "r" or "distance" (NEAREST's computed column)
+    side: str      # "l", "r", "distance" (NEAREST) or "count" (count_overlaps aggregate)
     column: str
     name: str      # output column name
 

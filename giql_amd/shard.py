@@ -30,6 +30,47 @@ def lpt_assign(weights: Sequence[float], n_bins: int) -> list[int]:
     return assign
 
 
+def plan_units(n_a: Sequence[int], n_b: Sequence[int], n_bins: int, split_over: float = 1.0):
+    """Work units for ``n_bins`` ranks: ``[(chrom, part, n_parts, split_side, weight)]``.
+
+    A chromosome is normally one unit.  One whose rows (A + B) exceed
+    ``split_over`` x the ideal per-rank share is cut into ``n_parts`` units by ROW
+    RANGES of its larger side (``split_side`` "a" or "b"); every such unit carries
+    the whole of the chromosome's other side, so each (a, b) pair is still found
+    exactly once ("if one chromosome dominates, split by row
+    ranges and replicate the other side").  Deterministic.
+    """
+    if n_bins < 1:
+        raise ValueError("n_bins must be >= 1")
+    total = float(sum(n_a) + sum(n_b))
+    share = total / n_bins if n_bins else total
+    units = []
+    for c, (na, nb) in enumerate(zip(n_a, n_b)):
+        na, nb = int(na), int(nb)
+        w = na + nb
+        if w == 0:
+            continue
+        big, small = max(na, nb), min(na, nb)
+        k = 1
+        if n_bins > 1 and w > split_over * share and big > 1:
+            # smallest k whose units (big/k + replicated small) fit the share, capped at n_bins
+            k = n_bins
+            for cand in range(2, n_bins + 1):
+                if big / cand + small <= share:
+                    k = cand
+                    break
+            k = min(k, big)
+        side = "a" if na >= nb else "b"
+        for j in range(k):
+            units.append((c, j, k, side, big / k + small))
+    return units
+
+
+def assign_units(units, n_bins: int) -> list[int]:
+    """LPT assignment of :func:`plan_units` units to ranks."""
+    return lpt_assign([u[4] for u in units], n_bins)
+
+
 def span_groups(spans: Sequence[int], limit: int = 2**32 - 2) -> list[list[int]]:
     """Split chromosomes into groups whose summed coordinate span fits 32 bits.
 

@@ -108,6 +108,7 @@ class _ColRef:
     table_quoted: bool
     column: str
     star: bool = False
+    count: bool = False  # COUNT(<this column>)
 
 
 @dataclass
@@ -218,15 +219,30 @@ def _genomic_col(name: str, tables: Tables) -> str:
 
 
 def _parse_projection(p: _Parser) -> list[tuple[_ColRef, str | None]]:
+    """SELECT list: qualified columns, plus at most the count_overlaps aggregate
+    ``COUNT(<right col>) AS <alias>`` (returned as a _ColRef with ``count=True``)."""
     items: list[tuple[_ColRef, str | None]] = []
     while True:
         if p.peek().kind == "kw" and not p.at_kw("FROM"):
             raise _decline(f"projection starting with {p.peek().text}")
         if p.peek().kind in ("num", "str") or p.at_punct("("):
             raise _decline("expression in the SELECT list")
-        ref = p.colref()
-        if p.at_punct("("):
-            raise _decline("function call / aggregate in the SELECT list")
+        is_count = (p.peek().kind == "id" and not p.peek().quoted and p.peek().text.upper() == "COUNT"
+                    and p.peek(1).kind == "punct" and p.peek(1).text == "(")
+        if is_count:
+            p.next()
+            p.next()
+            if p.at_kw("DISTINCT"):
+                raise _decline("COUNT(DISTINCT ...)")
+            if p.at_punct("*"):
+                raise _decline("COUNT(*)")  # _match_count_overlaps wants COUNT(<right col>)
+            ref = p.colref()
+            p.expect_punct(")")
+            ref.count = True
+        else:
+            ref = p.colref()
+            if p.at_punct("("):
+                raise _decline("function call / aggregate in the SELECT list")
         if p.peek().kind == "punct" and p.peek().text in "+-/*=<>":
             raise _decline("expression in the SELECT list")
         alias = None
@@ -247,6 +263,8 @@ def _resolve_projection(items, left: PlanSide, right: PlanSide, left_only: bool,
                         distance_alias: str | None = None) -> tuple[Projection, ...]:
     out = []
     for ref, alias in items:
+        if ref.count:
+            raise _decline("COUNT(...) outside the count_overlaps LEFT JOIN ... GROUP BY shape")
         if ref.star:
             # schema-less star enumeration would narrow the result (#202)
             raise _decline("star projection")
@@ -269,6 +287,43 @@ def _resolve_projection(items, left: PlanSide, right: PlanSide, left_only: bool,
                 out.append(Projection("r", ref.column, name))
         else:
             raise ValueError(f"Unknown table qualifier {ref.table!r} in the SELECT list")
+    return tuple(out)
+
+
+def _resolve_count_projection(items, group_cols, left: PlanSide, right: PlanSide):
+    """The count_overlaps projection: left key columns + ONE aliased COUNT(<right col>);
+    GROUP BY must be exactly the projected left columns (intersects_duckdb.py:484-539)."""
+    out = []
+    n_count = 0
+    keys = set()
+    for ref, alias in items:
+        if ref.star or ref.table is None:
+            raise _decline("count_overlaps projection that is not a qualified column")
+        q = _norm(ref.table, ref.table_quoted)
+        if ref.count:
+            n_count += 1
+            if q != right.alias:
+                raise _decline("COUNT over a left-side column")
+            if not alias:
+                raise _decline("count_overlaps COUNT without an alias")
+            out.append(Projection("count", ref.column, alias))
+        else:
+            if q != left.alias:
+                raise _decline("count_overlaps key from the right side")
+            keys.add(ref.column)
+            out.append(Projection("l", ref.column, alias or ref.column))
+    if n_count != 1 or not keys:
+        raise _decline("count_overlaps needs left key columns and exactly one COUNT")
+    gkeys = set()
+    for g in group_cols:
+        if g.table is None or _norm(g.table, g.table_quoted) != left.alias:
+            raise _decline("GROUP BY column that is not a left-side qualified column")
+        gkeys.add(g.column)
+    if gkeys != keys:
+        raise _decline("GROUP BY keys differ from the projected left columns")
+    names = [p.name for p in out]
+    if len(set(names)) != len(names):
+        raise _decline("duplicate output names in count_overlaps")
     return tuple(out)
 
 
@@ -408,6 +463,12 @@ def _lower(giql: str, tables, want_sql: bool):
             side = p.next().text
             if p.at_kw("SEMI", "ANTI"):
                 kind = p.next().text
+            elif side == "LEFT" and any(ref.count for ref, _ in items):
+                # count_overlaps: LEFT [OUTER] JOIN ... COUNT(b.col) ... GROUP BY left keys
+                # (_match_count_overlaps, intersects_duckdb.py:432-548)
+                if p.at_kw("OUTER"):
+                    p.next()
+                kind = "COUNT"
             else:
                 raise _decline(f"{side} outer join")  # intersects_duckdb.py:661-662
         elif p.at_kw("INNER", "CROSS", "SEMI", "ANTI"):
@@ -440,6 +501,8 @@ def _lower(giql: str, tables, want_sql: bool):
         proj = _resolve_projection(items, left, right, False, distance_alias=right.alias)
         return JoinPlan("NEAREST", left, right, proj, distinct, 1, nearest[0], nearest[1])
 
+    if kind == "COUNT" and not on_seen:
+        raise _decline("count_overlaps without an ON clause")
     if not on_seen:
         if kind in ("SEMI", "ANTI"):
             raise _decline("SEMI/ANTI join with its INTERSECTS outside ON")  # #201
@@ -459,6 +522,20 @@ def _lower(giql: str, tables, want_sql: bool):
     rhs = p.colref()
     if p.at_kw("AND", "OR"):
         raise _decline("extra predicates beside the INTERSECTS")
+    group_cols: list[_ColRef] = []
+    if kind == "COUNT":
+        if not p.at_kw("GROUP"):
+            raise _decline("count_overlaps without GROUP BY")
+        p.next()
+        p.expect_kw("BY")
+        while True:
+            if p.peek().kind != "id":
+                raise _decline("GROUP BY expression")
+            group_cols.append(p.colref())
+            if p.at_punct(","):
+                p.next()
+                continue
+            break
     if p.peek().kind == "kw" and p.peek().text in _UNSUPPORTED_TAIL + ("WHERE", "JOIN", "INNER",
                                                                        "LEFT", "CROSS"):
         raise _decline(f"{p.peek().text} clause")
@@ -486,6 +563,10 @@ def _lower(giql: str, tables, want_sql: bool):
         raise ValueError(
             f"INTERSECTS operands must be the tables' genomic columns "
             f"({_genomic_col(left.table, tbls)!r} / {_genomic_col(right.table, tbls)!r})")
+    if kind == "COUNT":
+        if distinct:
+            raise _decline("DISTINCT with count_overlaps")
+        return JoinPlan("COUNT", left, right, _resolve_count_projection(items, group_cols, left, right))
     proj = _resolve_projection(items, left, right, kind in ("SEMI", "ANTI"))
     return JoinPlan(kind, left, right, proj, distinct)
 

@@ -26,17 +26,19 @@ def _free_port() -> int:
     return p
 
 
-def _tables(seed=3):
+def _tables(seed=3, skew=False):
     r = np.random.default_rng(seed)
     def side(n, nch):
         ch = r.integers(0, nch, n).astype(np.int32)
+        if skew:  # one dominant chromosome (BASELINE config 2 is the limit case: a single chromosome)
+            ch[r.random(n) < 0.8] = 2
         st = r.integers(0, 200_000, n).astype(np.int32)
         ln = r.integers(1, 900, n).astype(np.int32)
         return ch, st, st + ln
     return side(4000, 7), side(6000, 6)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, skew=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -49,7 +51,11 @@ def _worker(rank, world, port, out_dir):
             ra, rb = ora.c_inner(ora.Side(ca, sa, ea, *offs_a), ora.Side(cb, sb, eb, *offs_b), "sweep", threads=1)
             return torch.from_numpy(ra), torch.from_numpy(rb)
 
-        a, b = _tables()
+        a, b = _tables(skew=skew)
+        if skew:  # the dominant chromosome must really be spread over the ranks
+            ia, ib = D.unit_rows(a[0], b[0], 7, world, rank)
+            assert 0 < int((a[0][ia] == 2).sum()) or 0 < int((b[0][ib] == 2).sum())
+            assert len(ia) + len(ib) < 0.75 * (len(a[0]) + len(b[0]))
         out_a, out_b = D.sharded_inner_join(a, b, 7, local_join)
         np.save(os.path.join(out_dir, f"pairs_{rank}.npy"),
                 np.stack([out_a.numpy(), out_b.numpy()]))
@@ -78,6 +84,52 @@ def test_sharded_join_matches_single_process(tmp_path, world):
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"pairs_{r}.npy"))
         assert np.array_equal(ora.sort_pairs(got[0], got[1]), want), r
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_dominant_chromosome_is_split_by_row_ranges(tmp_path, world):
+    from oracle import pyoracle as ora
+
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), True), nprocs=world, join=True)
+    a, b = _tables(skew=True)
+    want = ora.sort_pairs(*ora.c_inner(ora.Side(*a), ora.Side(*b), "sweep", threads=2))
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"pairs_{r}.npy"))
+        assert np.array_equal(ora.sort_pairs(got[0], got[1]), want), r
+
+
+def test_plan_units_splits_only_dominant_chromosomes():
+    from giql_amd import distributed as D
+    from giql_amd import shard, synth
+
+    na = synth.rows_per_chrom(10_000_000, 5).tolist()
+    nb = synth.rows_per_chrom(100_000_000, 6).tolist()
+    for n in (1, 2, 4, 8):  # hg38: no chromosome exceeds one rank's share up to 8 ranks
+        assert all(u[2] == 1 for u in shard.plan_units(na, nb, n))
+    # single chromosome (config 2): split the larger side into one slice per rank
+    units = shard.plan_units([1000], [4000], 4)
+    assert [(u[0], u[1], u[2], u[3]) for u in units] == [(0, j, 4, "b") for j in range(4)]
+    assert sorted(shard.assign_units(units, 4)) == [0, 1, 2, 3]
+    # every row of the split side lands on exactly one rank; the other side is replicated
+    ca = np.zeros(1000, np.int32)
+    cb = np.zeros(4000, np.int32)
+    seen_b = np.zeros(4000, int)
+    for r in range(4):
+        ia, ib = D.unit_rows(ca, cb, 1, 4, r)
+        assert len(ia) == 1000
+        seen_b[ib] += 1
+    assert (seen_b == 1).all()
+    # mixed: one heavy chromosome among light ones; empty chromosomes make no unit
+    units = shard.plan_units([100, 10, 0, 10], [900, 10, 0, 10], 2)
+    assert [u[0] for u in units if u[2] > 1] == [0, 0] and all(u[0] != 2 for u in units)
+    seen = np.zeros(4, int)
+    chrom_b = np.array([0, 0, 1, 3, 0, 0], np.int32)
+    chrom_a = np.array([0, 1, 3], np.int32)
+    for r in range(2):
+        ia, ib = D.unit_rows(chrom_a, chrom_b, 4, 2, r)
+        seen[np.isin(np.arange(6), ib)[[0, 1, 4, 5]]] += 1
+    assert (seen == 1).all()
 
 
 def test_lpt_assign_and_shard_rows():

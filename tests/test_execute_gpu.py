@@ -161,6 +161,61 @@ def test_nearest_drops_rows_whose_chromosome_has_no_target():
     assert rows_of(execute(transpile(q, tables=["peaks", "genes"], dialect="hip"), t)) == [("chr1", 280)]
 
 
+COUNT_Q = ('SELECT a.chrom, a.start, a."end", COUNT(b.chrom) AS n FROM peaks a '
+           'LEFT JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom, a.start, a."end"')
+
+
+def _python_count_overlaps(peaks, genes):
+    # the reference's test oracle for this shape (tests/test_duckdb_iejoin.py:66-81), restated
+    out = []
+    for key in set(peaks):
+        pc, ps, pe = key
+        dup = sum(1 for p in peaks if p == key)
+        hits = sum(1 for (gc, gs, ge) in genes if pc == gc and pe > gs and ge > ps)
+        out.append((pc, ps, pe, dup * hits))
+    return sorted(out)
+
+
+def test_count_overlaps_zero_fills_and_groups_duplicate_keys(peaks_genes):
+    got = rows_of(execute(transpile(COUNT_Q, tables=["peaks", "genes"], dialect="hip"), peaks_genes))
+    assert got == [("chr1", 100, 200, 1), ("chr1", 300, 400, 0), ("chr1", 500, 600, 1),
+                   ("chr2", 100, 200, 1), ("chr2", 800, 900, 0)]
+
+
+def test_count_overlaps_matches_python_reference_for_random_inputs():
+    # reference tests/test_duckdb_iejoin.py:3520-3564: random rows incl. duplicate keys,
+    # left-only chromosomes and zero-overlap keys
+    rng = np.random.default_rng(20260209)
+    def rows(n, chroms):
+        out = []
+        for _ in range(n):
+            s = int(rng.integers(0, 400))
+            out.append((str(rng.choice(chroms)), s, s + int(rng.integers(1, 60))))
+        return out
+    peak_rows = rows(150, ["chr1", "chr2", "chr3"])
+    peak_rows += peak_rows[:20]  # duplicate keys
+    gene_rows = rows(200, ["chr1", "chr2"])
+    t = {"peaks": make_table([(c, s, e, "p", 0, "+") for c, s, e in peak_rows]),
+         "genes": make_table([(c, s, e, "g", 0, "+") for c, s, e in gene_rows])}
+    got = rows_of(execute(transpile(COUNT_Q, tables=["peaks", "genes"], dialect="hip"), t))
+    assert got == _python_count_overlaps(peak_rows, gene_rows)
+
+
+def test_count_overlaps_handles_empty_sides():
+    plan = transpile(COUNT_Q, tables=["peaks", "genes"], dialect="hip")
+    one = make_table([("chr1", 150, 250, "g1", 0, "+")])
+    assert rows_of(execute(plan, {"peaks": make_table([]), "genes": one})) == []
+    assert rows_of(execute(plan, {"peaks": one, "genes": make_table([])})) == [("chr1", 150, 250, 0)]
+
+
+def test_count_overlaps_rejects_null_count_column(peaks_genes):
+    # COUNT(col) skips NULLs; the kernels count rows, so a nullable argument is refused
+    q = COUNT_Q.replace("COUNT(b.chrom)", "COUNT(b.name)")
+    genes = peaks_genes["genes"].set_column(3, "name", pa.array(["g1", None, "g3", "g4", "g5"], pa.string()))
+    with pytest.raises(ValueError, match="NULL"):
+        execute(transpile(q, tables=["peaks", "genes"], dialect="hip"), {"peaks": peaks_genes["peaks"], "genes": genes})
+
+
 def test_nulls_and_out_of_range_are_rejected(peaks_genes):
     bad = peaks_genes["peaks"].set_column(1, "start", pa.array([100, None, 500, 100, 800], pa.int32()))
     plan = transpile(Q6, tables=["peaks", "genes"], dialect="hip")

@@ -122,6 +122,51 @@ def test_user_mistakes_raise_value_error(query, match):
     assert not isinstance(ei.value, HipDeclined)
 
 
+COUNT_Q = ('SELECT a.chrom, a.start, a."end", COUNT(b.chrom) AS n FROM peaks a '
+           'LEFT JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom, a.start, a."end"')
+
+
+def test_count_overlaps_shape_engages_the_path():
+    # reference tests/test_duckdb_iejoin.py:3220-3250 (the count_overlaps fast path, #209)
+    plan = build_plan(COUNT_Q, ["peaks", "genes"])
+    assert plan.kind == "COUNT"
+    assert [(p.side, p.column, p.name) for p in plan.projection] == [
+        ("l", "chrom", "chrom"), ("l", "start", "start"), ("l", "end", "end"), ("count", "chrom", "n")]
+    assert JoinPlan.from_string(plan.to_string()) == plan
+    outer = build_plan(COUNT_Q.replace("LEFT JOIN", "LEFT OUTER JOIN"), ["peaks", "genes"])
+    assert outer == plan
+
+
+@pytest.mark.parametrize("query", [
+    # the reference's decline matrix for this shape, tests/test_duckdb_iejoin.py:3252-3446
+    "SELECT a.chrom, COUNT(*) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom",
+    "SELECT a.chrom, SUM(b.score) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom",
+    "SELECT COUNT(b.chrom) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval",
+    "SELECT a.chrom, COUNT(b.chrom) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval "
+    "GROUP BY a.chrom ORDER BY a.chrom",
+    "SELECT a.chrom, COUNT(b.chrom) AS n FROM peaks a LEFT JOIN peaks b ON a.interval INTERSECTS b.interval GROUP BY a.chrom",
+    "SELECT a.chrom, COUNT(b.chrom) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval "
+    "GROUP BY a.chrom, a.start",
+    "SELECT a.score AS n, COUNT(b.chrom) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval "
+    "GROUP BY a.score",
+    "SELECT a.chrom, COUNT(b.chrom) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval "
+    "WHERE a.score > 1 GROUP BY a.chrom",
+    # shapes the hip target does not take even though the DuckDB matcher does / might
+    "SELECT a.chrom, COUNT(DISTINCT b.name) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval "
+    "GROUP BY a.chrom",
+    "SELECT a.chrom, COUNT(b.chrom) FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom",
+    "SELECT a.chrom, COUNT(a.start) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom",
+    "SELECT a.chrom, b.start, COUNT(b.chrom) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval "
+    "GROUP BY a.chrom",
+    "SELECT a.chrom, COUNT(b.chrom) AS n FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom",
+    "SELECT a.chrom, COUNT(b.chrom) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval "
+    "GROUP BY a.chrom HAVING COUNT(b.chrom) > 1",
+])
+def test_count_overlaps_lookalikes_decline(query):
+    with pytest.raises(HipDeclined):
+        build_plan(query, ["peaks", "genes"])
+
+
 def test_nearest_plan():
     plan = build_plan(
         "SELECT a.start AS a_start, b.start AS b_start, b.distance AS d FROM peaks a "
