@@ -158,6 +158,29 @@ def run_cpu_baseline(args, n_a, kind_a, seed_a, n_b, kind_b, seed_b):
     }
 
 
+def measured_copy_gbs(dev, mb: int = 1600, reps: int = 5):
+    """Device-to-device copy bandwidth of this GPU in GB/s (bytes read + written)."""
+    import torch
+
+    try:
+        n = mb * (1 << 20) // 4
+        x = torch.empty(n, dtype=torch.int32, device=dev)
+        y = torch.empty_like(x)
+        x.fill_(1)
+        y.copy_(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(reps):
+            y.copy_(x)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / reps
+        return round(2 * n * 4 / ms / 1e6, 1) if ms > 0 else None
+    except RuntimeError:  # not enough free HBM next to the workload
+        return None
+
+
 def main() -> None:
     args = parse_args()
     import torch
@@ -217,10 +240,15 @@ def main() -> None:
         idmap_a = (torch.arange(loc_na, device=dev, dtype=torch.int64) + base[0]).to(torch.int32)
         idmap_b = (torch.arange(loc_nb, device=dev, dtype=torch.int64) + base[1]).to(torch.int32)
 
+    xg = D.PairGather(xdev) if distributed and not args.no_gather else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if distributed else None
     split_ms = [0.0, 0.0]  # [local join, exchange] summed over the timed steps
 
-    def step():
+    phase_ms = {}
+    phase_launches = {}
+    last_stats = [None]
+
+    def step(collect=False):
         """One pass of the hot path; returns this rank's pair count."""
         nonlocal out, out_cap
         if ev:
@@ -233,11 +261,25 @@ def main() -> None:
         eng.inner_fill(out[0, :n], out[1, :n])
         if ev:
             ev[1].record()
-        if distributed and not args.no_gather:
-            # the path's one exchange step: global ids, counts, then the padded pairs
-            ga = idmap_a[out[0, :n].long()]
-            gb = idmap_b[out[1, :n].long()]
-            D.gather_pairs(ga.to(xdev), gb.to(xdev))
+        if collect:  # the join's phase times, before the exchange's take calls reset them
+            st = eng.stats()
+            last_stats[0] = st
+            for k, v in st["phase_ms"].items():
+                phase_ms[k] = phase_ms.get(k, 0.0) + v
+            for k, v in st["phase_launches"].items():
+                phase_launches[k] = phase_launches.get(k, 0) + v
+        if xg is not None:
+            # the path's one exchange step: counts, then the pairs as GLOBAL row ids,
+            # mapped by the take kernel straight into the send block of the all-gather
+            counts = xg.counts(n)
+            send = xg.send_block(max(counts))
+            if send.device == dev:
+                eng.take([idmap_a], out[0, :n], outs=[send[0, :n]])
+                eng.take([idmap_b], out[1, :n], outs=[send[1, :n]])
+            else:  # gloo rehearsal: the exchange runs through host memory
+                send[0, :n] = eng.take([idmap_a], out[0, :n])[0].to(xdev)
+                send[1, :n] = eng.take([idmap_b], out[1, :n])[0].to(xdev)
+            xg.all_gather(counts)
         if ev:
             ev[2].record()
             ev[2].synchronize()
@@ -256,20 +298,14 @@ def main() -> None:
     # hipEvent phase timing stays ON inside the timed region (two events per
     # phase on the launch stream); stats() waits for the step's last event.
     eng.set_profiling(True)
-    phase_ms = {}
-    phase_launches = {}
     sync_all()
     split_ms[0] = split_ms[1] = 0.0
     t0 = time.perf_counter()
     n_local = 0
     for _ in range(args.steps):
-        n_local = step()
-        st = eng.stats()
-        for k, v in st["phase_ms"].items():
-            phase_ms[k] = phase_ms.get(k, 0.0) + v
-        for k, v in st["phase_launches"].items():
-            phase_launches[k] = phase_launches.get(k, 0) + v
+        n_local = step(collect=True)
     sync_all()
+    st = last_stats[0]
     elapsed = time.perf_counter() - t0
     eng.set_profiling(False)
 
@@ -292,6 +328,7 @@ def main() -> None:
         achieved = (dom_bytes / dom_launches) / (dom_ms / dom_launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         join_bytes = 12.0 * (loc_na + loc_nb) + 8.0 * n_local
         device_ms = sum(per_step_ms.values())
+        copy_gbs = measured_copy_gbs(dev)
         roofline = {
             "bound": "hbm",
             "kernel": dom,
@@ -302,7 +339,12 @@ def main() -> None:
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(args.workload, st["join_form"], dom, dom_launches),
+            # this box's own streaming-copy rate (read + written bytes of a 1.6 GB d2d copy,
+            # SURVEY.md 8d) and the kernel's fraction of THAT; "frac" stays against the 8 TB/s peak
+            "measured_copy": copy_gbs,
+            "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
+            # the PMC passes were collected on the whole workload on one GPU
+            "traffic": pmc_traffic(args.workload, st["join_form"], dom, dom_launches) if world == 1 else None,
             "whole_join": {
                 "algorithmic_bytes": join_bytes,
                 "device_ms": round(device_ms, 3),

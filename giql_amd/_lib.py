@@ -34,6 +34,7 @@ SYMBOLS = [
     "giql_hip_semi_anti_dev", "giql_hip_count_dev", "giql_hip_nearest_dev", "giql_hip_chrom_spans_dev",
     "giql_hip_inner", "giql_hip_semi_anti", "giql_hip_count", "giql_hip_nearest",
     "giql_hip_free_host", "giql_hip_pairs_checksum_dev",
+    "giql_hip_take_dev", "giql_hip_take_utf8_plan_dev", "giql_hip_take_utf8_fill_dev",
 ]
 
 
@@ -134,6 +135,9 @@ def load() -> ctypes.CDLL:
     L.giql_hip_free_host.argtypes = [vp]
     L.giql_hip_free_host.restype = None
     L.giql_hip_pairs_checksum_dev.argtypes = [vp, vp, vp, i64, vp, P(ctypes.c_uint64)]
+    L.giql_hip_take_dev.argtypes = [vp, P(vp), P(i32), i32, i64, vp, i64, P(vp), vp]
+    L.giql_hip_take_utf8_plan_dev.argtypes = [vp, vp, i64, vp, i64, vp, P(i64), vp]
+    L.giql_hip_take_utf8_fill_dev.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int and name not in ("giql_hip_abi_version",):

@@ -14,6 +14,7 @@
 
 #include "../../include/giql_hip.h"
 #include "aux_kernels.hip.h"
+#include "take_kernels.hip.h"
 #include "dev_common.hip.h"
 #include "join_kernels.hip.h"
 #include "onesweep.hip.h"
@@ -1098,6 +1099,120 @@ int giql_hip_pairs_checksum_dev(giql_hip_ctx* ctx, const int32_t* row_a, const i
   HIP_TRY(hipMemcpyAsync(&h, ctx->d_scratch64, sizeof(u64), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   *out = h;
+  return GIQL_OK;
+}
+
+// ------------------------------------------------ projection (Arrow take)
+int giql_hip_take_dev(giql_hip_ctx* ctx, const void* const* cols, const int32_t* elem_bytes,
+                      int32_t n_cols, int64_t n_rows, const int32_t* idx, int64_t n,
+                      void* const* outs, void* stream) {
+  if (!ctx || n_cols < 0 || n < 0 || n_rows < 0 || n_rows > 0x7FFFFFFFll || (n_cols && (!cols || !elem_bytes || !outs)))
+    return set_err(GIQL_ERR_INVALID, "bad arguments");
+  if (n > 0 && !idx) return set_err(GIQL_ERR_INVALID, "idx is NULL");
+  for (int c = 0; c < n_cols; c++) {
+    const int e = elem_bytes[c];
+    if (e != 1 && e != 2 && e != 4 && e != 8 && e != 16)
+      return set_err(GIQL_ERR_INVALID, "column %d: elem_bytes=%d not in {1,2,4,8,16}", c, e);
+    if (n > 0 && (!outs[c] || (n_rows > 0 && !cols[c])))
+      return set_err(GIQL_ERR_INVALID, "column %d: NULL buffer", c);
+    if (((uintptr_t)cols[c] | (uintptr_t)outs[c]) % (uintptr_t)e)
+      return set_err(GIQL_ERR_INVALID, "column %d: buffer not aligned to its element size", c);
+  }
+  if (n == 0 || n_cols == 0) return GIQL_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  reset_stats(ctx);
+  HIP_TRY(hipMemsetAsync(&ctx->d_meta->status, 0, sizeof(int), st));
+  u32 grid = cdiv((u64)n, (u64)TK_NT * 4 * 4);
+  if (grid > 16384u) grid = 16384u;
+  for (int c0 = 0; c0 < n_cols; c0 += TK_MAX_COLS) {
+    TakeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_cols = n_cols - c0 < TK_MAX_COLS ? n_cols - c0 : TK_MAX_COLS;
+    a.vec = ((uintptr_t)idx % 16) == 0;
+    for (int c = 0; c < a.n_cols; c++) {
+      a.col[c] = cols[c0 + c];
+      a.out[c] = outs[c0 + c];
+      a.elem[c] = elem_bytes[c0 + c];
+      if ((uintptr_t)a.out[c] % 16) a.vec = 0;
+    }
+    Phase ph(ctx, st, GIQL_PH_AUX);
+    hipLaunchKernelGGL(k_take, dim3(grid), dim3(TK_NT), 0, st, a, idx, (u64)n, (u32)n_rows,
+                       ctx->d_meta);
+    GIQL_TRY(post_launch("take"));
+  }
+  GIQL_TRY(read_meta(ctx, st));
+  collect_spans(ctx);
+  ctx->stats.n_out = n;
+  return GIQL_OK;
+}
+
+int giql_hip_take_utf8_plan_dev(giql_hip_ctx* ctx, const int32_t* offsets, int64_t n_rows,
+                                const int32_t* idx, int64_t n, int32_t* out_offsets,
+                                int64_t* n_bytes, void* stream) {
+  if (!ctx || !out_offsets || !n_bytes || n < 0 || n > 0x7FFFFFF0ll || n_rows < 0 || n_rows > 0x7FFFFFFFll)
+    return set_err(GIQL_ERR_INVALID, "bad arguments");
+  if ((n > 0 && !idx) || (n_rows > 0 && !offsets)) return set_err(GIQL_ERR_INVALID, "NULL buffer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  reset_stats(ctx);
+  *n_bytes = 0;
+  if (n == 0) {
+    HIP_TRY(hipMemsetAsync(out_offsets, 0, sizeof(int32_t), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GIQL_OK;
+  }
+  Carver c{nullptr};
+  u64* bsums = c.take<u64>(cdiv((u64)n, SCAN_TILE) + 1);
+  u64* total = c.take<u64>(1);
+  GIQL_TRY(ensure_arena(ctx, c.off, st));
+  c = Carver{ctx->arena};
+  bsums = c.take<u64>(cdiv((u64)n, SCAN_TILE) + 1);
+  total = c.take<u64>(1);
+  HIP_TRY(hipMemsetAsync(&ctx->d_meta->status, 0, sizeof(int), st));
+  u32 grid = cdiv((u64)n, (u64)TK_NT * 4);
+  if (grid > 16384u) grid = 16384u;
+  {
+    Phase ph(ctx, st, GIQL_PH_AUX);
+    hipLaunchKernelGGL(k_take_utf8_len, dim3(grid), dim3(TK_NT), 0, st, offsets, (u32)n_rows, idx,
+                       (u64)n, reinterpret_cast<u32*>(out_offsets), ctx->d_meta);
+    GIQL_TRY(post_launch("take_utf8_len"));
+  }
+  GIQL_TRY(run_scan<u32>(ctx, st, GIQL_PH_SCAN, reinterpret_cast<u32*>(out_offsets), (u64)n,
+                         reinterpret_cast<u32*>(out_offsets), bsums, total));
+  // out_offsets[n] = total (low word; the range check below rejects anything wider)
+  HIP_TRY(hipMemcpyAsync(out_offsets + n, total, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  u64 h_total = 0;
+  HIP_TRY(hipMemcpyAsync(&h_total, total, sizeof(u64), hipMemcpyDeviceToHost, st));
+  GIQL_TRY(read_meta(ctx, st));
+  collect_spans(ctx);
+  if (h_total > 0x7FFFFFFFull)
+    return set_err(GIQL_ERR_CAPACITY, "taken utf8 data is %llu bytes: exceeds int32 offsets",
+                   (unsigned long long)h_total);
+  *n_bytes = (int64_t)h_total;
+  return GIQL_OK;
+}
+
+int giql_hip_take_utf8_fill_dev(giql_hip_ctx* ctx, const int32_t* offsets, const uint8_t* data,
+                                int64_t n_rows, const int32_t* idx, int64_t n,
+                                const int32_t* out_offsets, uint8_t* out_data, void* stream) {
+  if (!ctx || n < 0 || n_rows < 0 || n_rows > 0x7FFFFFFFll) return set_err(GIQL_ERR_INVALID, "bad arguments");
+  if (n == 0) return GIQL_OK;
+  if (!idx || !out_offsets || (n_rows > 0 && !offsets)) return set_err(GIQL_ERR_INVALID, "NULL buffer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  reset_stats(ctx);
+  u32 grid = cdiv((u64)n, (u64)TK_NT * 2);
+  if (grid > 32768u) grid = 32768u;
+  {
+    Phase ph(ctx, st, GIQL_PH_AUX);
+    hipLaunchKernelGGL(k_take_utf8_copy, dim3(grid), dim3(TK_NT), 0, st, offsets, data, (u32)n_rows,
+                       idx, (u64)n, out_offsets, out_data);
+    GIQL_TRY(post_launch("take_utf8_copy"));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  collect_spans(ctx);
+  ctx->stats.n_out = n;
   return GIQL_OK;
 }
 

@@ -102,6 +102,66 @@ def gather_pairs(row_a, row_b, group=None):
     return out_a, out_b, counts_h
 
 
+class PairGather:
+    """The path's exchange step with persistent buffers and no repacking.
+
+    ``gather_pairs`` above is the simple form (pack, all-gather, concatenate).  At
+    BASELINE config 4 the pairs are 3.2 GB, so every extra copy of them costs about
+    as much as a kernel of the join itself; this form lets the producer write its
+    GLOBAL row ids straight into the send block and hands the result back as one
+    zero-copy ``(row_a, row_b)`` view per rank (rank order, then local order -- the
+    pair *set* is what matters):
+
+        n = plan(...)                         # this rank's pair count
+        counts = xg.counts(n)                 # collective 1: one int64 per rank
+        send = xg.send_block(max(counts))     # [2, m] int32 on the exchange device
+        ... write send[0, :n], send[1, :n] ...
+        blocks = xg.all_gather(counts)        # collective 2: padded all-gather
+    """
+
+    def __init__(self, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.group = group
+        self.device = torch.device(device)
+        self.world = dist.get_world_size(group)
+        self._m = -1
+        self._send = None
+        self._recv = None
+        self._count = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._counts = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+
+    def counts(self, n: int) -> list[int]:
+        import torch.distributed as dist
+
+        self._count.fill_(int(n))
+        dist.all_gather_into_tensor(self._counts, self._count, group=self.group)
+        return [int(x) for x in self._counts.tolist()]
+
+    def send_block(self, m: int):
+        """``[2, m]`` int32 send block (grown geometrically, reused across steps)."""
+        import torch
+
+        if m > self._m:
+            self._send = self._recv = None
+            cap = int(m * 1.05) + 1024
+            self._send = torch.empty((2, cap), dtype=torch.int32, device=self.device)
+            self._recv = torch.empty((self.world, 2, cap), dtype=torch.int32, device=self.device)
+            self._m = cap
+        return self._send
+
+    def all_gather(self, counts):
+        """All-gather the send block; returns ``[(row_a_r, row_b_r)]``, views into the
+        receive buffer, one per rank."""
+        import torch.distributed as dist
+
+        if self._send is None:
+            self.send_block(max(counts) if counts else 0)
+        dist.all_gather_into_tensor(self._recv.view(-1), self._send.view(-1), group=self.group)
+        return [(self._recv[r, 0, :c], self._recv[r, 1, :c]) for r, c in enumerate(counts)]
+
+
 def sharded_inner_join(a, b, n_chrom: int, local_join: Callable, *, device=None, group=None,
                        gather: bool = True):
     """Join host tables ``a``/``b`` = ``(chrom, start, end[, start_off, end_off])``

@@ -311,6 +311,68 @@ class HipEngine:
             idx.data_ptr() if a.n else None, dist.data_ptr() if a.n else None, self._stream()))
         return idx, dist
 
+    # ------------------------------------------------------------- projection
+    def take(self, cols, idx, outs=None):
+        """Arrow ``take`` of fixed-width device columns by int32 row ids ``idx``
+        (the reference's outer SELECT, ``intersects_duckdb.py:1402-1644``); one
+        fused launch per 8 columns.  ``idx < 0`` yields zeros.  Returns new tensors,
+        or fills the caller's ``outs`` (contiguous, same dtype, ``len(idx)`` rows)."""
+        torch = _torch()
+        cols = list(cols)
+        if idx.dtype != torch.int32 or not idx.is_contiguous():
+            raise ValueError("idx must be a contiguous int32 tensor")
+        n = int(idx.shape[0])
+        n_rows = int(cols[0].shape[0]) if cols else 0
+        given = None if outs is None else list(outs)
+        if given is not None and len(given) != len(cols):
+            raise ValueError("outs must match cols")
+        outs = []
+        for k, c in enumerate(cols):
+            if c.dim() != 1 or not c.is_contiguous() or int(c.shape[0]) != n_rows:
+                raise ValueError("columns must be contiguous 1-D tensors of equal length")
+            if c.device != idx.device:
+                raise ValueError("columns and idx must live on the same device")
+            if given is None:
+                outs.append(torch.empty(n, dtype=c.dtype, device=c.device))
+            else:
+                o = given[k]
+                if (o.dtype != c.dtype or o.device != c.device or o.dim() != 1 or int(o.shape[0]) != n
+                        or not o.is_contiguous()):
+                    raise ValueError("outs[k] must be a contiguous 1-D tensor of len(idx) rows and the column's dtype")
+                outs.append(o)
+        k = len(cols)
+        if k == 0 or n == 0:
+            return outs
+        vp = ctypes.c_void_p
+        c_cols = (vp * k)(*[c.data_ptr() if n_rows else None for c in cols])
+        c_outs = (vp * k)(*[o.data_ptr() for o in outs])
+        c_elem = (ctypes.c_int32 * k)(*[c.element_size() for c in cols])
+        _lib.check(self._L.giql_hip_take_dev(self._h, c_cols, c_elem, k, n_rows, idx.data_ptr(), n,
+                                             c_outs, self._stream()))
+        return outs
+
+    def take_utf8(self, offsets, data, idx):
+        """``take`` of an Arrow utf8/binary column held as device tensors: int32
+        ``offsets[n_rows + 1]`` and uint8 ``data``.  Returns ``(out_offsets, out_data)``."""
+        torch = _torch()
+        if offsets.dtype != torch.int32 or data.dtype != torch.uint8 or idx.dtype != torch.int32:
+            raise ValueError("offsets/idx must be int32 and data uint8")
+        n = int(idx.shape[0])
+        n_rows = int(offsets.shape[0]) - 1
+        if n_rows < 0:
+            raise ValueError("offsets must hold n_rows + 1 entries")
+        out_off = torch.empty(n + 1, dtype=torch.int32, device=idx.device)
+        nbytes = ctypes.c_int64(0)
+        _lib.check(self._L.giql_hip_take_utf8_plan_dev(
+            self._h, offsets.data_ptr(), n_rows, idx.data_ptr() if n else None, n, out_off.data_ptr(),
+            ctypes.byref(nbytes), self._stream()))
+        out = torch.empty(int(nbytes.value), dtype=torch.uint8, device=idx.device)
+        if nbytes.value:
+            _lib.check(self._L.giql_hip_take_utf8_fill_dev(
+                self._h, offsets.data_ptr(), data.data_ptr() if data.numel() else None, n_rows,
+                idx.data_ptr(), n, out_off.data_ptr(), out.data_ptr(), self._stream()))
+        return out_off, out
+
     # --------------------------------------------------------------- checksum
     def pairs_checksum(self, row_a, row_b) -> int:
         h = ctypes.c_uint64(0)

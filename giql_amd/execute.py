@@ -136,15 +136,85 @@ def _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices):
     return out.select([p.name for p in plan.projection])
 
 
-def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, return_indices=False):
+def _device_take(table, names, idx_dev, eng: HipEngine):
+    """Gather the projected columns ``names`` of ``table`` by the device-resident
+    row ids ``idx_dev`` ON THE GPU (``giql_hip_take_dev`` / ``giql_hip_take_utf8_*``;
+    the reference's outer SELECT, ``intersects_duckdb.py:1402-1644``).
+
+    Fixed-width numeric columns go through one fused launch; utf8/binary columns
+    through the two-call offsets+bytes take; a validity bitmap travels as a
+    byte-per-row column.  Returns ``{name: pyarrow.Array}``.  Column types the
+    kernels do not cover (nested, dictionary, large_*) use ``pyarrow.take`` on
+    the host ids -- boundary plumbing, no join arithmetic.
+    """
+    import pyarrow as pa
+    import torch
+
+    dev = idx_dev.device
+    out: dict = {}
+    fixed: list[tuple[str, object, object]] = []   # (name, arrow type, numpy values)
+    masks: dict[str, np.ndarray] = {}
+    strings: list[tuple[str, object, pa.Array]] = []
+    host: list[str] = []
+    for name in dict.fromkeys(names):
+        col = _column(table, name)
+        if isinstance(col, pa.ChunkedArray):
+            col = col.combine_chunks() if col.num_chunks != 1 else col.chunk(0)
+        if not isinstance(col, pa.Array):
+            col = pa.array(np.asarray(col))
+        t = col.type
+        if pa.types.is_integer(t) or pa.types.is_floating(t) and t.bit_width in (16, 32, 64):
+            vals = col.fill_null(0).to_numpy(zero_copy_only=False) if col.null_count else col.to_numpy(zero_copy_only=False)
+            fixed.append((name, t, np.ascontiguousarray(vals)))
+        elif pa.types.is_string(t) or pa.types.is_binary(t):
+            strings.append((name, t, col))
+        else:
+            host.append(name)
+            continue
+        if col.null_count:
+            masks[name] = np.ascontiguousarray(col.is_valid().to_numpy(zero_copy_only=False).astype(np.uint8))
+    n = int(idx_dev.shape[0])
+    cols_dev = [torch.from_numpy(v).to(dev) for _, _, v in fixed]
+    mask_names = list(masks)
+    cols_dev += [torch.from_numpy(masks[m]).to(dev) for m in mask_names]
+    taken = eng.take(cols_dev, idx_dev) if cols_dev else []
+    valid = {m: taken[len(fixed) + i].cpu().numpy().astype(bool) for i, m in enumerate(mask_names)}
+    for (name, t, v), tk in zip(fixed, taken):
+        arr = tk.cpu().numpy()
+        out[name] = pa.array(arr, type=t, mask=(~valid[name]) if name in valid else None)
+    for name, t, col in strings:
+        bufs = col.buffers()
+        off = np.frombuffer(bufs[1], dtype=np.int32, count=len(col) + 1 + col.offset)[col.offset:]
+        data = np.frombuffer(bufs[2], dtype=np.uint8) if bufs[2] is not None else np.zeros(0, np.uint8)
+        o_dev, d_dev = eng.take_utf8(torch.from_numpy(np.ascontiguousarray(off)).to(dev),
+                                     torch.from_numpy(np.ascontiguousarray(data)).to(dev), idx_dev)
+        vbuf = None
+        nulls = 0
+        if name in valid:
+            vbuf = pa.py_buffer(np.packbits(valid[name], bitorder="little").tobytes())
+            nulls = int(n - valid[name].sum())
+        out[name] = pa.Array.from_buffers(t, n, [vbuf, pa.py_buffer(o_dev.cpu().numpy().tobytes()),
+                                                 pa.py_buffer(d_dev.cpu().numpy().tobytes())], null_count=nulls)
+    if host:
+        idx_h = pa.array(idx_dev.cpu().numpy(), type=pa.int64())
+        for name in host:
+            out[name] = _column(table, name).take(idx_h)
+    return out
+
+
+def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, return_indices=False,
+            device_projection: bool = True):
     """Run *plan* (a :class:`JoinPlan`, its string form, or a GIQL query string)
     against ``tables`` (``{name: pyarrow.Table | dict of arrays}``).
 
     Returns a ``pyarrow.Table`` with the plan's projected columns (bag semantics,
     unspecified row order, as upstream), or ``{column: array}`` when pyarrow is
     absent.  ``return_indices=True`` returns the raw row indices instead:
-    ``(row_a, row_b)`` for INNER, ``rows_a`` for SEMI/ANTI and
-    ``(rows_a, idx_b, distance)`` for NEAREST.
+    ``(row_a, row_b)`` for INNER, ``rows_a`` for SEMI/ANTI,
+    ``(rows_a, idx_b, distance)`` for NEAREST and the per-left-row counts for
+    count_overlaps.  ``device_projection`` (default) gathers the projected columns
+    on the GPU from the device-resident row ids; ``False`` ships the ids to the
+    host and takes there.
     """
     if isinstance(plan, str):
         plan = JoinPlan.from_string(plan) if is_plan_string(plan) else build_plan(plan, giql_tables)
@@ -164,40 +234,53 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
         return _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices)
     if plan.kind == "INNER":
         ra, rb = eng.inner_join(a, b, n_chrom)
-        ra, rb = ra.cpu().numpy(), rb.cpu().numpy()
         if return_indices:
-            return ra, rb
+            return ra.cpu().numpy(), rb.cpu().numpy()
         idx = {"l": ra, "r": rb}
         extra = {}
     elif plan.kind in ("SEMI", "ANTI"):
-        rows = eng.semi_anti(a, b, n_chrom, plan.kind == "ANTI").cpu().numpy()
+        rows = eng.semi_anti(a, b, n_chrom, plan.kind == "ANTI")
         if return_indices:
-            return rows
+            return rows.cpu().numpy()
         idx = {"l": rows}
         extra = {}
     else:  # NEAREST k=1: A rows whose chromosome has no target row yield no row
+        import torch
+
         ib_dev, dist = eng.nearest(a, b, n_chrom, signed=plan.signed, max_distance=plan.max_distance)
-        ibn, dn = ib_dev.cpu().numpy(), dist.cpu().numpy()
-        keep = np.nonzero(ibn >= 0)[0]
+        keep = torch.nonzero(ib_dev >= 0).flatten().to(torch.int32)
+        ib_keep = ib_dev[keep.long()].contiguous()
+        dn = dist[keep.long()].cpu().numpy()
         if return_indices:
-            return keep, ibn[keep], dn[keep]
-        idx = {"l": keep, "r": ibn[keep]}
-        extra = {"distance": dn[keep]}
+            return keep.cpu().numpy(), ib_keep.cpu().numpy(), dn
+        idx = {"l": keep, "r": ib_keep}
+        extra = {"distance": dn}
+
+    try:
+        import pyarrow as pa
+    except ImportError:  # pragma: no cover
+        pa = None
+    taken: dict = {}
+    if pa is not None and device_projection and all(isinstance(t, pa.Table) for t in (lt, rt)):
+        for s, tbl in (("l", lt), ("r", rt)):
+            want = [p.column for p in plan.projection if p.side == s]
+            if want:
+                taken[s] = _device_take(tbl, want, idx[s], eng)
+    idx_h = {s: v.cpu().numpy() for s, v in idx.items() if s not in taken}
 
     names, cols = [], []
     for p in plan.projection:
         names.append(p.name)
         if p.side == "distance":
             cols.append(extra["distance"])
+        elif p.side in taken:
+            cols.append(taken[p.side][p.column])
         else:
-            cols.append(_take(lt if p.side == "l" else rt, p.column, idx[p.side]))
-    try:
-        import pyarrow as pa
-
-        arrays = [c if isinstance(c, (pa.Array, pa.ChunkedArray)) else pa.array(c) for c in cols]
-        out = pa.Table.from_arrays(arrays, names=names)
-        if plan.distinct:
-            out = out.group_by(names, use_threads=False).aggregate([])
-        return out
-    except ImportError:  # pragma: no cover
+            cols.append(_take(lt if p.side == "l" else rt, p.column, idx_h[p.side]))
+    if pa is None:  # pragma: no cover
         return dict(zip(names, cols))
+    arrays = [c if isinstance(c, (pa.Array, pa.ChunkedArray)) else pa.array(c) for c in cols]
+    out = pa.Table.from_arrays(arrays, names=names)
+    if plan.distinct:
+        out = out.group_by(names, use_threads=False).aggregate([])
+    return out

@@ -157,6 +157,32 @@ int giql_hip_chrom_spans_dev(giql_hip_ctx* ctx, const giql_side* a,
                              const giql_side* b, int32_t n_chrom,
                              int64_t* spans_out /* host */, void* stream);
 
+/* ---- projection materialisation (Arrow `take` by the join's row ids) ------
+ * Replaces the outer SELECT that rebuilds the projected columns of both sides
+ * around the per-chromosome join, src/giql/expanders/intersects_duckdb.py:
+ * 1402-1644.  All pointers are DEVICE pointers except
+ * the small argument arrays (cols / elem_bytes / outs), which are host arrays.
+ *
+ * Fixed-width columns: outs[c][i] = cols[c][idx[i]] for i < n, elem_bytes[c] in
+ * {1,2,4,8,16}; every column has n_rows rows.  idx[i] < 0 (NEAREST's "none")
+ * yields zero bytes; idx[i] >= n_rows is GIQL_ERR_INVALID. */
+int giql_hip_take_dev(giql_hip_ctx* ctx, const void* const* cols,
+                      const int32_t* elem_bytes, int32_t n_cols, int64_t n_rows,
+                      const int32_t* idx, int64_t n, void* const* outs,
+                      void* stream);
+/* utf8 / binary columns (Arrow int32 offsets[n_rows + 1] + data bytes), in two
+ * calls so the caller owns the output: plan writes out_offsets[n + 1] and
+ * returns the byte count; fill copies the bytes into out_data[n_bytes]. */
+int giql_hip_take_utf8_plan_dev(giql_hip_ctx* ctx, const int32_t* offsets,
+                                int64_t n_rows, const int32_t* idx, int64_t n,
+                                int32_t* out_offsets, int64_t* n_bytes,
+                                void* stream);
+int giql_hip_take_utf8_fill_dev(giql_hip_ctx* ctx, const int32_t* offsets,
+                                const uint8_t* data, int64_t n_rows,
+                                const int32_t* idx, int64_t n,
+                                const int32_t* out_offsets, uint8_t* out_data,
+                                void* stream);
+
 /* ---- host-buffer entry points (Arrow buffers in host memory) ------------ */
 int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
                    int32_t n_chrom, int64_t* n_pairs, int32_t** row_a,

@@ -69,6 +69,20 @@ def _worker(rank, world, port, out_dir, skew=False):
         assert counts == [r + 1 for r in range(world)]
         assert ga.tolist() == [r for r in range(world) for _ in range(r + 1)]
         assert gb.tolist() == [r + 10 for r in range(world) for _ in range(r + 1)]
+        # the buffered, zero-copy form bench.py uses: two steps with different sizes
+        xg = D.PairGather("cpu")
+        for step_no in (1, 3):
+            n = (rank + 1) * step_no
+            counts = xg.counts(n)
+            assert counts == [(r + 1) * step_no for r in range(world)]
+            send = xg.send_block(max(counts))
+            send[0, :n] = rank
+            send[1, :n] = rank + 100 * step_no
+            blocks = xg.all_gather(counts)
+            for r, (ba, bb) in enumerate(blocks):
+                assert ba.tolist() == [r] * counts[r] and bb.tolist() == [r + 100 * step_no] * counts[r]
+        assert xg.counts(0) == [0] * world
+        assert [tuple(x.numel() for x in blk) for blk in xg.all_gather([0] * world)] == [(0, 0)] * world
     finally:
         dist.destroy_process_group()
 

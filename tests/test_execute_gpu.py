@@ -216,6 +216,32 @@ def test_count_overlaps_rejects_null_count_column(peaks_genes):
         execute(transpile(q, tables=["peaks", "genes"], dialect="hip"), {"peaks": peaks_genes["peaks"], "genes": genes})
 
 
+def test_device_projection_matches_host_projection_for_every_column_type():
+    # the projected columns are gathered on the GPU (giql_hip_take_*); same rows as pyarrow.take
+    rng = np.random.default_rng(11)
+    def tbl(n, tag):
+        s = rng.integers(0, 5000, n)
+        names = [None if i % 7 == 3 else f"{tag}{i}" * (1 + i % 5) for i in range(n)]
+        score = [None if i % 5 == 1 else float(i) / 3 for i in range(n)]
+        return pa.table({"chrom": pa.array(rng.choice(["chr1", "chr2", "chrX"], n), pa.string()),
+                         "start": pa.array(s, pa.int32()), "end": pa.array(s + rng.integers(1, 300, n), pa.int32()),
+                         "name": pa.array(names, pa.string()), "score": pa.array(score, pa.float64()),
+                         "tiny": pa.array(rng.integers(-5, 5, n), pa.int8()),
+                         "flag": pa.array(rng.integers(0, 2, n).astype(bool)),
+                         "strand": pa.array(rng.choice(["+", "-"], n)).dictionary_encode()})
+    t = {"peaks": tbl(400, "p"), "genes": tbl(700, "g")}
+    q = ("SELECT a.name AS an, a.score AS asc_, a.tiny AS at, a.flag AS af, a.strand AS ast, a.start AS s, "
+         "b.name AS bn, b.score AS bs, b.end AS be, b.strand AS bst "
+         "FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval")
+    plan = transpile(q, tables=["peaks", "genes"], dialect="hip")
+    dev_rows = execute(plan, t)
+    host_rows = execute(plan, t, device_projection=False)
+    assert dev_rows.num_rows == host_rows.num_rows > 1000
+    key = lambda tb: sorted(map(repr, tb.to_pylist()))
+    assert key(dev_rows) == key(host_rows)
+    assert dev_rows.schema.types == host_rows.schema.types
+
+
 def test_nulls_and_out_of_range_are_rejected(peaks_genes):
     bad = peaks_genes["peaks"].set_column(1, "start", pa.array([100, None, 500, 100, 800], pa.int32()))
     plan = transpile(Q6, tables=["peaks", "genes"], dialect="hip")

@@ -476,3 +476,63 @@ def test_config4_full_size_properties(eng):
         e2.close()
     finally:
         del os.environ["GIQL_HIP_NO_UNIFORM"]
+
+
+# ---------------------------------------------------------------- projection (take)
+@pytest.mark.parametrize("dtype", ["int8", "int16", "int32", "int64", "float32", "float64"])
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 1023, 70_001])
+def test_take_fixed_width_matches_numpy(eng, dtype, n):
+    rng = np.random.default_rng(n + 7)
+    n_rows = 5000
+    col = (rng.integers(-100, 100, n_rows) if "int" in dtype else rng.standard_normal(n_rows)).astype(dtype)
+    other = rng.integers(0, 2**31 - 1, n_rows).astype(np.int32)
+    idx = rng.integers(0, n_rows, n).astype(np.int32)
+    if n > 4:
+        idx[[1, n - 1]] = -1  # NEAREST's "none": zero-filled
+    d = lambda x: torch.from_numpy(x).cuda()
+    got = eng.take([d(col), d(other)], d(idx))
+    for src, g in zip((col, other), got):
+        want = np.where(idx >= 0, src[np.maximum(idx, 0)], 0).astype(src.dtype)
+        assert np.array_equal(g.cpu().numpy(), want)
+
+
+def test_take_many_columns_and_unaligned_views(eng):
+    rng = np.random.default_rng(5)
+    n_rows, n = 3000, 4099
+    cols = [rng.integers(0, 1 << 30, n_rows).astype(np.int32) for _ in range(11)]  # > 8: two launches
+    idx_full = torch.from_numpy(rng.integers(0, n_rows, n + 1).astype(np.int32)).cuda()
+    idx = idx_full[1:]  # 4-byte-aligned only: scalar path
+    got = eng.take([torch.from_numpy(c).cuda() for c in cols], idx.contiguous() if not idx.is_contiguous() else idx)
+    ih = idx.cpu().numpy()
+    for c, g in zip(cols, got):
+        assert np.array_equal(g.cpu().numpy(), c[ih])
+
+
+def test_take_rejects_out_of_range_ids(eng):
+    col = torch.arange(10, dtype=torch.int32).cuda()
+    idx = torch.tensor([0, 3, 10], dtype=torch.int32).cuda()
+    from giql_amd._lib import GiqlHipError
+
+    with pytest.raises(GiqlHipError) as ei:
+        eng.take([col], idx)
+    assert ei.value.code == -1
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 10_000])
+def test_take_utf8_matches_pyarrow(eng, n):
+    pa = pytest.importorskip("pyarrow")
+    rng = np.random.default_rng(n)
+    words = ["", "a", "chr1", "gene_%d" % 7, "x" * 33, "y" * 200, "z" * 31, "é-ü"]
+    vals = [words[i] + str(i) if i % 3 else words[i % len(words)] for i in rng.integers(0, len(words), 500)]
+    arr = pa.array(vals, pa.string())
+    off = np.frombuffer(arr.buffers()[1], dtype=np.int32, count=len(arr) + 1)
+    data = np.frombuffer(arr.buffers()[2], dtype=np.uint8)
+    idx = rng.integers(0, len(arr), n).astype(np.int32)
+    if n > 2:
+        idx[2] = -1
+    o, dbytes = eng.take_utf8(torch.from_numpy(off.copy()).cuda(), torch.from_numpy(data.copy()).cuda(),
+                                 torch.from_numpy(idx).cuda())
+    want = [vals[i] if i >= 0 else "" for i in idx]
+    got = pa.Array.from_buffers(pa.string(), n, [None, pa.py_buffer(o.cpu().numpy().tobytes()),
+                                                  pa.py_buffer(dbytes.cpu().numpy().tobytes())]).to_pylist()
+    assert got == want

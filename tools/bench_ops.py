@@ -74,6 +74,32 @@ def main():
 
         run(f"cfg2_inner_1Mx1M_{tag}", inner, n, "pairs")
         del out
+    # ---- projection: gather payload columns by the ~7e7 pairs of a 10M x 10M join
+    if not args.only or "take" in args.only:
+        ca = synth.make_table(10_000_000, 7, "peaks")
+        cb = synth.make_table(10_000_000, 8, "peaks")
+        a, b = side(ca), side(cb)
+        ra, rb = eng.inner_join(a, b, 24)
+        p = int(ra.shape[0])
+        a_cols = [a.start, a.end]
+        b_cols = [b.start, torch.arange(b.n, dtype=torch.int64, device=dev)]
+
+        def take_fixed():
+            eng.take(a_cols, ra)
+            return eng.take(b_cols, rb)[0]
+
+        # algorithmic bytes: 2 idx reads + (4+4) + (4+8) gathered + the same written
+        run("take_fixed_4cols", take_fixed, p * (8 + 20 + 20) / 1e9, "GB")
+        names = np.array([f"read_{i:08d}" for i in range(100_000)])
+        import pyarrow as pa
+
+        arr = pa.array(names[np.arange(b.n) % len(names)], pa.string())
+        if isinstance(arr, pa.ChunkedArray):
+            arr = arr.combine_chunks()
+        off = torch.from_numpy(np.frombuffer(arr.buffers()[1], np.int32, count=len(arr) + 1).copy()).to(dev)
+        data = torch.from_numpy(np.frombuffer(arr.buffers()[2], np.uint8).copy()).to(dev)
+        run("take_utf8_13B", lambda: eng.take_utf8(off, data, rb)[0], p * (4 + 8 + 4 + 13 + 13) / 1e9, "GB")
+        del ra, rb, off, data
     # ---- cfg 3
     a = side(synth.make_table(1_000_000, 3, "peaks"))
     b = side(synth.make_table(10_000_000, 4, "reads"))
