@@ -35,6 +35,7 @@ SYMBOLS = [
     "giql_hip_inner", "giql_hip_semi_anti", "giql_hip_count", "giql_hip_nearest",
     "giql_hip_free_host", "giql_hip_pairs_checksum_dev",
     "giql_hip_take_dev", "giql_hip_take_utf8_plan_dev", "giql_hip_take_utf8_fill_dev",
+    "giql_hip_select_dev", "giql_hip_mark_dev",
 ]
 
 
@@ -85,6 +86,31 @@ class CStats(ctypes.Structure):
 def lib_path() -> str:
     return os.environ.get("GIQL_HIP_LIB") or os.path.join(_HERE, "libgiql_hip.so")
 
+
+class COperand(ctypes.Structure):
+    """``giql_operand`` (include/giql_hip.h)."""
+
+    _fields_ = [
+        ("side", ctypes.c_int32),
+        ("type", ctypes.c_int32),
+        ("data", ctypes.c_void_p),
+        ("valid", ctypes.c_void_p),
+        ("lit_i", ctypes.c_int64),
+        ("lit_f", ctypes.c_double),
+        ("lit_is_float", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class CPred(ctypes.Structure):
+    """``giql_pred`` (include/giql_hip.h)."""
+
+    _fields_ = [("lhs", COperand), ("rhs", COperand), ("op", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+OPS = {"=": 0, "==": 0, "!=": 1, "<>": 1, "<": 2, "<=": 3, ">": 4, ">=": 5}
+SIDE_A, SIDE_B, SIDE_LIT = 0, 1, 2
+T_I32, T_I64, T_F32, T_F64, T_U8 = range(5)
 
 _lib = None
 
@@ -138,6 +164,8 @@ def load() -> ctypes.CDLL:
     L.giql_hip_take_dev.argtypes = [vp, P(vp), P(i32), i32, i64, vp, i64, P(vp), vp]
     L.giql_hip_take_utf8_plan_dev.argtypes = [vp, vp, i64, vp, i64, vp, P(i64), vp]
     L.giql_hip_take_utf8_fill_dev.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, vp]
+    L.giql_hip_select_dev.argtypes = [vp, P(CPred), i32, vp, i64, vp, i64, i64, vp, vp, P(i64), vp]
+    L.giql_hip_mark_dev.argtypes = [vp, vp, i64, vp, i64, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int and name not in ("giql_hip_abi_version",):

@@ -15,6 +15,7 @@
 #include "../../include/giql_hip.h"
 #include "aux_kernels.hip.h"
 #include "take_kernels.hip.h"
+#include "select_kernels.hip.h"
 #include "dev_common.hip.h"
 #include "join_kernels.hip.h"
 #include "onesweep.hip.h"
@@ -1213,6 +1214,106 @@ int giql_hip_take_utf8_fill_dev(giql_hip_ctx* ctx, const int32_t* offsets, const
   HIP_TRY(hipStreamSynchronize(st));
   collect_spans(ctx);
   ctx->stats.n_out = n;
+  return GIQL_OK;
+}
+
+// ------------------------------------------------ residual predicates (select)
+static int check_operand(const giql_operand& o, int k, const char* which) {
+  if (o.side == GIQL_SIDE_LIT) return GIQL_OK;
+  if (o.side != GIQL_SIDE_A && o.side != GIQL_SIDE_B)
+    return set_err(GIQL_ERR_INVALID, "predicate %d %s: side %d", k, which, o.side);
+  if (o.type < GIQL_T_I32 || o.type > GIQL_T_U8)
+    return set_err(GIQL_ERR_INVALID, "predicate %d %s: type %d", k, which, o.type);
+  if (!o.data) return set_err(GIQL_ERR_INVALID, "predicate %d %s: NULL column", k, which);
+  return GIQL_OK;
+}
+
+int giql_hip_select_dev(giql_hip_ctx* ctx, const giql_pred* preds, int32_t n_preds,
+                        const int32_t* idx_a, int64_t n_rows_a, const int32_t* idx_b,
+                        int64_t n_rows_b, int64_t n, int32_t* out_a, int32_t* out_b,
+                        int64_t* n_kept, void* stream) {
+  if (!ctx || !n_kept || n < 0 || n > 0x7FFFFFF0ll || n_preds < 0 || n_preds > SEL_MAX_PREDS ||
+      (n_preds && !preds) || n_rows_a < 0 || n_rows_b < 0 || n_rows_a > 0x7FFFFFFFll ||
+      n_rows_b > 0x7FFFFFFFll)
+    return set_err(GIQL_ERR_INVALID, "bad arguments (at most %d predicates, n < 2^31)", SEL_MAX_PREDS);
+  static_assert(sizeof(giql_operand) == sizeof(DevOperand), "giql_operand layout");
+  static_assert(sizeof(giql_pred) == sizeof(DevPred), "giql_pred layout");
+  DevPreds ps;
+  memset(&ps, 0, sizeof(ps));
+  ps.n = n_preds;
+  bool uses[2] = {false, false};
+  for (int k = 0; k < n_preds; k++) {
+    if (preds[k].op < GIQL_OP_EQ || preds[k].op > GIQL_OP_GE)
+      return set_err(GIQL_ERR_INVALID, "predicate %d: operator %d", k, preds[k].op);
+    GIQL_TRY(check_operand(preds[k].lhs, k, "lhs"));
+    GIQL_TRY(check_operand(preds[k].rhs, k, "rhs"));
+    memcpy(&ps.p[k], &preds[k], sizeof(DevPred));
+    for (const giql_operand* o : {&preds[k].lhs, &preds[k].rhs})
+      if (o->side != GIQL_SIDE_LIT) uses[o->side] = true;
+  }
+  // a side given neither ids nor a row count is addressed by the candidate index
+  if (!idx_a && n_rows_a == 0 && !uses[0]) n_rows_a = n;
+  if (!idx_b && n_rows_b == 0 && !uses[1]) n_rows_b = n;
+  *n_kept = 0;
+  if (n == 0) return GIQL_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  reset_stats(ctx);
+  const u32 nb = cdiv((u64)n, SEL_TILE);
+  Carver c{nullptr};
+  auto carve = [&](Carver& cv, u64*& mask, u32*& cnt, u64*& bsums, u64*& total) {
+    mask = cv.take<u64>(((size_t)n + 63) / 64);
+    cnt = cv.take<u32>(nb);
+    bsums = cv.take<u64>(cdiv((u64)nb, SCAN_TILE) + 1);
+    total = cv.take<u64>(1);
+  };
+  u64 *mask, *bsums, *total;
+  u32* cnt;
+  carve(c, mask, cnt, bsums, total);
+  GIQL_TRY(ensure_arena(ctx, c.off, st));
+  c = Carver{ctx->arena};
+  carve(c, mask, cnt, bsums, total);
+  HIP_TRY(hipMemsetAsync(&ctx->d_meta->status, 0, sizeof(int), st));
+  {
+    Phase ph(ctx, st, GIQL_PH_COUNT);
+    hipLaunchKernelGGL(k_select_count, dim3(nb), dim3(SEL_NT), 0, st, ps, idx_a, (u32)n_rows_a, idx_b,
+                       (u32)n_rows_b, (u64)n, mask, cnt, ctx->d_meta);
+    GIQL_TRY(post_launch("select_count"));
+  }
+  GIQL_TRY(run_scan<u32>(ctx, st, GIQL_PH_SCAN, cnt, (u64)nb, cnt, bsums, total));
+  if (out_a || out_b) {
+    Phase ph(ctx, st, GIQL_PH_FILL);
+    hipLaunchKernelGGL(k_select_scatter, dim3(nb), dim3(SEL_NT), 0, st, idx_a, idx_b, (u64)n, mask, cnt,
+                       out_a, out_b);
+    GIQL_TRY(post_launch("select_scatter"));
+  }
+  u64 h_total = 0;
+  HIP_TRY(hipMemcpyAsync(&h_total, total, sizeof(u64), hipMemcpyDeviceToHost, st));
+  GIQL_TRY(read_meta(ctx, st));
+  collect_spans(ctx);
+  *n_kept = (int64_t)h_total;
+  ctx->stats.n_out = (int64_t)h_total;
+  return GIQL_OK;
+}
+
+int giql_hip_mark_dev(giql_hip_ctx* ctx, const int32_t* idx, int64_t n, uint8_t* flags,
+                      int64_t n_rows, void* stream) {
+  if (!ctx || n < 0 || n_rows < 0 || n_rows > 0x7FFFFFFFll || (n > 0 && (!idx || !flags)))
+    return set_err(GIQL_ERR_INVALID, "bad arguments");
+  if (n == 0) return GIQL_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  reset_stats(ctx);
+  HIP_TRY(hipMemsetAsync(&ctx->d_meta->status, 0, sizeof(int), st));
+  u32 grid = cdiv((u64)n, 256 * 8);
+  if (grid > 16384u) grid = 16384u;
+  {
+    Phase ph(ctx, st, GIQL_PH_AUX);
+    hipLaunchKernelGGL(k_mark, dim3(grid), dim3(256), 0, st, idx, (u64)n, (u32)n_rows, flags, ctx->d_meta);
+    GIQL_TRY(post_launch("mark"));
+  }
+  GIQL_TRY(read_meta(ctx, st));
+  collect_spans(ctx);
   return GIQL_OK;
 }
 

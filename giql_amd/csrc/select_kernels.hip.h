@@ -1,0 +1,191 @@
+// select_kernels.hip.h -- residual predicates: the extra ON / WHERE conjuncts that
+// sit beside the INTERSECTS.
+//
+// The reference inlines them into the per-chromosome join's ON clause
+// (src/giql/expanders/intersects_duckdb.py:1164-1177, 1239-1243: "a.start < b.end
+// AND a.end > b.start AND <residual> ...").  Here a residual is a comparison between
+// two operands, each a payload column of one side (addressed through the pair's
+// row id) or a literal; a conjunction of them is evaluated per pair -- or per input
+// row when a predicate names one side only -- and the survivors are compacted
+// stably: evaluate + ballot mask + per-block count, scan, scatter.
+//
+// HBM-bound: the pairs are read twice (8 B each), every referenced column is
+// gathered once per pair, the kept pairs are written once.
+#pragma once
+#include "dev_common.hip.h"
+
+namespace giql {
+
+constexpr int SEL_NT = 256;
+constexpr int SEL_ITEMS = 8;
+constexpr int SEL_TILE = SEL_NT * SEL_ITEMS;
+constexpr int SEL_MAX_PREDS = 8;
+
+// mirrors giql_operand / giql_pred of include/giql_hip.h
+struct DevOperand {
+  int side;  // 0 = A (row_a), 1 = B (row_b), 2 = literal
+  int type;  // 0 i32, 1 i64, 2 f32, 3 f64, 4 u8
+  const void* data;
+  const uint8_t* valid;
+  i64 lit_i;
+  double lit_f;
+  int lit_is_float;
+  int pad;
+};
+struct DevPred {
+  DevOperand lhs, rhs;
+  int op;  // 0 ==, 1 !=, 2 <, 3 <=, 4 >, 5 >=
+  int pad;
+};
+struct DevPreds {
+  DevPred p[SEL_MAX_PREDS];
+  int n;
+};
+
+struct SelValue {
+  i64 i;
+  double f;
+  bool is_float;
+  bool null;
+};
+
+__device__ __forceinline__ SelValue sel_load(const DevOperand& o, int ia, int ib) {
+  SelValue v;
+  v.null = false;
+  if (o.side == 2) {
+    v.is_float = o.lit_is_float != 0;
+    v.i = o.lit_i;
+    v.f = o.lit_f;
+    return v;
+  }
+  const int r = o.side == 0 ? ia : ib;
+  if (o.valid && !o.valid[r]) v.null = true;
+  v.is_float = o.type == 2 || o.type == 3;
+  v.i = 0;
+  v.f = 0.0;
+  switch (o.type) {
+    case 0: v.i = reinterpret_cast<const int*>(o.data)[r]; break;
+    case 1: v.i = reinterpret_cast<const i64*>(o.data)[r]; break;
+    case 2: v.f = (double)reinterpret_cast<const float*>(o.data)[r]; break;
+    case 3: v.f = reinterpret_cast<const double*>(o.data)[r]; break;
+    default: v.i = reinterpret_cast<const uint8_t*>(o.data)[r]; break;
+  }
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ bool sel_cmp(T a, T b, int op) {
+  switch (op) {
+    case 0: return a == b;
+    case 1: return a != b;
+    case 2: return a < b;
+    case 3: return a <= b;
+    case 4: return a > b;
+    default: return a >= b;
+  }
+}
+
+// SQL three-valued logic collapsed for a filter: NULL on either side -> not kept.
+__device__ __forceinline__ bool sel_eval(const DevPreds& ps, int ia, int ib) {
+  bool keep = true;
+  for (int k = 0; k < ps.n; k++) {
+    const SelValue a = sel_load(ps.p[k].lhs, ia, ib);
+    const SelValue b = sel_load(ps.p[k].rhs, ia, ib);
+    bool t;
+    if (a.is_float || b.is_float)
+      t = sel_cmp<double>(a.is_float ? a.f : (double)a.i, b.is_float ? b.f : (double)b.i, ps.p[k].op);
+    else
+      t = sel_cmp<i64>(a.i, b.i, ps.p[k].op);
+    keep = keep && t && !a.null && !b.null;
+  }
+  return keep;
+}
+
+// pass 1: ballot masks (one 64-bit word per 64 consecutive candidates) + block counts.
+// A row id outside its side's row count raises GIQL_ERR_INVALID and drops the pair.
+__global__ __launch_bounds__(SEL_NT) void k_select_count(DevPreds ps, const int* __restrict__ idx_a,
+                                                         u32 n_rows_a,
+                                                         const int* __restrict__ idx_b,
+                                                         u32 n_rows_b, u64 n,
+                                                         u64* __restrict__ mask,
+                                                         u32* __restrict__ cnt, DevMeta* meta) {
+  __shared__ u32 s_cnt[SEL_NT / WAVE];
+  const u64 base = (u64)blockIdx.x * SEL_TILE;
+  u32 kept = 0;
+  bool bad = false;
+#pragma unroll 2
+  for (int j = 0; j < SEL_ITEMS; j++) {
+    const u64 i = base + (u64)j * SEL_NT + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+      const int ia = idx_a ? idx_a[i] : (int)i;
+      const int ib = idx_b ? idx_b[i] : (int)i;
+      if (ia < 0 || (u32)ia >= n_rows_a || ib < 0 || (u32)ib >= n_rows_b)
+        bad = true;
+      else
+        keep = sel_eval(ps, ia, ib);
+    }
+    const u64 m = __ballot(keep);
+    if (lane_id() == 0 && (base + (u64)j * SEL_NT + wave_id() * WAVE) < n) mask[i >> 6] = m;
+    kept += (u32)__popcll(m);
+  }
+  if (lane_id() == 0) s_cnt[wave_id()] = kept;  // every lane of a wave holds the wave total
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 t = 0;
+    for (int w = 0; w < SEL_NT / WAVE; w++) t += s_cnt[w];
+    cnt[blockIdx.x] = t;
+  }
+  if (bad) atomicMin(&meta->status, -1);
+}
+
+// pass 2: stable scatter of the kept candidates.  Candidate i of the block sits in
+// mask word (i - base) / 64; word w of the block covers item j = w / 4, wave w % 4.
+__global__ __launch_bounds__(SEL_NT) void k_select_scatter(const int* __restrict__ idx_a,
+                                                           const int* __restrict__ idx_b, u64 n,
+                                                           const u64* __restrict__ mask,
+                                                           const u32* __restrict__ off,
+                                                           int* __restrict__ out_a,
+                                                           int* __restrict__ out_b) {
+  constexpr int WORDS = SEL_TILE / WAVE;  // 32
+  __shared__ u32 s_pre[WORDS];
+  const u64 base = (u64)blockIdx.x * SEL_TILE;
+  const u64 w0 = base >> 6;
+  const u64 n_words = (n + 63) >> 6;
+  if (threadIdx.x < WAVE) {
+    const u32 l = threadIdx.x;
+    u32 c = (l < WORDS && w0 + l < n_words) ? (u32)__popcll(mask[w0 + l]) : 0u;
+    const u32 incl = wave_incl_scan_add_u32(c);
+    if (l < WORDS) s_pre[l] = incl - c;
+  }
+  __syncthreads();
+  const u32 o0 = off[blockIdx.x];
+#pragma unroll 2
+  for (int j = 0; j < SEL_ITEMS; j++) {
+    const u64 i = base + (u64)j * SEL_NT + threadIdx.x;
+    if (i >= n) continue;
+    const u32 w = (u32)((i - base) >> 6);
+    const u64 m = mask[w0 + w];
+    if ((m >> lane_id()) & 1ull) {
+      const u32 pos = o0 + s_pre[w] + (u32)__popcll(m & lanemask_lt());
+      if (out_a) out_a[pos] = idx_a ? idx_a[i] : (int)i;
+      if (out_b) out_b[pos] = idx_b ? idx_b[i] : (int)i;
+    }
+  }
+}
+
+// flags[idx[i]] = 1 (SEMI / ANTI with two-sided residuals: the left rows that keep
+// at least one pair)
+__global__ __launch_bounds__(256) void k_mark(const int* __restrict__ idx, u64 n, u32 n_rows,
+                                              uint8_t* __restrict__ flags, DevMeta* meta) {
+  const u64 stride = (u64)gridDim.x * 256;
+  bool bad = false;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int r = idx[i];
+    if (r < 0 || (u32)r >= n_rows) bad = true;
+    else flags[r] = 1;
+  }
+  if (bad) atomicMin(&meta->status, -1);
+}
+
+}  // namespace giql

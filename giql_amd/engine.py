@@ -373,6 +373,90 @@ class HipEngine:
                 idx.data_ptr(), n, out_off.data_ptr(), out.data_ptr(), self._stream()))
         return out_off, out
 
+    # ----------------------------------------------------- residual predicates
+    def _c_operand(self, spec):
+        """``("a" | "b", tensor[, valid_u8_tensor])`` or ``("lit", int | float)`` -> COperand."""
+        torch = _torch()
+        o = _lib.COperand()
+        if spec[0] == "lit":
+            o.side = _lib.SIDE_LIT
+            v = spec[1]
+            if isinstance(v, bool):
+                v = int(v)
+            if isinstance(v, int):
+                if not -(2**63) <= v < 2**63:
+                    raise ValueError("integer literal does not fit int64")
+                o.lit_i, o.lit_is_float = v, 0
+            elif isinstance(v, float):
+                o.lit_f, o.lit_is_float = v, 1
+            else:
+                raise ValueError(f"unsupported literal {v!r}")
+            return o, ()
+        if spec[0] not in ("a", "b"):
+            raise ValueError(f"operand side {spec[0]!r}")
+        t = spec[1]
+        types = {torch.int32: _lib.T_I32, torch.int64: _lib.T_I64, torch.float32: _lib.T_F32,
+                 torch.float64: _lib.T_F64, torch.uint8: _lib.T_U8, torch.bool: _lib.T_U8}
+        if t.dtype not in types or t.dim() != 1 or not t.is_contiguous():
+            raise ValueError("predicate columns must be contiguous 1-D int32/int64/float32/float64/uint8 tensors")
+        o.side = _lib.SIDE_A if spec[0] == "a" else _lib.SIDE_B
+        o.type = types[t.dtype]
+        o.data = t.data_ptr() if t.numel() else 1  # never dereferenced when empty
+        valid = spec[2] if len(spec) > 2 else None
+        if valid is not None:
+            if valid.dtype not in (torch.uint8, torch.bool) or valid.shape != t.shape or not valid.is_contiguous():
+                raise ValueError("validity must be a contiguous uint8/bool tensor of the column's length")
+            o.valid = valid.data_ptr() if valid.numel() else None
+        return o, (t, valid)
+
+    def select(self, preds, idx_a=None, idx_b=None, n=None, n_rows_a=0, n_rows_b=0, want=("a", "b")):
+        """Stable filter by a conjunction of residual predicates (the extra ON / WHERE
+        conjuncts the reference inlines beside the INTERSECTS,
+        ``intersects_duckdb.py:1164-1177, 1239-1243``).
+
+        ``preds`` = ``[(lhs, op, rhs)]`` with operands ``("a" | "b", column[, valid])`` or
+        ``("lit", value)`` and ``op`` one of ``= != <> < <= > >=``.  Candidates are the
+        pairs ``(idx_a[i], idx_b[i])``; a missing id array means "the candidate index".
+        Returns the kept ``(ids_a, ids_b)`` (``None`` for a side not in ``want``)."""
+        torch = _torch()
+        if n is None:
+            n = int((idx_a if idx_a is not None else idx_b).shape[0])
+        k = len(preds)
+        c_preds = (_lib.CPred * max(k, 1))()
+        keep_alive = []
+        for j, (lhs, op, rhs) in enumerate(preds):
+            if op not in _lib.OPS:
+                raise ValueError(f"operator {op!r}")
+            c_preds[j].lhs, ka = self._c_operand(lhs)
+            keep_alive.append(ka)
+            c_preds[j].rhs, ka = self._c_operand(rhs)
+            keep_alive.append(ka)
+            c_preds[j].op = _lib.OPS[op]
+        for t in (idx_a, idx_b):
+            if t is not None and (t.dtype != torch.int32 or not t.is_contiguous() or int(t.shape[0]) != n):
+                raise ValueError("id arrays must be contiguous int32 tensors of n rows")
+        out_a = torch.empty(n, dtype=torch.int32, device=self.device) if "a" in want else None
+        out_b = torch.empty(n, dtype=torch.int32, device=self.device) if "b" in want else None
+        kept = ctypes.c_int64(0)
+        _lib.check(self._L.giql_hip_select_dev(
+            self._h, c_preds, k,
+            idx_a.data_ptr() if idx_a is not None and n else None, int(n_rows_a),
+            idx_b.data_ptr() if idx_b is not None and n else None, int(n_rows_b), int(n),
+            out_a.data_ptr() if out_a is not None and n else None,
+            out_b.data_ptr() if out_b is not None and n else None, ctypes.byref(kept), self._stream()))
+        m = int(kept.value)
+        return (out_a[:m] if out_a is not None else None, out_b[:m] if out_b is not None else None)
+
+    def mark(self, idx, n_rows: int):
+        """``flags[idx] = 1`` over ``n_rows`` zero-initialised bytes (which left rows keep a pair)."""
+        torch = _torch()
+        flags = torch.zeros(int(n_rows), dtype=torch.uint8, device=self.device)
+        n = int(idx.shape[0])
+        if n:
+            _lib.check(self._L.giql_hip_mark_dev(self._h, idx.data_ptr(), n, flags.data_ptr(), int(n_rows),
+                                                 self._stream()))
+        return flags
+
     # --------------------------------------------------------------- checksum
     def pairs_checksum(self, row_a, row_b) -> int:
         h = ctypes.c_uint64(0)

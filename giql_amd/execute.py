@@ -109,6 +109,175 @@ def _take(table, name: str, idx: np.ndarray):
     return np.asarray(col)[idx]
 
 
+class _Residuals:
+    """Bind a plan's residual predicates to device columns for ``HipEngine.select``.
+
+    Numeric columns are uploaded as int32 / int64 / float32 / float64 / uint8; a
+    string comparison (column vs column or column vs literal) is dictionary-encoded
+    with one SORTED dictionary shared by both operands, so ``=`` / ``<`` on the int32
+    codes is the comparison on the strings (binary collation).  Validity bitmaps
+    travel as byte columns: a NULL operand makes the predicate not true.
+    """
+
+    def __init__(self, plan: JoinPlan, lt, rt, eng: HipEngine):
+        self.plan, self.tables, self.eng = plan, {"l": lt, "r": rt}, eng
+        self._cache: dict = {}
+
+    @staticmethod
+    def sides(res) -> set:
+        return {o.kind for o in (res.lhs, res.rhs) if o.kind in ("l", "r")}
+
+    def _arrow(self, side: str, column: str):
+        import pyarrow as pa
+
+        col = _column(self.tables[side], column)
+        if isinstance(col, pa.ChunkedArray):
+            col = col.combine_chunks() if col.num_chunks != 1 else col.chunk(0)
+        if not isinstance(col, pa.Array):
+            col = pa.array(np.asarray(col))
+        if pa.types.is_dictionary(col.type):
+            col = col.dictionary_decode()
+        return col
+
+    def _valid(self, col):
+        import torch
+
+        if not col.null_count:
+            return None
+        return torch.from_numpy(np.ascontiguousarray(col.is_valid().to_numpy(zero_copy_only=False).astype(np.uint8))
+                                ).to(self.eng.device)
+
+    def _numeric(self, side: str, column: str):
+        import pyarrow as pa
+        import torch
+
+        key = (side, column)
+        if key in self._cache:
+            return self._cache[key]
+        col = self._arrow(side, column)
+        t = col.type
+        if pa.types.is_boolean(t):
+            vals = col.fill_null(False).to_numpy(zero_copy_only=False).astype(np.uint8)
+        elif pa.types.is_integer(t):
+            vals = col.fill_null(0).to_numpy(zero_copy_only=False)
+            if vals.dtype == np.uint64:
+                if vals.size and vals.max() > np.iinfo(np.int64).max:
+                    raise ValueError(f"column {column!r}: uint64 values beyond int64 are not supported in a predicate")
+                vals = vals.astype(np.int64)
+            elif vals.dtype.itemsize < 4 or vals.dtype == np.int32:
+                vals = vals.astype(np.int32)
+            else:
+                vals = vals.astype(np.int64)
+        elif pa.types.is_floating(t):
+            vals = col.fill_null(0).to_numpy(zero_copy_only=False)
+            vals = vals.astype(np.float64 if vals.dtype == np.float64 else np.float32)
+        else:
+            return None
+        out = (torch.from_numpy(np.ascontiguousarray(vals)).to(self.eng.device), self._valid(col))
+        self._cache[key] = out
+        return out
+
+    def _is_string(self, o) -> bool:
+        import pyarrow as pa
+
+        if o.kind == "str":
+            return True
+        if o.kind in ("l", "r"):
+            t = self._arrow(o.kind, o.value).type
+            return pa.types.is_string(t) or pa.types.is_large_string(t)
+        return False
+
+    def pred(self, res):
+        """``(lhs_spec, op, rhs_spec)`` for :meth:`HipEngine.select`; left = side "a"."""
+        import torch
+
+        ops = (res.lhs, res.rhs)
+        eside = {"l": "a", "r": "b"}
+        if any(self._is_string(o) for o in ops):
+            if not all(self._is_string(o) for o in ops):
+                raise ValueError(f"cannot compare a string with a number in {res.lhs.value!r} {res.op} {res.rhs.value!r}")
+            arrs = []
+            for o in ops:
+                if o.kind == "str":
+                    arrs.append(np.asarray([o.value], dtype=object))
+                else:
+                    arrs.append(self._arrow(o.kind, o.value).fill_null("").to_numpy(zero_copy_only=False).astype(object))
+            both = np.concatenate(arrs).astype(str)
+            _, inv = np.unique(both, return_inverse=True)
+            inv = inv.astype(np.int32)
+            specs, pos = [], 0
+            for o, arr in zip(ops, arrs):
+                codes = inv[pos:pos + len(arr)]
+                pos += len(arr)
+                if o.kind == "str":
+                    specs.append(("lit", int(codes[0])))
+                else:
+                    col = self._arrow(o.kind, o.value)
+                    specs.append((eside[o.kind], torch.from_numpy(np.ascontiguousarray(codes)).to(self.eng.device),
+                                  self._valid(col)))
+            return specs[0], res.op, specs[1]
+        specs = []
+        for o in ops:
+            if o.kind in ("int", "float"):
+                specs.append(("lit", o.value))
+            else:
+                nv = self._numeric(o.kind, o.value)
+                if nv is None:
+                    raise ValueError(f"column {o.value!r}: type {self._arrow(o.kind, o.value).type} is not supported "
+                                     "in a dialect='hip' predicate")
+                specs.append((eside[o.kind], nv[0], nv[1]))
+        return specs[0], res.op, specs[1]
+
+    def preds(self, residuals):
+        return [self.pred(r) for r in residuals]
+
+
+def _subset(eng: HipEngine, side: DeviceSide, ids):
+    """The rows ``ids`` of a device side (a prefilter's survivors)."""
+    if ids is None:
+        return side
+    c, s, e = eng.take([side.chrom, side.start, side.end], ids)
+    return DeviceSide(c, s, e, side.start_off, side.end_off)
+
+
+def _join_with_residuals(plan: JoinPlan, lt, rt, a: DeviceSide, b: DeviceSide, n_chrom: int, eng: HipEngine):
+    """INNER / SEMI / ANTI with residual predicates; returns device row ids.
+
+    One-sided predicates shrink that side BEFORE the join, two-sided ones filter the
+    pairs after it (what inlining them into the per-chromosome ON amounts to,
+    intersects_duckdb.py:1239-1243).  For SEMI / ANTI only the ON residuals take part
+    in the existence test; WHERE residuals filter the surviving left rows (#200,
+    intersects_duckdb.py:1164-1177)."""
+    rb_ = _Residuals(plan, lt, rt, eng)
+    semi = plan.kind in ("SEMI", "ANTI")
+    joinside = [r for r in plan.residuals if not (semi and r.clause == "where")]
+    outer = [r for r in plan.residuals if semi and r.clause == "where"]
+    left_only = [r for r in joinside if rb_.sides(r) == {"l"}]
+    right_only = [r for r in joinside if rb_.sides(r) == {"r"}]
+    both = [r for r in joinside if rb_.sides(r) == {"l", "r"}]
+    ids_a = eng.select(rb_.preds(left_only), n=a.n, n_rows_a=a.n, want=("a",))[0] if left_only else None
+    ids_b = eng.select(rb_.preds(right_only), n=b.n, n_rows_b=b.n, want=("b",))[1] if right_only else None
+    a_sub, b_sub = _subset(eng, a, ids_a), _subset(eng, b, ids_b)
+
+    def globalise(rows, ids):
+        return rows if ids is None else eng.take([ids], rows)[0]
+
+    if not semi or both:
+        ra, rb = eng.inner_join(a_sub, b_sub, n_chrom)
+        ra, rb = globalise(ra, ids_a), globalise(rb, ids_b)
+        if both:
+            ra, rb = eng.select(rb_.preds(both), idx_a=ra.contiguous(), idx_b=rb.contiguous(),
+                                n_rows_a=a.n, n_rows_b=b.n)
+        if not semi:
+            return ra, rb
+        matched = ra
+    else:
+        matched = globalise(eng.semi_anti(a_sub, b_sub, n_chrom, False), ids_a)
+    flags = eng.mark(matched.contiguous(), a.n)
+    final = [(("a", flags), "=", ("lit", 0 if plan.kind == "ANTI" else 1))] + rb_.preds(outer)
+    return eng.select(final, n=a.n, n_rows_a=a.n, want=("a",))[0]
+
+
 def _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices):
     """count_overlaps: COUNT(b.col) per distinct left key, zero-filled
     (src/giql/expanders/intersects_duckdb.py:806-854; oracle semantics of
@@ -233,13 +402,19 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
     if plan.kind == "COUNT":
         return _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices)
     if plan.kind == "INNER":
-        ra, rb = eng.inner_join(a, b, n_chrom)
+        if plan.residuals:
+            ra, rb = _join_with_residuals(plan, lt, rt, a, b, n_chrom, eng)
+        else:
+            ra, rb = eng.inner_join(a, b, n_chrom)
         if return_indices:
             return ra.cpu().numpy(), rb.cpu().numpy()
         idx = {"l": ra, "r": rb}
         extra = {}
     elif plan.kind in ("SEMI", "ANTI"):
-        rows = eng.semi_anti(a, b, n_chrom, plan.kind == "ANTI")
+        if plan.residuals:
+            rows = _join_with_residuals(plan, lt, rt, a, b, n_chrom, eng)
+        else:
+            rows = eng.semi_anti(a, b, n_chrom, plan.kind == "ANTI")
         if return_indices:
             return rows.cpu().numpy()
         idx = {"l": rows}

@@ -42,6 +42,27 @@ class Projection:
 
 
 @dataclass(frozen=True)
+class Operand:
+    """One side of a residual comparison: a column of the left / right table
+    (``kind`` "l" / "r", ``value`` = column name) or a literal ("int", "float", "str")."""
+
+    kind: str
+    value: object
+
+
+@dataclass(frozen=True)
+class Residual:
+    """An extra conjunct beside the INTERSECTS: ``lhs op rhs`` from the ON or the
+    WHERE clause (the reference inlines these into the per-chromosome join,
+    intersects_duckdb.py:1157-1177, 1239-1243)."""
+
+    clause: str    # "on" | "where"
+    lhs: Operand
+    op: str        # = != < <= > >=
+    rhs: Operand
+
+
+@dataclass(frozen=True)
 class JoinPlan:
     kind: str
     left: PlanSide
@@ -52,6 +73,7 @@ class JoinPlan:
     k: int = 1
     max_distance: int | None = None
     signed: bool = False
+    residuals: tuple[Residual, ...] = field(default_factory=tuple)
 
     def __post_init__(self) -> None:
         if self.kind not in KINDS:
@@ -60,6 +82,7 @@ class JoinPlan:
     def to_string(self) -> str:
         d = asdict(self)
         d["projection"] = [asdict(p) for p in self.projection]
+        d["residuals"] = [asdict(r) for r in self.residuals]
         return PLAN_PREFIX + json.dumps(d, sort_keys=True, separators=(",", ":"))
 
     @classmethod
@@ -71,7 +94,9 @@ class JoinPlan:
             kind=d["kind"], left=PlanSide(**d["left"]), right=PlanSide(**d["right"]),
             projection=tuple(Projection(**p) for p in d["projection"]),
             distinct=d.get("distinct", False), k=d.get("k", 1),
-            max_distance=d.get("max_distance"), signed=d.get("signed", False))
+            max_distance=d.get("max_distance"), signed=d.get("signed", False),
+            residuals=tuple(Residual(r["clause"], Operand(**r["lhs"]), r["op"], Operand(**r["rhs"]))
+                            for r in d.get("residuals", ())))
 
 
 def is_plan_string(text) -> bool:

@@ -1,7 +1,8 @@
 """``transpile(giql, tables, dialect="hip")`` -- host-side mirror of the reference's
 ``giql.transpile`` (``src/giql/transpile.py:55-214``) for the one path this
-backend executes: the column-to-column INTERSECTS join (INNER / SEMI / ANTI) and
-the correlated NEAREST k=1 join.
+backend executes: the column-to-column INTERSECTS join (INNER / SEMI / ANTI, with
+comparison residuals beside the INTERSECTS), the count_overlaps shape, and the
+correlated NEAREST k=1 join.
 
 The reference parses with sqlglot, which is not installable here, so this module
 carries a small hand-written parser for exactly the query shapes the reference's
@@ -13,8 +14,8 @@ IEJoin override engages on (the whitelist of
 * user mistakes (unqualified / unknown-alias columns, right-side columns under
   SEMI / ANTI)                                    -> ``ValueError``
   (``_UnqualifiedProjectionError`` -> ``ValueError``, intersects_duckdb.py:803-804);
-* valid GIQL the hip path does not execute (stars, outer joins, self-joins, extra
-  predicates, aggregates, 3+ tables, ...)         -> :class:`HipDeclined`
+* valid GIQL the hip path does not execute (stars, outer joins, self-joins, OR / NOT /
+  arithmetic in the join condition, other aggregates, 3+ tables, ...)         -> :class:`HipDeclined`
   (a ``ValueError``): the reference *declines* such shapes to the naive predicate
   (intersects_duckdb.py:1715); without sqlglot there is no naive emitter to fall
   back to, so the caller is told to use ``giql.transpile`` for that query.
@@ -32,7 +33,7 @@ from __future__ import annotations
 import re
 from dataclasses import dataclass
 
-from .plan import JoinPlan, PlanSide, Projection
+from .plan import JoinPlan, Operand, PlanSide, Projection, Residual
 from .table import Table, Tables, build_tables
 
 
@@ -45,10 +46,10 @@ _TOKEN = re.compile(
     r"""\s*(?:
         (?P<str>'(?:[^']|'')*')
       | (?P<qid>"(?:[^"]|"")*")
-      | (?P<num>\d+)
+      | (?P<num>\d+(?:\.\d+)?)
       | (?P<assign>:=)
       | (?P<id>[A-Za-z_][A-Za-z_0-9]*)
-      | (?P<punct>[(),.*;=<>+\-/])
+      | (?P<punct>[(),.*;=<>+\-/!])
     )""",
     re.X,
 )
@@ -192,6 +193,84 @@ class _Parser:
         return _TableRef(name.text, alias, aq)
 
 
+_CLAUSE_END = ("WHERE", "GROUP", "ORDER", "HAVING", "LIMIT", "OFFSET", "UNION", "JOIN", "INNER", "LEFT",
+               "RIGHT", "FULL", "CROSS", "SEMI", "ANTI", "NATURAL")
+
+
+def _parse_operand(p: _Parser):
+    """A residual operand: [-]number, 'string' or a column reference."""
+    neg = False
+    if p.at_punct("-") and p.peek(1).kind == "num":
+        p.next()
+        neg = True
+    t = p.peek()
+    if t.kind == "num":
+        p.next()
+        v = float(t.text) if "." in t.text else int(t.text)
+        return ("lit", -v if neg else v)
+    if t.kind == "str":
+        p.next()
+        return ("lit", t.text)
+    if t.kind == "kw" and t.text in ("TRUE", "FALSE"):
+        raise _decline("boolean literal in a join condition")
+    if t.kind != "id":
+        raise _decline(f"join condition operand near {t.text!r}")
+    ref = p.colref()
+    if p.at_punct("("):
+        raise _decline("function call in a join condition")
+    return ("col", ref)
+
+
+def _parse_conjunction(p: _Parser):
+    """``term (AND term)*`` where a term is ``<col> INTERSECTS <col>`` or a comparison
+    ``<operand> op <operand>``.  Everything else (OR, NOT, parentheses, arithmetic,
+    IN / BETWEEN / LIKE / IS, sub-queries) declines: the reference either routes those
+    to the naive plan (``_classify_extras``, intersects_duckdb.py:889-912) or inlines
+    SQL text this target has no evaluator for."""
+    terms = []
+    while True:
+        if p.at_kw("NOT", "EXISTS") or p.at_punct("("):
+            raise _decline("NOT / parenthesised / EXISTS condition")
+        lhs = _parse_operand(p)
+        if p.at_kw("INTERSECTS"):
+            p.next()
+            if lhs[0] != "col":
+                raise _decline("INTERSECTS with a literal on the left")
+            if p.peek().kind == "str":
+                raise _decline("literal-range INTERSECTS inside a join")
+            if p.at_kw("ANY", "ALL"):
+                raise _decline("INTERSECTS ANY/ALL")
+            if p.peek().kind != "id":
+                raise _decline("INTERSECTS operand that is not a column")
+            terms.append(("intersects", lhs[1], p.colref()))
+        elif p.at_kw("CONTAINS", "WITHIN"):
+            raise _decline(f"{p.peek().text} predicate")
+        else:
+            op = None
+            t = p.peek()
+            if t.kind == "punct" and t.text in "=<>!":
+                p.next()
+                op = t.text
+                n = p.peek()
+                if n.kind == "punct" and ((op == "<" and n.text in "=>") or (op == ">" and n.text == "=")
+                                          or (op == "!" and n.text == "=")):
+                    p.next()
+                    op += n.text
+            if op is None or op == "!":
+                raise _decline("join condition other than INTERSECTS / simple comparisons")
+            op = {"<>": "!=", "==": "="}.get(op, op)
+            rhs = _parse_operand(p)
+            if p.peek().kind == "punct" and p.peek().text in "+-*/":
+                raise _decline("arithmetic in a join condition")
+            terms.append(("cmp", lhs, op, rhs))
+        if p.at_kw("AND"):
+            p.next()
+            continue
+        if p.at_kw("OR"):
+            raise _decline("OR in the join condition")
+        return terms
+
+
 _UNSUPPORTED_TAIL = ("GROUP", "ORDER", "HAVING", "LIMIT", "OFFSET", "UNION")
 
 
@@ -288,6 +367,39 @@ def _resolve_projection(items, left: PlanSide, right: PlanSide, left_only: bool,
         else:
             raise ValueError(f"Unknown table qualifier {ref.table!r} in the SELECT list")
     return tuple(out)
+
+
+def _resolve_residual(clause: str, term, left: PlanSide, right: PlanSide, kind: str) -> Residual:
+    """Bind a comparison's operands to the two sides; qualifier mistakes are user
+    errors, as in ``_validate_extra_qualifiers`` (intersects_duckdb.py:914-959)."""
+    _, lhs, op, rhs = term
+
+    def bind(o) -> Operand:
+        if o[0] == "lit":
+            v = o[1]
+            return Operand("str" if isinstance(v, str) else ("float" if isinstance(v, float) else "int"), v)
+        ref: _ColRef = o[1]
+        if ref.star:
+            raise _decline("star in a join condition")
+        if ref.table is None:
+            raise ValueError(
+                f"dialect='hip' cannot inline the extra predicate: column {ref.column!r} must be "
+                f"qualified with {left.alias!r} or {right.alias!r}")
+        q = _norm(ref.table, ref.table_quoted)
+        if q == left.alias:
+            return Operand("l", ref.column)
+        if q == right.alias:
+            if kind in ("SEMI", "ANTI") and clause == "where":
+                raise ValueError(f"{kind} join: the WHERE clause cannot reference the right side "
+                                 f"({ref.table}.{ref.column})")
+            return Operand("r", ref.column)
+        raise ValueError(f"dialect='hip' cannot inline the extra predicate: unknown table qualifier "
+                         f"{ref.table!r}; expected {left.alias!r} or {right.alias!r}")
+
+    a, b = bind(lhs), bind(rhs)
+    if a.kind not in ("l", "r") and b.kind not in ("l", "r"):
+        raise _decline("constant predicate in the join condition")
+    return Residual(clause, a, op, b)
 
 
 def _resolve_count_projection(items, group_cols, left: PlanSide, right: PlanSide):
@@ -503,25 +615,27 @@ def _lower(giql: str, tables, want_sql: bool):
 
     if kind == "COUNT" and not on_seen:
         raise _decline("count_overlaps without an ON clause")
-    if not on_seen:
-        if kind in ("SEMI", "ANTI"):
-            raise _decline("SEMI/ANTI join with its INTERSECTS outside ON")  # #201
-        if not p.at_kw("WHERE"):
-            raise _decline("join without an INTERSECTS predicate")
+    on_terms, where_terms = [], []
+    if on_seen:
+        if p.peek().kind not in ("id", "num", "str") and not p.at_punct("-"):
+            raise _decline("join condition other than INTERSECTS / simple comparisons")
+        on_terms = _parse_conjunction(p)
+    elif kind in ("SEMI", "ANTI"):
+        raise _decline("SEMI/ANTI join with its INTERSECTS outside ON")  # #201
+    if p.at_kw("WHERE"):
         p.next()
-    if p.peek().kind != "id":
-        raise _decline("join condition other than a single INTERSECTS")
-    lhs = p.colref()
-    if not p.at_kw("INTERSECTS"):
-        raise _decline("join condition other than a single INTERSECTS")
-    p.next()
-    if p.peek().kind == "str":
-        raise _decline("literal-range INTERSECTS inside a join")
-    if p.at_kw("ANY", "ALL"):
-        raise _decline("INTERSECTS ANY/ALL")
-    rhs = p.colref()
-    if p.at_kw("AND", "OR"):
-        raise _decline("extra predicates beside the INTERSECTS")
+        where_terms = _parse_conjunction(p)
+    n_int = sum(t[0] == "intersects" for t in on_terms + where_terms)
+    if n_int == 0:
+        raise _decline("join without an INTERSECTS predicate")
+    if n_int > 1:
+        raise _decline("more than one INTERSECTS")
+    if kind in ("SEMI", "ANTI") and not any(t[0] == "intersects" for t in on_terms):
+        raise _decline("SEMI/ANTI join with its INTERSECTS outside ON")  # #201
+    _, lhs, rhs = [t for t in on_terms + where_terms if t[0] == "intersects"][0]
+    cmp_terms = [("on", t) for t in on_terms if t[0] == "cmp"] + [("where", t) for t in where_terms if t[0] == "cmp"]
+    if kind == "COUNT" and (cmp_terms or where_terms):
+        raise _decline("count_overlaps with predicates beside the INTERSECTS")  # bare ON only (:432-548)
     group_cols: list[_ColRef] = []
     if kind == "COUNT":
         if not p.at_kw("GROUP"):
@@ -536,8 +650,7 @@ def _lower(giql: str, tables, want_sql: bool):
                 p.next()
                 continue
             break
-    if p.peek().kind == "kw" and p.peek().text in _UNSUPPORTED_TAIL + ("WHERE", "JOIN", "INNER",
-                                                                       "LEFT", "CROSS"):
+    if p.peek().kind == "kw" and p.peek().text in _CLAUSE_END:
         raise _decline(f"{p.peek().text} clause")
     if p.at_punct(","):
         raise _decline("a third table")
@@ -568,7 +681,8 @@ def _lower(giql: str, tables, want_sql: bool):
             raise _decline("DISTINCT with count_overlaps")
         return JoinPlan("COUNT", left, right, _resolve_count_projection(items, group_cols, left, right))
     proj = _resolve_projection(items, left, right, kind in ("SEMI", "ANTI"))
-    return JoinPlan(kind, left, right, proj, distinct)
+    residuals = tuple(_resolve_residual(clause, t, left, right, kind) for clause, t in cmp_terms)
+    return JoinPlan(kind, left, right, proj, distinct, residuals=residuals)
 
 
 def _render(toks: list[Tok]) -> str:

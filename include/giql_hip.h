@@ -183,6 +183,51 @@ int giql_hip_take_utf8_fill_dev(giql_hip_ctx* ctx, const int32_t* offsets,
                                 const int32_t* out_offsets, uint8_t* out_data,
                                 void* stream);
 
+/* ---- residual predicates (extra ON / WHERE conjuncts beside the INTERSECTS) --
+ * The reference inlines them into the per-chromosome join's ON clause,
+ * src/giql/expanders/intersects_duckdb.py:1164-1177, 1239-1243 (SURVEY.md
+ * section 8f-3).  Here a predicate is `lhs op rhs`; an operand is a payload
+ * column of side A / side B (DEVICE pointer, addressed through the candidate's
+ * row id) or a literal.  Integers compare as int64, anything involving a float
+ * as double; a NULL operand (valid[row] == 0) makes the predicate not true. */
+enum { GIQL_OP_EQ = 0, GIQL_OP_NE = 1, GIQL_OP_LT = 2, GIQL_OP_LE = 3, GIQL_OP_GT = 4, GIQL_OP_GE = 5 };
+enum { GIQL_T_I32 = 0, GIQL_T_I64 = 1, GIQL_T_F32 = 2, GIQL_T_F64 = 3, GIQL_T_U8 = 4 };
+enum { GIQL_SIDE_A = 0, GIQL_SIDE_B = 1, GIQL_SIDE_LIT = 2 };
+
+typedef struct giql_operand {
+  int32_t side;          /* GIQL_SIDE_*                                          */
+  int32_t type;          /* GIQL_T_* of the column (unused for a literal)        */
+  const void* data;      /* device column                                        */
+  const uint8_t* valid;  /* device byte-per-row validity, NULL = all valid       */
+  int64_t lit_i;         /* literal: integer value ...                           */
+  double lit_f;          /* ... or floating value when lit_is_float              */
+  int32_t lit_is_float;
+  int32_t reserved;
+} giql_operand;
+
+typedef struct giql_pred {
+  giql_operand lhs, rhs;
+  int32_t op;            /* GIQL_OP_*                                            */
+  int32_t reserved;
+} giql_pred;
+
+/* Stable filter of n candidates by the conjunction of n_preds (<= 8) predicates.
+ * Candidate i addresses side A by idx_a[i] (i itself when idx_a is NULL) and side
+ * B by idx_b[i] likewise; the kept candidates' ids are written, in input order,
+ * to out_a / out_b (capacity n each; either may be NULL) and *n_kept receives
+ * their number.  With idx_a / idx_b = the join's pairs this is the post-join
+ * residual filter; with both NULL it filters the rows of one table. */
+int giql_hip_select_dev(giql_hip_ctx* ctx, const giql_pred* preds, int32_t n_preds,
+                        const int32_t* idx_a, int64_t n_rows_a,
+                        const int32_t* idx_b, int64_t n_rows_b, int64_t n,
+                        int32_t* out_a, int32_t* out_b, int64_t* n_kept,
+                        void* stream);
+/* flags[idx[i]] = 1 for i < n (flags: device, n_rows bytes, caller-initialised):
+ * the left rows that keep at least one pair, for SEMI / ANTI with two-sided
+ * residuals (src/giql/expanders/intersects_duckdb.py:1254-1282). */
+int giql_hip_mark_dev(giql_hip_ctx* ctx, const int32_t* idx, int64_t n,
+                      uint8_t* flags, int64_t n_rows, void* stream);
+
 /* ---- host-buffer entry points (Arrow buffers in host memory) ------------ */
 int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
                    int32_t n_chrom, int64_t* n_pairs, int32_t** row_a,

@@ -216,6 +216,78 @@ def test_count_overlaps_rejects_null_count_column(peaks_genes):
         execute(transpile(q, tables=["peaks", "genes"], dialect="hip"), {"peaks": peaks_genes["peaks"], "genes": genes})
 
 
+def _rows(n, tag, rng):
+    out = []
+    for i in range(n):
+        s = int(rng.integers(0, 3000))
+        out.append((str(rng.choice(["chr1", "chr2", "chr3"])), s, s + int(rng.integers(1, 400)), f"{tag}{i % 17}",
+                    int(rng.integers(0, 6)), str(rng.choice(["+", "-"]))))
+    return out
+
+
+def _overlap(p, g):
+    return p[0] == g[0] and p[1] < g[2] and p[2] > g[1]
+
+
+RESIDUAL_CASES = [
+    # (ON / WHERE text after the INTERSECTS, python predicate over (peak row, gene row))
+    ("AND a.strand = b.strand", "", lambda p, g: p[5] == g[5]),                       # same-strand recipe
+    ("AND a.strand != b.strand", "", lambda p, g: p[5] != g[5]),                      # opposite-strand recipe
+    ("AND a.score > 2", "", lambda p, g: p[4] > 2),
+    ("", "WHERE b.score <= 3 AND a.score >= 1", lambda p, g: g[4] <= 3 and p[4] >= 1),
+    ("AND a.score < b.score", "WHERE a.name <> 'p3'", lambda p, g: p[4] < g[4] and p[3] != "p3"),
+    ("AND a.strand < b.strand AND 2 < b.score", "WHERE a.name >= 'p3'", lambda p, g: p[5] < g[5] and 2 < g[4] and p[3] >= "p3"),
+    ("AND a.score = 2.0", "", lambda p, g: p[4] == 2),
+]
+
+
+@pytest.mark.parametrize("on,where,pred", RESIDUAL_CASES, ids=[c[0] + " " + c[1] for c in RESIDUAL_CASES])
+def test_inner_join_with_residual_predicates(on, where, pred):
+    # the reference inlines these conjuncts into the per-chromosome join (intersects_duckdb.py:1239-1243);
+    # expected rows = brute force over (overlap AND residual)
+    rng = np.random.default_rng(42)
+    peaks, genes = _rows(300, "p", rng), _rows(500, "g", rng)
+    t = {"peaks": make_table(peaks), "genes": make_table(genes)}
+    q = ("SELECT a.name AS an, a.start AS s, b.name AS bn, b.end AS e FROM peaks a JOIN genes b "
+         f"ON a.interval INTERSECTS b.interval {on} {where}")
+    got = rows_of(execute(transpile(q, tables=["peaks", "genes"], dialect="hip"), t))
+    want = sorted((p[3], p[1], g[3], g[2]) for p in peaks for g in genes if _overlap(p, g) and pred(p, g))
+    assert got == want and len(want) > 0
+
+
+@pytest.mark.parametrize("kind", ["SEMI", "ANTI"])
+@pytest.mark.parametrize("on,where,on_pred,where_pred", [
+    ("AND a.strand = b.strand", "", lambda p, g: p[5] == g[5], lambda p: True),
+    ("AND b.score > 2", "WHERE a.score < 4", lambda p, g: g[4] > 2, lambda p: p[4] < 4),
+    ("AND a.score > 2", "", lambda p, g: p[4] > 2, lambda p: True),   # a left-only ON residual: ANTI KEEPS failing rows
+    ("AND a.score <= b.score AND a.score > 0", "WHERE a.name != 'p1'", lambda p, g: 0 < p[4] <= g[4], lambda p: p[3] != "p1"),
+], ids=["same_strand", "right_on+left_where", "left_on", "two_sided+where"])
+def test_semi_anti_with_residual_predicates(kind, on, where, on_pred, where_pred):
+    # ON residuals take part in the existence test, WHERE residuals filter the output (#200,
+    # intersects_duckdb.py:1164-1177)
+    rng = np.random.default_rng(7)
+    peaks, genes = _rows(250, "p", rng), _rows(150, "g", rng)
+    peaks.append(("chr9", 5, 50, "p1", 3, "+"))  # left-only chromosome
+    t = {"peaks": make_table(peaks), "genes": make_table(genes)}
+    q = f"SELECT a.name, a.start, a.score FROM peaks a {kind} JOIN genes b ON a.interval INTERSECTS b.interval {on} {where}"
+    got = rows_of(execute(transpile(q, tables=["peaks", "genes"], dialect="hip"), t))
+    def exists(p):
+        return any(_overlap(p, g) and on_pred(p, g) for g in genes)
+    want = sorted((p[3], p[1], p[4]) for p in peaks if where_pred(p) and (exists(p) != (kind == "ANTI")))
+    assert got == want and len(want) > 0
+
+
+def test_residual_null_operands_never_match_and_type_mismatch_raises(peaks_genes):
+    genes = peaks_genes["genes"].set_column(4, "score", pa.array([1, None, 3, 4, 5], pa.int32()))
+    t = {"peaks": peaks_genes["peaks"], "genes": genes}
+    q = "SELECT a.name, b.name AS g FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND b.score < 100"
+    got = rows_of(execute(transpile(q, tables=["peaks", "genes"], dialect="hip"), t))
+    assert got == [("p1", "g1"), ("p4", "g4")]  # (p3, g2) overlaps but g2.score is NULL
+    bad = "SELECT a.name FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.name > 3"
+    with pytest.raises(ValueError, match="string with a number"):
+        execute(transpile(bad, tables=["peaks", "genes"], dialect="hip"), t)
+
+
 def test_device_projection_matches_host_projection_for_every_column_type():
     # the projected columns are gathered on the GPU (giql_hip_take_*); same rows as pyarrow.take
     rng = np.random.default_rng(11)

@@ -536,3 +536,58 @@ def test_take_utf8_matches_pyarrow(eng, n):
     got = pa.Array.from_buffers(pa.string(), n, [None, pa.py_buffer(o.cpu().numpy().tobytes()),
                                                   pa.py_buffer(dbytes.cpu().numpy().tobytes())]).to_pylist()
     assert got == want
+
+
+# ------------------------------------------------------- residual predicates (select)
+_NP_OPS = {"=": np.equal, "!=": np.not_equal, "<": np.less, "<=": np.less_equal, ">": np.greater,
+           ">=": np.greater_equal}
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 100_003])
+def test_select_pairs_matches_numpy(eng, n):
+    rng = np.random.default_rng(n + 1)
+    na, nb = 700, 900
+    ca_i32 = rng.integers(-50, 50, na).astype(np.int32)
+    ca_f64 = rng.standard_normal(na)
+    va = rng.random(na) > 0.2
+    cb_i64 = rng.integers(-50, 50, nb).astype(np.int64)
+    cb_f32 = rng.standard_normal(nb).astype(np.float32)
+    cb_u8 = rng.integers(0, 2, nb).astype(np.uint8)
+    ia = rng.integers(0, na, n).astype(np.int32)
+    ib = rng.integers(0, nb, n).astype(np.int32)
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    dia, dib = d(ia), d(ib)
+    cases = [
+        ([(("a", d(ca_i32)), "<", ("b", d(cb_i64)))], ca_i32[ia] < cb_i64[ib]),
+        ([(("a", d(ca_f64)), ">=", ("b", d(cb_f32)))], ca_f64[ia] >= cb_f32[ib].astype(np.float64)),
+        ([(("a", d(ca_i32)), "!=", ("lit", 3)), (("b", d(cb_u8)), "=", ("lit", 1))], (ca_i32[ia] != 3) & (cb_u8[ib] == 1)),
+        ([(("lit", 0.25), "<", ("a", d(ca_f64), d(va.astype(np.uint8))))], (0.25 < ca_f64[ia]) & va[ia]),
+        ([(("a", d(ca_i32)), "<=", ("b", d(cb_f32)))], ca_i32[ia].astype(np.float64) <= cb_f32[ib].astype(np.float64)),
+        ([], np.ones(n, bool)),
+    ]
+    for preds, want in cases:
+        ga, gb = eng.select(preds, idx_a=dia, idx_b=dib, n_rows_a=na, n_rows_b=nb)
+        assert np.array_equal(ga.cpu().numpy(), ia[want]) and np.array_equal(gb.cpu().numpy(), ib[want])
+
+
+@pytest.mark.parametrize("op", sorted(_NP_OPS))
+def test_select_rows_every_operator(eng, op):
+    rng = np.random.default_rng(3)
+    col = rng.integers(0, 10, 5000).astype(np.int32)
+    got = eng.select([(("a", torch.from_numpy(col).cuda()), op, ("lit", 4))], n=5000, n_rows_a=5000, want=("a",))[0]
+    assert np.array_equal(got.cpu().numpy(), np.nonzero(_NP_OPS[op](col, 4))[0])
+    got = eng.select([(("b", torch.from_numpy(col).cuda()), op, ("lit", 4.5))], n=5000, n_rows_b=5000, want=("b",))[1]
+    assert np.array_equal(got.cpu().numpy(), np.nonzero(_NP_OPS[op](col, 4.5))[0])
+
+
+def test_select_rejects_bad_ids_and_mark_flags(eng):
+    from giql_amd._lib import GiqlHipError
+
+    col = torch.arange(10, dtype=torch.int32).cuda()
+    bad = torch.tensor([1, 10], dtype=torch.int32).cuda()
+    with pytest.raises(GiqlHipError):
+        eng.select([(("a", col), ">", ("lit", 0))], idx_a=bad, idx_b=bad, n_rows_a=10, n_rows_b=11)
+    flags = eng.mark(torch.tensor([3, 3, 7], dtype=torch.int32).cuda(), 9)
+    assert flags.cpu().tolist() == [0, 0, 0, 1, 0, 0, 0, 1, 0]
+    with pytest.raises(GiqlHipError):
+        eng.mark(torch.tensor([9], dtype=torch.int32).cuda(), 9)

@@ -91,8 +91,15 @@ def test_case_insensitive_aliases():
     "SELECT a.start FROM peaks a NATURAL JOIN genes b",
     "SELECT a.start FROM peaks a JOIN peaks b ON a.interval INTERSECTS b.interval",
     "SELECT a.start FROM peaks a JOIN genes a ON a.interval INTERSECTS a.interval",
-    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score > 5",
-    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval WHERE a.score > 5",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval OR a.score > 5",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND (a.score > 5)",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND NOT a.score > 5",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score + 1 > 5",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND ABS(a.score) > 5",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND 1 = 1",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval WHERE a.score IN (1, 2)",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.interval INTERSECTS b.interval",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.score > 5",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval ORDER BY a.start",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval LIMIT 5",
     "SELECT COUNT(*) FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
@@ -117,6 +124,44 @@ def test_valid_but_unsupported_shapes_decline(query):
     ("SELECT a.start FROM peaks a JOIN genes b ON a.start INTERSECTS b.interval", "genomic"),
 ])
 def test_user_mistakes_raise_value_error(query, match):
+    with pytest.raises(ValueError, match=match) as ei:
+        build_plan(query, ["peaks", "genes"])
+    assert not isinstance(ei.value, HipDeclined)
+
+
+def test_residual_predicates_are_lowered_into_the_plan():
+    # the reference inlines extra ON / WHERE conjuncts into the per-chromosome join
+    # (intersects_duckdb.py:1157-1177); the hip plan carries them as comparisons
+    q = ("SELECT a.start FROM peaks a JOIN genes b ON a.strand = b.strand AND a.interval INTERSECTS b.interval "
+         "AND a.score >= 10 WHERE b.score <= -2.5 AND a.name <> 'x' AND 7 < b.score")
+    plan = build_plan(q, ["peaks", "genes"])
+    got = [(r.clause, r.lhs.kind, r.lhs.value, r.op, r.rhs.kind, r.rhs.value) for r in plan.residuals]
+    assert got == [("on", "l", "strand", "=", "r", "strand"), ("on", "l", "score", ">=", "int", 10),
+                   ("where", "r", "score", "<=", "float", -2.5), ("where", "l", "name", "!=", "str", "x"),
+                   ("where", "int", 7, "<", "r", "score")]
+    assert JoinPlan.from_string(plan.to_string()) == plan
+    # implicit cross join: the INTERSECTS and its residuals all sit in WHERE
+    q2 = "SELECT a.start FROM peaks a, genes b WHERE a.score != b.score AND a.interval INTERSECTS b.interval"
+    p2 = build_plan(q2, ["peaks", "genes"])
+    assert p2.kind == "INNER" and [(r.clause, r.op) for r in p2.residuals] == [("where", "!=")]
+    # SEMI / ANTI keep the ON / WHERE distinction (WHERE is an outer filter, #200)
+    q3 = ("SELECT a.start FROM peaks a ANTI JOIN genes b ON a.interval INTERSECTS b.interval "
+          "AND a.strand = b.strand WHERE a.score > 1")
+    p3 = build_plan(q3, ["peaks", "genes"])
+    assert p3.kind == "ANTI" and [r.clause for r in p3.residuals] == ["on", "where"]
+    # no residuals -> empty tuple, and older plan strings without the key still load
+    bare = build_plan("SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval", ["peaks", "genes"])
+    assert bare.residuals == ()
+    assert JoinPlan.from_string(bare.to_string().replace(',"residuals":[]', "")) == bare
+
+
+@pytest.mark.parametrize("query,match", [
+    # qualifier mistakes in a residual are user errors (_validate_extra_qualifiers, :914-959)
+    ("SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND score > 5", "qualified"),
+    ("SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND c.score > 5", "unknown table"),
+    ("SELECT a.start FROM peaks a SEMI JOIN genes b ON a.interval INTERSECTS b.interval WHERE b.score > 5", "right side"),
+])
+def test_residual_qualifier_mistakes_raise_value_error(query, match):
     with pytest.raises(ValueError, match=match) as ei:
         build_plan(query, ["peaks", "genes"])
     assert not isinstance(ei.value, HipDeclined)
