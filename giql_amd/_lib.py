@@ -35,7 +35,7 @@ SYMBOLS = [
     "giql_hip_inner", "giql_hip_semi_anti", "giql_hip_count", "giql_hip_nearest",
     "giql_hip_free_host", "giql_hip_pairs_checksum_dev",
     "giql_hip_take_dev", "giql_hip_take_utf8_plan_dev", "giql_hip_take_utf8_fill_dev",
-    "giql_hip_select_dev", "giql_hip_mark_dev",
+    "giql_hip_select_dev", "giql_hip_mark_dev", "giql_hip_cluster_dev", "giql_hip_merge_dev",
 ]
 
 
@@ -166,6 +166,8 @@ def load() -> ctypes.CDLL:
     L.giql_hip_take_utf8_fill_dev.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, vp]
     L.giql_hip_select_dev.argtypes = [vp, P(CPred), i32, vp, i64, vp, i64, i64, vp, vp, P(i64), vp]
     L.giql_hip_mark_dev.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.giql_hip_cluster_dev.argtypes = [vp, P(CSide), i32, i64, vp, vp]
+    L.giql_hip_merge_dev.argtypes = [vp, P(CSide), i32, i64, vp, vp, vp, vp, i64, P(i64), vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int and name not in ("giql_hip_abi_version",):

@@ -16,6 +16,7 @@
 #include "aux_kernels.hip.h"
 #include "take_kernels.hip.h"
 #include "select_kernels.hip.h"
+#include "cluster_kernels.hip.h"
 #include "dev_common.hip.h"
 #include "join_kernels.hip.h"
 #include "onesweep.hip.h"
@@ -1041,6 +1042,157 @@ int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side*
   GIQL_TRY(read_meta(ctx, st));
   collect_spans(ctx);
   ctx->stats.n_out = a->n;
+  ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+  return GIQL_OK;
+}
+
+// ---------------------------------------------------------- CLUSTER / MERGE
+// Shared front half: keys + ends on the linear axis, sorted by start, inclusive
+// prefix max of the ends, new-cluster flags and their exclusive scan.
+struct ClusterBufs {
+  LinBufs lb;
+  SortBufs sb;
+  OsScratch os;
+  u32 *pmax = nullptr, *bmax = nullptr, *chrom_lo = nullptr, *flags = nullptr, *excl = nullptr;
+  u32* dummy_irr = nullptr;
+  u64 *bsums = nullptr, *total = nullptr;
+  u32* head_pos = nullptr;
+};
+
+static int cluster_front(giql_hip_ctx* ctx, hipStream_t st, const giql_side* s, int32_t n_chrom,
+                         int64_t distance, bool want_rids, bool want_heads, ClusterBufs& cb) {
+  const size_t n = (size_t)s->n;
+  auto carve = [&](char* base) {
+    Carver c{base};
+    common_sizes(c, n_chrom, cb.lb);
+    for (int k = 0; k < 2; k++) {
+      cb.sb.key[k] = c.take<u32>(n);
+      cb.sb.end[k] = c.take<u32>(n);
+      cb.sb.rid[k] = want_rids ? c.take<u32>(n) : nullptr;
+    }
+    os_scratch_sizes(c, n, cb.os);
+    cb.pmax = c.take<u32>(n);
+    cb.bmax = c.take<u32>(cdiv(n, PM_TILE) + 1);
+    cb.chrom_lo = c.take<u32>((size_t)n_chrom + 2);
+    cb.flags = c.take<u32>(n);
+    cb.excl = c.take<u32>(n + 1);
+    cb.bsums = c.take<u64>(cdiv((u64)n, SCAN_TILE) + 1);
+    cb.total = c.take<u64>(1);
+    cb.dummy_irr = c.take<u32>(16);
+    cb.head_pos = want_heads ? c.take<u32>(n + 1) : nullptr;
+    return c.off;
+  };
+  GIQL_TRY(ensure_arena(ctx, carve(nullptr), st));
+  carve(ctx->arena);
+  giql_side none;
+  memset(&none, 0, sizeof(none));
+  GIQL_TRY(run_spans(ctx, st, *s, none, n_chrom, cb.lb));
+  GIQL_TRY(run_linearize(ctx, st, *s, n_chrom, cb.lb, cb.sb.key[0], cb.sb.end[0], cb.dummy_irr, 0, 1,
+                         cb.os.hist, cb.os.gbase));
+  {
+    Phase ph(ctx, st, GIQL_PH_AUX);
+    hipLaunchKernelGGL(k_check_not_inverted, dim3(cdiv(n, 256)), dim3(256), 0, st, view_of(*s),
+                       ctx->d_meta);
+  }
+  GIQL_TRY(run_sort_onesweep(ctx, st, cb.sb, (u32)n, cb.os.gbase, cb.os.status, cb.os.tickets));
+  GIQL_TRY(run_pmax(ctx, st, cb.sb.end[0], (u32)n, cb.pmax, cb.bmax));
+  HIP_TRY(hipMemsetAsync(cb.flags, 0, n * sizeof(u32), st));
+  {
+    Phase ph(ctx, st, GIQL_PH_COUNT, 3);
+    hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st,
+                       cb.lb.chrom_first, n_chrom, cb.sb.key[0], (u32)n, cb.chrom_lo);
+    hipLaunchKernelGGL(k_cluster_firsts, dim3(cdiv((u64)n_chrom, 256)), dim3(256), 0, st, cb.chrom_lo,
+                       n_chrom, (u32)n, cb.flags);
+    hipLaunchKernelGGL(k_cluster_flags, dim3(cdiv(n, 256)), dim3(256), 0, st, cb.sb.key[0], cb.pmax,
+                       (u32)n, (u64)(distance > 0 ? distance : 0), cb.flags);
+    GIQL_TRY(post_launch("cluster flags"));
+  }
+  GIQL_TRY(run_scan<u32>(ctx, st, GIQL_PH_SCAN, cb.flags, (u64)n, cb.excl, cb.bsums, cb.total));
+  return GIQL_OK;
+}
+
+static int check_cluster_args(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom) {
+  if (!ctx) return set_err(GIQL_ERR_INVALID, "ctx is NULL");
+  GIQL_TRY(check_side(s, "s"));
+  if (n_chrom < 0) return set_err(GIQL_ERR_INVALID, "n_chrom < 0");
+  if (s->start_off != 0 || s->end_off != 0)
+    return set_err(GIQL_ERR_INVALID,
+                   "CLUSTER / MERGE read the raw start / end columns (cluster.py:246-263): offsets must be 0");
+  if ((size_t)s->n > OS_MAX_ROWS) return set_err(GIQL_ERR_INVALID, "side larger than 2^30 rows");
+  return GIQL_OK;
+}
+
+static int cluster_status(giql_hip_ctx* ctx, hipStream_t st) {
+  HIP_TRY(hipMemcpyAsync(ctx->h_meta, ctx->d_meta, sizeof(DevMeta), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (ctx->h_meta->status == -1)
+    return set_err(GIQL_ERR_INVALID, "CLUSTER / MERGE need start <= end on every row");
+  return read_meta(ctx, st);
+}
+
+int giql_hip_cluster_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
+                         int64_t* cluster_id_out, void* stream) {
+  GIQL_TRY(check_cluster_args(ctx, s, n_chrom));
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  ctx->planned = false;
+  reset_stats(ctx);
+  ctx->stats.n_a = s->n;
+  if (s->n == 0) return GIQL_OK;
+  if (!cluster_id_out) return set_err(GIQL_ERR_INVALID, "cluster_id_out is NULL");
+  if (n_chrom == 0) return set_err(GIQL_ERR_CHROM, "rows but n_chrom = 0");
+  ClusterBufs cb;
+  GIQL_TRY(cluster_front(ctx, st, s, n_chrom, distance, true, false, cb));
+  {
+    Phase ph(ctx, st, GIQL_PH_FILL);
+    hipLaunchKernelGGL(k_cluster_ids, dim3(cdiv((u64)s->n, 256)), dim3(256), 0, st, cb.sb.key[0],
+                       cb.sb.rid[0], cb.flags, cb.excl, (u32)s->n, cb.lb.chrom_first, n_chrom,
+                       cb.chrom_lo, (i64*)cluster_id_out);
+    GIQL_TRY(post_launch("cluster ids"));
+  }
+  GIQL_TRY(cluster_status(ctx, st));
+  collect_spans(ctx);
+  ctx->stats.n_out = s->n;
+  ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+  return GIQL_OK;
+}
+
+int giql_hip_merge_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
+                       int32_t* out_chrom, int32_t* out_start, int32_t* out_end,
+                       int64_t* out_count, int64_t capacity, int64_t* n_out, void* stream) {
+  GIQL_TRY(check_cluster_args(ctx, s, n_chrom));
+  if (!n_out) return set_err(GIQL_ERR_INVALID, "n_out is NULL");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  ctx->planned = false;
+  reset_stats(ctx);
+  ctx->stats.n_a = s->n;
+  *n_out = 0;
+  if (s->n == 0) return GIQL_OK;
+  if (!out_chrom || !out_start || !out_end) return set_err(GIQL_ERR_INVALID, "output buffer is NULL");
+  if (n_chrom == 0) return set_err(GIQL_ERR_CHROM, "rows but n_chrom = 0");
+  ClusterBufs cb;
+  GIQL_TRY(cluster_front(ctx, st, s, n_chrom, distance, false, true, cb));
+  u64 h_total = 0;
+  HIP_TRY(hipMemcpyAsync(&h_total, cb.total, sizeof(u64), hipMemcpyDeviceToHost, st));
+  GIQL_TRY(cluster_status(ctx, st));
+  if ((int64_t)h_total > capacity)
+    return set_err(GIQL_ERR_CAPACITY, "%llu merged regions, capacity %lld",
+                   (unsigned long long)h_total, (long long)capacity);
+  {
+    Phase ph(ctx, st, GIQL_PH_FILL, 2);
+    hipLaunchKernelGGL(k_merge_heads, dim3(cdiv((u64)s->n, 256)), dim3(256), 0, st, cb.flags, cb.excl,
+                       (u32)s->n, cb.head_pos);
+    if (h_total)
+      hipLaunchKernelGGL(k_merge_rows, dim3(cdiv(h_total, 256)), dim3(256), 0, st, cb.head_pos,
+                         (u32)h_total, (u32)s->n, cb.sb.key[0], cb.pmax, cb.lb.chrom_first,
+                         cb.lb.chrom_base, n_chrom, out_chrom, out_start, out_end, (i64*)out_count);
+    GIQL_TRY(post_launch("merge rows"));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  collect_spans(ctx);
+  *n_out = (int64_t)h_total;
+  ctx->stats.n_out = (int64_t)h_total;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
   return GIQL_OK;
 }

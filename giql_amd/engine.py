@@ -311,6 +311,65 @@ class HipEngine:
             idx.data_ptr() if a.n else None, dist.data_ptr() if a.n else None, self._stream()))
         return idx, dist
 
+    # --------------------------------------------------------- CLUSTER / MERGE
+    def _empty_side(self, like: DeviceSide) -> DeviceSide:
+        torch = _torch()
+        z = torch.empty(0, dtype=torch.int32, device=self.device)
+        return DeviceSide(z, z.clone(), z.clone(), 0, 0)
+
+    def cluster(self, s: DeviceSide, n_chrom: int, distance: int = 0):
+        """CLUSTER ids per row (int64, 1-based within each partition ``s.chrom``):
+        ``src/giql/expanders/cluster.py:210-300``.  Raw coordinates (offsets must be 0)."""
+        torch = _torch()
+        try:
+            return self._cluster_once(s, n_chrom, distance)
+        except _lib.GiqlHipError as exc:
+            if exc.code != _lib.GIQL_ERR_SPAN:
+                raise
+        ids = torch.zeros(s.n, dtype=torch.int64, device=self.device)
+        for sub, rows, _sb, _rb in self._groups(s, self._empty_side(s), n_chrom):
+            ids[rows] = self._cluster_once(sub, n_chrom, distance)
+        return ids
+
+    def _cluster_once(self, s: DeviceSide, n_chrom: int, distance: int):
+        torch = _torch()
+        ids = torch.empty(s.n, dtype=torch.int64, device=self.device)
+        _lib.check(self._L.giql_hip_cluster_dev(self._h, s.c_struct(), int(n_chrom), int(distance),
+                                                ids.data_ptr() if s.n else None, self._stream()))
+        return ids
+
+    def merge(self, s: DeviceSide, n_chrom: int, distance: int = 0):
+        """MERGE: ``(chrom, start, end, count)`` tensors of the merged regions ordered by
+        (chrom, start) (``src/giql/expanders/merge.py:186-330``)."""
+        torch = _torch()
+        try:
+            return self._merge_once(s, n_chrom, distance)
+        except _lib.GiqlHipError as exc:
+            if exc.code != _lib.GIQL_ERR_SPAN:
+                raise
+        parts = [self._merge_once(sub, n_chrom, distance)
+                 for sub, _rows, _sb, _rb in self._groups(s, self._empty_side(s), n_chrom)]
+        if not parts:
+            return self._merge_once(self._empty_side(s), n_chrom, distance)
+        c, st, en, cnt = (torch.cat([p[k] for p in parts]) for k in range(4))
+        order = torch.argsort(c.long() * (1 << 32) + (st.long() + (1 << 31)), stable=True)
+        return c[order], st[order], en[order], cnt[order]
+
+    def _merge_once(self, s: DeviceSide, n_chrom: int, distance: int):
+        torch = _torch()
+        n = s.n
+        c = torch.empty(n, dtype=torch.int32, device=self.device)
+        st = torch.empty(n, dtype=torch.int32, device=self.device)
+        en = torch.empty(n, dtype=torch.int32, device=self.device)
+        cnt = torch.empty(n, dtype=torch.int64, device=self.device)
+        m = ctypes.c_int64(0)
+        _lib.check(self._L.giql_hip_merge_dev(
+            self._h, s.c_struct(), int(n_chrom), int(distance), c.data_ptr() if n else None,
+            st.data_ptr() if n else None, en.data_ptr() if n else None, cnt.data_ptr() if n else None,
+            n, ctypes.byref(m), self._stream()))
+        k = int(m.value)
+        return c[:k], st[:k], en[:k], cnt[:k]
+
     # ------------------------------------------------------------- projection
     def take(self, cols, idx, outs=None):
         """Arrow ``take`` of fixed-width device columns by int32 row ids ``idx``

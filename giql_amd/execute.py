@@ -120,7 +120,7 @@ class _Residuals:
     """
 
     def __init__(self, plan: JoinPlan, lt, rt, eng: HipEngine):
-        self.plan, self.tables, self.eng = plan, {"l": lt, "r": rt}, eng
+        self.plan, self.tables, self.eng = plan, {"l": lt, "r": rt}, eng  # rt is None for CLUSTER / MERGE
         self._cache: dict = {}
 
     @staticmethod
@@ -278,6 +278,81 @@ def _join_with_residuals(plan: JoinPlan, lt, rt, a: DeviceSide, b: DeviceSide, n
     return eng.select(final, n=a.n, n_rows_a=a.n, want=("a",))[0]
 
 
+def _execute_cluster_merge(plan: JoinPlan, tables, eng: HipEngine, return_indices: bool):
+    """CLUSTER / MERGE over one table (src/giql/expanders/cluster.py:81-300,
+    src/giql/expanders/merge.py:62-330): partition ids = dictionary-encoded chrom
+    (sorted, so MERGE's ``ORDER BY chrom, start`` is the kernel's output order) with
+    the strand folded in when stranded; RAW coordinates, as the window SQL reads them."""
+    import pyarrow as pa
+    import torch
+
+    side = plan.left
+    if side.table not in tables:
+        raise ValueError(f"table {side.table!r} was not provided")
+    tbl = tables[side.table]
+    chrom = _to_numpy(_column(tbl, side.chrom_col), f"{side.table}.{side.chrom_col}")
+    start = _int32_column(_column(tbl, side.start_col), f"{side.table}.{side.start_col}")
+    end = _int32_column(_column(tbl, side.end_col), f"{side.table}.{side.end_col}")
+    chrom_dict, chrom_ids = np.unique(chrom.astype(str) if chrom.dtype.kind not in "iu" else chrom, return_inverse=True)
+    n_strand = 1
+    part = chrom_ids.astype(np.int64)
+    strand_dict = None
+    if plan.stranded:
+        strand = _to_numpy(_column(tbl, plan.strand_col), f"{side.table}.{plan.strand_col}")
+        strand_dict, strand_ids = np.unique(strand.astype(str), return_inverse=True)
+        n_strand = max(len(strand_dict), 1)
+        part = part * n_strand + strand_ids
+    n_part = len(chrom_dict) * n_strand
+    if n_part > 2**31 - 1:
+        raise ValueError("too many (chrom, strand) partitions")
+    dev_side = DeviceSide.from_numpy(part.astype(np.int32), start, end, device=eng.device)  # offsets 0: raw
+    keep = None
+    if plan.residuals:
+        keep = eng.select(_Residuals(plan, tbl, None, eng).preds(plan.residuals), n=dev_side.n,
+                          n_rows_a=dev_side.n, want=("a",))[0]
+        dev_side = _subset(eng, dev_side, keep)
+
+    if plan.kind == "CLUSTER":
+        ids = eng.cluster(dev_side, n_part, plan.distance)
+        if return_indices:
+            return (keep.cpu().numpy() if keep is not None else np.arange(dev_side.n)), ids.cpu().numpy()
+        is_arrow = isinstance(tbl, pa.Table)
+        all_cols = list(tbl.column_names) if is_arrow else list(tbl.keys() if isinstance(tbl, dict) else tbl.columns)
+        names, cols = [], []
+        want = [c for p in plan.projection for c in (all_cols if p.side == "star" else [p.column]) if p.side != "cluster"]
+        taken = None
+        if keep is not None:
+            taken = (_device_take(tbl, want, keep, eng) if is_arrow
+                     else {c: np.asarray(_column(tbl, c))[keep.cpu().numpy()] for c in want})
+        for p in plan.projection:
+            if p.side == "cluster":
+                names.append(p.name)
+                cols.append(pa.array(ids.cpu().numpy(), type=pa.int64()))
+                continue
+            for c, out_name in ([(c, c) for c in all_cols] if p.side == "star" else [(p.column, p.name)]):
+                names.append(out_name)
+                cols.append(taken[c] if taken is not None else _column(tbl, c))
+        arrays = [c if isinstance(c, (pa.Array, pa.ChunkedArray)) else pa.array(c) for c in cols]
+        return pa.Table.from_arrays(arrays, names=names)
+
+    c, s, e, cnt = (t.cpu().numpy() for t in eng.merge(dev_side, n_part, plan.distance))
+    chrom_out = chrom_dict[c // n_strand]
+    cols = {side.chrom_col: pa.array(chrom_out.tolist() if chrom_out.dtype.kind in "US" else chrom_out)}
+    if plan.stranded:
+        cols[plan.strand_col] = pa.array(strand_dict[c % n_strand].tolist())
+    cols[side.start_col] = pa.array(s, type=pa.int32())
+    cols[side.end_col] = pa.array(e, type=pa.int32())
+    for p in plan.projection:
+        if p.side == "count":
+            cols[p.name] = pa.array(cnt, type=pa.int64())
+    out = pa.table(cols)
+    if plan.stranded and out.num_rows:  # kernel order is (chrom, strand, start); SQL: ORDER BY chrom, start
+        out = out.sort_by([(side.chrom_col, "ascending"), (side.start_col, "ascending")])
+    if return_indices:
+        return c, s, e, cnt
+    return out
+
+
 def _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices):
     """count_overlaps: COUNT(b.col) per distinct left key, zero-filled
     (src/giql/expanders/intersects_duckdb.py:806-854; oracle semantics of
@@ -389,6 +464,8 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
         plan = JoinPlan.from_string(plan) if is_plan_string(plan) else build_plan(plan, giql_tables)
     if not isinstance(plan, JoinPlan):
         raise ValueError("plan must be a JoinPlan, a plan string or a GIQL query")
+    if plan.kind in ("CLUSTER", "MERGE"):
+        return _execute_cluster_merge(plan, tables, engine or default_engine(), return_indices)
     for side in (plan.left, plan.right):
         if side.table not in tables:
             raise ValueError(f"table {side.table!r} was not provided")

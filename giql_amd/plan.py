@@ -13,7 +13,7 @@ from dataclasses import asdict, dataclass, field
 
 PLAN_PREFIX = "GIQL-HIP-PLAN/1 "
 
-KINDS = ("INNER", "SEMI", "ANTI", "NEAREST", "COUNT")
+KINDS = ("INNER", "SEMI", "ANTI", "NEAREST", "COUNT", "CLUSTER", "MERGE")
 
 
 @dataclass(frozen=True)
@@ -36,7 +36,8 @@ class PlanSide:
 
 @dataclass(frozen=True)
 class Projection:
-    side: str      # "l", "r", "distance" (NEAREST) or "count" (count_overlaps aggregate)
+    side: str      # "l", "r", "distance" (NEAREST), "count" (COUNT aggregate); CLUSTER / MERGE:
+                   # "star" (every table column), "cluster" (the id), "count" (COUNT(*))
     column: str
     name: str      # output column name
 
@@ -66,7 +67,7 @@ class Residual:
 class JoinPlan:
     kind: str
     left: PlanSide
-    right: PlanSide
+    right: PlanSide | None      # None for the single-table operators (CLUSTER / MERGE)
     projection: tuple[Projection, ...] = field(default_factory=tuple)
     distinct: bool = False
     # NEAREST only (src/giql/expanders/nearest.py:240-252)
@@ -74,6 +75,10 @@ class JoinPlan:
     max_distance: int | None = None
     signed: bool = False
     residuals: tuple[Residual, ...] = field(default_factory=tuple)
+    # CLUSTER / MERGE only (src/giql/expanders/cluster.py:222-243)
+    distance: int = 0
+    stranded: bool = False
+    strand_col: str | None = None
 
     def __post_init__(self) -> None:
         if self.kind not in KINDS:
@@ -91,12 +96,14 @@ class JoinPlan:
             raise ValueError("not a GIQL hip plan string")
         d = json.loads(text[len(PLAN_PREFIX):])
         return cls(
-            kind=d["kind"], left=PlanSide(**d["left"]), right=PlanSide(**d["right"]),
+            kind=d["kind"], left=PlanSide(**d["left"]),
+            right=PlanSide(**d["right"]) if d.get("right") else None,
             projection=tuple(Projection(**p) for p in d["projection"]),
             distinct=d.get("distinct", False), k=d.get("k", 1),
             max_distance=d.get("max_distance"), signed=d.get("signed", False),
             residuals=tuple(Residual(r["clause"], Operand(**r["lhs"]), r["op"], Operand(**r["rhs"]))
-                            for r in d.get("residuals", ())))
+                            for r in d.get("residuals", ())),
+            distance=d.get("distance", 0), stranded=d.get("stranded", False), strand_col=d.get("strand_col"))
 
 
 def is_plan_string(text) -> bool:

@@ -522,8 +522,203 @@ def _literal_range_sql(p: _Parser, proj_text: str, from_ref: _TableRef, tables: 
             f"AND {q}\"{t.end_col}\" > {start})")
 
 
+def _has_cluster_or_merge(p: _Parser) -> bool:
+    depth = 0
+    for k, t in enumerate(p.toks):
+        if t.kind == "punct" and t.text in "()":
+            depth += 1 if t.text == "(" else -1
+        if t.kind == "kw" and t.text == "FROM" and depth == 0:
+            return False
+        if (t.kind == "id" and not t.quoted and t.text.upper() in ("CLUSTER", "MERGE")
+                and p.toks[k + 1].kind == "punct" and p.toks[k + 1].text == "("):
+            return True
+    return False
+
+
+def _parse_cluster_call(p: _Parser):
+    """``CLUSTER(`` / ``MERGE(`` argument list -> ``(genomic colref, distance, stranded)``;
+    named arguments accept ``:=``, ``=`` and ``=>`` (tests/test_cluster_parsing.py:22-75)."""
+    p.expect_punct("(")
+    this = None
+    distance = 0
+    stranded = False
+    n_pos = 0
+    while not p.at_punct(")"):
+        named = None
+        if p.peek().kind == "id" and (p.peek(1).kind == "assign" or (p.peek(1).kind == "punct" and p.peek(1).text == "=")):
+            named = p.next().text.lower()
+            p.next()
+            if p.at_punct(">"):
+                p.next()
+        if named is None:
+            if n_pos == 0:
+                if p.peek().kind != "id":
+                    raise ValueError("CLUSTER requires a genomic interval column as its first argument.")
+                this = p.colref()
+            elif n_pos == 1:
+                if p.peek().kind != "num" or "." in p.peek().text:
+                    raise _decline("non-literal CLUSTER / MERGE distance")
+                distance = int(p.next().text)
+            else:
+                raise _decline("more than two positional CLUSTER / MERGE arguments")
+            n_pos += 1
+        elif named == "stranded":
+            if not p.at_kw("TRUE", "FALSE"):
+                raise _decline("non-literal stranded argument")
+            stranded = p.next().text == "TRUE"
+        elif named == "distance":
+            if p.peek().kind != "num" or "." in p.peek().text:
+                raise _decline("non-literal CLUSTER / MERGE distance")
+            distance = int(p.next().text)
+        else:
+            raise _decline(f"CLUSTER / MERGE argument {named!r}")  # predicate := ... PREV(col)
+        if p.at_punct(","):
+            p.next()
+    p.expect_punct(")")
+    if this is None:
+        raise ValueError("CLUSTER requires a genomic interval column as its first argument.")
+    return this, distance, stranded
+
+
+def _lower_cluster(p: _Parser, tbls: Tables) -> JoinPlan:
+    """``SELECT <cols | *>, CLUSTER(interval[, d][, stranded := b]) AS id FROM t [WHERE ...]`` and
+    ``SELECT MERGE(interval[, d][, stranded := b]) [, COUNT(*) AS n] FROM t [WHERE ...]``
+    (src/giql/expanders/cluster.py:81-205, src/giql/expanders/merge.py:62-183).  A WHERE
+    of simple comparisons filters the rows before clustering, as in the reference, where
+    it lands inside the inner ``__giql_lag_calc`` subquery (cluster.py:404-420)."""
+    p.expect_kw("SELECT")
+    if p.at_kw("DISTINCT"):
+        raise _decline("DISTINCT with CLUSTER / MERGE")
+    items = []   # (kind, payload, alias)
+    while True:
+        t = p.peek()
+        if t.kind == "id" and not t.quoted and t.text.upper() in ("CLUSTER", "MERGE") and p.peek(1).kind == "punct" \
+                and p.peek(1).text == "(":
+            op = p.next().text.upper()
+            items.append((op, _parse_cluster_call(p)))
+        elif t.kind == "id" and not t.quoted and t.text.upper() == "COUNT" and p.peek(1).kind == "punct" \
+                and p.peek(1).text == "(":
+            p.next()
+            p.next()
+            if not p.at_punct("*"):
+                raise _decline("aggregate other than COUNT(*) beside MERGE")
+            p.next()
+            p.expect_punct(")")
+            items.append(("COUNT", None))
+        elif t.kind in ("num", "str") or p.at_punct("("):
+            raise _decline("expression in the SELECT list")
+        else:
+            ref = p.colref()
+            if p.at_punct("("):
+                raise _decline("function call in the SELECT list")
+            items.append(("COL", ref))
+        if p.peek().kind == "punct" and p.peek().text in "+-/*=<>":
+            raise _decline("expression in the SELECT list")
+        alias = None
+        if p.at_kw("AS"):
+            p.next()
+            alias = p.next().text
+        elif p.peek().kind == "id":
+            alias = p.next().text
+        items[-1] = items[-1] + (alias,)
+        if p.at_punct(","):
+            p.next()
+            continue
+        break
+    p.expect_kw("FROM")
+    if p.at_punct("("):
+        raise _decline("CLUSTER / MERGE over a sub-query")
+    ref = p.table_ref()
+    where_terms = []
+    if p.at_kw("WHERE"):
+        p.next()
+        where_terms = _parse_conjunction(p)
+        if any(t[0] != "cmp" for t in where_terms):
+            raise _decline("spatial predicate beside CLUSTER / MERGE")
+    if p.peek().kind == "kw" or p.at_punct(","):
+        raise _decline(f"{p.peek().text} clause with CLUSTER / MERGE")
+    if p.peek().kind != "end" and not p.at_punct(";"):
+        raise _decline(f"trailing input near {p.peek().text!r}")
+
+    side = _table_side(ref, tbls)
+    table = tbls.get(ref.name) or Table(ref.name)
+    ops = [it for it in items if it[0] in ("CLUSTER", "MERGE")]
+    if {it[0] for it in ops} == {"CLUSTER", "MERGE"}:
+        raise ValueError("CLUSTER and MERGE cannot be combined in one SELECT")  # reject_cluster_merge_mix
+    if len(ops) > 1:
+        raise ValueError(f"Multiple {ops[0][0]} expressions not yet supported")  # cluster.py:176-181, merge.py:173-175
+    op, (this, distance, stranded), op_alias = ops[0]
+    if this.star or (this.table is not None and _norm(this.table, this.table_quoted) != side.alias) \
+            or this.column != table.genomic_col:
+        raise ValueError(f"{op} operand must be the table's genomic column ({table.genomic_col!r})")
+    if stranded and not table.strand_col:
+        raise ValueError(f"{op}(stranded := true) needs a strand column on table {ref.name!r}")
+
+    def own(refc: _ColRef) -> str:
+        if refc.table is not None and _norm(refc.table, refc.table_quoted) != side.alias:
+            raise ValueError(f"Unknown table qualifier {refc.table!r}; expected {side.alias!r}")
+        return refc.column
+
+    proj = []
+    if op == "CLUSTER":
+        if not op_alias:
+            raise _decline("CLUSTER without an alias")
+        if sum(1 for it in items if it[0] == "COL" and it[1].star) > 1:
+            raise ValueError("CLUSTER does not support multiple star projections "
+                             "(e.g. SELECT *, *, CLUSTER(...)); project a single star")  # cluster.py:182-196
+        for kind, payload, alias in items:
+            if kind == "CLUSTER":
+                proj.append(Projection("cluster", "", op_alias))
+            elif kind == "COUNT":
+                raise _decline("aggregate beside CLUSTER")
+            elif payload.star:
+                own(payload) if payload.table else None
+                proj.append(Projection("star", "*", "*"))
+            else:
+                proj.append(Projection("l", own(payload), alias or payload.column))
+    else:
+        for kind, payload, alias in items:
+            if kind == "MERGE":
+                continue
+            if kind == "COUNT":
+                if not alias:
+                    raise _decline("COUNT(*) without an alias beside MERGE")
+                proj.append(Projection("count", "*", alias))
+            elif payload.star:
+                raise ValueError("MERGE cannot be combined with a star projection (e.g. SELECT *, MERGE(...))")  # merge.py:96-133
+            else:
+                # grouping keys (chrom, strand when stranded) are already projected by MERGE (merge.py:297-304)
+                keys = {side.chrom_col.lower()} | ({table.strand_col.lower()} if stranded else set())
+                if own(payload).lower() not in keys or (alias and alias.lower() != payload.column.lower()):
+                    raise ValueError(f"MERGE cannot project the non-aggregated column {payload.column!r}")
+        names = [pp.name.lower() for pp in proj]
+        if len(set(names)) != len(names) or set(names) & {side.chrom_col.lower(), side.start_col.lower(),
+                                                          side.end_col.lower()}:
+            raise ValueError("MERGE cannot project a column that collides with chrom/start/end")  # merge.py:317-323
+    residuals = []
+    for t in where_terms:
+        _, lhs, cmp_op, rhs = t
+
+        def bind(o) -> Operand:
+            if o[0] == "lit":
+                v = o[1]
+                return Operand("str" if isinstance(v, str) else ("float" if isinstance(v, float) else "int"), v)
+            return Operand("l", own(o[1]))
+
+        a, b = bind(lhs), bind(rhs)
+        if a.kind != "l" and b.kind != "l":
+            raise _decline("constant predicate")
+        residuals.append(Residual("where", a, cmp_op, b))
+    return JoinPlan(op, side, None, tuple(proj), residuals=tuple(residuals), distance=distance,
+                    stranded=stranded, strand_col=table.strand_col if stranded else None)
+
+
 def build_plan(giql: str, tables=None) -> JoinPlan:
-    """Parse *giql* and lower the INTERSECTS / NEAREST join to a :class:`JoinPlan`."""
+    """Parse *giql* and lower the INTERSECTS / NEAREST join (or a CLUSTER / MERGE
+    query) to a :class:`JoinPlan`."""
+    probe = _Parser(giql)
+    if probe.at_kw("SELECT") and _has_cluster_or_merge(probe):
+        return _lower_cluster(probe, tables if isinstance(tables, Tables) else build_tables(tables))
     plan = _lower(giql, tables, want_sql=False)
     assert isinstance(plan, JoinPlan)
     return plan

@@ -157,6 +157,25 @@ int giql_hip_chrom_spans_dev(giql_hip_ctx* ctx, const giql_side* a,
                              const giql_side* b, int32_t n_chrom,
                              int64_t* spans_out /* host */, void* stream);
 
+/* ---- CLUSTER / MERGE (the sort + scan operators next to the join) ---------
+ * CLUSTER: src/giql/expanders/cluster.py:210-300 -- per partition (s->chrom; the
+ * caller folds the strand into the id when stranded), rows ordered by start,
+ *   is_new = NOT (running MAX(end) of the preceding rows + distance >= start),
+ *   cluster_id = SUM(is_new) OVER (PARTITION BY chrom ORDER BY start),
+ * written per input row (1-based within the partition) to cluster_id_out[s->n].
+ * The window SQL reads the RAW columns: start_off / end_off must be 0.  Rows
+ * need start <= end (GIQL_ERR_INVALID otherwise). */
+int giql_hip_cluster_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom,
+                         int64_t distance, int64_t* cluster_id_out, void* stream);
+/* MERGE: src/giql/expanders/merge.py:186-330 -- GROUP BY chrom, cluster id ->
+ * chrom, MIN(start), MAX(end) [, COUNT(*) when out_count != NULL], ordered by
+ * (chrom, start).  Outputs have `capacity` entries (s->n always suffices);
+ * *n_out receives the number of merged regions. */
+int giql_hip_merge_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom,
+                       int64_t distance, int32_t* out_chrom, int32_t* out_start,
+                       int32_t* out_end, int64_t* out_count, int64_t capacity,
+                       int64_t* n_out, void* stream);
+
 /* ---- projection materialisation (Arrow `take` by the join's row ids) ------
  * Replaces the outer SELECT that rebuilds the projected columns of both sides
  * around the per-chromosome join, src/giql/expanders/intersects_duckdb.py:

@@ -565,3 +565,113 @@ uint64_t ora_pairs_checksum(const int32_t* row_a, const int32_t* row_b,
   }
   return acc;
 }
+
+
+/* ------------------------------------------------------------------ CLUSTER / MERGE
+ * Restates the window SQL of src/giql/expanders/cluster.py:210-300 and the GROUP BY of
+ * src/giql/expanders/merge.py:186-330 on raw coordinates. */
+typedef struct {
+  int32_t chrom, start, end;
+  int64_t row;
+} ora_crow;
+
+static int ora_crow_cmp(const void* x, const void* y) {
+  const ora_crow* a = (const ora_crow*)x;
+  const ora_crow* b = (const ora_crow*)y;
+  if (a->chrom != b->chrom) return a->chrom < b->chrom ? -1 : 1;
+  if (a->start != b->start) return a->start < b->start ? -1 : 1;
+  return a->row < b->row ? -1 : (a->row > b->row ? 1 : 0); /* stable */
+}
+
+/* sorted rows + per-row is_new flag; returns the sorted array (caller frees) */
+static ora_crow* ora_cluster_flags(const ora_side* s, int64_t distance, uint8_t** flags_out) {
+  const int64_t n = s->n;
+  ora_crow* r = (ora_crow*)malloc((size_t)(n > 0 ? n : 1) * sizeof(ora_crow));
+  uint8_t* f = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));
+  if (!r || !f) {
+    free(r);
+    free(f);
+    return NULL;
+  }
+  for (int64_t i = 0; i < n; i++) {
+    r[i].chrom = s->chrom[i];
+    r[i].start = s->start[i];
+    r[i].end = s->end[i];
+    r[i].row = i;
+  }
+  qsort(r, (size_t)n, sizeof(ora_crow), ora_crow_cmp);
+  int64_t run_max = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (i == 0 || r[i].chrom != r[i - 1].chrom) {
+      f[i] = 1; /* MAX over an empty frame is NULL -> CASE default 1 */
+    } else {
+      f[i] = (run_max + distance >= (int64_t)r[i].start) ? 0 : 1;
+    }
+    if (i == 0 || r[i].chrom != r[i - 1].chrom || (int64_t)r[i].end > run_max) run_max = r[i].end;
+  }
+  *flags_out = f;
+  return r;
+}
+
+int ora_cluster(const ora_side* s, int64_t distance, int64_t* ids) {
+  uint8_t* f = NULL;
+  ora_crow* r = ora_cluster_flags(s, distance, &f);
+  if (!r) return -1;
+  const int64_t n = s->n;
+  int64_t i = 0;
+  int64_t sum = 0;
+  while (i < n) {
+    if (i == 0 || r[i].chrom != r[i - 1].chrom) sum = 0;
+    /* peers: rows of this partition with the same start share SUM(...) (RANGE frame) */
+    int64_t j = i;
+    while (j < n && r[j].chrom == r[i].chrom && r[j].start == r[i].start) sum += f[j++];
+    for (int64_t k = i; k < j; k++) ids[r[k].row] = sum;
+    i = j;
+  }
+  free(r);
+  free(f);
+  return 0;
+}
+
+int ora_merge(const ora_side* s, int64_t distance, int64_t* n_out, int32_t** chrom,
+              int32_t** start, int32_t** end, int64_t** count) {
+  const int64_t n = s->n;
+  int64_t* ids = (int64_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+  if (!ids || ora_cluster(s, distance, ids) != 0) {
+    free(ids);
+    return -1;
+  }
+  /* GROUP BY chrom, cluster id over the (chrom, start)-sorted rows: the ids are
+   * non-decreasing along that order, so groups are runs */
+  uint8_t* f = NULL;
+  ora_crow* r = ora_cluster_flags(s, distance, &f);
+  if (!r) {
+    free(ids);
+    return -1;
+  }
+  int64_t m = 0;
+  for (int64_t i = 0; i < n; i++)
+    if (i == 0 || r[i].chrom != r[i - 1].chrom || ids[r[i].row] != ids[r[i - 1].row]) m++;
+  *chrom = (int32_t*)malloc((size_t)(m > 0 ? m : 1) * sizeof(int32_t));
+  *start = (int32_t*)malloc((size_t)(m > 0 ? m : 1) * sizeof(int32_t));
+  *end = (int32_t*)malloc((size_t)(m > 0 ? m : 1) * sizeof(int32_t));
+  *count = (int64_t*)malloc((size_t)(m > 0 ? m : 1) * sizeof(int64_t));
+  int64_t g = -1;
+  for (int64_t i = 0; i < n; i++) {
+    if (i == 0 || r[i].chrom != r[i - 1].chrom || ids[r[i].row] != ids[r[i - 1].row]) {
+      g++;
+      (*chrom)[g] = r[i].chrom;
+      (*start)[g] = r[i].start;
+      (*end)[g] = r[i].end;
+      (*count)[g] = 0;
+    }
+    if (r[i].start < (*start)[g]) (*start)[g] = r[i].start;
+    if (r[i].end > (*end)[g]) (*end)[g] = r[i].end;
+    (*count)[g]++;
+  }
+  *n_out = m;
+  free(r);
+  free(f);
+  free(ids);
+  return 0;
+}

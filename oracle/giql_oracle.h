@@ -70,6 +70,21 @@ int ora_nearest_k1_sweep(const ora_side* a, const ora_side* b, int is_signed,
                          int64_t max_distance, int n_threads, int32_t* idx_b,
                          int64_t* dist);
 
+/* CLUSTER (src/giql/expanders/cluster.py:210-300): per partition (chrom ids here;
+ * the caller folds strand into the id when stranded), rows ordered by RAW start
+ * (no canonicalisation: the emitted window SQL reads the raw columns), stable;
+ *   is_new = NOT (MAX(end) over the preceding rows + distance >= start)   (first row: new)
+ *   cluster_id = SUM(is_new) OVER (PARTITION BY chrom ORDER BY start)      -- RANGE frame:
+ *   rows with equal start are peers and share the sum.
+ * ids[i] (1-based within the partition) is written for every input row. */
+int ora_cluster(const ora_side* s, int64_t distance, int64_t* ids);
+
+/* MERGE (src/giql/expanders/merge.py:186-330): GROUP BY chrom, cluster id ->
+ * chrom, MIN(start), MAX(end), COUNT(*); ORDER BY chrom, start.  Outputs are
+ * malloc'ed arrays of *n_out entries (ora_free). */
+int ora_merge(const ora_side* s, int64_t distance, int64_t* n_out, int32_t** chrom,
+              int32_t** start, int32_t** end, int64_t** count);
+
 /* Order-independent 64-bit checksum of a pair multiset. */
 uint64_t ora_pairs_checksum(const int32_t* row_a, const int32_t* row_b,
                             int64_t n);

@@ -180,6 +180,9 @@ def lib() -> ctypes.CDLL:
                                            ctypes.c_void_p, ctypes.c_void_p]
         L.ora_nearest_k1_sweep.argtypes = [P(_CSide), P(_CSide), ctypes.c_int, ctypes.c_int64,
                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.ora_cluster.argtypes = [P(_CSide), ctypes.c_int64, ctypes.c_void_p]
+        L.ora_merge.argtypes = [P(_CSide), ctypes.c_int64, P(ctypes.c_int64), P(ctypes.c_void_p),
+                                P(ctypes.c_void_p), P(ctypes.c_void_p), P(ctypes.c_void_p)]
         L.ora_pairs_checksum.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
         L.ora_pairs_checksum.restype = ctypes.c_uint64
         L.ora_free.argtypes = [ctypes.c_void_p]
@@ -261,6 +264,65 @@ def c_nearest_k1(a: Side, b: Side, signed=False, max_distance=None, method="swee
     if rc:
         raise RuntimeError(f"oracle nearest failed rc={rc}")
     return idx, dist
+
+
+def py_cluster(s: Side, distance: int = 0) -> np.ndarray:
+    """CLUSTER ids per row: the window SQL of src/giql/expanders/cluster.py:210-300 in
+    plain Python (raw coordinates; stable order by (chrom, start); peers share the SUM)."""
+    order = sorted(range(s.n), key=lambda i: (int(s.chrom[i]), int(s.start[i]), i))
+    ids = np.zeros(s.n, np.int64)
+    flags = {}
+    run_max = None
+    prev_c = None
+    for i in order:
+        c = int(s.chrom[i])
+        if c != prev_c:
+            flags[i] = 1
+            run_max = int(s.end[i])
+        else:
+            flags[i] = 0 if run_max + distance >= int(s.start[i]) else 1
+            run_max = max(run_max, int(s.end[i]))
+        prev_c = c
+    for i in order:  # SUM(...) OVER (PARTITION BY chrom ORDER BY start): RANGE frame, peers included
+        ids[i] = sum(flags[j] for j in order
+                     if int(s.chrom[j]) == int(s.chrom[i]) and int(s.start[j]) <= int(s.start[i]))
+    return ids
+
+
+def py_merge(s: Side, distance: int = 0):
+    """MERGE rows ``(chrom, start, end, count)`` ordered by (chrom, start)
+    (src/giql/expanders/merge.py:186-330 over py_cluster's ids)."""
+    ids = py_cluster(s, distance)
+    groups = {}
+    for i in range(s.n):
+        k = (int(s.chrom[i]), int(ids[i]))
+        g = groups.setdefault(k, [int(s.start[i]), int(s.end[i]), 0])
+        g[0] = min(g[0], int(s.start[i]))
+        g[1] = max(g[1], int(s.end[i]))
+        g[2] += 1
+    return sorted((c, g[0], g[1], g[2]) for (c, _), g in groups.items())
+
+
+def c_cluster(s: Side, distance: int = 0) -> np.ndarray:
+    ids = np.zeros(s.n, np.int64)
+    rc = lib().ora_cluster(ctypes.byref(_cside(s)), int(distance), ids.ctypes.data)
+    if rc != 0:
+        raise MemoryError("ora_cluster")
+    return ids
+
+
+def c_merge(s: Side, distance: int = 0):
+    n = ctypes.c_int64(0)
+    pc, ps, pe, pn = (ctypes.c_void_p() for _ in range(4))
+    rc = lib().ora_merge(ctypes.byref(_cside(s)), int(distance), ctypes.byref(n), ctypes.byref(pc),
+                         ctypes.byref(ps), ctypes.byref(pe), ctypes.byref(pn))
+    if rc != 0:
+        raise MemoryError("ora_merge")
+    m = int(n.value)
+    cnt = (np.ctypeslib.as_array(ctypes.cast(pn, ctypes.POINTER(ctypes.c_int64)), shape=(m,)).copy()
+           if m else np.zeros(0, np.int64))
+    lib().ora_free(pn)
+    return _take(pc, m), _take(ps, m), _take(pe, m), cnt
 
 
 def c_pairs_checksum(row_a: np.ndarray, row_b: np.ndarray) -> int:

@@ -25,6 +25,13 @@ Two fixture files are written:
       generation time, inside the ``ORDER BY ABS(distance), start, end LIMIT k``
       wrapper of src/giql/expanders/nearest.py:387-396.
 
+``cluster_merge.json``
+    CLUSTER / MERGE: known answers transcribed from the reference's tests, plus seeded
+    random inputs whose cluster ids and merged regions are minted by sqlite3
+    executing the two-level window SQL the reference emits
+    (src/giql/expanders/cluster.py:210-420, src/giql/expanders/merge.py:186-330;
+    fragments pinned by tests/expanders/test_cluster.py:149-184).
+
 The reference tree cannot travel to the GPU box, so only the JSON (data) is
 committed; this script is the provenance record.
 """
@@ -318,6 +325,79 @@ def fuzz_cases(distance_mod):
     return cases
 
 
+# ------------------------------------------------------------- CLUSTER / MERGE
+def cluster_sql(distance: int, stranded: bool) -> str:
+    """The two-level window form src/giql/expanders/cluster.py:210-420 emits; fragments
+    pinned by tests/expanders/test_cluster.py:149-184 and
+    tests/test_cluster_predicate_transpilation.py:33-36."""
+    part = 'PARTITION BY "chrom"' + (', "strand"' if stranded else "")
+    window = f'OVER ({part} ORDER BY "start" NULLS LAST ROWS BETWEEN UNBOUNDED PRECEDING AND 1 PRECEDING)'
+    edge = f'MAX("end") {window}' + (f" + {distance}" if distance > 0 else "")
+    inner = (f'SELECT *, CASE WHEN {edge} >= "start" THEN 0 ELSE 1 END AS __giql_is_new_cluster '
+             "FROM features")
+    return (f'SELECT *, SUM(__giql_is_new_cluster) OVER ({part} ORDER BY "start" NULLS LAST) '
+            f"AS __giql_cluster_id FROM ({inner}) AS __giql_lag_calc")
+
+
+def run_sqlite_cluster(rows, distance, stranded):
+    conn = sqlite3.connect(":memory:")
+    conn.execute('CREATE TABLE features (rid INTEGER, chrom TEXT, "start" INTEGER, "end" INTEGER, strand TEXT)')
+    conn.executemany("INSERT INTO features VALUES (?, ?, ?, ?, ?)",
+                     [(i, r[0], r[1], r[2], r[3]) for i, r in enumerate(rows)])
+    csql = cluster_sql(distance, stranded)
+    ids = conn.execute(f"SELECT rid, __giql_cluster_id FROM ({csql}) ORDER BY rid").fetchall()
+    keys = '"chrom"' + (', "strand"' if stranded else "")
+    # src/giql/expanders/merge.py:186-330: GROUP BY chrom[, strand], cluster id; ORDER BY chrom, start
+    merged = conn.execute(
+        f'SELECT {keys}, MIN("start") AS "start", MAX("end") AS "end", COUNT(*) FROM ({csql}) AS __giql_clustered '
+        f'GROUP BY {keys}, __giql_cluster_id ORDER BY "chrom", "start"' + (', "strand"' if stranded else "")).fetchall()
+    conn.close()
+    return [r[1] for r in ids], [list(r) for r in merged]
+
+
+def cluster_merge_cases():
+    rng = random.Random(20261004)
+    cases = []
+
+    def known(name, src, rows, ids=None, merged=None, same=None, distinct=None):
+        cases.append({"kind": "known", "name": name, "source": src, "rows": [list(r) for r in rows],
+                      "distance": 0, "stranded": False, "ids": ids, "merged": merged,
+                      "same": same, "distinct": distinct})
+
+    P = "+"
+    known("cluster_shared_ids", "tests/integration/datafusion/test_cross_target_oracle.py:978-1003",
+          [("chr1", 100, 200, P), ("chr1", 150, 300, P), ("chr1", 5000, 6000, P)], ids=[1, 1, 2])
+    known("merge_collapses_overlapping", "tests/integration/datafusion/test_cross_target_oracle.py:1196-1217",
+          [("chr1", 100, 200, P), ("chr1", 150, 300, P), ("chr1", 5000, 6000, P)],
+          merged=[["chr1", 100, 300], ["chr1", 5000, 6000]])
+    known("merge_empty", "tests/integration/datafusion/test_cross_target_oracle.py:1219-1236", [], ids=[], merged=[])
+    known("cluster_basic", "tests/integration/bedtools/test_cluster.py:15-66",
+          [("chr1", 100, 200, P), ("chr1", 150, 250, P), ("chr1", 400, 500, P)], same=[[0, 1]], distinct=[[0, 2]])
+    known("cluster_contained", "tests/integration/bedtools/test_cluster.py:69-113",
+          [("chr1", 0, 1000, P), ("chr1", 100, 200, P), ("chr1", 300, 400, P)], same=[[0, 1], [1, 2]])
+    known("cluster_separated", "tests/integration/bedtools/test_cluster.py:116-160",
+          [("chr1", 100, 200, P), ("chr1", 300, 400, P), ("chr1", 500, 600, P)], distinct=[[0, 1], [1, 2], [0, 2]])
+
+    def rows(n, chroms, max_start, max_len):
+        return [(c, s, s + rng.randint(1, max_len), rng.choice("+-"))
+                for c, s in ((rng.choice(chroms), rng.randint(0, max_start)) for _ in range(n))]
+
+    idx = 0
+    for stranded in (False, True):
+        for distance in (0, 10, 100):
+            for (n, ms, ml) in [(0, 10, 5), (1, 10, 5), (12, 200, 40), (60, 600, 50), (80, 200, 30),
+                                (40, 1_000_000, 200_000)]:
+                r = rows(n, ["chr1", "chr2", "chr3"], ms, ml)
+                # fixtures of tests/integration/bedtools/test_merge.py:15-110 ride along as rows
+                if n == 12:
+                    r += [("chr1", 100, 200, P), ("chr1", 200, 300, P), ("chr1", 300, 400, P)]
+                ids, merged = run_sqlite_cluster(r, distance, stranded)
+                cases.append({"kind": "sqlite", "name": f"fuzz_cluster_{idx}", "rows": [list(x) for x in r],
+                              "distance": distance, "stranded": stranded, "ids": ids, "merged": merged})
+                idx += 1
+    return cases
+
+
 def main() -> None:
     distance_mod = _load_by_path(
         "_ref_distance", os.path.join(REF, "src/giql/expanders/_distance.py"))
@@ -335,7 +415,12 @@ def main() -> None:
         json.dump(known_answers(), f, indent=1)
     with open(os.path.join(HERE, "fuzz_sqlite.json"), "w") as f:
         json.dump(fuzz_cases(distance_mod), f)
-    print("wrote known_answers.json, fuzz_sqlite.json")
+    # CLUSTER / MERGE: self-check the window SQL against the reference's known answers first
+    ids, merged = run_sqlite_cluster([("chr1", 100, 200, "+"), ("chr1", 150, 300, "+"), ("chr1", 5000, 6000, "+")], 0, False)
+    assert ids == [1, 1, 2] and [m[:3] for m in merged] == [["chr1", 100, 300], ["chr1", 5000, 6000]], (ids, merged)
+    with open(os.path.join(HERE, "cluster_merge.json"), "w") as f:
+        json.dump(cluster_merge_cases(), f)
+    print("wrote known_answers.json, fuzz_sqlite.json, cluster_merge.json")
 
 
 if __name__ == "__main__":

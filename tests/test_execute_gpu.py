@@ -288,6 +288,76 @@ def test_residual_null_operands_never_match_and_type_mismatch_raises(peaks_genes
         execute(transpile(bad, tables=["peaks", "genes"], dialect="hip"), t)
 
 
+def test_cluster_query_known_answers():
+    # tests/integration/datafusion/test_cross_target_oracle.py:978-1003 and
+    # tests/integration/bedtools/test_cluster.py:69-113 (contained intervals share one cluster)
+    t = {"peaks": make_table([("chr1", 100, 200, "a", 0, "+"), ("chr1", 150, 300, "b", 0, "+"),
+                              ("chr1", 5000, 6000, "c", 0, "+")])}
+    q = 'SELECT chrom, start, "end", CLUSTER(interval) AS cid FROM peaks'
+    got = rows_of(execute(transpile(q, tables=["peaks"], dialect="hip"), t))
+    assert got == [("chr1", 100, 200, 1), ("chr1", 150, 300, 1), ("chr1", 5000, 6000, 2)]
+    t2 = {"intervals": make_table([("chr1", 0, 1000, "i1", 100, "+"), ("chr1", 100, 200, "i2", 150, "+"),
+                                   ("chr1", 300, 400, "i3", 200, "+")])}
+    star = execute(transpile("SELECT *, CLUSTER(interval) AS cluster_id FROM intervals", tables=["intervals"],
+                             dialect="hip"), t2)
+    assert star.column_names == ["chrom", "start", "end", "name", "score", "strand", "cluster_id"]
+    assert set(star.column("cluster_id").to_pylist()) == {1}
+
+
+def test_merge_query_known_answers():
+    # tests/integration/datafusion/test_cross_target_oracle.py:1196-1236;
+    # tests/integration/bedtools/test_merge.py:15-43 (book-ended half-open intervals merge)
+    t = {"peaks": make_table([("chr1", 100, 200, "a", 0, "+"), ("chr1", 150, 300, "b", 0, "+"),
+                              ("chr1", 5000, 6000, "c", 0, "+")])}
+    plan = transpile("SELECT MERGE(interval) FROM peaks", tables=["peaks"], dialect="hip")
+    out = execute(plan, t)
+    assert out.column_names == ["chrom", "start", "end"]
+    assert [tuple(d.values()) for d in out.to_pylist()] == [("chr1", 100, 300), ("chr1", 5000, 6000)]
+    assert execute(plan, {"peaks": make_table([])}).num_rows == 0
+    t2 = {"intervals": make_table([("chr1", 100, 200, "i1", 0, "+"), ("chr1", 200, 300, "i2", 0, "+"),
+                                   ("chr1", 300, 400, "i3", 0, "+")])}
+    out2 = execute(transpile("SELECT MERGE(interval), COUNT(*) AS n FROM intervals", tables=["intervals"],
+                             dialect="hip"), t2)
+    assert [tuple(d.values()) for d in out2.to_pylist()] == [("chr1", 100, 400, 3)]
+
+
+def test_cluster_and_merge_stranded_distance_and_where_vs_brute_force():
+    rng = np.random.default_rng(99)
+    rows = _rows(400, "f", rng)
+    t = {"features": make_table(rows)}
+    def brute(rows_in, distance, stranded):
+        ids, merged = {}, []
+        parts = {}
+        for i, r in enumerate(rows_in):
+            parts.setdefault((r[0], r[5]) if stranded else (r[0],), []).append(i)
+        for key, idx in parts.items():
+            idx.sort(key=lambda i: (rows_in[i][1], i))
+            cid, run_max = 0, None
+            for i in idx:
+                if run_max is None or run_max + distance < rows_in[i][1]:
+                    cid += 1
+                    merged.append([key, rows_in[i][1], rows_in[i][2], 0])
+                    run_max = rows_in[i][2]
+                run_max = max(run_max, rows_in[i][2])
+                merged[-1][2] = max(merged[-1][2], rows_in[i][2])
+                merged[-1][3] += 1
+                ids[i] = cid
+        return ids, merged
+    for distance, stranded in [(0, False), (25, True), (300, False)]:
+        arg = f"interval, {distance}" + (", stranded := true" if stranded else "")
+        q = f'SELECT name, start, CLUSTER({arg}) AS cid FROM features WHERE score >= 2'
+        kept = [r for r in rows if r[4] >= 2]
+        ids, merged = brute(kept, distance, stranded)
+        got = rows_of(execute(transpile(q, tables=["features"], dialect="hip"), t))
+        assert got == sorted((r[3], r[1], ids[i]) for i, r in enumerate(kept))
+        qm = f"SELECT MERGE({arg}), COUNT(*) AS n FROM features WHERE score >= 2"
+        out = execute(transpile(qm, tables=["features"], dialect="hip"), t)
+        want = sorted(tuple(k) + (s, e, n) for k, s, e, n in merged)
+        assert sorted(tuple(d.values()) for d in out.to_pylist()) == want
+        starts = list(zip(out.column("chrom").to_pylist(), out.column("start").to_pylist()))
+        assert starts == sorted(starts)  # ORDER BY chrom, start (merge.py:20)
+
+
 def test_device_projection_matches_host_projection_for_every_column_type():
     # the projected columns are gathered on the GPU (giql_hip_take_*); same rows as pyarrow.take
     rng = np.random.default_rng(11)

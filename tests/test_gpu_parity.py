@@ -591,3 +591,55 @@ def test_select_rejects_bad_ids_and_mark_flags(eng):
     assert flags.cpu().tolist() == [0, 0, 0, 1, 0, 0, 0, 1, 0]
     with pytest.raises(GiqlHipError):
         eng.mark(torch.tensor([9], dtype=torch.int32).cuda(), 9)
+
+
+# ------------------------------------------------------------------ CLUSTER / MERGE
+CLUSTER = G.load("cluster_merge.json")
+
+
+def _gpu_cluster_merge(eng, side, n_parts, distance):
+    d = dev(side)
+    ids = eng.cluster(d, n_parts, distance).cpu().numpy()
+    c, s, e, n = (t.cpu().numpy() for t in eng.merge(d, n_parts, distance))
+    return ids, list(zip(c, s, e, n))
+
+
+@pytest.mark.parametrize("case", CLUSTER, ids=lambda c: c["name"])
+def test_cluster_merge_golden(eng, case):
+    side, parts = G.cluster_side(case)
+    ids, merged = _gpu_cluster_merge(eng, side, len(parts), case["distance"])
+    G.check_cluster_case(case, ids, merged)
+
+
+@pytest.mark.parametrize("n,distance", [(1, 0), (5000, 0), (200_000, 0), (200_000, 75), (1_000_000, 1000)])
+def test_cluster_merge_random_vs_oracle(eng, n, distance):
+    rng = np.random.default_rng(n + distance)
+    chrom = rng.integers(0, 5, n).astype(np.int32)
+    start = rng.integers(0, 3_000_000, n).astype(np.int32)
+    side = ora.Side(chrom, start, start + rng.integers(0, 400, n).astype(np.int32))  # zero-length rows too
+    ids, merged = _gpu_cluster_merge(eng, side, 5, distance)
+    assert np.array_equal(ids, ora.c_cluster(side, distance))
+    c, s, e, cnt = ora.c_merge(side, distance)
+    assert merged == list(zip(c, s, e, cnt))
+
+
+def test_cluster_merge_edge_cases(eng):
+    from giql_amd._lib import GiqlHipError
+
+    empty = ora.Side(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    ids, merged = _gpu_cluster_merge(eng, empty, 0, 0)
+    assert ids.size == 0 and merged == []
+    # duplicates, contained intervals, book-ended rows, a chromosome with one row, INT32_MAX ends
+    rows = [(0, 10, 20)] * 3 + [(0, 0, 1000), (0, 20, 30), (0, 1000, 1001), (0, 1002, 1003), (2, 5, 2**31 - 1),
+            (1, 7, 7), (1, 7, 9), (1, 8, 8)]
+    side = ora.Side(*(np.array([r[k] for r in rows], np.int32) for k in range(3)))
+    ids, merged = _gpu_cluster_merge(eng, side, 3, 0)
+    assert np.array_equal(ids, ora.c_cluster(side, 0))
+    assert merged == list(zip(*ora.c_merge(side, 0)))
+    ids1, _ = _gpu_cluster_merge(eng, side, 3, 1)
+    assert np.array_equal(ids1, ora.c_cluster(side, 1)) and ids1[6] == ids1[5]  # gap of 1 bridged by distance 1
+    inverted = ora.Side(np.zeros(2, np.int32), np.array([5, 50], np.int32), np.array([9, 40], np.int32))
+    with pytest.raises(GiqlHipError):
+        eng.cluster(dev(inverted), 1, 0)
+    with pytest.raises(GiqlHipError):
+        eng.merge(dev(inverted), 1, 0)

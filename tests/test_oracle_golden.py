@@ -124,3 +124,17 @@ def test_sweep_matches_brute_on_larger_random():
     i2, d2 = ora.c_nearest_k1(a, b, method="sweep")
     assert np.array_equal(d1, d2)
     assert np.array_equal(b.start[i1], b.start[i2]) and np.array_equal(b.end[i1], b.end[i2])
+
+
+# ------------------------------------------------------------- CLUSTER / MERGE
+CLUSTER = G.load("cluster_merge.json")
+
+
+@pytest.mark.parametrize("case", CLUSTER, ids=lambda c: c["name"])
+def test_cluster_merge_golden(case):
+    side, _ = G.cluster_side(case)
+    d = case["distance"]
+    c, s, e, n = ora.c_merge(side, d)
+    G.check_cluster_case(case, ora.c_cluster(side, d), list(zip(c, s, e, n)))
+    if side.n <= 80:
+        G.check_cluster_case(case, ora.py_cluster(side, d), ora.py_merge(side, d))

@@ -167,6 +167,43 @@ def test_residual_qualifier_mistakes_raise_value_error(query, match):
     assert not isinstance(ei.value, HipDeclined)
 
 
+def test_cluster_and_merge_shapes():
+    # src/giql/expanders/cluster.py:81-205 / merge.py:62-183; argument spellings of
+    # tests/test_cluster_parsing.py:22-75
+    p = build_plan("SELECT *, CLUSTER(interval) AS cluster_id FROM peaks", ["peaks"])
+    assert (p.kind, p.right, p.distance, p.stranded) == ("CLUSTER", None, 0, False)
+    assert [(x.side, x.name) for x in p.projection] == [("star", "*"), ("cluster", "cluster_id")]
+    for spelling in ("stranded := true", "stranded = true", "stranded => true"):
+        q = f'SELECT chrom, start, "end", CLUSTER(interval, 1000, {spelling}) AS cid FROM peaks p WHERE p.score > 3'
+        p = build_plan(q, ["peaks"])
+        assert (p.distance, p.stranded, p.strand_col, len(p.residuals)) == (1000, True, "strand", 1)
+        assert JoinPlan.from_string(p.to_string()) == p
+    m = build_plan("SELECT MERGE(interval, 100), COUNT(*) AS n FROM peaks", ["peaks"])
+    assert (m.kind, m.distance, [(x.side, x.name) for x in m.projection]) == ("MERGE", 100, [("count", "n")])
+    assert build_plan("SELECT chrom, MERGE(interval) FROM peaks", ["peaks"]).projection == ()
+
+
+@pytest.mark.parametrize("query,exc,match", [
+    ("SELECT *, MERGE(interval) FROM peaks", ValueError, "star projection"),                   # merge.py:96-133
+    ("SELECT CLUSTER(interval) AS a, CLUSTER(interval, 5) AS b FROM peaks", ValueError, "Multiple CLUSTER"),
+    ("SELECT MERGE(interval), MERGE(interval, 5) FROM peaks", ValueError, "Multiple MERGE"),
+    ("SELECT CLUSTER(interval) AS a, MERGE(interval) FROM peaks", ValueError, "cannot be combined"),
+    ("SELECT score, MERGE(interval) FROM peaks", ValueError, "non-aggregated"),              # merge.py:279-296
+    ("SELECT *, *, CLUSTER(interval) AS c FROM peaks", ValueError, "multiple star"),          # cluster.py:182-196
+    ("SELECT CLUSTER(stranded := true) AS c FROM peaks", ValueError, "genomic interval column"),
+    ("SELECT *, CLUSTER(start) AS c FROM peaks", ValueError, "genomic column"),
+    ("SELECT *, CLUSTER(interval, predicate := depth = PREV(depth)) AS c FROM peaks", HipDeclined, "predicate"),
+    ("SELECT *, CLUSTER(interval) AS c FROM peaks ORDER BY chrom", HipDeclined, "ORDER"),
+    ("SELECT *, CLUSTER(interval) FROM peaks", HipDeclined, "alias"),
+    ("SELECT MERGE(interval), SUM(score) AS s FROM peaks", HipDeclined, "function call"),
+])
+def test_cluster_merge_mistakes_and_declines(query, exc, match):
+    with pytest.raises(exc, match=match) as ei:
+        build_plan(query, ["peaks"])
+    if exc is ValueError:
+        assert not isinstance(ei.value, HipDeclined)
+
+
 COUNT_Q = ('SELECT a.chrom, a.start, a."end", COUNT(b.chrom) AS n FROM peaks a '
            'LEFT JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom, a.start, a."end"')
 

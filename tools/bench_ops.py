@@ -100,6 +100,11 @@ def main():
         data = torch.from_numpy(np.frombuffer(arr.buffers()[2], np.uint8).copy()).to(dev)
         run("take_utf8_13B", lambda: eng.take_utf8(off, data, rb)[0], p * (4 + 8 + 4 + 13 + 13) / 1e9, "GB")
         del ra, rb, off, data
+    # ---- CLUSTER / MERGE: 10M peaks, 24 chromosomes
+    if not args.only or "cluster" in args.only or "merge" in args.only:
+        a = side(synth.make_table(10_000_000, 7, "peaks"))
+        run("cluster_10M", lambda: eng.cluster(a, 24, 0), 10_000_000, "input_rows")
+        run("merge_10M", lambda: eng.merge(a, 24, 0)[0], 10_000_000, "input_rows")
     # ---- cfg 3
     a = side(synth.make_table(1_000_000, 3, "peaks"))
     b = side(synth.make_table(10_000_000, 4, "reads"))
