@@ -92,7 +92,10 @@ struct giql_hip_ctx {
   bool classic_sort = false;  // GIQL_HIP_SORT=classic: three-launch radix passes
   int os_variant = 0;         // GIQL_HIP_OS_VARIANT: onesweep block shape (tuning)
   bool no_uniform = false;    // GIQL_HIP_NO_UNIFORM=1: always run the general two-class join
-  int n_cu = 256;             // compute units of the device (persistent grids)
+  int n_cu = 256;             // compute units of the device
+  int os_order = 2;           // onesweep tile order (GIQL_HIP_OS_ORDER, see k_onesweep)
+  int inject_timeout = 0;     // test hook: report one look-back timeout
+  int order_fallbacks = 0;    // calls repeated in the ticket order after a timeout
 
   // profiling
   bool profiling = false;
@@ -306,21 +309,25 @@ static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, 
   return post_launch("linearize");
 }
 
-// Onesweep LSD sort (4 passes, one launch each); input and result in buffer 0.
-// status: cdiv(n, OS_MIN_TILE) * 256 words per pass (4 passes, zeroed here in one
-// memset); tickets: 4 words.
-// Payload of a sort = which of end / rid buffers the SortBufs carries.
+// Onesweep LSD sort (4 passes, one launch each); input and result in
+// buffer 0.  Payload of a sort = which of end / rid buffers the SortBufs carries.
+// status words of ONE pass: a {flag,count} word per (tile, digit) + the ticket word
+static inline size_t os_pass_words(size_t n) {
+  return (size_t)cdiv(n ? n : 1, OS_MIN_TILE) * OS_BINS + 16;
+}
+
 template <int NT, int ITEMS>
-static void launch_onesweep(hipStream_t st, SortBufs& sb, int src, int dst, bool first, u32 n,
-                            int shift, const u32* gbase, u32* status, u32* ticket, DevMeta* meta) {
-  const u32 n_tiles = cdiv(n, NT * ITEMS);
+static void launch_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, int src, int dst, bool first,
+                            u32 n, int shift, const u32* gbase, u32* status, DevMeta* meta) {
+  const u32 grid = cdiv(n, NT * ITEMS);  // one block per tile
+  u32* claim = status + (size_t)cdiv(n, OS_MIN_TILE) * OS_BINS;  // the pass's ticket word
   const u32* rin = (first || !sb.rid[0]) ? (const u32*)nullptr : sb.rid[src];
   const int mode = (sb.rid[0] ? 1 : 0) | (sb.end[0] ? 2 : 0);
 #define GIQL_OS_LAUNCH(M)                                                                            \
-  hipLaunchKernelGGL((k_onesweep<M, NT, ITEMS>), dim3(n_tiles), dim3(NT), 0, st, sb.key[src],       \
+  hipLaunchKernelGGL((k_onesweep<M, NT, ITEMS>), dim3(grid), dim3(NT), 0, st, sb.key[src],           \
                      sb.end[0] ? sb.end[src] : (const u32*)nullptr, rin, sb.key[dst],                 \
                      sb.end[0] ? sb.end[dst] : (u32*)nullptr, sb.rid[0] ? sb.rid[dst] : (u32*)nullptr, \
-                     n, shift, gbase, status, ticket, meta)
+                     n, shift, gbase, status, claim, meta, ctx->os_order)
   switch (mode) {
     case 0: GIQL_OS_LAUNCH(0); break;
     case 1: GIQL_OS_LAUNCH(1); break;
@@ -330,37 +337,26 @@ static void launch_onesweep(hipStream_t st, SortBufs& sb, int src, int dst, bool
 #undef GIQL_OS_LAUNCH
 }
 
-// one- and two-array rows need fewer registers: a 12-row-per-thread tile (12288
-// rows, 192-byte runs) still fits two 1024-thread blocks per CU.
-static void launch_onesweep_small(hipStream_t st, SortBufs& sb, int src, int dst, bool first, u32 n,
-                                  int shift, const u32* gbase, u32* status, u32* ticket,
-                                  DevMeta* meta) {
-  launch_onesweep<1024, 12>(st, sb, src, dst, first, n, shift, gbase, status, ticket, meta);
-}
-
 // keep_rids: the rid buffer already holds row ids (second sort of a two-key sort).
+// status: 4 * os_pass_words(n) words, zeroed here in one memset.
 static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
-                             const u32* gbase, u32* status, u32* tickets, bool keep_rids = false) {
+                             const u32* gbase, u32* status, bool keep_rids = false) {
   if (n == 0) return GIQL_OK;
-  const size_t per_pass = (size_t)cdiv(n, OS_MIN_TILE) * OS_BINS;
-  HIP_TRY(hipMemsetAsync(tickets, 0, 4 * sizeof(u32), st));
+  const size_t per_pass = os_pass_words(n);
   HIP_TRY(hipMemsetAsync(status, 0, 4 * per_pass * sizeof(u32), st));
   for (int pass = 0; pass < 4; pass++) {
     const int src = pass & 1, dst = src ^ 1;
     u32* stat = status + pass * per_pass;
+    const bool first = pass == 0 && !keep_rids;
+    const u32* gb = gbase + pass * OS_BINS;
     Phase ph(ctx, st, GIQL_PH_SORT_SCATTER);
-    if (!(sb.end[0] && sb.rid[0]) && ctx->os_variant == 7) {  // 12-row tiles spill: tuning only
-      launch_onesweep_small(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat,
-                            tickets + pass, ctx->d_meta);
-      continue;
-    }
-    switch (ctx->os_variant) {
-      case 1: launch_onesweep<512, 8>(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
-      case 2: launch_onesweep<512, 16>(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
-      case 3: launch_onesweep<256, 16>(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
-      case 4: launch_onesweep<1024, 4>(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
-      case 5: launch_onesweep<1024, 12>(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
-      default: launch_onesweep<1024, 8>(st, sb, src, dst, pass == 0 && !keep_rids, n, pass * 8, gbase + pass * OS_BINS, stat, tickets + pass, ctx->d_meta); break;
+    switch (ctx->os_variant) {  // block-shape sweep (tools/os_variants.py); default 1024 x 8
+      case 1: launch_onesweep<512, 8>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
+      case 2: launch_onesweep<512, 16>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
+      case 3: launch_onesweep<256, 16>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
+      case 4: launch_onesweep<1024, 4>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
+      case 5: case 7: launch_onesweep<1024, 12>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
+      default: launch_onesweep<1024, 8>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
     }
   }
   return post_launch("onesweep sort");
@@ -411,7 +407,13 @@ static int run_pmax(giql_hip_ctx* ctx, hipStream_t st, const u32* in, u32 n, u32
 static int read_meta(giql_hip_ctx* ctx, hipStream_t st) {
   HIP_TRY(hipMemcpyAsync(ctx->h_meta, ctx->d_meta, sizeof(DevMeta), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  const int status = ctx->h_meta->status;
+  int status = ctx->h_meta->status;
+  if (ctx->inject_timeout && ctx->os_order != 0 && status == 0) {  // test hook (GIQL_HIP_INJECT_TIMEOUT)
+    ctx->inject_timeout = 0;
+    status = ctx->h_meta->status = GIQL_ERR_HIP;
+  }
+  if (status == GIQL_ERR_HIP)
+    return set_err(GIQL_ERR_HIP, "onesweep look-back timed out (tile order %d)", ctx->os_order);
   if (status == GIQL_ERR_CHROM)
     return set_err(GIQL_ERR_CHROM, "a chrom id is outside [0, n_chrom)");
   if (status == GIQL_ERR_SPAN)
@@ -437,6 +439,22 @@ static void sort_sizes(Carver& c, size_t n, SortBufs& sb, bool payload) {
     sb.end[k] = payload ? c.take<u32>(n) : nullptr;
     sb.rid[k] = payload ? c.take<u32>(n) : nullptr;
   }
+}
+
+// The default tile order of the sort (k_onesweep order 2) takes tiles from blockIdx and
+// so relies on workgroups being dispatched in blockIdx order for the look-back's
+// progress.  Spins are bounded: should that ever not hold, the call reports a timeout
+// instead of hanging, and it is repeated ONCE in the ticket order (order 0), which
+// needs no such assumption; the context then stays in that order.
+template <typename F>
+static int with_order_fallback(giql_hip_ctx* ctx, F&& call) {
+  int rc = call();
+  if (rc == GIQL_ERR_HIP && ctx && ctx->os_order != 0 && ctx->h_meta && ctx->h_meta->status == GIQL_ERR_HIP) {
+    ctx->os_order = 0;
+    ctx->order_fallbacks++;
+    rc = call();
+  }
+  return rc;
 }
 
 // ================================================================= C ABI
@@ -470,6 +488,10 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->classic_sort = e && strcmp(e, "classic") == 0;
     const char* v = getenv("GIQL_HIP_OS_VARIANT");
     ctx->os_variant = v ? atoi(v) : 0;
+    const char* o = getenv("GIQL_HIP_OS_ORDER");
+    if (o) ctx->os_order = atoi(o);
+    const char* it = getenv("GIQL_HIP_INJECT_TIMEOUT");
+    if (it) ctx->inject_timeout = atoi(it);
     const char* u = getenv("GIQL_HIP_NO_UNIFORM");
     ctx->no_uniform = u && atoi(u) != 0;
   }
@@ -525,11 +547,14 @@ int giql_hip_get_stats(giql_hip_ctx* ctx, giql_hip_stats* out) {
   }
   ctx->stats.workspace_bytes = (int64_t)ctx->arena_cap;
   *out = ctx->stats;
+  // byte 0: join form; byte 1: sort tile order in force; bytes 2-3: order fallbacks so far
+  out->reserved = (ctx->stats.reserved & 0xFF) | ((ctx->os_order & 0xFF) << 8) |
+                  ((ctx->order_fallbacks & 0x7FFF) << 16);
   return GIQL_OK;
 }
 
 // ------------------------------------------------------------------ INNER
-int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
+static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
                             int32_t n_chrom, void* stream, int64_t* n_pairs) {
   if (!ctx || !n_pairs) return set_err(GIQL_ERR_INVALID, "ctx/n_pairs is NULL");
   GIQL_TRY(check_side(a, "a"));
@@ -559,7 +584,7 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
   InnerState& S = ctx->inner;
   u32 *tile_hist = nullptr, *cnt2 = nullptr, *irr_cnt = nullptr;
   u32 *hist_a = nullptr, *hist_b = nullptr, *gbase_a = nullptr, *gbase_b = nullptr;
-  u32 *os_status = nullptr, *os_tickets = nullptr;
+  u32* os_status = nullptr;
   u64* bsums = nullptr;
   const bool onesweep = !ctx->classic_sort && na <= OS_MAX_ROWS && nb <= OS_MAX_ROWS;
   const size_t n_max = na > nb ? na : nb;
@@ -578,8 +603,7 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
       hist_b = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
       gbase_a = c.take<u32>(1024);
       gbase_b = c.take<u32>(1024);
-      os_status = c.take<u32>(4 * (size_t)cdiv(n_max, OS_MIN_TILE) * OS_BINS);
-      os_tickets = c.take<u32>(8);
+      os_status = c.take<u32>(4 * os_pass_words(n_max));
     } else {
       tile_hist = c.take<u32>(n_tiles_max * RS_BINS);
     }
@@ -639,9 +663,8 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
     GIQL_TRY(run_linearize(ctx, st, us_, n_chrom, lb, su.key[0], nullptr,
                            q_is_a ? ctx->irr_b_list : ctx->irr_a_list, q_is_a ? 1 : 0, 0,
                            q_is_a ? hist_b : hist_a, q_is_a ? gbase_b : gbase_a));
-    GIQL_TRY(run_sort_onesweep(ctx, st, sq, (u32)nqr, q_is_a ? gbase_a : gbase_b, os_status, os_tickets));
-    GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, os_status,
-                               os_tickets + 4));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sq, (u32)nqr, q_is_a ? gbase_a : gbase_b, os_status));
+    GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, os_status));
     constexpr u32 TQ = RC_NT * RC_ITEMS_C2;
     S.nt2 = cdiv(nqr, TQ);
     {
@@ -668,8 +691,8 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
   GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], ctx->irr_b_list, 1, 0,
                          hist_b, gbase_b));
   if (onesweep) {
-    GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, gbase_a, os_status, os_tickets));
-    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, gbase_b, os_status, os_tickets + 4));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, gbase_a, os_status));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, gbase_b, os_status));
   } else {
     GIQL_TRY(run_sort(ctx, st, sa, (u32)na, tile_hist, bsums));
     GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
@@ -727,6 +750,11 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
   *n_pairs = (int64_t)(ctx->n_reg + ctx->n_irr);
   ctx->planned = true;
   return GIQL_OK;
+}
+
+int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+                            void* stream, int64_t* n_pairs) {
+  return with_order_fallback(ctx, [&] { return giql_hip_inner_plan_dev_impl(ctx, a, b, n_chrom, stream, n_pairs); });
 }
 
 int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, int64_t capacity,
@@ -799,10 +827,10 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
 }
 
 // Scratch shared by the single-output operators: histogram replicas, digit bases,
-// onesweep status words and tickets for one side at a time.
+// onesweep status words (+ tile-claim state) for one side at a time.
 struct OsScratch {
   u32 *hist = nullptr, *gbase = nullptr, *hist_e = nullptr, *gbase_e = nullptr;
-  u32 *status = nullptr, *tickets = nullptr;
+  u32* status = nullptr;
 };
 
 static void os_scratch_sizes(Carver& c, size_t n_max, OsScratch& o) {
@@ -810,12 +838,11 @@ static void os_scratch_sizes(Carver& c, size_t n_max, OsScratch& o) {
   o.hist_e = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
   o.gbase = c.take<u32>(1024);
   o.gbase_e = c.take<u32>(1024);
-  o.status = c.take<u32>(4 * (size_t)cdiv(n_max ? n_max : 1, OS_MIN_TILE) * OS_BINS);
-  o.tickets = c.take<u32>(8);
+  o.status = c.take<u32>(4 * os_pass_words(n_max));
 }
 
 // -------------------------------------------------------------- SEMI / ANTI
-int giql_hip_semi_anti_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
+static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
                            int32_t n_chrom, int anti, int32_t* rows_out, int64_t* n_out,
                            void* stream) {
   if (!ctx || !n_out) return set_err(GIQL_ERR_INVALID, "ctx/n_out is NULL");
@@ -866,11 +893,11 @@ int giql_hip_semi_anti_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     // every B row keeps its real key: the prefix-max test is exact for any row
     GIQL_TRY(run_linearize(ctx, st, *b, nch, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist,
                            os.gbase));
-    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, os.tickets));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status));
     GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
   }
   GIQL_TRY(run_linearize(ctx, st, *a, nch, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist, os.gbase));
-  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, os.tickets + 4));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status));
   {
     Phase ph(ctx, st, GIQL_PH_COUNT);
     hipLaunchKernelGGL(k_semi_flags, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0],
@@ -892,8 +919,13 @@ int giql_hip_semi_anti_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   return GIQL_OK;
 }
 
+int giql_hip_semi_anti_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+                           int anti, int32_t* rows_out, int64_t* n_out, void* stream) {
+  return with_order_fallback(ctx, [&] { return giql_hip_semi_anti_dev_impl(ctx, a, b, n_chrom, anti, rows_out, n_out, stream); });
+}
+
 // ------------------------------------------------------------------- COUNT
-int giql_hip_count_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
                        int64_t* counts_out, void* stream) {
   if (!ctx) return set_err(GIQL_ERR_INVALID, "ctx is NULL");
   GIQL_TRY(check_side(a, "a"));
@@ -938,11 +970,11 @@ int giql_hip_count_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
   GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sstart.key[0], send.key[0], irr_b_list, 1, 0,
                          os.hist, os.gbase, os.hist_e, os.gbase_e));
-  GIQL_TRY(run_sort_onesweep(ctx, st, sstart, (u32)nb, os.gbase, os.status, os.tickets));
-  GIQL_TRY(run_sort_onesweep(ctx, st, send, (u32)nb, os.gbase_e, os.status, os.tickets + 4));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sstart, (u32)nb, os.gbase, os.status));
+  GIQL_TRY(run_sort_onesweep(ctx, st, send, (u32)nb, os.gbase_e, os.status));
   GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], irr_a_list, 0, 0, os.hist,
                          os.gbase));
-  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, os.tickets));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status));
   {
     Phase ph(ctx, st, GIQL_PH_COUNT);
     hipLaunchKernelGGL(k_count_rows, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0],
@@ -966,8 +998,13 @@ int giql_hip_count_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b
   return GIQL_OK;
 }
 
+int giql_hip_count_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+                       int64_t* counts_out, void* stream) {
+  return with_order_fallback(ctx, [&] { return giql_hip_count_dev_impl(ctx, a, b, n_chrom, counts_out, stream); });
+}
+
 // ----------------------------------------------------------------- NEAREST
-int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
                          int is_signed, int64_t max_distance, int32_t* idx_b_out, int64_t* dist_out,
                          void* stream) {
   if (!ctx) return set_err(GIQL_ERR_INVALID, "ctx is NULL");
@@ -1023,13 +1060,13 @@ int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side*
       by_end.key[k] = sbb.end[k];
       by_end.end[k] = sbb.key[k];
     }
-    GIQL_TRY(run_sort_onesweep(ctx, st, by_end, (u32)nb, os.gbase_e, os.status, os.tickets));
+    GIQL_TRY(run_sort_onesweep(ctx, st, by_end, (u32)nb, os.gbase_e, os.status));
   }
-  GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, os.tickets + 4, /*keep_rids=*/true));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, /*keep_rids=*/true));
   GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
   GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist,
                          os.gbase));
-  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, os.tickets));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status));
   {
     Phase ph(ctx, st, GIQL_PH_COUNT, 2);
     hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st,
@@ -1044,6 +1081,12 @@ int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side*
   ctx->stats.n_out = a->n;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
   return GIQL_OK;
+}
+
+int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+                         int is_signed, int64_t max_distance, int32_t* idx_b_out, int64_t* dist_out,
+                         void* stream) {
+  return with_order_fallback(ctx, [&] { return giql_hip_nearest_dev_impl(ctx, a, b, n_chrom, is_signed, max_distance, idx_b_out, dist_out, stream); });
 }
 
 // ---------------------------------------------------------- CLUSTER / MERGE
@@ -1094,7 +1137,7 @@ static int cluster_front(giql_hip_ctx* ctx, hipStream_t st, const giql_side* s, 
     hipLaunchKernelGGL(k_check_not_inverted, dim3(cdiv(n, 256)), dim3(256), 0, st, view_of(*s),
                        ctx->d_meta);
   }
-  GIQL_TRY(run_sort_onesweep(ctx, st, cb.sb, (u32)n, cb.os.gbase, cb.os.status, cb.os.tickets));
+  GIQL_TRY(run_sort_onesweep(ctx, st, cb.sb, (u32)n, cb.os.gbase, cb.os.status));
   GIQL_TRY(run_pmax(ctx, st, cb.sb.end[0], (u32)n, cb.pmax, cb.bmax));
   HIP_TRY(hipMemsetAsync(cb.flags, 0, n * sizeof(u32), st));
   {
@@ -1130,7 +1173,7 @@ static int cluster_status(giql_hip_ctx* ctx, hipStream_t st) {
   return read_meta(ctx, st);
 }
 
-int giql_hip_cluster_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
+static int giql_hip_cluster_dev_impl(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
                          int64_t* cluster_id_out, void* stream) {
   GIQL_TRY(check_cluster_args(ctx, s, n_chrom));
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1157,7 +1200,12 @@ int giql_hip_cluster_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom,
   return GIQL_OK;
 }
 
-int giql_hip_merge_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
+int giql_hip_cluster_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
+                         int64_t* cluster_id_out, void* stream) {
+  return with_order_fallback(ctx, [&] { return giql_hip_cluster_dev_impl(ctx, s, n_chrom, distance, cluster_id_out, stream); });
+}
+
+static int giql_hip_merge_dev_impl(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
                        int32_t* out_chrom, int32_t* out_start, int32_t* out_end,
                        int64_t* out_count, int64_t capacity, int64_t* n_out, void* stream) {
   GIQL_TRY(check_cluster_args(ctx, s, n_chrom));
@@ -1195,6 +1243,12 @@ int giql_hip_merge_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, i
   ctx->stats.n_out = (int64_t)h_total;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
   return GIQL_OK;
+}
+
+int giql_hip_merge_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
+                       int32_t* out_chrom, int32_t* out_start, int32_t* out_end, int64_t* out_count,
+                       int64_t capacity, int64_t* n_out, void* stream) {
+  return with_order_fallback(ctx, [&] { return giql_hip_merge_dev_impl(ctx, s, n_chrom, distance, out_chrom, out_start, out_end, out_count, capacity, n_out, stream); });
 }
 
 // -------------------------------------------------------------------- spans

@@ -14,8 +14,9 @@
 // {flag:2, count:30}.  It is written by ONE relaxed agent-scope atomic store and
 // polled with relaxed agent-scope atomic loads (sc1: L1 is bypassed), so no
 // fence is needed and nothing depends on workgroup placement.  Tiles take their
-// index from an atomic ticket, so every predecessor of a tile is already
-// running: the look-back cannot deadlock.  Spins are bounded all the same.
+// index from an atomic ticket (permuted inside 64-ticket groups, see
+// os_tile_of_ticket), so the predecessors of a tile are running or about to be:
+// the look-back cannot deadlock.  Spins are bounded all the same.
 #pragma once
 
 #include "dev_common.hip.h"
@@ -51,6 +52,33 @@ __device__ __forceinline__ void wave_match8(u32 d, u64 active, u32& below, u32& 
   below = __builtin_amdgcn_mbcnt_hi(p_hi, __builtin_amdgcn_mbcnt_lo(p_lo, 0u));
   total = (u32)__popc(p_lo) + (u32)__popc(p_hi);
 }
+
+// Tile order.  A block takes a ticket (so tiles start in ticket order whatever the
+// dispatch order is) and maps it to a tile through a fixed permutation inside groups of
+// 8 * OS_GROUP tickets: ticket 8j + x -> tile ((j / G) * 8 + x) * G + j % G.  Workgroups
+// are dealt round-robin to the 8 XCDs, so tickets x, x + 8, x + 16, ... -- and with
+// them G CONSECUTIVE tiles -- land on one XCD at about the same time: the adjacent
+// ~128-byte runs those tiles write into every digit bin meet in THAT XCD's L2, which
+// then writes whole lines back instead of two partial lines per run (measured on 100M
+// (key, end) rows: 0.471 -> 0.425 ms per pass with the mapping alone).  Only speed
+// depends on the placement; progress does not: a tile's predecessors hold tickets below
+// the end of its own 64-ticket group, complete groups are prefix-closed (tickets
+// [0, 64m) own tiles [0, 64m)) so their blocks always finish and free their slots, and
+// at most 63 blocks of the one incomplete group can be waiting, far fewer than the
+// device holds.  The tail (n_tiles % 64 tickets) keeps the identity order.
+constexpr u32 OS_GROUPS = 8;  // XCDs
+constexpr u32 OS_GROUP = 8;   // consecutive tiles per XCD turn
+
+__device__ __forceinline__ u32 os_tile_of_ticket(u32 t, u32 n_tiles) {
+  constexpr u32 SPAN = OS_GROUPS * OS_GROUP;
+  if (t >= (n_tiles / SPAN) * SPAN) return t;
+  const u32 x = t % OS_GROUPS, j = t / OS_GROUPS;
+  return ((j / OS_GROUP) * OS_GROUPS + x) * OS_GROUP + j % OS_GROUP;
+}
+
+// scatter store.  Kept temporal on purpose: the L2 merges the partial lines of adjacent
+// runs; a non-temporal hint took the random-key pass from 0.47 to 0.74 ms.
+__device__ __forceinline__ void os_store(u32* p, u32 v) { *p = v; }
 
 // PAYLOAD bit 0: carry rid, bit 1: carry end.  0 = keys only, 1 = (key, rid),
 // 2 = (key, end), 3 = (key, end, rid).
@@ -235,7 +263,7 @@ __device__ __forceinline__ void onesweep_tile(
     if (FULL || p < n_valid) {
       const u32 k = s_buf[p];
       dst[i] = s_goff[(k >> shift) & 0xFFu] + p;
-      keys_out[dst[i]] = k;
+      os_store(keys_out + dst[i], k);
     }
   }
   if (PAYLOAD == 3) {
@@ -256,7 +284,7 @@ __device__ __forceinline__ void onesweep_tile(
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 p = i * OS_NT + tid;
-      if (FULL || p < n_valid) ends_out[dst[i]] = s_buf[p];
+      if (FULL || p < n_valid) os_store(ends_out + dst[i], s_buf[p]);
     }
     __syncthreads();
 #pragma unroll
@@ -268,7 +296,7 @@ __device__ __forceinline__ void onesweep_tile(
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 p = i * OS_NT + tid;
-      if (FULL || p < n_valid) rids_out[dst[i]] = s_buf[p];
+      if (FULL || p < n_valid) os_store(rids_out + dst[i], s_buf[p]);
     }
   } else if (PAYLOAD != 0) {
     u32* out = (PAYLOAD & 2) ? ends_out : rids_out;
@@ -282,7 +310,7 @@ __device__ __forceinline__ void onesweep_tile(
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 p = i * OS_NT + tid;
-      if (FULL || p < n_valid) out[dst[i]] = s_buf[p];
+      if (FULL || p < n_valid) os_store(out + dst[i], s_buf[p]);
     }
   }
 }
@@ -294,7 +322,7 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
     int shift, const u32* __restrict__ gbase, u32* __restrict__ status, u32* __restrict__ ticket,
-    DevMeta* __restrict__ meta) {
+    DevMeta* __restrict__ meta, int order) {
   constexpr int OS_TILE = OS_NT * OS_ITEMS;
   constexpr int OS_NW = OS_NT / WAVE;
   __shared__ u32 s_buf[OS_TILE];          // staging, reused for key / end / rid
@@ -305,7 +333,10 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
   __shared__ u32 s_tile;
 
   const u32 tid = threadIdx.x;
-  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+  // order 0: tile = ticket; 1: tile = permuted ticket; 2: tile = permuted blockIdx (no atomic)
+  if (tid == 0)
+    s_tile = order == 2 ? os_tile_of_ticket(blockIdx.x, gridDim.x)
+                        : (order == 1 ? os_tile_of_ticket(atomicAdd(ticket, 1u), gridDim.x) : atomicAdd(ticket, 1u));
 #pragma unroll
   for (int k = tid; k < OS_NW * OS_BINS; k += OS_NT) (&s_wcnt[0][0])[k] = 0;
   __syncthreads();

@@ -128,7 +128,9 @@ class HipEngine:
         out = {k: int(getattr(st, k)) for k in
                ("n_a", "n_b", "n_out", "n_irregular_a", "n_irregular_b", "workspace_bytes", "span",
                 "profiled")}
-        out["join_form"] = {0: "general", 1: "uniform_b", 2: "uniform_a"}.get(int(st.reserved), "?")
+        out["join_form"] = {0: "general", 1: "uniform_b", 2: "uniform_a"}.get(int(st.reserved) & 0xFF, "?")
+        out["sort_tile_order"] = (int(st.reserved) >> 8) & 0xFF
+        out["sort_order_fallbacks"] = (int(st.reserved) >> 16) & 0x7FFF
         out["total_ms"] = float(st.total_ms)
         out["phase_ms"] = {name: float(st.phase_ms[i]) for i, name in enumerate(_lib.PHASES)}
         out["phase_launches"] = {name: int(st.phase_launches[i]) for i, name in enumerate(_lib.PHASES)}

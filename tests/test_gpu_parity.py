@@ -643,3 +643,28 @@ def test_cluster_merge_edge_cases(eng):
         eng.cluster(dev(inverted), 1, 0)
     with pytest.raises(GiqlHipError):
         eng.merge(dev(inverted), 1, 0)
+
+
+def test_sort_falls_back_to_ticket_order_after_a_lookback_timeout(monkeypatch):
+    # the default tile order assumes in-order workgroup dispatch; a (here: injected) look-back
+    # timeout must repeat the call in the assumption-free ticket order and still be exact
+    from giql_amd.engine import HipEngine
+
+    monkeypatch.setenv("GIQL_HIP_INJECT_TIMEOUT", "1")
+    e = HipEngine(0)
+    monkeypatch.delenv("GIQL_HIP_INJECT_TIMEOUT")
+    try:
+        rng = np.random.default_rng(8)
+        def side(n):
+            s = rng.integers(0, 2_000_000, n).astype(np.int32)
+            return ora.Side(rng.integers(0, 3, n).astype(np.int32), s, s + rng.integers(1, 300, n).astype(np.int32))
+        a, b = side(40_000), side(70_000)
+        assert e.stats()["sort_tile_order"] == 2
+        ra, rb = e.inner_join(dev(a), dev(b), 3)
+        st = e.stats()
+        assert (st["sort_tile_order"], st["sort_order_fallbacks"]) == (0, 1)
+        assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), ora.sort_pairs(*ora.c_inner(a, b, "sweep")))
+        assert np.array_equal(e.count_overlaps(dev(a), dev(b), 3).cpu().numpy(), ora.c_count(a, b, "sweep"))
+        assert e.stats()["sort_order_fallbacks"] == 1  # stays in ticket order, no further retries
+    finally:
+        e.close()
