@@ -31,6 +31,20 @@ struct DevMeta {
   int len_min_a, len_max_a, len_min_b, len_max_b;
 };
 
+// XCD-aware block -> tile map.  Workgroups are dealt round-robin to the 8 XCDs, each
+// with its own L2: inside groups of 64 blocks, block 8j + x takes tile
+// ((j / G) * 8 + x) * G + j % G, so G consecutive tiles run on one XCD at about the
+// same time and what neighbouring tiles share (adjacent output runs, overlapping input
+// windows) meets in one L2.  A bijection on [0, n_blocks); the tail keeps its order.
+constexpr u32 XCD_GROUPS = 8;
+constexpr u32 XCD_GROUP = 8;
+__device__ __forceinline__ u32 xcd_tile_of_block(u32 b, u32 n_blocks) {
+  constexpr u32 SPAN = XCD_GROUPS * XCD_GROUP;
+  if (b >= (n_blocks / SPAN) * SPAN) return b;
+  const u32 x = b % XCD_GROUPS, j = b / XCD_GROUPS;
+  return ((j / XCD_GROUP) * XCD_GROUPS + x) * XCD_GROUP + j % XCD_GROUP;
+}
+
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }

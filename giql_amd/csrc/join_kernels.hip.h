@@ -465,7 +465,8 @@ __global__ __launch_bounds__(RC_NT) void k_range_count(
   __shared__ u32 s_tile[CAP];
   const u32 nq = nq_total - *irr_q;
   const u32 ns = ns_total - *irr_s;
-  const u32 q0 = blockIdx.x * TQ;
+  const u32 bid = blockIdx.x;
+  const u32 q0 = bid * TQ;
   const u32 tid = threadIdx.x;
   u32 xs[ITEMS], xe[ITEMS];
 #pragma unroll
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(RC_NT) void k_range_count(
     xs[i] = ok ? shift_key(qs[q], lo_off) : U32_MAX;
     xe[i] = ok ? qe[q] : U32_MAX;
   }
-  const SWindow w = stage_window<CAP>(ss, ns, w_lo_arr[blockIdx.x], w_lo_arr[blockIdx.x + 1], s_tile);
+  const SWindow w = stage_window<CAP>(ss, ns, w_lo_arr[bid], w_lo_arr[bid + 1], s_tile);
 #pragma unroll
   for (int i = 0; i < ITEMS; i++) {
     const u32 q = q0 + i * RC_NT + tid;
@@ -803,12 +804,14 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
   __shared__ u32 s_qrid[FILL_QCAP];
   __shared__ u32 s_mark[FILL_NT / WAVE][WAVE];
   const u32 tid = threadIdx.x;
-  const u64 tile_rel = (u64)blockIdx.x * TILE;  // relative to out_base
+  // (an XCD-aware block -> tile map was measured here and in k_range_count: no gain)
+  const u32 bid = blockIdx.x;
+  const u64 tile_rel = (u64)bid * TILE;  // relative to out_base
   const u64 tile_start = out_base + tile_rel;
   const u64 rem = n_out - tile_rel;
   const u32 tile_len = rem < (u64)TILE ? (u32)rem : TILE;
-  const u32 qf = part[blockIdx.x];
-  u32 ql = part[blockIdx.x + 1];
+  const u32 qf = part[bid];
+  u32 ql = part[bid + 1];
   if (ql >= nq) ql = nq - 1;
   const u32 nqt = ql - qf + 1;
   const u64 first_delta = tile_start - off[qf];

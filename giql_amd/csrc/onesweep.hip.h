@@ -66,15 +66,10 @@ __device__ __forceinline__ void wave_match8(u32 d, u64 active, u32& below, u32& 
 // [0, 64m) own tiles [0, 64m)) so their blocks always finish and free their slots, and
 // at most 63 blocks of the one incomplete group can be waiting, far fewer than the
 // device holds.  The tail (n_tiles % 64 tickets) keeps the identity order.
-constexpr u32 OS_GROUPS = 8;  // XCDs
-constexpr u32 OS_GROUP = 8;   // consecutive tiles per XCD turn
+constexpr u32 OS_GROUPS = XCD_GROUPS;
+constexpr u32 OS_GROUP = XCD_GROUP;
 
-__device__ __forceinline__ u32 os_tile_of_ticket(u32 t, u32 n_tiles) {
-  constexpr u32 SPAN = OS_GROUPS * OS_GROUP;
-  if (t >= (n_tiles / SPAN) * SPAN) return t;
-  const u32 x = t % OS_GROUPS, j = t / OS_GROUPS;
-  return ((j / OS_GROUP) * OS_GROUPS + x) * OS_GROUP + j % OS_GROUP;
-}
+__device__ __forceinline__ u32 os_tile_of_ticket(u32 t, u32 n_tiles) { return xcd_tile_of_block(t, n_tiles); }
 
 // scatter store.  Kept temporal on purpose: the L2 merges the partial lines of adjacent
 // runs; a non-temporal hint took the random-key pass from 0.47 to 0.74 ms.
