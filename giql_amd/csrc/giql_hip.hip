@@ -893,6 +893,11 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
     // every B row keeps its real key: the prefix-max test is exact for any row
     GIQL_TRY(run_linearize(ctx, st, *b, nch, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist,
                            os.gbase));
+#if defined(GIQL_LIN_ABLATE)  // timing-only builds stop here: their keys / histograms are not valid
+    GIQL_TRY(read_meta(ctx, st));
+    collect_spans(ctx);
+    return GIQL_OK;
+#endif
     GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status));
     GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
   }

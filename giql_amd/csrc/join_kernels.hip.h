@@ -245,6 +245,10 @@ __global__ __launch_bounds__(256) void k_chrom_offsets(const int* __restrict__ g
 constexpr int LIN_NT = 256;
 constexpr int LIN_MAX_BLOCKS = 8192;
 constexpr int LIN_HIST_REPLICAS = 64;  // ghist[replica][4][256], block b adds to b % 64
+constexpr int LIN_BASE_CAP = 1024;     // chromosome bases staged in LDS (8 KB)
+#ifndef GIQL_LIN_UNROLL
+#define GIQL_LIN_UNROLL 4
+#endif
 
 // keys[i] = linearised canonical start, ends[i] = linearised canonical end.
 // Irregular rows (canonical end <= start) get the sentinel key and are appended
@@ -263,20 +267,26 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
     u32* __restrict__ hist_partial_end) {
   __shared__ u32 s_hist[4 * 256];
   __shared__ u32 s_hist_e[END_HIST ? 4 * 256 : 1];  // same histogram over the END keys
+  // the per-chromosome bases sit in LDS: the base lookup depends on the row's chrom
+  // load, and an LDS hit is a far shorter second hop than a global one
+  __shared__ i64 s_base[LIN_BASE_CAP];
+  const bool lds_base = n_chrom <= LIN_BASE_CAP;
+  if (lds_base)
+    for (int k = threadIdx.x; k < n_chrom; k += LIN_NT) s_base[k] = chrom_base[k];
   if (hist_partial) {
 #pragma unroll
     for (int k = threadIdx.x; k < 4 * 256; k += LIN_NT) {
       s_hist[k] = 0;
       if (END_HIST) s_hist_e[k] = 0;
     }
-    __syncthreads();
   }
+  __syncthreads();
   const u32 sentinel = meta->sentinel;
   u32* irr_count = which ? &meta->irr_b : &meta->irr_a;
   const u32 stride = gridDim.x * LIN_NT;
   // every lane runs the same number of iterations so the ballots are full-wave
   const u32 n_iter = (n + stride - 1) / stride;
-  constexpr int UNROLL = 4;  // rows in flight per thread (a 1-row loop is latency-bound)
+  constexpr int UNROLL = GIQL_LIN_UNROLL;  // rows in flight per thread (a 1-row loop is latency-bound)
   const u32 i0 = blockIdx.x * LIN_NT + threadIdx.x;
   for (u32 it0 = 0; it0 < n_iter; it0 += UNROLL) {
     u32 idx[UNROLL];
@@ -305,14 +315,22 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
         const bool c_ok = c >= 0 && c < n_chrom;  // bad ids were flagged by k_chrom_minmax
         irr = c_ok && !keep_irregular && ce <= cs;
         if (c_ok && !irr) {
-          const i64 b = chrom_base[c];
+          const i64 b = lds_base ? s_base[c] : chrom_base[c];
           k = (u32)(b + cs);
           ke = (u32)(b + ce);
         }
+#if defined(GIQL_LIN_ABLATE) && (GIQL_LIN_ABLATE & 2)  // timing-only build: no key stores
+        if (k == 0x12345u && ke == 0x54321u) keys[i] = k;
+#else
         if (keys) keys[i] = k;
         if (ends) ends[i] = ke;
+#endif
       }
+#if defined(GIQL_LIN_ABLATE) && (GIQL_LIN_ABLATE & 1)  // timing-only build: no histogram
+      if (false) {
+#else
       if (hist_partial) {
+#endif
         const u64 act = __ballot(ok);
 #pragma unroll
         for (int p = 0; p < 4; p++) {
