@@ -94,6 +94,7 @@ struct giql_hip_ctx {
   bool no_uniform = false;    // GIQL_HIP_NO_UNIFORM=1: always run the general two-class join
   int n_cu = 256;             // compute units of the device
   int os_order = 2;           // onesweep tile order (GIQL_HIP_OS_ORDER, see k_onesweep)
+  u32 os_help_after = OS_HELP_AFTER;  // look-back polls before a block helps (GIQL_HIP_OS_HELP_AFTER)
   int inject_timeout = 0;     // test hook: report one look-back timeout
   int order_fallbacks = 0;    // calls repeated in the ticket order after a timeout
 
@@ -327,7 +328,7 @@ static void launch_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, int
   hipLaunchKernelGGL((k_onesweep<M, NT, ITEMS>), dim3(grid), dim3(NT), 0, st, sb.key[src],           \
                      sb.end[0] ? sb.end[src] : (const u32*)nullptr, rin, sb.key[dst],                 \
                      sb.end[0] ? sb.end[dst] : (u32*)nullptr, sb.rid[0] ? sb.rid[dst] : (u32*)nullptr, \
-                     n, shift, gbase, status, claim, meta, ctx->os_order)
+                     n, shift, gbase, status, claim, meta, ctx->os_order, ctx->os_help_after)
   switch (mode) {
     case 0: GIQL_OS_LAUNCH(0); break;
     case 1: GIQL_OS_LAUNCH(1); break;
@@ -441,11 +442,10 @@ static void sort_sizes(Carver& c, size_t n, SortBufs& sb, bool payload) {
   }
 }
 
-// The default tile order of the sort (k_onesweep order 2) takes tiles from blockIdx and
-// so relies on workgroups being dispatched in blockIdx order for the look-back's
-// progress.  Spins are bounded: should that ever not hold, the call reports a timeout
-// instead of hanging, and it is repeated ONCE in the ticket order (order 0), which
-// needs no such assumption; the context then stays in that order.
+// Belt and braces around the sort: its look-back makes progress whatever the dispatch
+// order (blocks compute silent predecessors themselves, k_onesweep), so a timeout status
+// is never expected; should one be reported all the same, the call is repeated ONCE in
+// the ticket order (order 0) and the context stays in that order.
 template <typename F>
 static int with_order_fallback(giql_hip_ctx* ctx, F&& call) {
   int rc = call();
@@ -490,6 +490,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->os_variant = v ? atoi(v) : 0;
     const char* o = getenv("GIQL_HIP_OS_ORDER");
     if (o) ctx->os_order = atoi(o);
+    const char* ha = getenv("GIQL_HIP_OS_HELP_AFTER");
+    if (ha) ctx->os_help_after = (u32)strtoul(ha, nullptr, 10);
     const char* it = getenv("GIQL_HIP_INJECT_TIMEOUT");
     if (it) ctx->inject_timeout = atoi(it);
     const char* u = getenv("GIQL_HIP_NO_UNIFORM");

@@ -13,10 +13,9 @@
 // only cross-block data is one 32-bit status word per (tile, digit) holding
 // {flag:2, count:30}.  It is written by ONE relaxed agent-scope atomic store and
 // polled with relaxed agent-scope atomic loads (sc1: L1 is bypassed), so no
-// fence is needed and nothing depends on workgroup placement.  Tiles take their
-// index from an atomic ticket (permuted inside 64-ticket groups, see
-// os_tile_of_ticket), so the predecessors of a tile are running or about to be:
-// the look-back cannot deadlock.  Spins are bounded all the same.
+// fence is needed and nothing depends on workgroup placement.  The look-back
+// cannot deadlock whatever the dispatch order: a block that finds a predecessor
+// silent for too long computes that tile itself (see k_onesweep).
 #pragma once
 
 #include "dev_common.hip.h"
@@ -29,7 +28,8 @@ constexpr u32 OS_FLAG_AGG = 1u << 30;
 constexpr u32 OS_FLAG_PREFIX = 2u << 30;
 constexpr u32 OS_VALUE_MASK = (1u << 30) - 1u;
 constexpr u32 OS_MAX_ROWS = (1u << 30) - 1u;
-constexpr u32 OS_SPIN_LIMIT = 1u << 24;
+constexpr u32 OS_NO_TILE = 0xFFFFFFFFu;
+constexpr u32 OS_HELP_AFTER = 1u << 13;  // look-back polls (~100+ us) before a block computes a silent predecessor itself
 
 // Stable in-wave rank of one item by its 8-bit digit.  For every digit bit b the
 // wave ballots the bit (m) and each lane ORs into `mis` the lanes whose bit differs
@@ -53,19 +53,14 @@ __device__ __forceinline__ void wave_match8(u32 d, u64 active, u32& below, u32& 
   total = (u32)__popc(p_lo) + (u32)__popc(p_hi);
 }
 
-// Tile order.  A block takes a ticket (so tiles start in ticket order whatever the
-// dispatch order is) and maps it to a tile through a fixed permutation inside groups of
-// 8 * OS_GROUP tickets: ticket 8j + x -> tile ((j / G) * 8 + x) * G + j % G.  Workgroups
-// are dealt round-robin to the 8 XCDs, so tickets x, x + 8, x + 16, ... -- and with
-// them G CONSECUTIVE tiles -- land on one XCD at about the same time: the adjacent
-// ~128-byte runs those tiles write into every digit bin meet in THAT XCD's L2, which
-// then writes whole lines back instead of two partial lines per run (measured on 100M
-// (key, end) rows: 0.471 -> 0.425 ms per pass with the mapping alone).  Only speed
-// depends on the placement; progress does not: a tile's predecessors hold tickets below
-// the end of its own 64-ticket group, complete groups are prefix-closed (tickets
-// [0, 64m) own tiles [0, 64m)) so their blocks always finish and free their slots, and
-// at most 63 blocks of the one incomplete group can be waiting, far fewer than the
-// device holds.  The tail (n_tiles % 64 tickets) keeps the identity order.
+// Tile order.  A block maps its blockIdx to a tile through the XCD-aware permutation of
+// dev_common.hip.h (inside groups of 64 blocks, block 8j + x takes tile
+// ((j / G) * 8 + x) * G + j % G).  Workgroups are dealt round-robin to the 8 XCDs, so
+// blocks x, x + 8, x + 16, ... -- and with them G CONSECUTIVE tiles -- land on one XCD
+// at about the same time: the adjacent ~128-byte runs those tiles write into every
+// digit bin meet in THAT XCD's L2, which then writes whole lines back instead of two
+// partial lines per run (measured on 100M (key, end) rows: 0.471 -> 0.425 ms per pass).
+// Only speed depends on placement and dispatch order; progress does not (k_onesweep).
 constexpr u32 OS_GROUPS = XCD_GROUPS;
 constexpr u32 OS_GROUP = XCD_GROUP;
 
@@ -80,12 +75,12 @@ __device__ __forceinline__ void os_store(u32* p, u32 v) { *p = v; }
 // FULL = every row of the tile is valid (all tiles but the last): no per-item
 // bounds predicates.
 template <int PAYLOAD, int OS_NT, int OS_ITEMS, bool FULL>
-__device__ __forceinline__ void onesweep_tile(
+__device__ __forceinline__ u32 onesweep_tile(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n_valid,
     u32 tile, u32 tile_base, int shift, const u32* __restrict__ gbase, u32* __restrict__ status,
     DevMeta* __restrict__ meta, u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff,
-    u32* s_scan) {
+    u32* s_scan, u32* s_help, u32 help_after) {
   constexpr int OS_NW = OS_NT / WAVE;
   const u32 tid = threadIdx.x;
   const u32 lane = lane_id();
@@ -190,21 +185,28 @@ __device__ __forceinline__ void onesweep_tile(
         }
         t -= (u32)used;
         if (!done && used == 0) {
-          if (++spins > OS_SPIN_LIMIT) {
-            meta->status = -2;  // GIQL_ERR_HIP: look-back timed out (never expected)
+          if (++spins > help_after) {
+            // predecessor t-1 has published nothing for too long: whatever the reason (its
+            // block may not even have been dispatched yet), this block computes it itself
+            atomicMin(s_help, t - 1u);
             break;
           }
           __builtin_amdgcn_s_sleep(1);
         }
         if (t == 0) done = true;
       }
-      __hip_atomic_store(st, OS_FLAG_PREFIX | ((excl + count) & OS_VALUE_MASK), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      if (done)  // not when the walk was abandoned for a helping round
+        __hip_atomic_store(st, OS_FLAG_PREFIX | ((excl + count) & OS_VALUE_MASK), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
     s_goff[tid] = gbase[tid] + excl;  // finished below once dstart is known
     s_dstart[tid] = incl - count;     // wave-local exclusive; wave base added below
   }
   __syncthreads();
+  {
+    const u32 help = *s_help;  // block-uniform; nothing of this tile has been written yet
+    if (help != OS_NO_TILE) return help;
+  }
   if (tid < OS_BINS) {
     u32 wb = 0;
 #pragma unroll
@@ -308,16 +310,95 @@ __device__ __forceinline__ void onesweep_tile(
       if (FULL || p < n_valid) os_store(out + dst[i], s_buf[p]);
     }
   }
+  return OS_NO_TILE;
 }
 
 // OS_NT threads x OS_ITEMS rows per thread = one tile.  Default 1024 x 8: 16 waves
 // halve the per-wave serial work of 512 x 16 at the same 8192-row tile.
+//
+// order 2 (default): tile = xcd_tile_of_block(blockIdx) -- no ticket atomic, and the
+// XCD-aware order above.  order 0: tile = atomic ticket.  Neither relies on dispatch
+// order for PROGRESS: a block whose look-back finds a predecessor silent for
+// help_after polls abandons its own tile (nothing of it has been written), computes
+// that predecessor itself -- recursively the earliest silent one -- and then starts
+// over on its own tile.  A tile computed twice (by a helper and, later, by its own
+// block) publishes the same status values and writes the same bytes to the same
+// addresses, so the duplicate is harmless.
+// One tile with the block's LDS prepared (counters zeroed, s_help reset); returns
+// OS_NO_TILE when the tile is finished, else the silent predecessor to compute first.
+template <int PAYLOAD, int OS_NT, int OS_ITEMS>
+__device__ __forceinline__ u32 os_run_tile(
+    const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
+    u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n, u32 tile,
+    int shift, const u32* __restrict__ gbase, u32* __restrict__ status, DevMeta* __restrict__ meta,
+    u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff, u32* s_scan, u32* s_help,
+    u32 help_after) {
+  constexpr int OS_TILE = OS_NT * OS_ITEMS;
+  const u32 tile_base = tile * OS_TILE;
+  const u32 n_valid = (n - tile_base) < (u32)OS_TILE ? (n - tile_base) : (u32)OS_TILE;
+  if (n_valid == (u32)OS_TILE)
+    return onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, true>(keys_in, ends_in, rids_in, keys_out, ends_out,
+                                                         rids_out, n_valid, tile, tile_base, shift, gbase,
+                                                         status, meta, s_buf, s_wcnt, s_dstart, s_goff,
+                                                         s_scan, s_help, help_after);
+  return onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, false>(keys_in, ends_in, rids_in, keys_out, ends_out,
+                                                        rids_out, n_valid, tile, tile_base, shift, gbase,
+                                                        status, meta, s_buf, s_wcnt, s_dstart, s_goff,
+                                                        s_scan, s_help, help_after);
+}
+
+// The cold path: compute the silent predecessor `need` (recursively the earliest silent
+// one), then start over on the block's own tile, until that is finished.  Out of line
+// so that the hot path of k_onesweep keeps its register allocation.
+template <int PAYLOAD, int OS_NT, int OS_ITEMS>
+__device__ __noinline__ void os_help_loop(
+    const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
+    u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n, u32 own,
+    u32 need, int shift, const u32* __restrict__ gbase, u32* __restrict__ status,
+    DevMeta* __restrict__ meta, u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff,
+    u32* s_scan, u32* s_help, u32 help_after) {
+  constexpr int OS_NW = OS_NT / WAVE;
+  const u32 tid = threadIdx.x;
+  u32 cur = need;
+  for (u32 rounds = 0;; rounds++) {
+    __syncthreads();  // the LDS of the abandoned / finished tile is reused
+#pragma unroll
+    for (int k = tid; k < OS_NW * OS_BINS; k += OS_NT) (&s_wcnt[0][0])[k] = 0;
+    if (tid == 0) *s_help = OS_NO_TILE;
+    __syncthreads();
+    const u32 r = os_run_tile<PAYLOAD, OS_NT, OS_ITEMS>(keys_in, ends_in, rids_in, keys_out, ends_out, rids_out,
+                                                       n, cur, shift, gbase, status, meta, s_buf, s_wcnt,
+                                                       s_dstart, s_goff, s_scan, s_help, help_after);
+    if (r == OS_NO_TILE) {
+      if (cur == own) return;
+      cur = own;  // the helped tile is done: start over on this block's own tile
+    } else {
+      cur = r;
+      if (rounds > (1u << 20)) {  // cannot happen: every helping round completes a tile
+        if (tid == 0) meta->status = -2;
+        return;
+      }
+    }
+  }
+}
+
+// OS_NT threads x OS_ITEMS rows per thread = one tile.  Default 1024 x 8: 16 waves
+// halve the per-wave serial work of 512 x 16 at the same 8192-row tile.
+//
+// order 2 (default): tile = xcd_tile_of_block(blockIdx) -- no ticket atomic, and the
+// XCD-aware order above.  order 0: tile = atomic ticket.  Neither relies on dispatch
+// order for PROGRESS: a block whose look-back finds a predecessor silent for
+// help_after polls abandons its own tile (nothing of it has been written), computes
+// that predecessor itself -- recursively the earliest silent one -- and then starts
+// over on its own tile (os_help_loop).  A tile computed twice (by a helper and, later,
+// by its own block) publishes the same status values and writes the same bytes to the
+// same addresses, so the duplicate is harmless.
 template <int PAYLOAD, int OS_NT, int OS_ITEMS>
 __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS <= 8)) ? 8 : 1) void k_onesweep(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
     int shift, const u32* __restrict__ gbase, u32* __restrict__ status, u32* __restrict__ ticket,
-    DevMeta* __restrict__ meta, int order) {
+    DevMeta* __restrict__ meta, int order, u32 help_after) {
   constexpr int OS_TILE = OS_NT * OS_ITEMS;
   constexpr int OS_NW = OS_NT / WAVE;
   __shared__ u32 s_buf[OS_TILE];          // staging, reused for key / end / rid
@@ -326,27 +407,25 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
   __shared__ u32 s_goff[OS_BINS];
   __shared__ u32 s_scan[OS_BINS / WAVE + 1];
   __shared__ u32 s_tile;
+  __shared__ u32 s_help;
 
   const u32 tid = threadIdx.x;
-  // order 0: tile = ticket; 1: tile = permuted ticket; 2: tile = permuted blockIdx (no atomic)
-  if (tid == 0)
-    s_tile = order == 2 ? os_tile_of_ticket(blockIdx.x, gridDim.x)
-                        : (order == 1 ? os_tile_of_ticket(atomicAdd(ticket, 1u), gridDim.x) : atomicAdd(ticket, 1u));
+  if (tid == 0) {
+    s_tile = order == 2 ? xcd_tile_of_block(blockIdx.x, gridDim.x) : atomicAdd(ticket, 1u);
+    s_help = OS_NO_TILE;
+  }
 #pragma unroll
   for (int k = tid; k < OS_NW * OS_BINS; k += OS_NT) (&s_wcnt[0][0])[k] = 0;
   __syncthreads();
-  const u32 tile = s_tile;
-  const u32 tile_base = tile * OS_TILE;
-  if (tile_base >= n) return;  // block-uniform (cannot happen: grid = n_tiles)
-  const u32 n_valid = (n - tile_base) < (u32)OS_TILE ? (n - tile_base) : (u32)OS_TILE;
-  if (n_valid == (u32)OS_TILE)
-    onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, true>(keys_in, ends_in, rids_in, keys_out, ends_out,
-                                                  rids_out, n_valid, tile, tile_base, shift, gbase,
-                                                  status, meta, s_buf, s_wcnt, s_dstart, s_goff, s_scan);
-  else
-    onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, false>(keys_in, ends_in, rids_in, keys_out, ends_out,
-                                                   rids_out, n_valid, tile, tile_base, shift, gbase,
-                                                   status, meta, s_buf, s_wcnt, s_dstart, s_goff, s_scan);
+  const u32 own = s_tile;
+  if (own * OS_TILE >= n) return;  // block-uniform (cannot happen: grid = n_tiles)
+  const u32 need = os_run_tile<PAYLOAD, OS_NT, OS_ITEMS>(keys_in, ends_in, rids_in, keys_out, ends_out,
+                                                        rids_out, n, own, shift, gbase, status, meta, s_buf,
+                                                        s_wcnt, s_dstart, s_goff, s_scan, &s_help, help_after);
+  if (need != OS_NO_TILE)
+    os_help_loop<PAYLOAD, OS_NT, OS_ITEMS>(keys_in, ends_in, rids_in, keys_out, ends_out, rids_out, n, own,
+                                           need, shift, gbase, status, meta, s_buf, s_wcnt, s_dstart, s_goff,
+                                           s_scan, &s_help, help_after);
 }
 
 }  // namespace giql

@@ -668,3 +668,26 @@ def test_sort_falls_back_to_ticket_order_after_a_lookback_timeout(monkeypatch):
         assert e.stats()["sort_order_fallbacks"] == 1  # stays in ticket order, no further retries
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("help_after", ["0", "3"])
+def test_sort_progress_does_not_depend_on_dispatch_order(monkeypatch, help_after):
+    # with help_after ~ 0 every block that sees an unpublished predecessor abandons its tile and
+    # computes the predecessor itself (tiles are computed several times over): results stay exact
+    from giql_amd.engine import HipEngine
+
+    monkeypatch.setenv("GIQL_HIP_OS_HELP_AFTER", help_after)
+    e = HipEngine(0)
+    monkeypatch.delenv("GIQL_HIP_OS_HELP_AFTER")
+    try:
+        rng = np.random.default_rng(21)
+        def side(n):
+            s = rng.integers(0, 50_000_000, n).astype(np.int32)
+            return ora.Side(rng.integers(0, 4, n).astype(np.int32), s, s + rng.integers(1, 300, n).astype(np.int32))
+        a, b = side(300_000), side(1_500_000)   # 183 tiles on the B side
+        ra, rb = e.inner_join(dev(a), dev(b), 4)
+        assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), ora.sort_pairs(*ora.c_inner(a, b, "sweep")))
+        assert np.array_equal(e.semi_join(dev(a), dev(b), 4).cpu().numpy(), ora.c_semi_anti(a, b, False))
+        assert e.stats()["sort_order_fallbacks"] == 0
+    finally:
+        e.close()
