@@ -29,7 +29,7 @@ constexpr u32 OS_FLAG_PREFIX = 2u << 30;
 constexpr u32 OS_VALUE_MASK = (1u << 30) - 1u;
 constexpr u32 OS_MAX_ROWS = (1u << 30) - 1u;
 constexpr u32 OS_NO_TILE = 0xFFFFFFFFu;
-constexpr u32 OS_HELP_AFTER = 1u << 13;  // look-back polls (~100+ us) before a block computes a silent predecessor itself
+constexpr u32 OS_HELP_AFTER = 1u << 11;  // look-back polls (a few ms, several whole passes) before a block computes a silent predecessor itself
 
 // Stable in-wave rank of one item by its 8-bit digit.  For every digit bit b the
 // wave ballots the bit (m) and each lane ORs into `mis` the lanes whose bit differs
