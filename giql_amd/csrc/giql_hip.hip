@@ -284,8 +284,9 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
 static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, int n_chrom,
                          const LinBufs& lb, u32* keys, u32* ends, u32* irr_list, int which,
                          int keep_irregular, u32* hist_partial = nullptr, u32* gbase = nullptr,
-                         u32* hist_end = nullptr, u32* gbase_end = nullptr) {
+                         u32* hist_end = nullptr, u32* gbase_end = nullptr, bool skip_end = false) {
   if (s.n == 0) return GIQL_OK;
+  const int* end_col = skip_end ? (const int*)nullptr : s.end;  // a side known to hold no irregular row
   if (hist_partial)
     HIP_TRY(hipMemsetAsync(hist_partial, 0, (size_t)LIN_HIST_REPLICAS * 1024 * sizeof(u32), st));
   if (hist_end)
@@ -294,11 +295,11 @@ static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, 
   u32 grid = cdiv((u64)s.n, LIN_NT);
   if (grid > (u32)LIN_MAX_BLOCKS) grid = LIN_MAX_BLOCKS;
   if (hist_end)
-    hipLaunchKernelGGL((k_linearize<true>), dim3(grid), dim3(LIN_NT), 0, st, s.chrom, s.start, s.end,
+    hipLaunchKernelGGL((k_linearize<true>), dim3(grid), dim3(LIN_NT), 0, st, s.chrom, s.start, end_col,
                        (u32)s.n, s.start_off, s.end_off, n_chrom, lb.chrom_base, keys, ends, irr_list,
                        ctx->d_meta, which, keep_irregular, hist_partial, hist_end);
   else
-    hipLaunchKernelGGL((k_linearize<false>), dim3(grid), dim3(LIN_NT), 0, st, s.chrom, s.start, s.end,
+    hipLaunchKernelGGL((k_linearize<false>), dim3(grid), dim3(LIN_NT), 0, st, s.chrom, s.start, end_col,
                        (u32)s.n, s.start_off, s.end_off, n_chrom, lb.chrom_base, keys, ends, irr_list,
                        ctx->d_meta, which, keep_irregular, hist_partial, (u32*)nullptr);
   if (hist_partial)
@@ -630,7 +631,8 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
   SortBufs& sbb = S.sb;
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
-  // Uniform-length side?  (fixed-length reads: min == max over well-formed rows).
+  // Uniform-length side?  (fixed-length reads: min == max canonical length > 0 over ALL its
+  // rows; a single irregular row makes the minimum 0).
   // One 100-byte readback; it also surfaces chrom / span errors before the sort.
   S.uniform = 0;
   i64 uni_len = 0;
@@ -664,7 +666,8 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
                            q_is_a ? hist_a : hist_b, q_is_a ? gbase_a : gbase_b));
     GIQL_TRY(run_linearize(ctx, st, us_, n_chrom, lb, su.key[0], nullptr,
                            q_is_a ? ctx->irr_b_list : ctx->irr_a_list, q_is_a ? 1 : 0, 0,
-                           q_is_a ? hist_b : hist_a, q_is_a ? gbase_b : gbase_a));
+                           q_is_a ? hist_b : hist_a, q_is_a ? gbase_b : gbase_a, nullptr, nullptr,
+                           /*skip_end=*/true));  // uniform => no irregular row: `end` is not read
     GIQL_TRY(run_sort_onesweep(ctx, st, sq, (u32)nqr, q_is_a ? gbase_a : gbase_b, os_status));
     GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, os_status));
     constexpr u32 TQ = RC_NT * RC_ITEMS_C2;

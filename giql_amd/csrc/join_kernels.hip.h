@@ -75,7 +75,7 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
     __syncthreads();
   }
   int cur = -1, mn = INT_MAX, mx = INT_MIN;
-  int lmn = INT_MAX, lmx = 0;  // canonical length range of well-formed rows
+  int lmn = INT_MAX, lmx = 0;  // canonical length range (0 as soon as a row is irregular)
   bool bad = false;
   const i64 stride = (i64)gridDim.x * MM_NT;
   for (i64 i0 = (i64)blockIdx.x * MM_NT + threadIdx.x; i0 < n; i0 += 4 * stride) {
@@ -106,6 +106,8 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
         const int len = e - s + len_bias;
         lmn = len < lmn ? len : lmn;
         lmx = len > lmx ? len : lmx;
+      } else {
+        lmn = 0;  // an irregular row (canonical end <= start): this side is not uniform
       }
       if (c < 0 || c >= n_chrom) {
         bad = true;
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
       idx[u] = (u32)i64_;
       cv[u] = okv[u] ? chrom[idx[u]] : 0;
       sv[u] = okv[u] ? start[idx[u]] : 0;
-      ev[u] = okv[u] ? end[idx[u]] : 1;
+      ev[u] = (okv[u] && end) ? end[idx[u]] : 1;  // end == NULL: a side known to be regular
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
         const i64 ce = (i64)ev[u] + end_off;
         const int c = cv[u];
         const bool c_ok = c >= 0 && c < n_chrom;  // bad ids were flagged by k_chrom_minmax
-        irr = c_ok && !keep_irregular && ce <= cs;
+        irr = c_ok && !keep_irregular && end != nullptr && ce <= cs;
         if (c_ok && !irr) {
           const i64 b = lds_base ? s_base[c] : chrom_base[c];
           k = (u32)(b + cs);

@@ -380,17 +380,22 @@ def test_uniform_length_form(eng, which):
 
 
 def test_uniform_length_with_irregular_rows_and_encodings(eng):
-    """Zero-length / inverted rows go through the literal path; the canonical
-    offsets change the uniform length (closed intervals are one longer)."""
+    """Zero-length / inverted QUERY rows go through the literal path; the canonical
+    offsets change the uniform length (closed intervals are one longer).  An irregular
+    row on the fixed-length side itself makes that side non-uniform (general form)."""
     a = rand_side(83, 9000, 3, 40_000, 60, min_len=-5, enc=("1based", "closed"))
     b = uniform_side(84, 20_000, 3, 40_000, 30)
     b.end_off = 1  # 0-based closed: canonical length 31
-    bad = np.random.default_rng(1).integers(0, b.n, 50)
-    b.end[bad] = b.start[bad] - 3  # inverted rows on the uniform side
     want = ora.sort_pairs(*ora.c_inner(a, b, "brute"))
     assert np.array_equal(gpu_inner(eng, a, b, 3), want)
     st = eng.stats()
-    assert st["join_form"] == "uniform_b" and st["n_irregular_b"] > 0 and st["n_irregular_a"] > 0
+    assert st["join_form"] == "uniform_b" and st["n_irregular_b"] == 0 and st["n_irregular_a"] > 0
+    bad = np.random.default_rng(1).integers(0, b.n, 50)
+    b.end[bad] = b.start[bad] - 3  # inverted rows on the fixed-length side
+    want = ora.sort_pairs(*ora.c_inner(a, b, "brute"))
+    assert np.array_equal(gpu_inner(eng, a, b, 3), want)
+    st = eng.stats()
+    assert st["join_form"] == "general" and st["n_irregular_b"] > 0 and st["n_irregular_a"] > 0
 
 
 def test_uniform_form_can_be_disabled(monkeypatch):
