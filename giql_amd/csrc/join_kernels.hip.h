@@ -739,7 +739,7 @@ __device__ __noinline__ u32 fill_window_slow(const u32* s_rel, u32* mark, u32 nq
 }
 
 template <int ITEMS, bool FULL>
-__device__ __forceinline__ void fill_wave(const u32* s_rel, const int* s_rel0, const u32* s_lo,
+__device__ __forceinline__ void fill_wave(const u32* s_rel, const u32* s_jbase,
                                           const u32* s_qrid, u32* mark, u32 nqt, u32 tile_len,
                                           u64 tile_start, const u32* __restrict__ s_rid,
                                           int32_t* __restrict__ row_q, int32_t* __restrict__ row_s) {
@@ -766,37 +766,52 @@ __device__ __forceinline__ void fill_wave(const u32* s_rel, const int* s_rel0, c
     const u32 r0 = kk0 < nqt ? s_rel[kk0] : U32_MAX;
     const bool in0 = r0 < pc + WAVE;
     const u64 m0 = __ballot(in0);
-    // rows without matches share their successor's start: sorted, so compare with
-    // the previous lane (wave_shr:1 crosses the 16-lane rows on gfx9)
-    const u32 rprev = (u32)__builtin_amdgcn_update_dpp((int)(pc - 1u), (int)r0, 0x138, 0xF, 0xF, false);
-    const u64 mdup = __ballot(in0 && rprev == r0);
     u32 kd;
-    if (m0 != ~0ull && mdup == 0) {  // wave-uniform fast path
-      const u64 bit = in0 ? (1ull << (r0 - pc)) : 0ull;
-      u32 blo = (u32)bit, bhi = (u32)(bit >> 32);
+    // The in-window rows are a prefix of the lanes (starts are sorted).  With few of
+    // them -- the common case once rows average more than ~16 matches -- each is
+    // broadcast with one v_readlane and compared: ~3 VALU per row instead of the
+    // ~30 of the mask build below.  Rows without matches (shared starts) need no
+    // special care here: every row starting at or before the position counts.
+    const u32 n_in = (u32)__popcll(m0);
+    if (n_in <= 4u) {  // wave-uniform
+      const int ri = (int)(r0 - pc);  // in-window rows: 0..63
+      kd = 0;
+      if (n_in > 0u) kd += (u32)((int)lane >= __builtin_amdgcn_readlane(ri, 0));
+      if (n_in > 1u) kd += (u32)((int)lane >= __builtin_amdgcn_readlane(ri, 1));
+      if (n_in > 2u) kd += (u32)((int)lane >= __builtin_amdgcn_readlane(ri, 2));
+      if (n_in > 3u) kd += (u32)((int)lane >= __builtin_amdgcn_readlane(ri, 3));
+    } else {
+      // rows without matches share their successor's start: sorted, so compare with
+      // the previous lane (wave_shr:1 crosses the 16-lane rows on gfx9)
+      const u32 rprev = (u32)__builtin_amdgcn_update_dpp((int)(pc - 1u), (int)r0, 0x138, 0xF, 0xF, false);
+      const u64 mdup = __ballot(in0 && rprev == r0);
+      if (m0 != ~0ull && mdup == 0) {  // wave-uniform fast path
+        const u64 bit = in0 ? (1ull << (r0 - pc)) : 0ull;
+        u32 blo = (u32)bit, bhi = (u32)(bit >> 32);
 #define GIQL_OR_STEP(ctrl, rm)                                                  \
   blo |= (u32)__builtin_amdgcn_update_dpp(0, (int)blo, ctrl, rm, 0xF, false);  \
   bhi |= (u32)__builtin_amdgcn_update_dpp(0, (int)bhi, ctrl, rm, 0xF, false);
-      GIQL_OR_STEP(GIQL_DPP_ROW_SHR(1), 0xF)
-      GIQL_OR_STEP(GIQL_DPP_ROW_SHR(2), 0xF)
-      GIQL_OR_STEP(GIQL_DPP_ROW_SHR(4), 0xF)
-      GIQL_OR_STEP(GIQL_DPP_ROW_SHR(8), 0xF)
-      GIQL_OR_STEP(GIQL_DPP_ROW_BCAST15, 0xA)
-      GIQL_OR_STEP(GIQL_DPP_ROW_BCAST31, 0xC)
+        GIQL_OR_STEP(GIQL_DPP_ROW_SHR(1), 0xF)
+        GIQL_OR_STEP(GIQL_DPP_ROW_SHR(2), 0xF)
+        GIQL_OR_STEP(GIQL_DPP_ROW_SHR(4), 0xF)
+        GIQL_OR_STEP(GIQL_DPP_ROW_SHR(8), 0xF)
+        GIQL_OR_STEP(GIQL_DPP_ROW_BCAST15, 0xA)
+        GIQL_OR_STEP(GIQL_DPP_ROW_BCAST31, 0xC)
 #undef GIQL_OR_STEP
-      const u32 mlo = (u32)__builtin_amdgcn_readlane((int)blo, WAVE - 1);
-      const u32 mhi = (u32)__builtin_amdgcn_readlane((int)bhi, WAVE - 1);
-      // rows starting at positions <= my lane: mbcnt counts mask bits BELOW the
-      // lane, so add my own position's bit
-      kd = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) +
-           (u32)((lane < 32 ? (mlo >> lane) : (mhi >> (lane - 32))) & 1u);
-    } else {
-      kd = fill_window_slow(s_rel, mark, nqt, k_cur, pc);
+        const u32 mlo = (u32)__builtin_amdgcn_readlane((int)blo, WAVE - 1);
+        const u32 mhi = (u32)__builtin_amdgcn_readlane((int)bhi, WAVE - 1);
+        // rows starting at positions <= my lane: mbcnt counts mask bits BELOW the
+        // lane, so add my own position's bit
+        kd = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) +
+             (u32)((lane < 32 ? (mlo >> lane) : (mhi >> (lane - 32))) & 1u);
+      } else {
+        kd = fill_window_slow(s_rel, mark, nqt, k_cur, pc);
+      }
     }
     const u32 k = k_cur + kd;
     const u32 p_rel = pc + lane;
     // rel of row 0 is stored signed (-(tile_start - off[first row])): one formula
-    const u32 j = s_lo[k] + (u32)((int)p_rel - s_rel0[k]);
+    const u32 j = s_jbase[k] + p_rel;  // = lo[k] + (p_rel - rel0[k])
     qr[it] = s_qrid[k];
     // issued now, waited for at the stores: flies under the following windows
     if (FULL || p_rel < tile_len) sr[it] = s_rid[j];
@@ -819,8 +834,9 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
     int32_t* __restrict__ row_q, int32_t* __restrict__ row_s) {
   constexpr u32 TILE = FILL_NT * ITEMS;
   __shared__ u32 s_rel[FILL_QCAP];  // unsigned relative starts; [0] unused by searches
-  __shared__ int s_rel0[FILL_QCAP]; // same, signed, with the true (<= 0) value for row 0
-  __shared__ u32 s_lo[FILL_QCAP];
+  // lo[k] - rel0[k] (mod 2^32), rel0 = the relative start with its true (<= 0) value for row 0:
+  // the S index of output p of row k is s_jbase[k] + p
+  __shared__ u32 s_jbase[FILL_QCAP];
   __shared__ u32 s_qrid[FILL_QCAP];
   __shared__ u32 s_mark[FILL_NT / WAVE][WAVE];
   const u32 tid = threadIdx.x;
@@ -845,16 +861,15 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
         r = d > (u64)tile_len ? tile_len : (u32)d;
       }
       s_rel[k] = r;
-      s_rel0[k] = k == 0 ? -(int)(u32)first_delta : (int)r;
-      s_lo[k] = lo[qf + k];
+      s_jbase[k] = lo[qf + k] - (k == 0 ? (u32)(-(int)(u32)first_delta) : r);
       s_qrid[k] = q_rid[qf + k];
     }
     __syncthreads();
     if (tile_len == TILE)
-      fill_wave<ITEMS, true>(s_rel, s_rel0, s_lo, s_qrid, s_mark[wave_id()], nqt, tile_len,
+      fill_wave<ITEMS, true>(s_rel, s_jbase, s_qrid, s_mark[wave_id()], nqt, tile_len,
                              tile_start, s_rid, row_q, row_s);
     else
-      fill_wave<ITEMS, false>(s_rel, s_rel0, s_lo, s_qrid, s_mark[wave_id()], nqt, tile_len,
+      fill_wave<ITEMS, false>(s_rel, s_jbase, s_qrid, s_mark[wave_id()], nqt, tile_len,
                               tile_start, s_rid, row_q, row_s);
     return;
   }
