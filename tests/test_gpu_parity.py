@@ -696,3 +696,21 @@ def test_sort_progress_does_not_depend_on_dispatch_order(monkeypatch, help_after
         assert e.stats()["sort_order_fallbacks"] == 0
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("n_chrom", [1024, 1025, 5000])
+def test_many_chromosomes(eng, n_chrom):
+    # scaffolds / contigs: more partitions than the LDS tables of the min/max and linearise
+    # kernels hold (their global-memory paths), every operator against the oracle
+    rng = np.random.default_rng(n_chrom)
+    def side(n):
+        s = rng.integers(0, 20_000, n).astype(np.int32)
+        return ora.Side(rng.integers(0, n_chrom, n).astype(np.int32), s, s + rng.integers(1, 400, n).astype(np.int32))
+    a, b = side(60_000), side(90_000)
+    assert np.array_equal(gpu_inner(eng, a, b, n_chrom), ora.sort_pairs(*ora.c_inner(a, b, "sweep")))
+    assert np.array_equal(eng.semi_join(dev(a), dev(b), n_chrom).cpu().numpy(), ora.c_semi_anti(a, b, False))
+    assert np.array_equal(eng.count_overlaps(dev(a), dev(b), n_chrom).cpu().numpy(), ora.c_count(a, b, "sweep"))
+    idx, dist = eng.nearest(dev(a), dev(b), n_chrom)
+    _, od = ora.c_nearest_k1(a, b, method="sweep")
+    assert np.array_equal(dist.cpu().numpy(), od)
+    assert np.array_equal(eng.cluster(dev(a), n_chrom, 10).cpu().numpy(), ora.c_cluster(a, 10))
