@@ -1040,12 +1040,14 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
   SortBufs sa, sbb;
   OsScratch os;
   u32 *pmax = nullptr, *bmax = nullptr, *dummy_irr = nullptr, *chrom_lo = nullptr;
+  NearestRec* recs = nullptr;
   auto carve = [&](char* base) {
     Carver c{base};
     common_sizes(c, n_chrom, lb);
     sort_sizes(c, na, sa, true);
     sort_sizes(c, nb, sbb, true);
     os_scratch_sizes(c, na > nb ? na : nb, os);
+    recs = c.take<NearestRec>(na);
     pmax = c.take<u32>(nb);
     bmax = c.take<u32>(cdiv(nb, PM_TILE) + 1);
     chrom_lo = c.take<u32>((size_t)n_chrom + 2);
@@ -1078,12 +1080,14 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
                          os.gbase));
   GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status));
   {
-    Phase ph(ctx, st, GIQL_PH_COUNT, 2);
+    Phase ph(ctx, st, GIQL_PH_COUNT, 3);
     hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st,
                        lb.chrom_first, n_chrom, sbb.key[0], (u32)nb, chrom_lo);
     hipLaunchKernelGGL(k_nearest, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0], sa.rid[0],
                        (u32)na, n_chrom, lb.chrom_first, chrom_lo, sbb.key[0], pmax, sbb.rid[0], (u32)nb,
-                       is_signed, (i64)max_distance, idx_b_out, dist_out, ctx->d_meta);
+                       is_signed, (i64)max_distance, recs, ctx->d_meta);
+    hipLaunchKernelGGL(k_nearest_unpack, dim3(cdiv(na, 256)), dim3(256), 0, st, recs, (u32)na, idx_b_out,
+                       (i64*)dist_out);
     GIQL_TRY(post_launch("nearest"));
   }
   GIQL_TRY(read_meta(ctx, st));
