@@ -353,6 +353,33 @@ def _execute_cluster_merge(plan: JoinPlan, tables, eng: HipEngine, return_indice
     return out
 
 
+def _execute_filter(plan: JoinPlan, tables, eng: HipEngine, return_indices: bool):
+    """Literal-range filter of one table (BASELINE config 1): the plan's comparisons run
+    in the select kernel, the projected columns are gathered on the device."""
+    import pyarrow as pa
+
+    side = plan.left
+    if side.table not in tables:
+        raise ValueError(f"table {side.table!r} was not provided")
+    tbl = tables[side.table]
+    n = _n_rows(tbl)
+    keep = eng.select(_Residuals(plan, tbl, None, eng).preds(plan.residuals), n=n, n_rows_a=n, want=("a",))[0]
+    if return_indices:
+        return keep.cpu().numpy()
+    is_arrow = isinstance(tbl, pa.Table)
+    all_cols = list(tbl.column_names) if is_arrow else list(tbl.keys() if isinstance(tbl, dict) else tbl.columns)
+    want = [c for p in plan.projection for c in (all_cols if p.side == "star" else [p.column])]
+    taken = (_device_take(tbl, want, keep, eng) if is_arrow
+             else {c: np.asarray(_column(tbl, c))[keep.cpu().numpy()] for c in want})
+    names, cols = [], []
+    for p in plan.projection:
+        for c, out_name in ([(c, c) for c in all_cols] if p.side == "star" else [(p.column, p.name)]):
+            names.append(out_name)
+            cols.append(taken[c])
+    arrays = [c if isinstance(c, (pa.Array, pa.ChunkedArray)) else pa.array(c) for c in cols]
+    return pa.Table.from_arrays(arrays, names=names)
+
+
 def _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices):
     """count_overlaps: COUNT(b.col) per distinct left key, zero-filled
     (src/giql/expanders/intersects_duckdb.py:806-854; oracle semantics of
@@ -466,6 +493,8 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
         raise ValueError("plan must be a JoinPlan, a plan string or a GIQL query")
     if plan.kind in ("CLUSTER", "MERGE"):
         return _execute_cluster_merge(plan, tables, engine or default_engine(), return_indices)
+    if plan.kind == "FILTER":
+        return _execute_filter(plan, tables, engine or default_engine(), return_indices)
     for side in (plan.left, plan.right):
         if side.table not in tables:
             raise ValueError(f"table {side.table!r} was not provided")

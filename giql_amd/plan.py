@@ -13,7 +13,7 @@ from dataclasses import asdict, dataclass, field
 
 PLAN_PREFIX = "GIQL-HIP-PLAN/1 "
 
-KINDS = ("INNER", "SEMI", "ANTI", "NEAREST", "COUNT", "CLUSTER", "MERGE")
+KINDS = ("INNER", "SEMI", "ANTI", "NEAREST", "COUNT", "CLUSTER", "MERGE", "FILTER")
 
 
 @dataclass(frozen=True)
@@ -67,7 +67,7 @@ class Residual:
 class JoinPlan:
     kind: str
     left: PlanSide
-    right: PlanSide | None      # None for the single-table operators (CLUSTER / MERGE)
+    right: PlanSide | None      # None for the single-table operators (CLUSTER / MERGE / FILTER)
     projection: tuple[Projection, ...] = field(default_factory=tuple)
     distinct: bool = False
     # NEAREST only (src/giql/expanders/nearest.py:240-252)

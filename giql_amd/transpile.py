@@ -1,8 +1,9 @@
 """``transpile(giql, tables, dialect="hip")`` -- host-side mirror of the reference's
 ``giql.transpile`` (``src/giql/transpile.py:55-214``) for the one path this
 backend executes: the column-to-column INTERSECTS join (INNER / SEMI / ANTI, with
-comparison residuals beside the INTERSECTS), the count_overlaps shape, and the
-correlated NEAREST k=1 join.
+comparison residuals beside the INTERSECTS), the count_overlaps shape, the
+correlated NEAREST k=1 join, CLUSTER / MERGE over one table, and the single-table
+literal-range filter.
 
 The reference parses with sqlglot, which is not installable here, so this module
 carries a small hand-written parser for exactly the query shapes the reference's
@@ -221,7 +222,7 @@ def _parse_operand(p: _Parser):
     return ("col", ref)
 
 
-def _parse_conjunction(p: _Parser):
+def _parse_conjunction(p: _Parser, allow_literal: bool = False):
     """``term (AND term)*`` where a term is ``<col> INTERSECTS <col>`` or a comparison
     ``<operand> op <operand>``.  Everything else (OR, NOT, parentheses, arithmetic,
     IN / BETWEEN / LIKE / IS, sub-queries) declines: the reference either routes those
@@ -237,7 +238,15 @@ def _parse_conjunction(p: _Parser):
             if lhs[0] != "col":
                 raise _decline("INTERSECTS with a literal on the left")
             if p.peek().kind == "str":
-                raise _decline("literal-range INTERSECTS inside a join")
+                if not allow_literal:
+                    raise _decline("literal-range INTERSECTS inside a join")
+                terms.append(("intersects_lit", lhs[1], p.next().text))
+                if p.at_kw("AND"):
+                    p.next()
+                    continue
+                if p.at_kw("OR"):
+                    raise _decline("OR in the condition")
+                return terms
             if p.at_kw("ANY", "ALL"):
                 raise _decline("INTERSECTS ANY/ALL")
             if p.peek().kind != "id":
@@ -522,6 +531,117 @@ def _literal_range_sql(p: _Parser, proj_text: str, from_ref: _TableRef, tables: 
             f"AND {q}\"{t.end_col}\" > {start})")
 
 
+def _is_single_table_filter(p: _Parser) -> bool:
+    """``... FROM <one table> WHERE ...`` with a literal-range INTERSECTS and no join."""
+    depth = 0
+    seen_from = False
+    k = 0
+    toks = p.toks
+    while k < len(toks):
+        t = toks[k]
+        if t.kind == "punct" and t.text in "()":
+            depth += 1 if t.text == "(" else -1
+        if depth == 0 and t.kind == "kw":
+            if t.text == "FROM":
+                seen_from = True
+            elif seen_from and t.text in ("JOIN", "LATERAL"):
+                return False
+            elif seen_from and t.text == "WHERE":
+                return any(a.kind == "kw" and a.text == "INTERSECTS" and b.kind == "str"
+                           for a, b in zip(toks[k:], toks[k + 1:]))
+        if depth == 0 and seen_from and t.kind == "punct" and t.text == ",":
+            return False
+        k += 1
+    return False
+
+
+def _lower_filter(p: _Parser, tbls: Tables) -> JoinPlan:
+    """``SELECT <cols | *> FROM t WHERE interval INTERSECTS 'chr:lo-hi' [AND comparisons]``
+    (BASELINE config 1; the literal-range predicate of src/giql/expanders/intersects.py:85-107,
+    204-222: ``chrom = 'chr' AND start < hi AND end > lo`` on a canonical table).  Lowered to
+    three residual comparisons for the select kernel."""
+    p.expect_kw("SELECT")
+    if p.at_kw("DISTINCT"):
+        raise _decline("DISTINCT over a literal-range filter")
+    items = []
+    while True:
+        if p.peek().kind in ("num", "str") or p.at_punct("("):
+            raise _decline("expression in the SELECT list")
+        ref = p.colref()
+        if p.at_punct("("):
+            raise _decline("function call in the SELECT list")
+        if p.peek().kind == "punct" and p.peek().text in "+-/*=<>":
+            raise _decline("expression in the SELECT list")
+        alias = None
+        if p.at_kw("AS"):
+            p.next()
+            alias = p.next().text
+        elif p.peek().kind == "id":
+            alias = p.next().text
+        items.append((ref, alias))
+        if p.at_punct(","):
+            p.next()
+            continue
+        break
+    p.expect_kw("FROM")
+    ref_t = p.table_ref()
+    p.expect_kw("WHERE")
+    terms = _parse_conjunction(p, allow_literal=True)
+    if p.peek().kind == "kw" or p.at_punct(","):
+        raise _decline(f"{p.peek().text} clause after the literal predicate")
+    if p.peek().kind != "end" and not p.at_punct(";"):
+        raise _decline(f"trailing input near {p.peek().text!r}")
+    side = _table_side(ref_t, tbls)
+    table = tbls.get(ref_t.name) or Table(ref_t.name)
+    lits = [t for t in terms if t[0] == "intersects_lit"]
+    if len(lits) != 1 or any(t[0] == "intersects" for t in terms):
+        raise _decline("more than one spatial predicate")
+
+    def own(refc: _ColRef) -> str:
+        if refc.table is not None and _norm(refc.table, refc.table_quoted) != side.alias:
+            raise ValueError(f"Unknown table qualifier {refc.table!r}; expected {side.alias!r}")
+        return refc.column
+
+    _, col, text = lits[0]
+    if own(col) != table.genomic_col:
+        raise ValueError(f"{col.column!r} is not the genomic column of {ref_t.name}")
+    m = re.match(r"^(?P<chr>[\w.]+):(?P<start>\d+)-(?P<end>\d+)$", text.strip())
+    if not m:
+        raise _decline("literal range formats other than 'chr:start-end'")
+    lo, hi = int(m.group("start")), int(m.group("end"))
+    if lo >= hi:
+        raise ValueError(f"Start must be less than end: {lo} >= {hi}")
+    if table.encoding != ("0based", "half_open"):
+        raise _decline("literal predicate over a non-canonical table")
+    residuals = [Residual("where", Operand("l", side.chrom_col), "=", Operand("str", m.group("chr"))),
+                 Residual("where", Operand("l", side.start_col), "<", Operand("int", hi)),
+                 Residual("where", Operand("l", side.end_col), ">", Operand("int", lo))]
+    for t in terms:
+        if t[0] != "cmp":
+            continue
+        _, lhs, op, rhs = t
+
+        def bind(o) -> Operand:
+            if o[0] == "lit":
+                v = o[1]
+                return Operand("str" if isinstance(v, str) else ("float" if isinstance(v, float) else "int"), v)
+            return Operand("l", own(o[1]))
+
+        a, b = bind(lhs), bind(rhs)
+        if a.kind != "l" and b.kind != "l":
+            raise _decline("constant predicate")
+        residuals.append(Residual("where", a, op, b))
+    proj = []
+    for refc, alias in items:
+        if refc.star:
+            if refc.table:
+                own(refc)
+            proj.append(Projection("star", "*", "*"))
+        else:
+            proj.append(Projection("l", own(refc), alias or refc.column))
+    return JoinPlan("FILTER", side, None, tuple(proj), residuals=tuple(residuals))
+
+
 def _has_cluster_or_merge(p: _Parser) -> bool:
     depth = 0
     for k, t in enumerate(p.toks):
@@ -719,6 +839,8 @@ def build_plan(giql: str, tables=None) -> JoinPlan:
     probe = _Parser(giql)
     if probe.at_kw("SELECT") and _has_cluster_or_merge(probe):
         return _lower_cluster(probe, tables if isinstance(tables, Tables) else build_tables(tables))
+    if probe.at_kw("SELECT") and _is_single_table_filter(probe):
+        return _lower_filter(probe, tables if isinstance(tables, Tables) else build_tables(tables))
     plan = _lower(giql, tables, want_sql=False)
     assert isinstance(plan, JoinPlan)
     return plan

@@ -288,6 +288,25 @@ def test_residual_null_operands_never_match_and_type_mismatch_raises(peaks_genes
         execute(transpile(bad, tables=["peaks", "genes"], dialect="hip"), t)
 
 
+def test_literal_range_filter_runs_on_the_gpu():
+    # BASELINE config 1: SELECT * FROM peaks WHERE interval INTERSECTS 'chr1:1000-2000'
+    rng = np.random.default_rng(4)
+    rows = _rows(600, "p", rng)
+    rows += [("chr1", 900, 1000, "touch_lo", 1, "+"), ("chr1", 2000, 2100, "touch_hi", 1, "+"),
+             ("chr1", 999, 1001, "in1", 1, "+"), ("chr1", 1999, 2050, "in2", 1, "-")]
+    t = {"peaks": make_table(rows)}
+    got = rows_of(execute(transpile("SELECT * FROM peaks WHERE interval INTERSECTS 'chr1:1000-2000'",
+                                    tables=["peaks"], dialect="hip"), t))
+    want = sorted(r for r in rows if r[0] == "chr1" and r[1] < 2000 and r[2] > 1000)
+    assert got == want and ("chr1", 999, 1001, "in1", 1, "+") in got
+    assert not any(r[3] in ("touch_lo", "touch_hi") for r in got)
+    q = "SELECT name, score AS s FROM peaks p WHERE p.interval INTERSECTS 'chr2:100-900' AND p.score >= 3 AND p.strand = '-'"
+    got = rows_of(execute(transpile(q, tables=["peaks"], dialect="hip"), t))
+    assert got == sorted((r[3], r[4]) for r in rows if r[0] == "chr2" and r[1] < 900 and r[2] > 100 and r[4] >= 3 and r[5] == "-")
+    none = execute(transpile("SELECT * FROM peaks WHERE interval INTERSECTS 'chrZ:1-2'", tables=["peaks"], dialect="hip"), t)
+    assert none.num_rows == 0 and none.column_names == t["peaks"].column_names
+
+
 def test_cluster_query_known_answers():
     # tests/integration/datafusion/test_cross_target_oracle.py:978-1003 and
     # tests/integration/bedtools/test_cluster.py:69-113 (contained intervals share one cluster)

@@ -204,6 +204,27 @@ def test_cluster_merge_mistakes_and_declines(query, exc, match):
         assert not isinstance(ei.value, HipDeclined)
 
 
+def test_literal_range_filter_lowers_to_three_comparisons():
+    # BASELINE config 1 (README.md:35-50): chrom = 'chr1' AND start < 2000 AND end > 1000
+    # (src/giql/expanders/intersects.py:85-107, 204-222)
+    p = build_plan("SELECT * FROM peaks WHERE interval INTERSECTS 'chr1:1000-2000'", ["peaks"])
+    assert p.kind == "FILTER" and p.right is None
+    assert [(r.lhs.value, r.op, r.rhs.value) for r in p.residuals] == [
+        ("chrom", "=", "chr1"), ("start", "<", 2000), ("end", ">", 1000)]
+    assert JoinPlan.from_string(p.to_string()) == p
+    q = "SELECT name, score AS s FROM peaks p WHERE p.score > 5 AND p.interval INTERSECTS 'chr2:5-9'"
+    p = build_plan(q, ["peaks"])
+    assert [(x.column, x.name) for x in p.projection] == [("name", "name"), ("score", "s")]
+    assert [(r.lhs.value, r.op, r.rhs.value) for r in p.residuals][3:] == [("score", ">", 5)]
+    with pytest.raises(ValueError, match="Start must be less than end"):
+        build_plan("SELECT * FROM peaks WHERE interval INTERSECTS 'chr1:2000-1000'", ["peaks"])
+    with pytest.raises(HipDeclined):
+        build_plan("SELECT * FROM peaks WHERE interval INTERSECTS 'chr1:1000-2000' OR score > 1", ["peaks"])
+    with pytest.raises(HipDeclined):  # non-canonical encodings keep the reference's SQL path
+        build_plan("SELECT * FROM peaks WHERE interval INTERSECTS 'chr1:1000-2000'",
+                   [Table("peaks", coordinate_system="1based", interval_type="closed")])
+
+
 COUNT_Q = ('SELECT a.chrom, a.start, a."end", COUNT(b.chrom) AS n FROM peaks a '
            'LEFT JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom, a.start, a."end"')
 
