@@ -50,6 +50,7 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--workload", default="cfg4_10Mx100M_24chrom", choices=sorted(WORKLOADS))
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--force-exchange", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--no-gather", action="store_true",
                    help="N>1: skip the final RCCL gather of the pairs (compute-only scaling)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -195,13 +196,18 @@ def main() -> None:
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    distributed = world > 1
+    # --force-exchange: run the N>1 exchange code (process group, counts, take into the send
+    # block, all-gather) with a single rank -- the only way to drive it over RCCL on a 1-GPU box
+    distributed = world > 1 or args.force_exchange
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the exchange happens
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -227,18 +233,17 @@ def main() -> None:
     eng = HipEngine(dev_index)
     out_cap = 0
     out = None
-    # shard-local row index -> global row id (ranks own disjoint chromosome sets;
-    # global ids are "rows of lower ranks first")
-    idmap_a = idmap_b = None
+    # shard-local row index -> global row id: ranks own disjoint chromosome sets and the
+    # global table is "rows of lower ranks first", so the map is one offset per side
+    # (giql_amd.distributed.sharded_inner_join handles arbitrary row sets with the take kernel)
+    base_a = base_b = 0
     if distributed:
         from giql_amd import distributed as D
 
         sizes = torch.tensor([loc_na, loc_nb], dtype=torch.int64, device=xdev)
         all_sizes = torch.empty((world, 2), dtype=torch.int64, device=xdev)
         dist.all_gather_into_tensor(all_sizes.view(-1), sizes)
-        base = (all_sizes[:rank].sum(0) if rank else torch.zeros(2, dtype=torch.int64)).to(dev)
-        idmap_a = (torch.arange(loc_na, device=dev, dtype=torch.int64) + base[0]).to(torch.int32)
-        idmap_b = (torch.arange(loc_nb, device=dev, dtype=torch.int64) + base[1]).to(torch.int32)
+        base_a, base_b = (int(x) for x in all_sizes[:rank].sum(0).tolist()) if rank else (0, 0)
 
     xg = D.PairGather(xdev) if distributed and not args.no_gather else None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if distributed else None
@@ -254,14 +259,22 @@ def main() -> None:
         if ev:
             ev[0].record()
         n = eng.inner_plan(a, b, n_chrom)
-        if n > out_cap:
-            out = None
-            out_cap = int(n * 1.05) + 1024
-            out = torch.empty((2, out_cap), dtype=torch.int32, device=dev)
-        eng.inner_fill(out[0, :n], out[1, :n])
+        if xg is not None and xdev == dev:
+            # the path's one exchange step starts here: the counts are all-gathered, then the
+            # fill writes straight into the send block of the all-gather (no repacking)
+            counts = xg.counts(n)
+            send = xg.send_block(max(counts))
+            ra, rb = send[0, :n], send[1, :n]
+        else:
+            if n > out_cap:
+                out = None
+                out_cap = int(n * 1.05) + 1024
+                out = torch.empty((2, out_cap), dtype=torch.int32, device=dev)
+            ra, rb = out[0, :n], out[1, :n]
+        eng.inner_fill(ra, rb)
         if ev:
             ev[1].record()
-        if collect:  # the join's phase times, before the exchange's take calls reset them
+        if collect:  # the join's phase times, before anything else touches the engine
             st = eng.stats()
             last_stats[0] = st
             for k, v in st["phase_ms"].items():
@@ -269,16 +282,16 @@ def main() -> None:
             for k, v in st["phase_launches"].items():
                 phase_launches[k] = phase_launches.get(k, 0) + v
         if xg is not None:
-            # the path's one exchange step: counts, then the pairs as GLOBAL row ids,
-            # mapped by the take kernel straight into the send block of the all-gather
-            counts = xg.counts(n)
-            send = xg.send_block(max(counts))
-            if send.device == dev:
-                eng.take([idmap_a], out[0, :n], outs=[send[0, :n]])
-                eng.take([idmap_b], out[1, :n], outs=[send[1, :n]])
+            if xdev == dev:
+                if base_a:
+                    ra.add_(base_a)  # local -> global row ids, in place in the send block
+                if base_b:
+                    rb.add_(base_b)
             else:  # gloo rehearsal: the exchange runs through host memory
-                send[0, :n] = eng.take([idmap_a], out[0, :n])[0].to(xdev)
-                send[1, :n] = eng.take([idmap_b], out[1, :n])[0].to(xdev)
+                counts = xg.counts(n)
+                send = xg.send_block(max(counts))
+                send[0, :n] = (ra + base_a).to(xdev)
+                send[1, :n] = (rb + base_b).to(xdev)
             xg.all_gather(counts)
         if ev:
             ev[2].record()
