@@ -95,6 +95,10 @@ struct giql_hip_ctx {
   int n_cu = 256;             // compute units of the device
   int os_order = 2;           // onesweep tile order (GIQL_HIP_OS_ORDER, see k_onesweep)
   u32 os_help_after = OS_HELP_AFTER;  // look-back polls before a block helps (GIQL_HIP_OS_HELP_AFTER)
+  bool spec_valid = false;    // INNER: the previous plan's form decision, speculated on next time
+  int spec_form = 0;
+  i64 spec_len = 0;
+  int spec_misses = 0;
   int inject_timeout = 0;     // test hook: report one look-back timeout
   int order_fallbacks = 0;    // calls repeated in the ticket order after a timeout
 
@@ -636,18 +640,34 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
   // One 100-byte readback; it also surfaces chrom / span errors before the sort.
   S.uniform = 0;
   i64 uni_len = 0;
-  if (onesweep && !ctx->no_uniform) {
-    GIQL_TRY(read_meta(ctx, st));
-    const DevMeta& m = *ctx->h_meta;
+  // The form is decided from the length ranges the min/max pass just produced.  Reading
+  // them back costs a stream sync in the middle of the plan, so a context that has
+  // planned before SPECULATES on its previous decision and validates it against the same
+  // numbers at the read-back the plan ends with anyway; a wrong guess (the kernels are
+  // memory-safe on any input) repeats the plan once without speculation.
+  auto decide = [&](const DevMeta& m, int& form, i64& len) {
     const bool ub = m.len_min_b == m.len_max_b && m.len_max_b > 0;
     const bool ua = m.len_min_a == m.len_max_a && m.len_max_a > 0;
+    form = 0;
+    len = 0;
     // sort the uniform side without its end; prefer the larger side when both are
     if (ub && (!ua || nb >= na)) {
-      S.uniform = 1;
-      uni_len = m.len_max_b;
+      form = 1;
+      len = m.len_max_b;
     } else if (ua) {
-      S.uniform = 2;
-      uni_len = m.len_max_a;
+      form = 2;
+      len = m.len_max_a;
+    }
+  };
+  bool speculated = false;
+  if (onesweep && !ctx->no_uniform) {
+    if (ctx->spec_valid) {
+      S.uniform = ctx->spec_form;
+      uni_len = ctx->spec_len;
+      speculated = true;
+    } else {
+      GIQL_TRY(read_meta(ctx, st));
+      decide(*ctx->h_meta, S.uniform, uni_len);
     }
   }
   const u32* irr_a = &ctx->d_meta->irr_a;
@@ -730,6 +750,19 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
   GIQL_TRY(read_meta(ctx, st));
   ctx->n_c1 = ctx->h_meta->n_out_c1;
   ctx->n_reg = ctx->h_meta->n_out + ctx->n_c1;
+  }
+  if (onesweep && !ctx->no_uniform) {
+    int form;
+    i64 len;
+    decide(*ctx->h_meta, form, len);
+    if (speculated && (form != S.uniform || len != uni_len)) {
+      ctx->spec_valid = false;  // wrong guess: plan again from the numbers just read
+      ctx->spec_misses++;
+      return giql_hip_inner_plan_dev_impl(ctx, a, b, n_chrom, stream, n_pairs);
+    }
+    ctx->spec_valid = true;
+    ctx->spec_form = form;
+    ctx->spec_len = len;
   }
   ctx->stats.n_irregular_a = ctx->h_meta->irr_a;
   ctx->stats.n_irregular_b = ctx->h_meta->irr_b;

@@ -714,3 +714,20 @@ def test_many_chromosomes(eng, n_chrom):
     _, od = ora.c_nearest_k1(a, b, method="sweep")
     assert np.array_equal(dist.cpu().numpy(), od)
     assert np.array_equal(eng.cluster(dev(a), n_chrom, 10).cpu().numpy(), ora.c_cluster(a, 10))
+
+
+def test_join_form_speculation_survives_changing_inputs(eng):
+    # a context speculates on its previous form decision (uniform_b / uniform_a / general, and the
+    # fixed length) and validates it at the end of the plan: every switch must still be exact
+    seq = [
+        ("uniform_b", rand_side(201, 30_000, 4, 2_000_000, 700), uniform_side(202, 200_000, 4, 2_000_000, 150)),
+        ("uniform_b", rand_side(203, 30_000, 4, 2_000_000, 700), uniform_side(204, 200_000, 4, 2_000_000, 150)),
+        ("uniform_b", rand_side(205, 30_000, 4, 2_000_000, 700), uniform_side(206, 200_000, 4, 2_000_000, 90)),   # other length
+        ("general", rand_side(207, 30_000, 4, 2_000_000, 700), rand_side(208, 100_000, 4, 2_000_000, 300)),
+        ("uniform_a", uniform_side(209, 150_000, 4, 2_000_000, 60), rand_side(210, 40_000, 4, 2_000_000, 500)),
+        ("general", rand_side(211, 30_000, 4, 2_000_000, 700), rand_side(212, 100_000, 4, 2_000_000, 300)),
+        ("uniform_b", rand_side(213, 30_000, 4, 2_000_000, 700), uniform_side(214, 200_000, 4, 2_000_000, 150)),
+    ]
+    for form, a, b in seq:
+        assert np.array_equal(gpu_inner(eng, a, b, 4), ora.sort_pairs(*ora.c_inner(a, b, "sweep"))), form
+        assert eng.stats()["join_form"] == form
