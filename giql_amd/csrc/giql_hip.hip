@@ -307,10 +307,10 @@ static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, 
                        (u32)s.n, s.start_off, s.end_off, n_chrom, lb.chrom_base, keys, ends, irr_list,
                        ctx->d_meta, which, keep_irregular, hist_partial, (u32*)nullptr);
   if (hist_partial)
-    hipLaunchKernelGGL(k_digit_offsets, dim3(1), dim3(256), 0, st, hist_partial,
+    hipLaunchKernelGGL(k_digit_offsets, dim3(4), dim3(256), 0, st, hist_partial,
                        (u32)LIN_HIST_REPLICAS, gbase);
   if (hist_end)
-    hipLaunchKernelGGL(k_digit_offsets, dim3(1), dim3(256), 0, st, hist_end, (u32)LIN_HIST_REPLICAS,
+    hipLaunchKernelGGL(k_digit_offsets, dim3(4), dim3(256), 0, st, hist_end, (u32)LIN_HIST_REPLICAS,
                        gbase_end);
   return post_launch("linearize");
 }

@@ -375,18 +375,17 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
   }
 }
 
-// Single block: gbase[p][d] = exclusive scan over d of sum_r replica[r][p][d].
+// gbase[p][d] = exclusive scan over d of sum_r replica[r][p][d]; one block per digit p.
 __global__ __launch_bounds__(256) void k_digit_offsets(const u32* __restrict__ partial, u32 n_blocks,
                                                         u32* __restrict__ gbase) {
   __shared__ u32 lds[256 / WAVE + 1];
-  for (int p = 0; p < 4; p++) {
-    u32 c = 0;
+  const int p = blockIdx.x;
+  u32 c = 0;
 #pragma unroll 8
-    for (u32 b = 0; b < n_blocks; b++) c += partial[(size_t)b * 1024 + p * 256 + threadIdx.x];
-    u32 total;
-    const u32 ex = block_excl_scan<u32, 256>(c, lds, total);
-    gbase[p * 256 + threadIdx.x] = ex;
-  }
+  for (u32 b = 0; b < n_blocks; b++) c += partial[(size_t)b * 1024 + p * 256 + threadIdx.x];
+  u32 total;
+  const u32 ex = block_excl_scan<u32, 256>(c, lds, total);
+  gbase[p * 256 + threadIdx.x] = ex;
 }
 
 // ------------------------------------------------------------- range count
