@@ -206,6 +206,40 @@ __global__ void k_chrom_bounds(const u32* __restrict__ chrom_first, int n_chrom,
   if (c <= n_chrom) chrom_lo[c] = lower_bound_u32(b_keys, 0, n_b, chrom_first[c]);
 }
 
+// NEAREST wants B in (start, end) order.  Equal starts are short runs in real tables,
+// so instead of a second full sort (stable by end first, then by start) the run heads
+// fix their runs in place after ONE sort by start: an insertion sort of (end, rid) by
+// end, one thread per run.  A run longer than NEAREST_TIE_MAX sets meta->aux0 and the
+// host repeats the call with the two-sort plan (and keeps using it).
+constexpr u32 NEAREST_TIE_MAX = 32;
+
+__global__ __launch_bounds__(256) void k_fix_start_ties(const u32* __restrict__ keys,
+                                                        u32* __restrict__ ends, u32* __restrict__ rids,
+                                                        u32 n, DevMeta* __restrict__ meta) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 k = keys[i];
+  if (i > 0 && keys[i - 1] == k) return;  // not a run head
+  u32 len = 1;
+  while (i + len < n && len <= NEAREST_TIE_MAX && keys[i + len] == k) len++;
+  if (len == 1) return;
+  if (len > NEAREST_TIE_MAX) {
+    meta->aux0 = 1;
+    return;
+  }
+  for (u32 a = 1; a < len; a++) {
+    const u32 e = ends[i + a], r = rids[i + a];
+    u32 b = a;
+    while (b > 0 && ends[i + b - 1] > e) {
+      ends[i + b] = ends[i + b - 1];
+      rids[i + b] = rids[i + b - 1];
+      b--;
+    }
+    ends[i + b] = e;
+    rids[i + b] = r;
+  }
+}
+
 struct alignas(16) NearestRec {
   i64 dist;
   int32_t idx;

@@ -95,6 +95,7 @@ struct giql_hip_ctx {
   int n_cu = 256;             // compute units of the device
   int os_order = 2;           // onesweep tile order (GIQL_HIP_OS_ORDER, see k_onesweep)
   u32 os_help_after = OS_HELP_AFTER;  // look-back polls before a block helps (GIQL_HIP_OS_HELP_AFTER)
+  bool nearest_two_sorts = false;  // NEAREST: a B table with long equal-start runs was seen
   bool spec_valid = false;    // INNER: the previous plan's form decision, speculated on next time
   int spec_form = 0;
   i64 spec_len = 0;
@@ -1091,23 +1092,30 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
   carve(ctx->arena);
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
+  const bool two_sorts = ctx->nearest_two_sorts;
   GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist,
-                         os.gbase, os.hist_e, os.gbase_e));
+                         os.gbase, two_sorts ? os.hist_e : nullptr, two_sorts ? os.gbase_e : nullptr));
   {
     Phase ph(ctx, st, GIQL_PH_AUX);
     hipLaunchKernelGGL(k_check_not_inverted, dim3(cdiv(nb, 256)), dim3(256), 0, st, view_of(*b),
                        ctx->d_meta);
   }
-  // (start, end) lexicographic order = stable sort by end, then stable sort by start
-  {
+  if (two_sorts) {
+    // (start, end) lexicographic order = stable sort by end, then stable sort by start
     SortBufs by_end = sbb;
     for (int k = 0; k < 2; k++) {
       by_end.key[k] = sbb.end[k];
       by_end.end[k] = sbb.key[k];
     }
     GIQL_TRY(run_sort_onesweep(ctx, st, by_end, (u32)nb, os.gbase_e, os.status));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, /*keep_rids=*/true));
+  } else {
+    // one sort by start; the (short) runs of equal starts are ordered by end in place
+    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status));
+    Phase ph(ctx, st, GIQL_PH_AUX);
+    hipLaunchKernelGGL(k_fix_start_ties, dim3(cdiv(nb, 256)), dim3(256), 0, st, sbb.key[0], sbb.end[0],
+                       sbb.rid[0], (u32)nb, ctx->d_meta);
   }
-  GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, /*keep_rids=*/true));
   GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
   GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist,
                          os.gbase));
@@ -1124,6 +1132,11 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
     GIQL_TRY(post_launch("nearest"));
   }
   GIQL_TRY(read_meta(ctx, st));
+  if (!two_sorts && ctx->h_meta->aux0 != 0) {
+    // a long run of equal starts (pile-ups): this table wants the two-sort plan
+    ctx->nearest_two_sorts = true;
+    return giql_hip_nearest_dev_impl(ctx, a, b, n_chrom, is_signed, max_distance, idx_b_out, dist_out, stream);
+  }
   collect_spans(ctx);
   ctx->stats.n_out = a->n;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;

@@ -731,3 +731,36 @@ def test_join_form_speculation_survives_changing_inputs(eng):
     for form, a, b in seq:
         assert np.array_equal(gpu_inner(eng, a, b, 4), ora.sort_pairs(*ora.c_inner(a, b, "sweep"))), form
         assert eng.stats()["join_form"] == form
+
+
+def test_nearest_equal_starts_short_runs_and_pileups():
+    # NEAREST orders ties by (start, end): short runs of equal starts are fixed in place after one
+    # sort, a pile-up (> 32 equal starts) makes the context switch to the two-sort plan
+    from giql_amd.engine import HipEngine
+
+    e = HipEngine(0)
+    try:
+        rng = np.random.default_rng(77)
+        def check(b):
+            n = 4000
+            s = rng.integers(0, 3000, n).astype(np.int32)
+            a = ora.Side(rng.integers(0, 2, n).astype(np.int32), s, s + rng.integers(0, 40, n).astype(np.int32))
+            idx, dist = e.nearest(dev(a), dev(b), 2, signed=True)
+            oi, od = ora.c_nearest_k1(a, b, signed=True, method="sweep")
+            j = idx.cpu().numpy()
+            assert np.array_equal(dist.cpu().numpy(), od)
+            ok = j >= 0
+            assert np.array_equal(ok, oi >= 0)
+            assert np.array_equal(b.start[j[ok]], b.start[oi[ok]]) and np.array_equal(b.end[j[ok]], b.end[oi[ok]])
+        # runs of 1-6 equal starts with shuffled ends
+        st = np.repeat(rng.integers(0, 3000, 800), rng.integers(1, 7, 800)).astype(np.int32)
+        b = ora.Side(rng.integers(0, 2, st.size).astype(np.int32), st, st + rng.integers(1, 60, st.size).astype(np.int32))
+        check(b)
+        # a pile-up: 200 rows starting at the same base
+        st2 = np.concatenate([st, np.full(200, 1500, np.int32)])
+        b2 = ora.Side(np.concatenate([b.chrom, np.zeros(200, np.int32)]), st2,
+                      st2 + np.concatenate([b.end - b.start, rng.integers(1, 500, 200).astype(np.int32)]))
+        check(b2)
+        check(b)  # stays correct (two-sort plan from now on)
+    finally:
+        e.close()
