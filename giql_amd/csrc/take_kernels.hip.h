@@ -140,10 +140,9 @@ __global__ __launch_bounds__(TK_NT) void k_take_utf8_len(const int* __restrict__
   if (bad) atomicMin(&meta->status, -1);
 }
 
-// pass 2: copy the bytes.  One lane per output row for short values (a byte loop
-// bounded by the wave's longest short row: adjacent lanes write adjacent output
-// segments); rows longer than TKS_SHORT bytes are copied by the whole wave, 64
-// bytes per step.
+// pass 2: copy the bytes.  One lane per output row for short values (adjacent lanes
+// write adjacent output segments); rows longer than TKS_SHORT bytes are copied by the
+// whole wave, 64 bytes per step.
 constexpr u32 TKS_SHORT = 32;
 
 __device__ __forceinline__ u64 shfl_u64(u64 v, int src_lane) {
@@ -176,10 +175,31 @@ __global__ __launch_bounds__(TK_NT) void k_take_utf8_copy(const int* __restrict_
     }
     const bool is_long = len > TKS_SHORT;
     const u32 slen = is_long ? 0u : len;
-    u32 wmax = slen;
-    wmax = wave_reduce_max_u32(wmax);
-    for (u32 k = 0; k < wmax; k++)
-      if (k < slen) dst[k] = src[k];
+    // short rows: 16 / 8 / 4-byte pieces at the row's own (arbitrary) alignment -- gfx950
+    // serves unaligned global accesses, and hipcc lowers these fixed-size memcpys to single
+    // dwordx4 / dwordx2 / dword instructions -- then at most 3 single bytes: a 13-byte value
+    // is 3 load/store pairs instead of 13
+    {
+      u32 k = 0;
+      for (; k + 16 <= slen; k += 16) {
+        TkU128 w;
+        __builtin_memcpy(&w, src + k, 16);
+        __builtin_memcpy(dst + k, &w, 16);
+      }
+      if (k + 8 <= slen) {
+        u64 w;
+        __builtin_memcpy(&w, src + k, 8);
+        __builtin_memcpy(dst + k, &w, 8);
+        k += 8;
+      }
+      if (k + 4 <= slen) {
+        u32 w;
+        __builtin_memcpy(&w, src + k, 4);
+        __builtin_memcpy(dst + k, &w, 4);
+        k += 4;
+      }
+      for (; k < slen; k++) dst[k] = src[k];
+    }
     u64 longs = __ballot(is_long);
     while (longs) {
       const int l = __ffsll((long long)longs) - 1;
@@ -189,7 +209,14 @@ __global__ __launch_bounds__(TK_NT) void k_take_utf8_copy(const int* __restrict_
       const u32 ln = (u32)__shfl((int)len, l, 64);
       const uint8_t* ws = reinterpret_cast<const uint8_t*>((uintptr_t)s);
       uint8_t* wd = reinterpret_cast<uint8_t*>((uintptr_t)d);
-      for (u32 k = lane_id(); k < ln; k += 64) wd[k] = ws[k];
+      // 4 bytes per lane per step (unaligned dwords), then the last ln % 4 bytes
+      const u32 body = ln & ~3u;
+      for (u32 k = lane_id() * 4u; k < body; k += 256u) {
+        u32 w;
+        __builtin_memcpy(&w, ws + k, 4);
+        __builtin_memcpy(wd + k, &w, 4);
+      }
+      if (lane_id() < (ln & 3u)) wd[body + lane_id()] = ws[body + lane_id()];
     }
   }
 }
