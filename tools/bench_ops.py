@@ -75,7 +75,7 @@ def main():
         run(f"cfg2_inner_1Mx1M_{tag}", inner, n, "pairs")
         del out
     # ---- projection: gather payload columns by the ~7e7 pairs of a 10M x 10M join
-    if not args.only or "take" in args.only:
+    if not args.only or "take" in args.only or "select" in args.only:
         ca = synth.make_table(10_000_000, 7, "peaks")
         cb = synth.make_table(10_000_000, 8, "peaks")
         a, b = side(ca), side(cb)
@@ -99,6 +99,13 @@ def main():
         off = torch.from_numpy(np.frombuffer(arr.buffers()[1], np.int32, count=len(arr) + 1).copy()).to(dev)
         data = torch.from_numpy(np.frombuffer(arr.buffers()[2], np.uint8).copy()).to(dev)
         run("take_utf8_13B", lambda: eng.take_utf8(off, data, rb)[0], p * (4 + 8 + 4 + 13 + 13) / 1e9, "GB")
+        # residual predicates: same-strand filter over the pairs, int-compare filter over rows
+        strand_a = torch.randint(0, 2, (a.n,), dtype=torch.int32, device=dev)
+        strand_b = torch.randint(0, 2, (b.n,), dtype=torch.int32, device=dev)
+        run("select_pairs_same_strand", lambda: eng.select([(("a", strand_a), "=", ("b", strand_b))], idx_a=ra, idx_b=rb,
+                                                           n_rows_a=a.n, n_rows_b=b.n)[0], p * (8 + 8 + 8) / 1e9, "GB")
+        run("select_rows_10M", lambda: eng.select([(("a", a.start), ">", ("lit", 1_000_000))], n=a.n, n_rows_a=a.n,
+                                                  want=("a",))[0], a.n * 8 / 1e9, "GB")
         del ra, rb, off, data
     # ---- CLUSTER / MERGE: 10M peaks, 24 chromosomes
     if not args.only or "cluster" in args.only or "merge" in args.only:
