@@ -764,3 +764,18 @@ def test_nearest_equal_starts_short_runs_and_pileups():
         check(b)  # stays correct (two-sort plan from now on)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("n_tiles,extra", [(1, 0), (1, 1), (63, 5), (64, 0), (64, 1), (65, 8191), (127, 17), (128, 0), (129, 4096), (200, 1)])
+def test_sort_tile_order_edges(eng, n_tiles, extra):
+    # the sort maps blocks to tiles through an XCD-aware permutation inside groups of 64 tiles, with an
+    # identity tail: exercise tile counts around the group size and partial last tiles (8192-row tiles)
+    n_b = n_tiles * 8192 + extra - (8192 if extra else 0) if n_tiles > 1 or extra else 8192
+    n_b = max(n_b, 1)
+    rng = np.random.default_rng(n_tiles * 10007 + extra)
+    sb = rng.integers(0, 40_000_000, n_b).astype(np.int32)
+    b = ora.Side(rng.integers(0, 3, n_b).astype(np.int32), sb, sb + rng.integers(1, 200, n_b).astype(np.int32))
+    sa = rng.integers(0, 40_000_000, 20_000).astype(np.int32)
+    a = ora.Side(rng.integers(0, 3, 20_000).astype(np.int32), sa, sa + rng.integers(1, 3000, 20_000).astype(np.int32))
+    assert np.array_equal(eng.count_overlaps(dev(a), dev(b), 3).cpu().numpy(), ora.c_count(a, b, "sweep"))
+    assert np.array_equal(gpu_inner(eng, a, b, 3), ora.sort_pairs(*ora.c_inner(a, b, "sweep")))
