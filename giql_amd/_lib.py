@@ -36,6 +36,7 @@ SYMBOLS = [
     "giql_hip_free_host", "giql_hip_pairs_checksum_dev",
     "giql_hip_take_dev", "giql_hip_take_utf8_plan_dev", "giql_hip_take_utf8_fill_dev",
     "giql_hip_select_dev", "giql_hip_mark_dev", "giql_hip_cluster_dev", "giql_hip_merge_dev",
+    "giql_hip_group_rows_dev", "giql_hip_segment_sum_dev",
 ]
 
 
@@ -166,6 +167,8 @@ def load() -> ctypes.CDLL:
     L.giql_hip_take_utf8_fill_dev.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, vp]
     L.giql_hip_select_dev.argtypes = [vp, P(CPred), i32, vp, i64, vp, i64, i64, vp, vp, P(i64), vp]
     L.giql_hip_mark_dev.argtypes = [vp, vp, i64, vp, i64, vp]
+    L.giql_hip_group_rows_dev.argtypes = [vp, P(CSide), i32, vp, vp, P(i64), vp]
+    L.giql_hip_segment_sum_dev.argtypes = [vp, vp, vp, i64, vp, i64, vp]
     L.giql_hip_cluster_dev.argtypes = [vp, P(CSide), i32, i64, vp, vp]
     L.giql_hip_merge_dev.argtypes = [vp, P(CSide), i32, i64, vp, vp, vp, vp, i64, P(i64), vp]
     for name in SYMBOLS:

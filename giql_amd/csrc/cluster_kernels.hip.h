@@ -87,4 +87,44 @@ __global__ __launch_bounds__(256) void k_merge_rows(const u32* __restrict__ head
   if (out_count) out_count[g] = (i64)(i1 - i0);
 }
 
+// ---- distinct intervals (GROUP BY chrom, start, end) -------------------------------------
+// rows sorted by (start, end): a row heads a group when its (key, end) differs from the
+// previous row's
+__global__ __launch_bounds__(256) void k_group_flags(const u32* __restrict__ keys,
+                                                     const u32* __restrict__ ends, u32 n,
+                                                     u32* __restrict__ flags) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flags[i] = (i == 0 || keys[i] != keys[i - 1] || ends[i] != ends[i - 1]) ? 1u : 0u;
+}
+
+// group index of every row (scattered by row id) and one representative row per group
+__global__ __launch_bounds__(256) void k_group_ids(const u32* __restrict__ rids,
+                                                   const u32* __restrict__ flags,
+                                                   const u32* __restrict__ excl, u32 n,
+                                                   int* __restrict__ group_of_row,
+                                                   int* __restrict__ rep_row) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u32 g = excl[i] + flags[i] - 1u;
+  const u32 r = rids[i];
+  group_of_row[r] = (int)g;
+  if (flags[i]) rep_row[g] = (int)r;
+}
+
+// sums[group_of_row[i]] += values[i]
+__global__ __launch_bounds__(256) void k_segment_sum(const i64* __restrict__ values,
+                                                     const int* __restrict__ group_of_row, u64 n,
+                                                     u32 n_groups, unsigned long long* __restrict__ sums,
+                                                     DevMeta* __restrict__ meta) {
+  const u64 stride = (u64)gridDim.x * 256;
+  bool bad = false;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int g = group_of_row[i];
+    if (g < 0 || (u32)g >= n_groups) bad = true;
+    else atomicAdd(&sums[g], (unsigned long long)values[i]);
+  }
+  if (bad) atomicMin(&meta->status, -1);
+}
+
 }  // namespace giql

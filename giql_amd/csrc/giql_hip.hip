@@ -1311,6 +1311,124 @@ int giql_hip_merge_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, i
   return with_order_fallback(ctx, [&] { return giql_hip_merge_dev_impl(ctx, s, n_chrom, distance, out_chrom, out_start, out_end, out_count, capacity, n_out, stream); });
 }
 
+// ------------------------------------------- distinct intervals + segment sums
+// (the aggregate half of count_overlaps: GROUP BY the left interval, SUM of the per-row
+// counts -- src/giql/expanders/intersects_duckdb.py:806-854)
+static int giql_hip_group_rows_dev_impl(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom,
+                                        int32_t* group_of_row, int32_t* rep_row, int64_t* n_groups,
+                                        void* stream) {
+  if (!ctx || !n_groups) return set_err(GIQL_ERR_INVALID, "ctx/n_groups is NULL");
+  GIQL_TRY(check_side(s, "s"));
+  if (n_chrom < 0) return set_err(GIQL_ERR_INVALID, "n_chrom < 0");
+  if ((size_t)s->n > OS_MAX_ROWS) return set_err(GIQL_ERR_INVALID, "side larger than 2^30 rows");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  ctx->planned = false;
+  reset_stats(ctx);
+  ctx->stats.n_a = s->n;
+  *n_groups = 0;
+  if (s->n == 0) return GIQL_OK;
+  if (!group_of_row || !rep_row) return set_err(GIQL_ERR_INVALID, "output buffer is NULL");
+  if (n_chrom == 0) return set_err(GIQL_ERR_CHROM, "rows but n_chrom = 0");
+  const size_t n = (size_t)s->n;
+  LinBufs lb;
+  SortBufs sb;
+  OsScratch os;
+  u32 *flags = nullptr, *excl = nullptr, *dummy_irr = nullptr;
+  u64 *bsums = nullptr, *total = nullptr;
+  auto carve = [&](char* base) {
+    Carver c{base};
+    common_sizes(c, n_chrom, lb);
+    sort_sizes(c, n, sb, true);
+    os_scratch_sizes(c, n, os);
+    flags = c.take<u32>(n);
+    excl = c.take<u32>(n + 1);
+    bsums = c.take<u64>(cdiv((u64)n, SCAN_TILE) + 1);
+    total = c.take<u64>(1);
+    dummy_irr = c.take<u32>(16);
+    return c.off;
+  };
+  GIQL_TRY(ensure_arena(ctx, carve(nullptr), st));
+  carve(ctx->arena);
+  giql_side raw = *s;  // identical RAW coordinates are what GROUP BY compares
+  raw.start_off = raw.end_off = 0;
+  giql_side none;
+  memset(&none, 0, sizeof(none));
+  const bool two_sorts = ctx->nearest_two_sorts;
+  GIQL_TRY(run_spans(ctx, st, raw, none, n_chrom, lb));
+  GIQL_TRY(run_linearize(ctx, st, raw, n_chrom, lb, sb.key[0], sb.end[0], dummy_irr, 0, 1, os.hist,
+                         os.gbase, two_sorts ? os.hist_e : nullptr, two_sorts ? os.gbase_e : nullptr));
+  if (two_sorts) {  // (start, end) order = stable sort by end, then stable sort by start
+    SortBufs by_end = sb;
+    for (int k = 0; k < 2; k++) {
+      by_end.key[k] = sb.end[k];
+      by_end.end[k] = sb.key[k];
+    }
+    GIQL_TRY(run_sort_onesweep(ctx, st, by_end, (u32)n, os.gbase_e, os.status));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sb, (u32)n, os.gbase, os.status, /*keep_rids=*/true));
+  } else {
+    GIQL_TRY(run_sort_onesweep(ctx, st, sb, (u32)n, os.gbase, os.status));
+    Phase ph(ctx, st, GIQL_PH_AUX);
+    hipLaunchKernelGGL(k_fix_start_ties, dim3(cdiv(n, 256)), dim3(256), 0, st, sb.key[0], sb.end[0],
+                       sb.rid[0], (u32)n, ctx->d_meta);
+  }
+  {
+    Phase ph(ctx, st, GIQL_PH_COUNT);
+    hipLaunchKernelGGL(k_group_flags, dim3(cdiv(n, 256)), dim3(256), 0, st, sb.key[0], sb.end[0], (u32)n,
+                       flags);
+    GIQL_TRY(post_launch("group flags"));
+  }
+  GIQL_TRY(run_scan<u32>(ctx, st, GIQL_PH_SCAN, flags, (u64)n, excl, bsums, total));
+  {
+    Phase ph(ctx, st, GIQL_PH_FILL);
+    hipLaunchKernelGGL(k_group_ids, dim3(cdiv(n, 256)), dim3(256), 0, st, sb.rid[0], flags, excl, (u32)n,
+                       group_of_row, rep_row);
+    GIQL_TRY(post_launch("group ids"));
+  }
+  u64 h_total = 0;
+  HIP_TRY(hipMemcpyAsync(&h_total, total, sizeof(u64), hipMemcpyDeviceToHost, st));
+  GIQL_TRY(read_meta(ctx, st));
+  if (!two_sorts && ctx->h_meta->aux0 != 0) {  // a long run of equal starts: two-sort plan
+    ctx->nearest_two_sorts = true;
+    return giql_hip_group_rows_dev_impl(ctx, s, n_chrom, group_of_row, rep_row, n_groups, stream);
+  }
+  collect_spans(ctx);
+  *n_groups = (int64_t)h_total;
+  ctx->stats.n_out = (int64_t)h_total;
+  return GIQL_OK;
+}
+
+int giql_hip_group_rows_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int32_t* group_of_row,
+                            int32_t* rep_row, int64_t* n_groups, void* stream) {
+  return with_order_fallback(ctx, [&] {
+    return giql_hip_group_rows_dev_impl(ctx, s, n_chrom, group_of_row, rep_row, n_groups, stream);
+  });
+}
+
+int giql_hip_segment_sum_dev(giql_hip_ctx* ctx, const int64_t* values, const int32_t* group_of_row,
+                             int64_t n, int64_t* sums, int64_t n_groups, void* stream) {
+  if (!ctx || n < 0 || n_groups < 0 || n_groups > 0x7FFFFFFFll) return set_err(GIQL_ERR_INVALID, "bad arguments");
+  if ((n > 0 && (!values || !group_of_row)) || (n_groups > 0 && !sums))
+    return set_err(GIQL_ERR_INVALID, "NULL buffer");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  reset_stats(ctx);
+  if (n_groups > 0) HIP_TRY(hipMemsetAsync(sums, 0, (size_t)n_groups * sizeof(int64_t), st));
+  if (n == 0) return GIQL_OK;
+  HIP_TRY(hipMemsetAsync(&ctx->d_meta->status, 0, sizeof(int), st));
+  u32 grid = cdiv((u64)n, 256 * 8);
+  if (grid > 16384u) grid = 16384u;
+  {
+    Phase ph(ctx, st, GIQL_PH_AUX);
+    hipLaunchKernelGGL(k_segment_sum, dim3(grid), dim3(256), 0, st, (const i64*)values, group_of_row, (u64)n,
+                       (u32)n_groups, (unsigned long long*)sums, ctx->d_meta);
+    GIQL_TRY(post_launch("segment sum"));
+  }
+  GIQL_TRY(read_meta(ctx, st));
+  collect_spans(ctx);
+  return GIQL_OK;
+}
+
 // -------------------------------------------------------------------- spans
 int giql_hip_chrom_spans_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
                              int32_t n_chrom, int64_t* spans_out, void* stream) {

@@ -313,6 +313,32 @@ class HipEngine:
             idx.data_ptr() if a.n else None, dist.data_ptr() if a.n else None, self._stream()))
         return idx, dist
 
+    # ------------------------------------------------ GROUP BY interval + SUM
+    def group_rows(self, s: DeviceSide, n_chrom: int):
+        """Rows with identical (chrom, raw start, raw end) share a group: returns
+        ``(group_of_row int32[n], rep_row int32[n_groups])`` -- the GROUP BY half of
+        count_overlaps (``intersects_duckdb.py:806-854``)."""
+        torch = _torch()
+        gid = torch.empty(s.n, dtype=torch.int32, device=self.device)
+        rep = torch.empty(s.n, dtype=torch.int32, device=self.device)
+        g = ctypes.c_int64(0)
+        _lib.check(self._L.giql_hip_group_rows_dev(
+            self._h, s.c_struct(), int(n_chrom), gid.data_ptr() if s.n else None,
+            rep.data_ptr() if s.n else None, ctypes.byref(g), self._stream()))
+        return gid, rep[: int(g.value)]
+
+    def segment_sum(self, values, group_of_row, n_groups: int):
+        """``sums[g] = sum(values[i] for rows i of group g)`` (int64)."""
+        torch = _torch()
+        if values.dtype != torch.int64 or group_of_row.dtype != torch.int32:
+            raise ValueError("values must be int64 and group_of_row int32")
+        n = int(values.shape[0])
+        sums = torch.empty(int(n_groups), dtype=torch.int64, device=self.device)
+        _lib.check(self._L.giql_hip_segment_sum_dev(
+            self._h, values.data_ptr() if n else None, group_of_row.data_ptr() if n else None, n,
+            sums.data_ptr() if n_groups else None, int(n_groups), self._stream()))
+        return sums
+
     # --------------------------------------------------------- CLUSTER / MERGE
     def _empty_side(self, like: DeviceSide) -> DeviceSide:
         torch = _torch()

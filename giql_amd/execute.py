@@ -393,15 +393,33 @@ def _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices):
         # COUNT(col) skips NULLs; the kernels count rows
         raise ValueError(f"COUNT({plan.right.alias}.{cnt_proj.column}) over a column with NULLs is not "
                          "supported by dialect='hip'")
-    counts = eng.count_overlaps(a, b, n_chrom).cpu().numpy()
+    counts_dev = eng.count_overlaps(a, b, n_chrom)
     if return_indices:
-        return counts
+        return counts_dev.cpu().numpy()
     keys = [p for p in plan.projection if p.side == "l"]
+    interval_cols = {plan.left.chrom_col, plan.left.start_col, plan.left.end_col}
+    if {p.column for p in keys} == interval_cols and isinstance(lt, pa.Table) and a.n:
+        # GROUP BY the left interval itself: grouped and summed on the GPU
+        # (giql_hip_group_rows_dev / giql_hip_segment_sum_dev), keys gathered by the take kernel
+        try:
+            gid, rep = eng.group_rows(a, n_chrom)
+        except Exception as exc:  # e.g. a genome wider than 32 bits: group on the host below
+            if getattr(exc, "code", None) != -5:
+                raise
+            gid = None
+        if gid is not None:
+            sums = eng.segment_sum(counts_dev, gid, int(rep.shape[0]))
+            taken = _device_take(lt, [p.column for p in keys], rep, eng)
+            cols = {p.name: taken[p.column] for p in keys}
+            cols[cnt_proj.name] = pa.array(sums.cpu().numpy(), type=pa.int64())
+            return pa.table(cols).select([p.name for p in plan.projection])
+    counts = counts_dev.cpu().numpy()
     cols = {p.name: _column(lt, p.column) for p in keys}
     cols[cnt_proj.name] = pa.array(counts, type=pa.int64())
     tbl = pa.table({k: (v if isinstance(v, (pa.Array, pa.ChunkedArray)) else pa.array(v)) for k, v in cols.items()})
     if tbl.num_rows == 0:
         return tbl
+    # other key sets (a subset of the interval columns, or extra payload columns): host GROUP BY
     out = tbl.group_by([p.name for p in keys], use_threads=False).aggregate([(cnt_proj.name, "sum")])
     out = out.rename_columns([cnt_proj.name if c == cnt_proj.name + "_sum" else c for c in out.column_names])
     return out.select([p.name for p in plan.projection])

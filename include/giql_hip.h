@@ -179,6 +179,21 @@ int giql_hip_merge_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom,
                        int32_t* out_end, int64_t* out_count, int64_t capacity,
                        int64_t* n_out, void* stream);
 
+/* ---- the aggregate half of count_overlaps --------------------------------
+ * GROUP BY the left interval + SUM of the per-row counts
+ * (src/giql/expanders/intersects_duckdb.py:806-854; a key held by k duplicate left
+ * rows counts k times its overlaps, tests/test_duckdb_iejoin.py:66-81).
+ * group_rows: rows with identical (chrom, raw start, raw end) share a group;
+ * group_of_row[i] in [0, *n_groups) per input row, rep_row[g] = one row id of
+ * group g (both device, s->n entries).  segment_sum: sums[g] = sum of values[i]
+ * over the rows of group g (sums: device, n_groups entries, zeroed here). */
+int giql_hip_group_rows_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom,
+                            int32_t* group_of_row, int32_t* rep_row,
+                            int64_t* n_groups, void* stream);
+int giql_hip_segment_sum_dev(giql_hip_ctx* ctx, const int64_t* values,
+                             const int32_t* group_of_row, int64_t n, int64_t* sums,
+                             int64_t n_groups, void* stream);
+
 /* ---- projection materialisation (Arrow `take` by the join's row ids) ------
  * Replaces the outer SELECT that rebuilds the projected columns of both sides
  * around the per-chromosome join, src/giql/expanders/intersects_duckdb.py:

@@ -779,3 +779,31 @@ def test_sort_tile_order_edges(eng, n_tiles, extra):
     a = ora.Side(rng.integers(0, 3, 20_000).astype(np.int32), sa, sa + rng.integers(1, 3000, 20_000).astype(np.int32))
     assert np.array_equal(eng.count_overlaps(dev(a), dev(b), 3).cpu().numpy(), ora.c_count(a, b, "sweep"))
     assert np.array_equal(gpu_inner(eng, a, b, 3), ora.sort_pairs(*ora.c_inner(a, b, "sweep")))
+
+
+def test_group_rows_and_segment_sum(eng):
+    rng = np.random.default_rng(31)
+    n = 120_000
+    base = rng.integers(0, 4000, (3000, 2))
+    pick = rng.integers(0, 3000, n)
+    chrom = rng.integers(0, 3, 3000)[pick].astype(np.int32)
+    start = base[pick, 0].astype(np.int32)
+    end = (base[pick, 0] + base[pick, 1] % 90 - 5).astype(np.int32)   # some zero-length / inverted rows too
+    side = ora.Side(chrom, start, end)
+    gid, rep = eng.group_rows(dev(side), 3)
+    gid, rep = gid.cpu().numpy(), rep.cpu().numpy()
+    keys = {}
+    for i in range(n):
+        keys.setdefault((int(chrom[i]), int(start[i]), int(end[i])), []).append(i)
+    assert rep.size == len(keys) and gid.min() == 0 and gid.max() == len(keys) - 1
+    for rows in list(keys.values())[:2000]:
+        assert len({int(gid[r]) for r in rows}) == 1
+    assert len(set(gid.tolist())) == len(keys)
+    assert all((int(chrom[r]), int(start[r]), int(end[r])) in keys and gid[r] == g for g, r in enumerate(rep))
+    vals = rng.integers(0, 1000, n).astype(np.int64)
+    sums = eng.segment_sum(torch.from_numpy(vals).cuda(), torch.from_numpy(gid).cuda(), rep.size).cpu().numpy()
+    assert np.array_equal(sums, np.bincount(gid, weights=vals, minlength=rep.size).astype(np.int64))
+    # a pile-up of equal starts (two-sort plan) still groups exactly
+    s2 = ora.Side(np.zeros(500, np.int32), np.full(500, 77, np.int32), (77 + rng.integers(0, 7, 500)).astype(np.int32))
+    g2, r2 = eng.group_rows(dev(s2), 1)
+    assert r2.shape[0] == len(set(s2.end.tolist()))
