@@ -807,3 +807,40 @@ def test_group_rows_and_segment_sum(eng):
     s2 = ora.Side(np.zeros(500, np.int32), np.full(500, 77, np.int32), (77 + rng.integers(0, 7, 500)).astype(np.int32))
     g2, r2 = eng.group_rows(dev(s2), 1)
     assert r2.shape[0] == len(set(s2.end.tolist()))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_sweep_all_operators(eng, seed):
+    # hypothesis-style differential sweep: random sizes (incl. 0 / 1), chromosome counts, coordinate
+    # ranges from "everything collides" to sparse, zero-length / inverted rows on odd seeds, random
+    # encodings -- every operator against the oracle
+    r = np.random.default_rng(1000 + seed)
+    encs = list(ora.ENCODING_OFFSETS)
+    n_chrom = int(r.integers(1, 7))
+    max_start = int(r.choice([30, 2_000, 400_000, 80_000_000]))
+    max_len = int(r.choice([3, 80, 5_000]))
+    min_len = -3 if seed % 2 else 1
+    na, nb = (int(r.choice([0, 1, 2, 65, 700, 9_000])) for _ in range(2))
+    a = rand_side(5000 + seed, na, n_chrom, max_start, max_len + 1, min_len=min_len, enc=encs[int(r.integers(0, 4))])
+    b = rand_side(6000 + seed, nb, n_chrom, max_start, max_len + 1, min_len=min_len, enc=encs[int(r.integers(0, 4))])
+    assert np.array_equal(gpu_inner(eng, a, b, n_chrom), ora.sort_pairs(*ora.c_inner(a, b, "brute")))
+    assert np.array_equal(eng.semi_join(dev(a), dev(b), n_chrom).cpu().numpy(), ora.c_semi_anti(a, b, False))
+    assert np.array_equal(eng.anti_join(dev(a), dev(b), n_chrom).cpu().numpy(), ora.c_semi_anti(a, b, True))
+    assert np.array_equal(eng.count_overlaps(dev(a), dev(b), n_chrom).cpu().numpy(), ora.c_count(a, b, "brute"))
+    if min_len >= 0:  # NEAREST / CLUSTER / MERGE need start <= end
+        signed = bool(seed % 3 == 0)
+        md = None if seed % 4 else 50
+        idx, dist = eng.nearest(dev(a), dev(b), n_chrom, signed=signed, max_distance=md)
+        oi, od = ora.c_nearest_k1(a, b, signed=signed, max_distance=md, method="brute")
+        assert np.array_equal(dist.cpu().numpy(), od)
+        j = idx.cpu().numpy()
+        assert np.array_equal(j >= 0, oi >= 0)
+        ok = j >= 0
+        assert np.array_equal(b.start[j[ok]], b.start[oi[ok]]) and np.array_equal(b.end[j[ok]], b.end[oi[ok]])
+        raw = ora.Side(a.chrom, a.start, a.end)  # CLUSTER / MERGE read raw coordinates
+        d = int(r.choice([0, 7, 900]))
+        assert np.array_equal(eng.cluster(dev(raw), n_chrom, d).cpu().numpy(), ora.c_cluster(raw, d))
+        c, s, e, n = (t.cpu().numpy() for t in eng.merge(dev(raw), n_chrom, d))
+        assert list(zip(c, s, e, n)) == list(zip(*ora.c_merge(raw, d)))
+    gid, rep = eng.group_rows(dev(a), max(n_chrom, 1))
+    assert rep.shape[0] == len({(int(x), int(y), int(z)) for x, y, z in zip(a.chrom, a.start, a.end)})
