@@ -255,6 +255,9 @@ constexpr int LIN_BASE_CAP = 1024;     // chromosome bases staged in LDS (8 KB)
 #ifndef GIQL_LIN_UNROLL
 #define GIQL_LIN_UNROLL 4
 #endif
+#ifndef GIQL_LIN_UNIFORM_FROM
+#define GIQL_LIN_UNIFORM_FROM 2  // digits >= this try the wave-uniform shortcut
+#endif
 
 // keys[i] = linearised canonical start, ends[i] = linearised canonical end.
 // Irregular rows (canonical end <= start) get the sentinel key and are appended
@@ -341,14 +344,19 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
 #pragma unroll
         for (int p = 0; p < 4; p++) {
           const u32 d = (k >> (8 * p)) & 0xFFu;
-          // chromosome-sorted input makes the high digits wave-uniform: one add.
-          // Valid lanes are a prefix of the wave (row index grows with the lane),
-          // so lane 0 is valid whenever any lane is: readfirstlane, no LDS shuffle.
-          const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
-          const u64 same = __ballot(ok && d == d0);
-          if (act != 0 && same == act) {
-            if (lane_id() == 0)
-              atomicAdd(&s_hist[p * 256 + d0], (u32)__popcll(act));
+          if (p >= GIQL_LIN_UNIFORM_FROM) {
+            // chromosome-sorted input makes the HIGH digits wave-uniform: one add.
+            // Valid lanes are a prefix of the wave (row index grows with the lane),
+            // so lane 0 is valid whenever any lane is: readfirstlane, no LDS shuffle.
+            // (The low digits never are: they skip the test and its ballots.)
+            const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
+            const u64 same = __ballot(ok && d == d0);
+            if (act != 0 && same == act) {
+              if (lane_id() == 0)
+                atomicAdd(&s_hist[p * 256 + d0], (u32)__popcll(act));
+            } else if (ok) {
+              atomicAdd(&s_hist[p * 256 + d], 1u);
+            }
           } else if (ok) {
             atomicAdd(&s_hist[p * 256 + d], 1u);
           }
