@@ -53,7 +53,10 @@ static int set_err(int code, const char* fmt, ...) {
 // tile shapes per class: class 1 = many queries with ~0.5 match each (B rows as
 // queries), class 2 = fewer queries with tens of matches each (A rows)
 constexpr int RC_ITEMS_C2 = 2;     // 512 A-queries per count block
-constexpr int FILL_ITEMS_C2 = 16;  // 4096 outputs per fill block
+#ifndef GIQL_FILL_ITEMS
+#define GIQL_FILL_ITEMS 16
+#endif
+constexpr int FILL_ITEMS_C2 = GIQL_FILL_ITEMS;  // pairs per thread of a fill block (tile = FILL_NT x this)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
