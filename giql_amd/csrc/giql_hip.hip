@@ -52,7 +52,10 @@ static int set_err(int code, const char* fmt, ...) {
 
 // tile shapes per class: class 1 = many queries with ~0.5 match each (B rows as
 // queries), class 2 = fewer queries with tens of matches each (A rows)
-constexpr int RC_ITEMS_C2 = 2;     // 512 A-queries per count block
+#ifndef GIQL_RC_ITEMS
+#define GIQL_RC_ITEMS 1
+#endif
+constexpr int RC_ITEMS_C2 = GIQL_RC_ITEMS;  // queries per thread of a count block
 #ifndef GIQL_FILL_ITEMS
 #define GIQL_FILL_ITEMS 16
 #endif
@@ -733,7 +736,7 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt1 + 1, 256)), dim3(256), 0, st,
                        sbb.key[0], (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, (i64)0, (u32)C1_TQ, S.nt1,
                        S.wlo1);
-    hipLaunchKernelGGL(k_c1_count, dim3(S.nt1), dim3(RC_NT), 0, st, sbb.key[0], sbb.end[0], (u32)nb,
+    hipLaunchKernelGGL(k_c1_count, dim3(S.nt1), dim3(C1_NT), 0, st, sbb.key[0], sbb.end[0], (u32)nb,
                        irr_b, sa.key[0], (u32)na, irr_a, S.wlo1, S.c1_base);
     // class 2: queries = sorted A, points = sorted B starts, range (a.start, a.end)
     hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt2 + 1, 256)), dim3(256), 0, st,
@@ -844,7 +847,7 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
     Phase ph(ctx, st, GIQL_PH_FILL, 2);
     // class 1 -> outputs [0, p1): query = B row, matches = A rows
     if (p1 > 0)
-      hipLaunchKernelGGL(k_c1_emit, dim3(S.nt1), dim3(RC_NT), 0, st, S.sb.key[0], S.sb.end[0],
+      hipLaunchKernelGGL(k_c1_emit, dim3(S.nt1), dim3(C1_NT), 0, st, S.sb.key[0], S.sb.end[0],
                          S.sb.rid[0], ctx->n_b, irr_b, S.sa.key[0], S.sa.rid[0], ctx->n_a, irr_a,
                          S.wlo1, S.c1_base, (u64)0, row_b, row_a);
     // range fill -> outputs [p1, p1 + p2)

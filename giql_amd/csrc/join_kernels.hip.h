@@ -401,8 +401,18 @@ __global__ __launch_bounds__(256) void k_digit_offsets(const u32* __restrict__ p
 }
 
 // ------------------------------------------------------------- range count
-constexpr int RC_NT = 256;
-constexpr int RC_LDS_CAP = 10240;  // staged S keys (40 KB)
+// 512 threads x 1 query each, 8192 staged keys (32 KB): 0.149 ms against 0.225 ms for the
+// former 256 x 2 / 10240 (tools/phase_ab.sh count); two queries per thread serialise four
+// dependent LDS searches
+#ifndef GIQL_RC_NT
+#define GIQL_RC_NT 512
+#endif
+#ifndef GIQL_RC_CAP
+#define GIQL_RC_CAP 8192
+#endif
+constexpr int RC_NT = GIQL_RC_NT;
+constexpr int RC_LDS_CAP = GIQL_RC_CAP;  // staged S keys
+constexpr int C1_NT = 256;               // class-1 kernels keep 256-thread blocks
 constexpr int RC_MARGIN = 1024;    // S entries staged past the next tile's window
 
 // query start + signed offset, clamped to the u32 key axis
@@ -445,7 +455,7 @@ struct SWindow {
   }
 };
 
-template <int CAP>
+template <int CAP, int NT>
 __device__ __forceinline__ SWindow stage_window(const u32* __restrict__ ss, u32 ns, u32 w0, u32 w1,
                                                 u32* s_tile) {
   u32 len = ns - w0;
@@ -453,8 +463,8 @@ __device__ __forceinline__ SWindow stage_window(const u32* __restrict__ ss, u32 
   if (want < len) len = (u32)want;
   if (len > (u32)CAP) len = CAP;
   // 4 independent loads in flight per thread (a plain loop waits for each load)
-  for (u32 k = threadIdx.x; k < len; k += 4 * RC_NT) {
-    const u32 k1 = k + RC_NT, k2 = k + 2 * RC_NT, k3 = k + 3 * RC_NT;
+  for (u32 k = threadIdx.x; k < len; k += 4 * NT) {
+    const u32 k1 = k + NT, k2 = k + 2 * NT, k3 = k + 3 * NT;
     const u32 v0 = ss[w0 + k];
     const u32 v1 = k1 < len ? ss[w0 + k1] : 0u;
     const u32 v2 = k2 < len ? ss[w0 + k2] : 0u;
@@ -507,7 +517,7 @@ __global__ __launch_bounds__(RC_NT) void k_range_count(
     xs[i] = ok ? shift_key(qs[q], lo_off) : U32_MAX;
     xe[i] = ok ? qe[q] : U32_MAX;
   }
-  const SWindow w = stage_window<CAP>(ss, ns, w_lo_arr[bid], w_lo_arr[bid + 1], s_tile);
+  const SWindow w = stage_window<CAP, RC_NT>(ss, ns, w_lo_arr[bid], w_lo_arr[bid + 1], s_tile);
 #pragma unroll
   for (int i = 0; i < ITEMS; i++) {
     const u32 q = q0 + i * RC_NT + tid;
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(RC_NT) void k_range_count(
 // loads), so after one binary search the next bound is found by galloping forward
 // from the previous one: ~2 LDS probes per bound instead of ~11.
 constexpr int C1_ITEMS = 8;
-constexpr int C1_TQ = RC_NT * C1_ITEMS;  // 2048 B rows per block
+constexpr int C1_TQ = C1_NT * C1_ITEMS;  // 2048 B rows per block
 constexpr int C1_CAP = 3072;             // staged A starts (12 KB)
 constexpr u32 C1_COOP = 16;              // matches per row above which a wave co-writes
 
@@ -596,12 +606,12 @@ __device__ __forceinline__ void c1_load8(const u32* __restrict__ p, u32 q, u32 n
   }
 }
 
-__global__ __launch_bounds__(RC_NT) void k_c1_count(
+__global__ __launch_bounds__(C1_NT) void k_c1_count(
     const u32* __restrict__ qs, const u32* __restrict__ qe, u32 nq_total,
     const u32* __restrict__ irr_q, const u32* __restrict__ ss, u32 ns_total,
     const u32* __restrict__ irr_s, const u32* __restrict__ w_lo_arr, u64* __restrict__ block_sum) {
   __shared__ u32 s_tile[C1_CAP];
-  __shared__ u64 s_red[RC_NT / WAVE];
+  __shared__ u64 s_red[C1_NT / WAVE];
   const u32 nq = nq_total - *irr_q;
   const u32 ns = ns_total - *irr_s;
   const u32 tid = threadIdx.x;
@@ -609,7 +619,7 @@ __global__ __launch_bounds__(RC_NT) void k_c1_count(
   u32 xs[C1_ITEMS], xe[C1_ITEMS];
   c1_load8(qs, q, nq, U32_MAX, xs);
   c1_load8(qe, q, nq, U32_MAX, xe);
-  const SWindow w = stage_window<C1_CAP>(ss, ns, w_lo_arr[blockIdx.x], w_lo_arr[blockIdx.x + 1], s_tile);
+  const SWindow w = stage_window<C1_CAP, C1_NT>(ss, ns, w_lo_arr[blockIdx.x], w_lo_arr[blockIdx.x + 1], s_tile);
   C1Bounds b;
   c1_bounds(w, xs, xe, q, nq, b);
   u64 total = 0;
@@ -621,7 +631,7 @@ __global__ __launch_bounds__(RC_NT) void k_c1_count(
   if (tid == 0) {
     u64 t = 0;
 #pragma unroll
-    for (int k = 0; k < RC_NT / WAVE; k++) t += s_red[k];
+    for (int k = 0; k < C1_NT / WAVE; k++) t += s_red[k];
     block_sum[blockIdx.x] = t;
   }
 }
@@ -629,14 +639,14 @@ __global__ __launch_bounds__(RC_NT) void k_c1_count(
 // block_base[] = exclusive scan of block_sum.  Output slots of a block are given
 // out thread by thread (row order), so every slot is written exactly once; rows
 // with many matches are written cooperatively by their wave (coalesced).
-__global__ __launch_bounds__(RC_NT) void k_c1_emit(
+__global__ __launch_bounds__(C1_NT) void k_c1_emit(
     const u32* __restrict__ qs, const u32* __restrict__ qe, const u32* __restrict__ q_rid,
     u32 nq_total, const u32* __restrict__ irr_q, const u32* __restrict__ ss,
     const u32* __restrict__ s_rid, u32 ns_total, const u32* __restrict__ irr_s,
     const u32* __restrict__ w_lo_arr, const u64* __restrict__ block_base, u64 out_base,
     int32_t* __restrict__ row_q, int32_t* __restrict__ row_s) {
   __shared__ u32 s_tile[C1_CAP];
-  __shared__ u64 s_scan[RC_NT / WAVE + 1];
+  __shared__ u64 s_scan[C1_NT / WAVE + 1];
   const u32 nq = nq_total - *irr_q;
   const u32 ns = ns_total - *irr_s;
   const u32 tid = threadIdx.x;
@@ -645,14 +655,14 @@ __global__ __launch_bounds__(RC_NT) void k_c1_emit(
   c1_load8(qs, q, nq, U32_MAX, xs);
   c1_load8(qe, q, nq, U32_MAX, xe);
   c1_load8(q_rid, q, nq, 0u, rid);
-  const SWindow w = stage_window<C1_CAP>(ss, ns, w_lo_arr[blockIdx.x], w_lo_arr[blockIdx.x + 1], s_tile);
+  const SWindow w = stage_window<C1_CAP, C1_NT>(ss, ns, w_lo_arr[blockIdx.x], w_lo_arr[blockIdx.x + 1], s_tile);
   C1Bounds b;
   c1_bounds(w, xs, xe, q, nq, b);
   u64 mine = 0;
 #pragma unroll
   for (int i = 0; i < C1_ITEMS; i++) mine += b.cnt[i];
   u64 total;
-  u64 o = out_base + block_base[blockIdx.x] + block_excl_scan<u64, RC_NT>(mine, s_scan, total);
+  u64 o = out_base + block_base[blockIdx.x] + block_excl_scan<u64, C1_NT>(mine, s_scan, total);
   if (total == 0) return;  // block-uniform
   // most rows match 0-2 points: fetch those ids for all rows first (16 gathers
   // in flight) instead of one dependent gather per pair
