@@ -48,10 +48,19 @@ __global__ void k_init_minmax(int* __restrict__ gmin, int* __restrict__ gmax, in
   }
 }
 
-constexpr int MM_NT = 256;
+#ifndef GIQL_MM_NT
+#define GIQL_MM_NT 256
+#endif
+// grid caps = ONE resident wave of blocks on 256 CUs (4 / 8 blocks per CU): measured, the
+// min/max pass takes 0.28 ms with 1024 blocks against 0.35 ms with 2048, linearize 0.34 ms
+// with 2048 against 0.38 ms with 8192 (tools/phase_ab.sh)
+#ifndef GIQL_MM_BLOCKS
+#define GIQL_MM_BLOCKS 1024
+#endif
+constexpr int MM_NT = GIQL_MM_NT;
 constexpr int MM_ITEMS = 8;
 constexpr int MM_LDS_CHROMS = 4096;
-constexpr int MM_MAX_BLOCKS = 2048;  // grid cap; len_part holds 2 sides x blocks x {min,max}
+constexpr int MM_MAX_BLOCKS = GIQL_MM_BLOCKS;  // grid cap; len_part holds 2 sides x blocks x {min,max}
 
 // Per-chromosome min/max of the raw coordinates (both columns).  LDS-privatised
 // atomics; a per-thread run cache keeps chromosome-sorted input (the common BED
@@ -248,8 +257,14 @@ __global__ __launch_bounds__(256) void k_chrom_offsets(const int* __restrict__ g
 }
 
 // -------------------------------------------------------------- linearise
-constexpr int LIN_NT = 256;
-constexpr int LIN_MAX_BLOCKS = 8192;
+#ifndef GIQL_LIN_NT
+#define GIQL_LIN_NT 256
+#endif
+#ifndef GIQL_LIN_BLOCKS
+#define GIQL_LIN_BLOCKS 2048
+#endif
+constexpr int LIN_NT = GIQL_LIN_NT;
+constexpr int LIN_MAX_BLOCKS = GIQL_LIN_BLOCKS;
 constexpr int LIN_HIST_REPLICAS = 64;  // ghist[replica][4][256], block b adds to b % 64
 constexpr int LIN_BASE_CAP = 1024;     // chromosome bases staged in LDS (8 KB)
 #ifndef GIQL_LIN_UNROLL
