@@ -36,7 +36,7 @@ SYMBOLS = [
     "giql_hip_free_host", "giql_hip_pairs_checksum_dev",
     "giql_hip_take_dev", "giql_hip_take_utf8_plan_dev", "giql_hip_take_utf8_fill_dev",
     "giql_hip_select_dev", "giql_hip_mark_dev", "giql_hip_cluster_dev", "giql_hip_merge_dev",
-    "giql_hip_group_rows_dev", "giql_hip_segment_sum_dev",
+    "giql_hip_group_rows_dev", "giql_hip_segment_sum_dev", "giql_hip_inner_join_dev",
 ]
 
 
@@ -151,6 +151,7 @@ def load() -> ctypes.CDLL:
     L.giql_hip_get_stats.argtypes = [vp, P(CStats)]
     L.giql_hip_inner_plan_dev.argtypes = [vp, P(CSide), P(CSide), i32, vp, P(i64)]
     L.giql_hip_inner_fill_dev.argtypes = [vp, vp, vp, i64, vp]
+    L.giql_hip_inner_join_dev.argtypes = [vp, P(CSide), P(CSide), i32, vp, vp, i64, vp, P(i64)]
     L.giql_hip_semi_anti_dev.argtypes = [vp, P(CSide), P(CSide), i32, ctypes.c_int, vp, P(i64), vp]
     L.giql_hip_count_dev.argtypes = [vp, P(CSide), P(CSide), i32, vp, vp]
     L.giql_hip_nearest_dev.argtypes = [vp, P(CSide), P(CSide), i32, ctypes.c_int, i64, vp, vp, vp]

@@ -108,6 +108,13 @@ struct giql_hip_ctx {
   int n_cu = 256;             // compute units of the device
   int os_order = 2;           // onesweep tile order (GIQL_HIP_OS_ORDER, see k_onesweep)
   u32 os_help_after = OS_HELP_AFTER;  // look-back polls before a block helps (GIQL_HIP_OS_HELP_AFTER)
+  // fused join (giql_hip_inner_join_dev): outputs offered to the plan for a fill launched
+  // before the host has learned the pair count
+  int32_t* fuse_a = nullptr;
+  int32_t* fuse_b = nullptr;
+  u64 fuse_cap = 0;
+  bool fuse_done = false;
+  bool last_no_irr = false;   // the previous plan met no irregular row
   bool nearest_two_sorts = false;  // NEAREST: a B table with long equal-start runs was seen
   bool spec_valid = false;    // INNER: the previous plan's form decision, speculated on next time
   int spec_form = 0;
@@ -117,7 +124,7 @@ struct giql_hip_ctx {
   int order_fallbacks = 0;    // calls repeated in the ticket order after a timeout
 
   // profiling
-  bool profiling = false;
+  int profiling = 0;          // 0 off, 1 every phase, 2 only the sort passes (the dominant kernel)
   std::vector<hipEvent_t> ev_pool;
   struct Span {
     int phase;
@@ -175,7 +182,7 @@ struct Phase {
   hipEvent_t a = nullptr, b = nullptr;
   Phase(giql_hip_ctx* c, hipStream_t s, int ph, int launches = 1) : ctx(c), stream(s), phase(ph) {
     ctx->stats.phase_launches[ph] += launches;
-    if (!ctx->profiling) return;
+    if (!ctx->profiling || (ctx->profiling == 2 && ph != GIQL_PH_SORT_SCATTER)) return;
     while (ctx->ev_used + 2 > ctx->ev_pool.size()) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) return;
@@ -364,12 +371,14 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
   if (n == 0) return GIQL_OK;
   const size_t per_pass = os_pass_words(n);
   HIP_TRY(hipMemsetAsync(status, 0, 4 * per_pass * sizeof(u32), st));
+  // one event pair around the four passes (an event record between two launches costs the
+  // stream ~8 us of idle time; the per-launch time is phase time / launches)
+  Phase ph(ctx, st, GIQL_PH_SORT_SCATTER, 4);
   for (int pass = 0; pass < 4; pass++) {
     const int src = pass & 1, dst = src ^ 1;
     u32* stat = status + pass * per_pass;
     const bool first = pass == 0 && !keep_rids;
     const u32* gb = gbase + pass * OS_BINS;
-    Phase ph(ctx, st, GIQL_PH_SORT_SCATTER);
     switch (ctx->os_variant) {  // block-shape sweep (tools/os_variants.py); default 1024 x 8
       case 1: launch_onesweep<512, 8>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
       case 2: launch_onesweep<512, 16>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
@@ -555,7 +564,7 @@ int giql_hip_reserve(giql_hip_ctx* ctx, int64_t bytes) {
 
 int giql_hip_set_profiling(giql_hip_ctx* ctx, int enabled) {
   if (!ctx) return set_err(GIQL_ERR_INVALID, "ctx is NULL");
-  ctx->profiling = enabled != 0;
+  ctx->profiling = enabled < 0 ? 0 : (enabled > 2 ? 1 : enabled);
   return GIQL_OK;
 }
 
@@ -570,7 +579,7 @@ int giql_hip_get_stats(giql_hip_ctx* ctx, giql_hip_stats* out) {
   *out = ctx->stats;
   // byte 0: join form; byte 1: sort tile order in force; bytes 2-3: order fallbacks so far
   out->reserved = (ctx->stats.reserved & 0xFF) | ((ctx->os_order & 0xFF) << 8) |
-                  ((ctx->order_fallbacks & 0x7FFF) << 16);
+                  ((ctx->order_fallbacks & 0x3FFF) << 16) | (ctx->fuse_done ? (1 << 30) : 0);
   return GIQL_OK;
 }
 
@@ -584,6 +593,7 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   ctx->planned = false;
+  ctx->fuse_done = false;
   reset_stats(ctx);
   ctx->stats.n_a = a->n;
   ctx->stats.n_b = b->n;
@@ -721,9 +731,40 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     }
     GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt2, nqr, S.off2, bsums, S.off2 + nqr));
     HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out, S.off2 + nqr, sizeof(u64), hipMemcpyDeviceToDevice, st));
+    bool fused = false;
+    if (ctx->fuse_a && speculated && ctx->last_no_irr && ctx->fuse_cap > 0) {
+      // Fused join: the caller's buffers are here and everything about this plan is a guess
+      // that has held so far (same form as last time, no irregular rows), so the fill is
+      // launched NOW with a grid bounded by the capacity and the true count read on the device
+      // -- no stream sync between plan and fill.  Validated below; a wrong guess leaves the
+      // buffers to the ordinary fill.
+      constexpr u32 T2 = FILL_NT * FILL_ITEMS_C2;
+      const u64 nt_cap64 = (ctx->fuse_cap + T2 - 1) / T2;
+      if (nt_cap64 <= 0x7FFFFFF0ull && (size_t)nt_cap64 + 2 <= ctx->part_cap) {
+        const u32 nt_cap = (u32)nt_cap64;
+        const u32* qrid = q_is_a ? sa.rid[0] : sbb.rid[0];
+        const u32* srid = q_is_a ? sbb.rid[0] : sa.rid[0];
+        int32_t* rq = q_is_a ? ctx->fuse_a : ctx->fuse_b;
+        int32_t* rs = q_is_a ? ctx->fuse_b : ctx->fuse_a;
+        {
+          Phase ph(ctx, st, GIQL_PH_PARTITION);
+          hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt_cap + 1, 256)), dim3(256), 0, st, S.off2,
+                             (u32)nqr, (u64)0, T2, nt_cap, ctx->part, (const u64*)(S.off2 + nqr));
+        }
+        {
+          Phase ph(ctx, st, GIQL_PH_FILL);
+          hipLaunchKernelGGL((k_fill<FILL_ITEMS_C2>), dim3(nt_cap), dim3(FILL_NT), 0, st, S.off2, S.lo2, qrid,
+                             (u32)nqr, srid, ctx->part, (u64)0, (u64)0, rq, rs, (const u64*)(S.off2 + nqr));
+        }
+        GIQL_TRY(post_launch("fused fill"));
+        fused = true;
+      }
+    }
     GIQL_TRY(read_meta(ctx, st));
     ctx->n_c1 = 0;
     ctx->n_reg = ctx->h_meta->n_out;
+    // the early fill stands only if every guess held and the pairs fitted
+    ctx->fuse_done = fused && ctx->h_meta->irr_a + ctx->h_meta->irr_b == 0 && ctx->n_reg <= ctx->fuse_cap;
   } else {
   GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], ctx->irr_a_list, 0, 0,
                          hist_a, gbase_a));
@@ -772,6 +813,7 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     if (speculated && (form != S.uniform || len != uni_len)) {
       ctx->spec_valid = false;  // wrong guess: plan again from the numbers just read
       ctx->spec_misses++;
+      ctx->fuse_done = false;
       return giql_hip_inner_plan_dev_impl(ctx, a, b, n_chrom, stream, n_pairs);
     }
     ctx->spec_valid = true;
@@ -781,6 +823,7 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
   ctx->stats.n_irregular_a = ctx->h_meta->irr_a;
   ctx->stats.n_irregular_b = ctx->h_meta->irr_b;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+  ctx->last_no_irr = ctx->h_meta->irr_a + ctx->h_meta->irr_b == 0;
 
   if (ctx->h_meta->irr_a + ctx->h_meta->irr_b > 0) {
     {
@@ -876,6 +919,46 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
     GIQL_TRY(post_launch("irregular fill"));
   }
   return GIQL_OK;
+}
+
+// Plan + fill in one call into caller-owned buffers.  When the context's guesses hold (same
+// join form as its previous plan, no irregular rows, the pairs fit `capacity`) the fill has
+// already been launched inside the plan, with no stream sync between the two; otherwise the
+// ordinary fill runs here.  GIQL_ERR_CAPACITY leaves the plan valid: *n_pairs tells the
+// size to offer to giql_hip_inner_fill_dev.
+int giql_hip_inner_join_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+                            int32_t* row_a, int32_t* row_b, int64_t capacity, void* stream,
+                            int64_t* n_pairs) {
+  if (!ctx || !n_pairs) return set_err(GIQL_ERR_INVALID, "ctx/n_pairs is NULL");
+  if (capacity < 0 || (capacity > 0 && (!row_a || !row_b)))
+    return set_err(GIQL_ERR_INVALID, "bad output buffers");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  {  // the merge-path partition array must exist before the plan can launch the fill
+    constexpr u32 T2 = FILL_NT * FILL_ITEMS_C2;
+    const u64 nt_cap = ((u64)capacity + T2 - 1) / T2;
+    const size_t part_need = (size_t)nt_cap + 2;
+    if (nt_cap <= 0x7FFFFFF0ull && part_need > ctx->part_cap) {
+      HIP_TRY(hipStreamSynchronize(st));
+      if (ctx->part) HIP_TRY(hipFree(ctx->part));
+      ctx->part = nullptr;
+      ctx->part_cap = 0;
+      const size_t want = part_need + part_need / 4;
+      HIP_TRY(hipMalloc((void**)&ctx->part, want * sizeof(u32)));
+      ctx->part_cap = want;
+    }
+  }
+  ctx->fuse_a = row_a;
+  ctx->fuse_b = row_b;
+  ctx->fuse_cap = (u64)capacity;
+  const int rc = giql_hip_inner_plan_dev(ctx, a, b, n_chrom, stream, n_pairs);
+  ctx->fuse_a = ctx->fuse_b = nullptr;
+  ctx->fuse_cap = 0;
+  if (rc != GIQL_OK) return rc;
+  if (ctx->fuse_done) return GIQL_OK;
+  if (*n_pairs > capacity)
+    return set_err(GIQL_ERR_CAPACITY, "capacity %lld < %lld pairs", (long long)capacity, (long long)*n_pairs);
+  return giql_hip_inner_fill_dev(ctx, row_a, row_b, capacity, stream);
 }
 
 // Scratch shared by the single-output operators: histogram replicas, digit bases,

@@ -116,8 +116,9 @@ class HipEngine:
         torch = _torch()
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def set_profiling(self, enabled: bool) -> None:
-        _lib.check(self._L.giql_hip_set_profiling(self._h, int(bool(enabled))))
+    def set_profiling(self, enabled) -> None:
+        """``False`` / ``True`` (hipEvent pairs around every phase) / ``2`` (only around the sort passes)."""
+        _lib.check(self._L.giql_hip_set_profiling(self._h, int(enabled)))
 
     def reserve(self, nbytes: int) -> None:
         _lib.check(self._L.giql_hip_reserve(self._h, int(nbytes)))
@@ -130,7 +131,8 @@ class HipEngine:
                 "profiled")}
         out["join_form"] = {0: "general", 1: "uniform_b", 2: "uniform_a"}.get(int(st.reserved) & 0xFF, "?")
         out["sort_tile_order"] = (int(st.reserved) >> 8) & 0xFF
-        out["sort_order_fallbacks"] = (int(st.reserved) >> 16) & 0x7FFF
+        out["sort_order_fallbacks"] = (int(st.reserved) >> 16) & 0x3FFF
+        out["fused_fill"] = bool((int(st.reserved) >> 30) & 1)  # the last plan launched its own fill
         out["total_ms"] = float(st.total_ms)
         out["phase_ms"] = {name: float(st.phase_ms[i]) for i, name in enumerate(_lib.PHASES)}
         out["phase_launches"] = {name: int(st.phase_launches[i]) for i, name in enumerate(_lib.PHASES)}
@@ -156,6 +158,22 @@ class HipEngine:
         _lib.check(self._L.giql_hip_inner_fill_dev(
             self._h, row_a.data_ptr() if cap else None, row_b.data_ptr() if cap else None, cap,
             self._stream()))
+
+    def inner_join_into(self, a: DeviceSide, b: DeviceSide, n_chrom: int, row_a, row_b) -> int:
+        """Plan + fill into caller-owned int32 tensors in ONE C-ABI call (no stream sync between
+        the two when the context's guesses hold); returns the pair count.  Raises
+        :class:`GiqlHipError` with ``GIQL_ERR_CAPACITY`` when the buffers are too small (the
+        plan stays valid for :meth:`inner_fill`)."""
+        self._check_sides(a, b)
+        cap = min(int(row_a.shape[0]), int(row_b.shape[0]))
+        n = ctypes.c_int64(0)
+        self.last_pairs = None
+        rc = self._L.giql_hip_inner_join_dev(
+            self._h, a.c_struct(), b.c_struct(), int(n_chrom), row_a.data_ptr() if cap else None,
+            row_b.data_ptr() if cap else None, cap, self._stream(), ctypes.byref(n))
+        self.last_pairs = int(n.value)
+        _lib.check(rc)
+        return int(n.value)
 
     def inner_join(self, a: DeviceSide, b: DeviceSide, n_chrom: int, out=None):
         """All ``(row_a, row_b)`` with ``a INTERSECTS b``; two int32 device tensors."""

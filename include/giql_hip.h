@@ -106,8 +106,10 @@ typedef struct giql_hip_stats {
   int32_t reserved;         /* byte 0: INNER join form (0 = general two-class join,
                                1 / 2 = uniform-length form with B / A as the fixed-
                                length side); byte 1: sort tile order in force (2 =
-                               blockIdx order, 0 = ticket order); bytes 2-3: calls
-                               repeated in ticket order after a look-back timeout */
+                               blockIdx order, 0 = ticket order); bits 16-29: calls
+                               repeated in ticket order after a look-back timeout;
+                               bit 30: the last plan launched its own fill
+                               (giql_hip_inner_join_dev) */
 } giql_hip_stats;
 
 /* ---- library / context ------------------------------------------------- */
@@ -118,6 +120,8 @@ int giql_hip_create(int device, giql_hip_ctx** out);
 int giql_hip_destroy(giql_hip_ctx* ctx);
 /* Pre-size the device arena (bytes); optional, the arena grows on demand. */
 int giql_hip_reserve(giql_hip_ctx* ctx, int64_t bytes);
+/* enabled: 0 = off, 1 = hipEvent pairs around every phase, 2 = only around the sort passes
+ * (an event pair costs the stream a few microseconds of idle time per phase). */
 int giql_hip_set_profiling(giql_hip_ctx* ctx, int enabled);
 int giql_hip_get_stats(giql_hip_ctx* ctx, giql_hip_stats* out);
 
@@ -130,6 +134,16 @@ int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a,
                             int64_t* n_pairs);
 int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b,
                             int64_t capacity, void* stream);
+
+/* Plan + fill in one call into caller-owned buffers (capacity pairs each).  When the
+ * context's guesses hold -- same join form as its previous plan, no irregular
+ * rows, the pairs fit -- the fill is launched inside the plan with no stream sync
+ * in between.  GIQL_ERR_CAPACITY leaves the plan valid: *n_pairs is the size to
+ * offer to giql_hip_inner_fill_dev. */
+int giql_hip_inner_join_dev(giql_hip_ctx* ctx, const giql_side* a,
+                            const giql_side* b, int32_t n_chrom, int32_t* row_a,
+                            int32_t* row_b, int64_t capacity, void* stream,
+                            int64_t* n_pairs);
 
 /* SEMI (anti = 0) / ANTI (anti = 1): A row ids with / without an overlapping
  * B row.  rows_out has capacity a->n; *n_out receives the count. */

@@ -844,3 +844,45 @@ def test_randomized_sweep_all_operators(eng, seed):
         assert list(zip(c, s, e, n)) == list(zip(*ora.c_merge(raw, d)))
     gid, rep = eng.group_rows(dev(a), max(n_chrom, 1))
     assert rep.shape[0] == len({(int(x), int(y), int(z)) for x, y, z in zip(a.chrom, a.start, a.end)})
+
+
+def test_fused_inner_join_into_caller_buffers():
+    # plan + fill in one call: the second call on a context launches the fill inside the plan (no sync
+    # in between) when its guesses hold; every other situation must end in the same exact pairs
+    from giql_amd._lib import GiqlHipError
+    from giql_amd.engine import HipEngine
+
+    e = HipEngine(0)
+    try:
+        def run(a, b, cap):
+            ra = torch.empty(cap, dtype=torch.int32, device="cuda")
+            rb = torch.empty(cap, dtype=torch.int32, device="cuda")
+            n = e.inner_join_into(dev(a), dev(b), 4, ra, rb)
+            return ora.sort_pairs(ra[:n].cpu().numpy(), rb[:n].cpu().numpy())
+        a1, b1 = rand_side(301, 20_000, 4, 1_500_000, 700), uniform_side(302, 150_000, 4, 1_500_000, 120)
+        want1 = ora.sort_pairs(*ora.c_inner(a1, b1, "sweep"))
+        cap = want1.shape[0] + 5000
+        assert np.array_equal(run(a1, b1, cap), want1)      # first plan: nothing to guess from
+        assert np.array_equal(run(a1, b1, cap), want1)      # fused
+        a2, b2 = rand_side(303, 25_000, 4, 1_500_000, 700), uniform_side(304, 140_000, 4, 1_500_000, 120)
+        want2 = ora.sort_pairs(*ora.c_inner(a2, b2, "sweep"))
+        assert np.array_equal(run(a2, b2, want2.shape[0]), want2)   # fused, exact capacity
+        with pytest.raises(GiqlHipError) as ei:             # too small: the plan stays valid
+            run(a2, b2, want2.shape[0] - 1)
+        assert ei.value.code == -6 and e.last_pairs == want2.shape[0]
+        ra = torch.empty(want2.shape[0], dtype=torch.int32, device="cuda")
+        rb = torch.empty_like(ra)
+        e.inner_fill(ra, rb)
+        assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), want2)
+        a3 = rand_side(305, 20_000, 4, 1_500_000, 700, min_len=-3)   # irregular query rows: guess fails
+        want3 = ora.sort_pairs(*ora.c_inner(a3, b1, "sweep"))
+        assert np.array_equal(run(a3, b1, want3.shape[0] + 10), want3)
+        b4 = rand_side(306, 90_000, 4, 1_500_000, 400)               # general form
+        want4 = ora.sort_pairs(*ora.c_inner(a1, b4, "sweep"))
+        assert np.array_equal(run(a1, b4, want4.shape[0] + 10), want4)
+        assert np.array_equal(run(a1, b1, cap), want1)
+        assert np.array_equal(run(a1, b1, cap), want1)
+        empty = ora.Side(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+        assert run(empty, b1, 16).shape[0] == 0
+    finally:
+        e.close()
