@@ -431,7 +431,8 @@ def test_config4_full_size_properties(eng):
     every pair satisfies the literal predicate, no pair is repeated, the count
     equals the sum of per-row counts from the independent two-sorted-arrays COUNT
     kernel, per-chromosome pair counts equal the oracle's on two sampled
-    chromosomes, and the uniform and general forms agree (multiset checksum)."""
+    chromosomes, the uniform and general forms agree (multiset checksum), and that checksum
+    equals the oracle's over the whole 404M-pair result."""
     from giql_amd import synth
     from giql_amd.engine import DeviceSide, HipEngine
     import os
@@ -481,6 +482,11 @@ def test_config4_full_size_properties(eng):
         e2.close()
     finally:
         del os.environ["GIQL_HIP_NO_UNIFORM"]
+    # 6. the WHOLE pair multiset against the oracle: same count, same order-independent 64-bit
+    #    checksum (the oracle's sort-merge over all host cores, a few seconds at this size)
+    wa, wb = ora.c_inner(ora.Side(ac, as_, ae), ora.Side(bc, bs, be), "sweep")
+    assert wa.shape[0] == n
+    assert ora.c_pairs_checksum(wa, wb) == chk
 
 
 # ---------------------------------------------------------------- projection (take)
