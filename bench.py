@@ -126,13 +126,21 @@ def run_cpu_baseline(args, n_a, kind_a, seed_a, n_b, kind_b, seed_b):
 
     threads = ora.max_threads()
 
+    n_chrom_all = len(synth.HG38_LENGTHS)
+    checksum = [None]
+
     def run(chroms):
-        sa = synth.make_table(n_a, seed_a, kind_a, chroms=chroms)
-        sb = synth.make_table(n_b, seed_b, kind_b, chroms=chroms)
+        sel = None if len(chroms) == n_chrom_all else chroms  # None = the GPU run's row order
+        sa = synth.make_table(n_a, seed_a, kind_a, chroms=sel)
+        sb = synth.make_table(n_b, seed_b, kind_b, chroms=sel)
         oa, ob = ora.Side(*sa), ora.Side(*sb)
         t1 = time.perf_counter()
-        ra, _rb = ora.c_inner(oa, ob, "sweep", threads=threads)
-        return oa.n, ob.n, int(ra.shape[0]), time.perf_counter() - t1
+        ra, rb = ora.c_inner(oa, ob, "sweep", threads=threads)
+        dt = time.perf_counter() - t1
+        # whole workload only: the same order-independent 64-bit checksum as
+        # giql_hip_pairs_checksum_dev, for the parity line (outside the timing)
+        checksum[0] = ora.c_pairs_checksum(ra, rb) if len(chroms) == n_chrom_all else None
+        return oa.n, ob.n, int(ra.shape[0]), dt
 
     probe = [int(c) for c in args.cpu_sample_chroms.split(",") if c != ""]
     pa_, pb_, pp, pt = run(probe)
@@ -156,6 +164,9 @@ def run_cpu_baseline(args, n_a, kind_a, seed_a, n_b, kind_b, seed_b):
                    + f": {sa_n} x {sb_n} rows -> {sp} pairs in {st_:.2f} s "
                    "(oracle OpenMP sort-merge port, not DuckDB: duckdb is not installed on the box)"),
         "host_cpu_count": os.cpu_count(),
+        # popped by main() into the "parity" entry (parity check in the same run)
+        "pairs": sp if whole else None,
+        "pairs_checksum": checksum[0] if whole else None,
     }
 
 
@@ -253,6 +264,7 @@ def main() -> None:
     phase_ms = {}
     phase_launches = {}
     last_stats = [None]
+    last_pairs = [None]  # views of the last step's (row_a, row_b), for the parity line
 
     def step(collect=False):
         """One pass of the hot path; returns this rank's pair count."""
@@ -287,6 +299,7 @@ def main() -> None:
             out = torch.empty((2, out_cap), dtype=torch.int32, device=dev)
             ra, rb = out[0, :n], out[1, :n]
             eng.inner_fill(ra, rb)
+        last_pairs[0] = (ra, rb)
         if ev:
             ev[1].record()
         if collect:  # the join's phase times, before anything else touches the engine
@@ -399,6 +412,12 @@ def main() -> None:
         cpu_baseline = None
         if not args.no_cpu_baseline:
             cpu_baseline = run_cpu_baseline(args, n_a, kind_a, seed_a, n_b, kind_b, seed_b)
+            cpu_sum = cpu_baseline.pop("pairs_checksum", None)
+            cpu_pairs = cpu_baseline.pop("pairs", None)
+            if world == 1 and cpu_sum is not None and last_pairs[0] is not None:
+                gpu_sum = eng.pairs_checksum(*last_pairs[0])
+                cpu_baseline["parity"] = {"pairs_equal": cpu_pairs == n_pairs, "multiset_checksum_equal": gpu_sum == cpu_sum,
+                                          "checked": "all %d pairs of the last timed step" % n_pairs}
 
         value = n_pairs * args.steps / elapsed
         line = {
