@@ -277,6 +277,42 @@ def test_semi_anti_with_residual_predicates(kind, on, where, on_pred, where_pred
     assert got == want and len(want) > 0
 
 
+REFERENCE_RESIDUAL_CASES = [
+    # (source test in the reference's tests/test_duckdb_iejoin.py, peaks, genes, query, expected rows)
+    (":347-392 combine ON and WHERE extras",
+     [("chr1", 100, 200, "p1", 10, "+"), ("chr1", 300, 400, "p2", 25, "+"), ("chr1", 500, 600, "p3", 30, "+")],
+     [("chr1", 150, 250, "g1", 5, "+"), ("chr1", 350, 450, "g2", 5, "+"), ("chr1", 550, 650, "g3", 50, "+")],
+     "SELECT a.start AS s FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score > 20 WHERE b.score < 40",
+     [(300,)]),
+    (":6201-6249 ANTI + WHERE residual is an outer filter (#200)",
+     [("chr1", 100, 200, "p1", 1, "+"), ("chr1", 500, 600, "p2", 2, "+"), ("chr1", 700, 800, "p3", 3, "+")],
+     [("chr1", 150, 250, "g1", 1, "+"), ("chr1", 500, 600, "g2", 2, "+")],
+     "SELECT a.start FROM peaks a ANTI JOIN genes b ON a.interval INTERSECTS b.interval WHERE a.start >= 550",
+     [(700,)]),
+    (":6251-6289 ANTI + WHERE on a column absent from SELECT",
+     [("chr1", 100, 200, "p1", 1, "+"), ("chr1", 700, 800, "p3", 3, "+")],
+     [("chr1", 150, 250, "g1", 1, "+")],
+     "SELECT a.start FROM peaks a ANTI JOIN genes b ON a.interval INTERSECTS b.interval WHERE a.end > 750",
+     [(700,)]),
+    (":6291-6338 SEMI + WHERE residual",
+     [("chr1", 100, 200, "p1", 1, "+"), ("chr1", 500, 600, "p2", 2, "+"), ("chr1", 700, 800, "p3", 3, "+")],
+     [("chr1", 150, 250, "g1", 1, "+"), ("chr1", 500, 600, "g2", 2, "+")],
+     "SELECT a.start FROM peaks a SEMI JOIN genes b ON a.interval INTERSECTS b.interval WHERE a.start >= 300",
+     [(500,)]),
+    (":6413-6463 ANTI + ON residual on the right side stays a join condition",
+     [("chr1", 100, 200, "p1", 1, "+"), ("chr1", 500, 600, "p2", 2, "+"), ("chr1", 700, 800, "p3", 3, "+")],
+     [("chr1", 150, 250, "g1", 10, "+"), ("chr1", 500, 600, "g2", 50, "+")],
+     "SELECT a.start FROM peaks a ANTI JOIN genes b ON a.interval INTERSECTS b.interval AND b.score > 100",
+     [(100,), (500,), (700,)]),
+]
+
+
+@pytest.mark.parametrize("src,peaks,genes,query,expected", REFERENCE_RESIDUAL_CASES, ids=[c[0] for c in REFERENCE_RESIDUAL_CASES])
+def test_residual_known_answers_from_the_reference(src, peaks, genes, query, expected):
+    t = {"peaks": make_table(peaks), "genes": make_table(genes)}
+    assert rows_of(execute(transpile(query, tables=["peaks", "genes"], dialect="hip"), t)) == expected
+
+
 def test_residual_null_operands_never_match_and_type_mismatch_raises(peaks_genes):
     genes = peaks_genes["genes"].set_column(4, "score", pa.array([1, None, 3, 4, 5], pa.int32()))
     t = {"peaks": peaks_genes["peaks"], "genes": genes}
