@@ -410,7 +410,7 @@ def main() -> None:
         }
 
         cpu_baseline = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only (the other ranks would idle in the barrier)
             cpu_baseline = run_cpu_baseline(args, n_a, kind_a, seed_a, n_b, kind_b, seed_b)
             cpu_sum = cpu_baseline.pop("pairs_checksum", None)
             cpu_pairs = cpu_baseline.pop("pairs", None)
