@@ -61,12 +61,14 @@ def parse_args():
     return p.parse_args()
 
 
-def phase_bytes(phase: str, n_a: int, n_b: int, n_out: int, form: str = "general") -> float:
+def phase_bytes(phase: str, n_a: int, n_b: int, n_out: int, form: str = "general", span_hist: bool = False) -> float:
     """Algorithmic (minimal) HBM bytes moved by ALL launches of one phase per step.
 
     DESIGN.md §3 states each figure: read every input of the kernel once, write
     every output once, nothing else.  In the uniform-length forms the fixed-length
-    side is sorted as (key, rid) -- 8 B/row -- and there is no class-1 stage.
+    side is sorted as (key, rid) -- 8 B/row -- and there is no class-1 stage.  With
+    ``span_hist`` (the digit histogram taken in the span pass) that side has no linearize pass
+    and its first sort pass reads (chrom, start) -- 8 B/row -- instead of the 4-byte key.
     """
     n = n_a + n_b
     if form == "uniform_b":
@@ -84,6 +86,9 @@ def phase_bytes(phase: str, n_a: int, n_b: int, n_out: int, form: str = "general
     else:
         sort = (24.0 * n_q + 16.0 * n_u) * 4     # the uniform side carries (key, rid)
         lin = 12.0 * n + 8.0 * n_q + 4.0 * n_u
+        if span_hist:
+            sort += 4.0 * n_u
+            lin = 12.0 * n_q + 8.0 * n_q
         count = 8.0 * n_q + 4.0 * n_u + 8.0 * n_q
         scan = 12.0 * n_q
         fill = 8.0 * n_out + 16.0 * n_q + 4.0 * n_u
@@ -376,7 +381,7 @@ def main() -> None:
         dom = "sort_scatter" if light else max(per_step_ms, key=lambda k: per_step_ms[k])
         dom_ms = per_step_ms[dom]
         dom_launches = max(per_step_launches[dom], 1)
-        dom_bytes = phase_bytes(dom, loc_na, loc_nb, n_local, st["join_form"])
+        dom_bytes = phase_bytes(dom, loc_na, loc_nb, n_local, st["join_form"], st.get("span_hist", False))
         achieved = (dom_bytes / dom_launches) / (dom_ms / dom_launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         join_bytes = 12.0 * (loc_na + loc_nb) + 8.0 * n_local
         device_ms = sum(per_step_ms.values())
@@ -441,6 +446,7 @@ def main() -> None:
                                                              else " + gloo (rehearsal) all-gather of pairs")),
                 "inputs": "resident in HBM before the timed region",
                 "join_form": st["join_form"],
+                "span_hist": bool(st.get("span_hist", False)),
             },
             "hbm_algorithmic_GBps": round((12.0 * (tot_na + tot_nb) + 8.0 * n_pairs) * args.steps / elapsed / 1e9, 1),
             "roofline": roofline,

@@ -29,6 +29,9 @@ struct DevMeta {
   // canonical length (end - start) range over the well-formed rows of each side;
   // min == max means "uniform length" (fixed-length reads): see k_range_count
   int len_min_a, len_max_a, len_min_b, len_max_b;
+  // 1 when k_chrom_offsets laid the chromosomes out on 2^24-aligned bases (the
+  // histogram-in-the-span-pass form, see k_chrom_minmax<true>); 0 = tight packing
+  u32 aligned_ok;
 };
 
 // XCD-aware block -> tile map.  Workgroups are dealt round-robin to the 8 XCDs, each

@@ -120,6 +120,8 @@ struct giql_hip_ctx {
   int spec_form = 0;
   i64 spec_len = 0;
   int spec_misses = 0;
+  bool spec_aligned = false;  // ... and whether the aligned layout (histogram in the span pass) held
+  bool no_span_hist = false;  // GIQL_HIP_NO_SPAN_HIST=1: always linearize the fixed-length side (A/B aid)
   int inject_timeout = 0;     // test hook: report one look-back timeout
   int order_fallbacks = 0;    // calls repeated in the ticket order after a timeout
 
@@ -274,10 +276,22 @@ struct LinBufs {
   i64* chrom_base;
   u32* chrom_first;
   int* len_part;  // [2 sides][MM_MAX_BLOCKS][min,max]
+  // histogram-in-the-span-pass form (INNER plan only; NULL elsewhere)
+  u32* abase = nullptr;        // [MM_HIST_CHROMS] 2^24-aligned chromosome bases
+  u32* top_partial = nullptr;  // [LIN_HIST_REPLICAS][MM_HIST_CHROMS][256]
 };
 
+// hist_side = 0 / 1 (with hist_partial and lb.abase / lb.top_partial): that side's span pass
+// also counts the digits of its aligned keys (k_chrom_minmax<true>) and the chromosome bases
+// are laid out 2^24-aligned when they fit (meta->aligned_ok).
 static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, const giql_side& b,
-                     int n_chrom, const LinBufs& lb) {
+                     int n_chrom, const LinBufs& lb, int hist_side = -1, u32* hist_partial = nullptr) {
+  const bool hist = hist_side >= 0 && hist_partial && lb.abase && lb.top_partial &&
+                    n_chrom <= MM_HIST_CHROMS && (hist_side ? b.n : a.n) > 0;
+  if (hist) {
+    HIP_TRY(hipMemsetAsync(hist_partial, 0, (size_t)LIN_HIST_REPLICAS * 1024 * sizeof(u32), st));
+    HIP_TRY(hipMemsetAsync(lb.top_partial, 0, (size_t)LIN_HIST_REPLICAS * MM_TOP_WORDS * sizeof(u32), st));
+  }
   Phase ph(ctx, st, GIQL_PH_SPAN, 4);
   hipLaunchKernelGGL(k_init_minmax, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st, lb.gmin,
                      lb.gmax, n_chrom, ctx->d_meta);
@@ -290,9 +304,14 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
     u32 grid = cdiv((u64)s.n, (u64)MM_NT * MM_ITEMS);
     if (grid > (u32)MM_MAX_BLOCKS) grid = MM_MAX_BLOCKS;
     nblk[k] = (int)grid;
-    hipLaunchKernelGGL(k_chrom_minmax, dim3(grid), dim3(MM_NT), lds, st, s.chrom, s.start, s.end,
-                       (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
-                       lb.len_part);
+    if (hist && k == hist_side)
+      hipLaunchKernelGGL((k_chrom_minmax<true>), dim3(grid), dim3(MM_NT), lds, st, s.chrom, s.start, s.end,
+                         (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
+                         lb.len_part, s.start_off, hist_partial, lb.top_partial);
+    else
+      hipLaunchKernelGGL((k_chrom_minmax<false>), dim3(grid), dim3(MM_NT), lds, st, s.chrom, s.start, s.end,
+                         (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
+                         lb.len_part, 0, (u32*)nullptr, (u32*)nullptr);
   }
   int omin = a.start_off, omax = a.start_off;
   const int offs[3] = {a.end_off, b.start_off, b.end_off};
@@ -301,7 +320,8 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
     if (offs[k] > omax) omax = offs[k];
   }
   hipLaunchKernelGGL(k_chrom_offsets, dim3(1), dim3(256), 0, st, lb.gmin, lb.gmax, n_chrom, omin,
-                     omax, lb.chrom_base, lb.chrom_first, ctx->d_meta, lb.len_part, nblk[0], nblk[1]);
+                     omax, lb.chrom_base, lb.chrom_first, ctx->d_meta, lb.len_part, nblk[0], nblk[1],
+                     hist ? 1 : 0, lb.abase);
   return post_launch("spans");
 }
 
@@ -366,8 +386,12 @@ static void launch_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, int
 
 // keep_rids: the rid buffer already holds row ids (second sort of a two-key sort).
 // status: 4 * os_pass_words(n) words, zeroed here in one memset.
+// keygen (with abase): the first pass builds the keys from that side's raw (chrom, start)
+// columns instead of reading sb.key[0] (k_onesweep<.., KEYGEN>; (key, rid) sorts, default
+// block shape only).
 static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
-                             const u32* gbase, u32* status, bool keep_rids = false) {
+                             const u32* gbase, u32* status, bool keep_rids = false,
+                             const giql_side* keygen = nullptr, const u32* abase = nullptr) {
   if (n == 0) return GIQL_OK;
   const size_t per_pass = os_pass_words(n);
   HIP_TRY(hipMemsetAsync(status, 0, 4 * per_pass * sizeof(u32), st));
@@ -379,6 +403,15 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
     u32* stat = status + pass * per_pass;
     const bool first = pass == 0 && !keep_rids;
     const u32* gb = gbase + pass * OS_BINS;
+    if (pass == 0 && keygen) {
+      const u32 grid = cdiv(n, 1024 * 8);
+      u32* claim = stat + (size_t)cdiv(n, OS_MIN_TILE) * OS_BINS;
+      hipLaunchKernelGGL((k_onesweep<1, 1024, 8, true>), dim3(grid), dim3(1024), 0, st,
+                         reinterpret_cast<const u32*>(keygen->start), reinterpret_cast<const u32*>(keygen->chrom),
+                         (const u32*)nullptr, sb.key[dst], (u32*)nullptr, sb.rid[dst], n, 0, gb, stat, claim,
+                         ctx->d_meta, ctx->os_order, ctx->os_help_after, abase, (u32)keygen->start_off);
+      continue;
+    }
     switch (ctx->os_variant) {  // block-shape sweep (tools/os_variants.py); default 1024 x 8
       case 1: launch_onesweep<512, 8>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
       case 2: launch_onesweep<512, 16>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
@@ -524,6 +557,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     if (it) ctx->inject_timeout = atoi(it);
     const char* u = getenv("GIQL_HIP_NO_UNIFORM");
     ctx->no_uniform = u && atoi(u) != 0;
+    const char* nh = getenv("GIQL_HIP_NO_SPAN_HIST");
+    ctx->no_span_hist = nh && atoi(nh) != 0;
   }
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   {
@@ -635,6 +670,8 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
       gbase_a = c.take<u32>(1024);
       gbase_b = c.take<u32>(1024);
       os_status = c.take<u32>(4 * os_pass_words(n_max));
+      lb.abase = c.take<u32>(MM_HIST_CHROMS);
+      lb.top_partial = c.take<u32>((size_t)LIN_HIST_REPLICAS * MM_TOP_WORDS);
     } else {
       tile_hist = c.take<u32>(n_tiles_max * RS_BINS);
     }
@@ -658,7 +695,17 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
   SortBufs& sa = S.sa;
   SortBufs& sbb = S.sb;
 
-  GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
+  // The larger side is the one the uniform form prefers as its fixed-length side: its span pass
+  // also counts the digits of its keys (aligned layout), so that, if the form and the layout
+  // hold, it is sorted straight from its raw columns with no linearize pass.  A context that
+  // has planned before asks for it only when its last plan ended that way.
+  const int big_side = nb >= na ? 1 : 0;
+  bool want_hist = onesweep && !ctx->no_uniform && !ctx->no_span_hist && ctx->os_variant == 0 &&
+                   n_chrom <= MM_HIST_CHROMS;
+  if (want_hist && ctx->spec_valid)
+    want_hist = ctx->spec_aligned && ctx->spec_form == (big_side ? 1 : 2);
+  GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb, want_hist ? big_side : -1, big_side ? hist_b : hist_a));
+  bool aligned = false;
   // Uniform-length side?  (fixed-length reads: min == max canonical length > 0 over ALL its
   // rows; a single irregular row makes the minimum 0).
   // One 100-byte readback; it also surfaces chrom / span errors before the sort.
@@ -688,12 +735,15 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     if (ctx->spec_valid) {
       S.uniform = ctx->spec_form;
       uni_len = ctx->spec_len;
+      aligned = want_hist;  // = ctx->spec_aligned when the form matches
       speculated = true;
     } else {
       GIQL_TRY(read_meta(ctx, st));
       decide(*ctx->h_meta, S.uniform, uni_len);
+      aligned = want_hist && ctx->h_meta->aligned_ok != 0;
     }
   }
+  const bool keygen = aligned && S.uniform == (big_side ? 1 : 2);
   const u32* irr_a = &ctx->d_meta->irr_a;
   const u32* irr_b = &ctx->d_meta->irr_b;
   if (S.uniform) {
@@ -708,12 +758,24 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     GIQL_TRY(run_linearize(ctx, st, qs_, n_chrom, lb, sq.key[0], sq.end[0],
                            q_is_a ? ctx->irr_a_list : ctx->irr_b_list, q_is_a ? 0 : 1, 0,
                            q_is_a ? hist_a : hist_b, q_is_a ? gbase_a : gbase_b));
-    GIQL_TRY(run_linearize(ctx, st, us_, n_chrom, lb, su.key[0], nullptr,
-                           q_is_a ? ctx->irr_b_list : ctx->irr_a_list, q_is_a ? 1 : 0, 0,
-                           q_is_a ? hist_b : hist_a, q_is_a ? gbase_b : gbase_a, nullptr, nullptr,
-                           /*skip_end=*/true));  // uniform => no irregular row: `end` is not read
+    if (keygen) {
+      // the span pass counted U's digits already: fold the per-chromosome top digits onto the
+      // bases, scan, and let the first sort pass build the keys from (chrom, start)
+      Phase ph(ctx, st, GIQL_PH_LINEARIZE, 2);
+      u32* hist_u = q_is_a ? hist_b : hist_a;
+      hipLaunchKernelGGL(k_fold_top, dim3(MM_HIST_CHROMS), dim3(256), 0, st, lb.top_partial, lb.abase, hist_u);
+      hipLaunchKernelGGL(k_digit_offsets, dim3(4), dim3(256), 0, st, hist_u, (u32)LIN_HIST_REPLICAS,
+                         q_is_a ? gbase_b : gbase_a);
+      GIQL_TRY(post_launch("digit offsets (span histogram)"));
+    } else {
+      GIQL_TRY(run_linearize(ctx, st, us_, n_chrom, lb, su.key[0], nullptr,
+                             q_is_a ? ctx->irr_b_list : ctx->irr_a_list, q_is_a ? 1 : 0, 0,
+                             q_is_a ? hist_b : hist_a, q_is_a ? gbase_b : gbase_a, nullptr, nullptr,
+                             /*skip_end=*/true));  // uniform => no irregular row: `end` is not read
+    }
     GIQL_TRY(run_sort_onesweep(ctx, st, sq, (u32)nqr, q_is_a ? gbase_a : gbase_b, os_status));
-    GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, os_status));
+    GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, os_status, false,
+                               keygen ? &us_ : nullptr, lb.abase));
     constexpr u32 TQ = RC_NT * RC_ITEMS_C2;
     S.nt2 = cdiv(nqr, TQ);
     {
@@ -810,7 +872,8 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     int form;
     i64 len;
     decide(*ctx->h_meta, form, len);
-    if (speculated && (form != S.uniform || len != uni_len)) {
+    const bool aligned_now = ctx->h_meta->aligned_ok != 0;
+    if (speculated && (form != S.uniform || len != uni_len || (want_hist && !aligned_now))) {
       ctx->spec_valid = false;  // wrong guess: plan again from the numbers just read
       ctx->spec_misses++;
       ctx->fuse_done = false;
@@ -819,6 +882,9 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     ctx->spec_valid = true;
     ctx->spec_form = form;
     ctx->spec_len = len;
+    // the layout is probed only when the span histogram ran; a plan that skipped it for a
+    // form mismatch leaves the last answer (a later form change re-plans unspeculated anyway)
+    if (want_hist) ctx->spec_aligned = aligned_now;
   }
   ctx->stats.n_irregular_a = ctx->h_meta->irr_a;
   ctx->stats.n_irregular_b = ctx->h_meta->irr_b;
@@ -840,7 +906,9 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     ctx->n_irr = ctx->h_meta->n_out_irr;
   }
   collect_spans(ctx);
-  ctx->stats.reserved = S.uniform;  // which form ran: 0 general, 1 B uniform, 2 A uniform
+  // which form ran: 0 general, 1 B uniform, 2 A uniform; bit 4: the fixed-length side was sorted
+  // from its raw columns (histogram in the span pass, no linearize pass)
+  ctx->stats.reserved = S.uniform | (keygen ? 0x10 : 0);
   ctx->stats.n_out = (int64_t)(ctx->n_reg + ctx->n_irr);
   *n_pairs = (int64_t)(ctx->n_reg + ctx->n_irr);
   ctx->planned = true;

@@ -45,6 +45,7 @@ __global__ void k_init_minmax(int* __restrict__ gmin, int* __restrict__ gmax, in
     meta->len_max_a = 0;
     meta->len_min_b = INT_MAX;
     meta->len_max_b = 0;
+    meta->aligned_ok = 0;
   }
 }
 
@@ -62,17 +63,40 @@ constexpr int MM_ITEMS = 8;
 constexpr int MM_LDS_CHROMS = 4096;
 constexpr int MM_MAX_BLOCKS = GIQL_MM_BLOCKS;  // grid cap; len_part holds 2 sides x blocks x {min,max}
 
+// Digit histogram inside the span pass (HIST).  With every chromosome base a multiple of
+// 2^24 (k_chrom_offsets, aligned form) the three low digits of key = base[c] + pos are the
+// three low bytes of pos whatever the base turns out to be, and the top digit is
+// base[c] >> 24 plus pos >> 24: so the pass that finds the bases can already count the
+// digits -- the low three directly, the top one per (chromosome, pos >> 24), folded once
+// the bases are known (k_fold_top).  The fixed-length side of the uniform form then needs
+// no linearize pass at all: its first sort pass computes the keys from (chrom, start).
+// All arithmetic wraps in u32, so histogram and keys agree on ANY input (memory safety of
+// the sort does not depend on the layout being meaningful; aligned_ok says whether it is).
+constexpr int LIN_HIST_REPLICAS = 64;  // ghist[replica][4][256], block b adds to b % 64
+constexpr int MM_HIST_CHROMS = 32;   // chromosomes the per-chromosome top-digit histogram holds
+constexpr int MM_TOP_WORDS = MM_HIST_CHROMS * 256;
+
 // Per-chromosome min/max of the raw coordinates (both columns).  LDS-privatised
 // atomics; a per-thread run cache keeps chromosome-sorted input (the common BED
 // case) from serialising on one LDS address.
+template <bool HIST>
 __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ chrom,
                                                          const int* __restrict__ start,
                                                          const int* __restrict__ end, i64 n,
                                                          int n_chrom, int* __restrict__ gmin,
                                                          int* __restrict__ gmax,
                                                          DevMeta* __restrict__ meta, int len_bias,
-                                                         int which, int* __restrict__ len_part) {
+                                                         int which, int* __restrict__ len_part,
+                                                         int start_off, u32* __restrict__ hist_partial,
+                                                         u32* __restrict__ top_partial) {
   extern __shared__ int mm_lds[];
+  __shared__ u32 s_hist[HIST ? 3 * 256 : 1];
+  __shared__ u32 s_top[HIST ? MM_TOP_WORDS : 1];
+  if (HIST) {
+    for (int k = threadIdx.x; k < 3 * 256; k += MM_NT) s_hist[k] = 0;
+    for (int k = threadIdx.x; k < MM_TOP_WORDS; k += MM_NT) s_top[k] = 0;
+    __syncthreads();
+  }
   const bool use_lds = n_chrom <= MM_LDS_CHROMS;
   int* lmin = use_lds ? mm_lds : gmin;
   int* lmax = use_lds ? mm_lds + n_chrom : gmax;
@@ -139,6 +163,51 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
       mn = lo < mn ? lo : mn;
       mx = hi > mx ? hi : mx;
     }
+    if (HIST) {
+      // n_chrom <= MM_HIST_CHROMS here (host); a bad id (flagged above) is masked into range
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool ok = okv[u];
+        const u32 pos = (u32)(sv[u] + start_off);
+        const u32 tb = ((u32)cv[u] & (MM_HIST_CHROMS - 1)) * 256u + (pos >> 24);
+        if (ok) {
+          atomicAdd(&s_hist[pos & 0xFFu], 1u);
+          atomicAdd(&s_hist[256 + ((pos >> 8) & 0xFFu)], 1u);
+        }
+        // chromosome- and position-sorted input makes the two high digits wave-uniform:
+        // one add per wave instead of 64 serialised ones on the same LDS word
+        const u64 act = __ballot(ok);
+        if (act == 0) continue;
+        const u32 d2 = (pos >> 16) & 0xFFu;
+        const u32 first = (u32)__ffsll((long long)act) - 1u;
+        const u32 d2f = (u32)__shfl((int)d2, (int)first, WAVE);
+        const u32 tbf = (u32)__shfl((int)tb, (int)first, WAVE);
+        if (__ballot(ok && d2 == d2f) == act) {
+          if (lane_id() == first) atomicAdd(&s_hist[512 + d2f], (u32)__popcll(act));
+        } else if (ok) {
+          atomicAdd(&s_hist[512 + d2], 1u);
+        }
+        if (__ballot(ok && tb == tbf) == act) {
+          if (lane_id() == first) atomicAdd(&s_top[tbf], (u32)__popcll(act));
+        } else if (ok) {
+          atomicAdd(&s_top[tb], 1u);
+        }
+      }
+    }
+  }
+  if (HIST) {
+    __syncthreads();
+    const size_t rep = blockIdx.x % LIN_HIST_REPLICAS;
+    u32* g = hist_partial + rep * 1024;
+    for (int k = threadIdx.x; k < 3 * 256; k += MM_NT) {
+      const u32 v = s_hist[k];
+      if (v) atomicAdd(&g[k], v);
+    }
+    u32* gt = top_partial + rep * MM_TOP_WORDS;
+    for (int k = threadIdx.x; k < MM_TOP_WORDS; k += MM_NT) {
+      const u32 v = s_top[k];
+      if (v) atomicAdd(&gt[k], v);
+    }
   }
   if (cur >= 0) {
     atomicMin(&lmin[cur], mn);
@@ -191,7 +260,8 @@ __global__ __launch_bounds__(256) void k_chrom_offsets(const int* __restrict__ g
                                                         u32* __restrict__ chrom_first,
                                                         DevMeta* __restrict__ meta,
                                                         const int* __restrict__ len_part, int nblk_a,
-                                                        int nblk_b) {
+                                                        int nblk_b, int want_aligned,
+                                                        u32* __restrict__ abase) {
   __shared__ u64 lds[256 / WAVE + 1];
   __shared__ u64 carry_s;
   if (threadIdx.x == 0) carry_s = 0;
@@ -253,7 +323,56 @@ __global__ __launch_bounds__(256) void k_chrom_offsets(const int* __restrict__ g
     } else {
       meta->sentinel = (u32)total;  // one past the largest real key
     }
+    if (want_aligned) {
+      // Aligned form (n_chrom <= MM_HIST_CHROMS): base[c] = (2^24-buckets of the chromosomes
+      // before c) << 24, key = base[c] + canonical coordinate.  abase is written whatever the
+      // outcome -- wrapped mod 2^32 it stays consistent with the span pass's histogram -- and
+      // replaces the tight bases only when every coordinate is >= 0 and the buckets fit below
+      // the top one (kept for the sentinel).
+      u32 running = 0;
+      bool ok = true;
+      // (ids past n_chrom are an error, reported after the call; their rows are counted and
+      // keyed under id & 31 with base 0, so the sort stays consistent until then)
+      for (int c = n_chrom; c < MM_HIST_CHROMS; c++) abase[c] = 0;
+      for (int c = 0; c < n_chrom; c++) {
+        abase[c] = (running & 0xFFu) << 24;
+        if (gmin[c] <= gmax[c]) {
+          const i64 lo = (i64)gmin[c] + off_min, hi = (i64)gmax[c] + off_max;
+          if (lo < 0 || hi > 0x7FFFFFFFll) ok = false;
+          const u32 nb = (u32)((hi < 0 ? 0 : hi) >> 24) + 1u;
+          running += nb;
+          if (running > 255u) ok = false;
+        }
+      }
+      if (ok) {
+        running = 0;
+        for (int c = 0; c < n_chrom; c++) {
+          chrom_base[c] = (i64)running << 24;
+          chrom_first[c] = running << 24;
+          if (gmin[c] <= gmax[c]) running += (u32)(((i64)gmax[c] + off_max) >> 24) + 1u;
+        }
+        const u64 atotal = (u64)running << 24;
+        meta->total_span = atotal;
+        chrom_first[n_chrom] = (u32)atotal;
+        meta->sentinel = (u32)atotal;
+        meta->aligned_ok = 1;
+      }
+    }
   }
+}
+
+// Top-digit histogram of the aligned keys from the per-(chromosome, pos >> 24) counts of the
+// span pass: hist[3][(j + base[c] >> 24) mod 256] += sum_r top[r][c][j], added into replica 0's
+// digit-3 row (zero in every replica until now) for k_digit_offsets.
+__global__ __launch_bounds__(256) void k_fold_top(const u32* __restrict__ top_partial,
+                                                   const u32* __restrict__ abase,
+                                                   u32* __restrict__ hist_partial) {
+  // one block per chromosome slot, thread = pos >> 24 bin: 64 replica loads per thread
+  const u32 c = blockIdx.x, j = threadIdx.x;
+  u32 sum = 0;
+#pragma unroll 8
+  for (int r = 0; r < LIN_HIST_REPLICAS; r++) sum += top_partial[(size_t)r * MM_TOP_WORDS + c * 256 + j];
+  if (sum) atomicAdd(&hist_partial[3 * 256 + ((j + (abase[c] >> 24)) & 0xFFu)], sum);
 }
 
 // -------------------------------------------------------------- linearise
@@ -265,7 +384,6 @@ __global__ __launch_bounds__(256) void k_chrom_offsets(const int* __restrict__ g
 #endif
 constexpr int LIN_NT = GIQL_LIN_NT;
 constexpr int LIN_MAX_BLOCKS = GIQL_LIN_BLOCKS;
-constexpr int LIN_HIST_REPLICAS = 64;  // ghist[replica][4][256], block b adds to b % 64
 constexpr int LIN_BASE_CAP = 1024;     // chromosome bases staged in LDS (8 KB)
 #ifndef GIQL_LIN_UNROLL
 #define GIQL_LIN_UNROLL 4

@@ -74,13 +74,17 @@ __device__ __forceinline__ void os_store(u32* p, u32 v) { *p = v; }
 // 2 = (key, end), 3 = (key, end, rid).
 // FULL = every row of the tile is valid (all tiles but the last): no per-item
 // bounds predicates.
-template <int PAYLOAD, int OS_NT, int OS_ITEMS, bool FULL>
+// KEYGEN (first pass of the fixed-length side in the aligned form, PAYLOAD 1 only): the keys
+// are not read but built from the raw columns -- keys_in = the start column, ends_in = the
+// chrom column, key = abase[chrom] + start + start_off (u32, wrapping: exactly what the span
+// pass's histogram counted, k_chrom_minmax<true>) -- so that side has no linearize pass.
+template <int PAYLOAD, int OS_NT, int OS_ITEMS, bool FULL, bool KEYGEN = false>
 __device__ __forceinline__ u32 onesweep_tile(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n_valid,
     u32 tile, u32 tile_base, int shift, const u32* __restrict__ gbase, u32* __restrict__ status,
     DevMeta* __restrict__ meta, u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff,
-    u32* s_scan, u32* s_help, u32 help_after) {
+    u32* s_scan, u32* s_help, u32 help_after, const u32* s_abase = nullptr, u32 start_off = 0) {
   constexpr int OS_NW = OS_NT / WAVE;
   const u32 tid = threadIdx.x;
   const u32 lane = lane_id();
@@ -94,11 +98,29 @@ __device__ __forceinline__ u32 onesweep_tile(
   const u32* kin = keys_in + tile_base;  // block-uniform bases: 32-bit lane offsets
   const u32* ein = (PAYLOAD & 2) ? ends_in + tile_base : nullptr;
   const u32* rin = ((PAYLOAD & 1) && rids_in) ? rids_in + tile_base : nullptr;
+  if (KEYGEN) {
+    const int* cin = reinterpret_cast<const int*>(ends_in) + tile_base;
+    u32 cc[OS_ITEMS];
 #pragma unroll
-  for (int i = 0; i < OS_ITEMS; i++) {
-    const u32 r = wbase + i * WAVE + lane;
-    const bool ok = FULL || r < n_valid;
-    key[i] = ok ? kin[r] : U32_MAX;
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      const bool ok = FULL || r < n_valid;
+      cc[i] = ok ? (u32)cin[r] : 0u;
+      key[i] = ok ? kin[r] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      const bool ok = FULL || r < n_valid;
+      key[i] = ok ? s_abase[cc[i] & 31u] + key[i] + start_off : U32_MAX;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      const bool ok = FULL || r < n_valid;
+      key[i] = ok ? kin[r] : U32_MAX;
+    }
   }
 
   // stable rank inside the wave (peers = lanes with the same digit)
@@ -326,37 +348,37 @@ __device__ __forceinline__ u32 onesweep_tile(
 // addresses, so the duplicate is harmless.
 // One tile with the block's LDS prepared (counters zeroed, s_help reset); returns
 // OS_NO_TILE when the tile is finished, else the silent predecessor to compute first.
-template <int PAYLOAD, int OS_NT, int OS_ITEMS>
+template <int PAYLOAD, int OS_NT, int OS_ITEMS, bool KEYGEN = false>
 __device__ __forceinline__ u32 os_run_tile(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n, u32 tile,
     int shift, const u32* __restrict__ gbase, u32* __restrict__ status, DevMeta* __restrict__ meta,
     u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff, u32* s_scan, u32* s_help,
-    u32 help_after) {
+    u32 help_after, const u32* s_abase = nullptr, u32 start_off = 0) {
   constexpr int OS_TILE = OS_NT * OS_ITEMS;
   const u32 tile_base = tile * OS_TILE;
   const u32 n_valid = (n - tile_base) < (u32)OS_TILE ? (n - tile_base) : (u32)OS_TILE;
   if (n_valid == (u32)OS_TILE)
-    return onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, true>(keys_in, ends_in, rids_in, keys_out, ends_out,
-                                                         rids_out, n_valid, tile, tile_base, shift, gbase,
-                                                         status, meta, s_buf, s_wcnt, s_dstart, s_goff,
-                                                         s_scan, s_help, help_after);
-  return onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, false>(keys_in, ends_in, rids_in, keys_out, ends_out,
-                                                        rids_out, n_valid, tile, tile_base, shift, gbase,
-                                                        status, meta, s_buf, s_wcnt, s_dstart, s_goff,
-                                                        s_scan, s_help, help_after);
+    return onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, true, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
+                                                                 rids_out, n_valid, tile, tile_base, shift, gbase,
+                                                                 status, meta, s_buf, s_wcnt, s_dstart, s_goff,
+                                                                 s_scan, s_help, help_after, s_abase, start_off);
+  return onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, false, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
+                                                                rids_out, n_valid, tile, tile_base, shift, gbase,
+                                                                status, meta, s_buf, s_wcnt, s_dstart, s_goff,
+                                                                s_scan, s_help, help_after, s_abase, start_off);
 }
 
 // The cold path: compute the silent predecessor `need` (recursively the earliest silent
 // one), then start over on the block's own tile, until that is finished.  Out of line
 // so that the hot path of k_onesweep keeps its register allocation.
-template <int PAYLOAD, int OS_NT, int OS_ITEMS>
+template <int PAYLOAD, int OS_NT, int OS_ITEMS, bool KEYGEN = false>
 __device__ __noinline__ void os_help_loop(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n, u32 own,
     u32 need, int shift, const u32* __restrict__ gbase, u32* __restrict__ status,
     DevMeta* __restrict__ meta, u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff,
-    u32* s_scan, u32* s_help, u32 help_after) {
+    u32* s_scan, u32* s_help, u32 help_after, const u32* s_abase = nullptr, u32 start_off = 0) {
   constexpr int OS_NW = OS_NT / WAVE;
   const u32 tid = threadIdx.x;
   u32 cur = need;
@@ -366,9 +388,10 @@ __device__ __noinline__ void os_help_loop(
     for (int k = tid; k < OS_NW * OS_BINS; k += OS_NT) (&s_wcnt[0][0])[k] = 0;
     if (tid == 0) *s_help = OS_NO_TILE;
     __syncthreads();
-    const u32 r = os_run_tile<PAYLOAD, OS_NT, OS_ITEMS>(keys_in, ends_in, rids_in, keys_out, ends_out, rids_out,
-                                                       n, cur, shift, gbase, status, meta, s_buf, s_wcnt,
-                                                       s_dstart, s_goff, s_scan, s_help, help_after);
+    const u32 r = os_run_tile<PAYLOAD, OS_NT, OS_ITEMS, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
+                                                               rids_out, n, cur, shift, gbase, status, meta, s_buf,
+                                                               s_wcnt, s_dstart, s_goff, s_scan, s_help, help_after,
+                                                               s_abase, start_off);
     if (r == OS_NO_TILE) {
       if (cur == own) return;
       cur = own;  // the helped tile is done: start over on this block's own tile
@@ -393,12 +416,13 @@ __device__ __noinline__ void os_help_loop(
 // over on its own tile (os_help_loop).  A tile computed twice (by a helper and, later,
 // by its own block) publishes the same status values and writes the same bytes to the
 // same addresses, so the duplicate is harmless.
-template <int PAYLOAD, int OS_NT, int OS_ITEMS>
+template <int PAYLOAD, int OS_NT, int OS_ITEMS, bool KEYGEN = false>
 __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS <= 8)) ? 8 : 1) void k_onesweep(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
     int shift, const u32* __restrict__ gbase, u32* __restrict__ status, u32* __restrict__ ticket,
-    DevMeta* __restrict__ meta, int order, u32 help_after) {
+    DevMeta* __restrict__ meta, int order, u32 help_after, const u32* __restrict__ abase = nullptr,
+    u32 start_off = 0) {
   constexpr int OS_TILE = OS_NT * OS_ITEMS;
   constexpr int OS_NW = OS_NT / WAVE;
   __shared__ u32 s_buf[OS_TILE];          // staging, reused for key / end / rid
@@ -408,8 +432,10 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
   __shared__ u32 s_scan[OS_BINS / WAVE + 1];
   __shared__ u32 s_tile;
   __shared__ u32 s_help;
+  __shared__ u32 s_abase[KEYGEN ? 32 : 1];
 
   const u32 tid = threadIdx.x;
+  if (KEYGEN && tid < 32) s_abase[tid] = abase[tid];
   if (tid == 0) {
     s_tile = order == 2 ? xcd_tile_of_block(blockIdx.x, gridDim.x) : atomicAdd(ticket, 1u);
     s_help = OS_NO_TILE;
@@ -419,13 +445,14 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
   __syncthreads();
   const u32 own = s_tile;
   if (own * OS_TILE >= n) return;  // block-uniform (cannot happen: grid = n_tiles)
-  const u32 need = os_run_tile<PAYLOAD, OS_NT, OS_ITEMS>(keys_in, ends_in, rids_in, keys_out, ends_out,
-                                                        rids_out, n, own, shift, gbase, status, meta, s_buf,
-                                                        s_wcnt, s_dstart, s_goff, s_scan, &s_help, help_after);
+  const u32 need = os_run_tile<PAYLOAD, OS_NT, OS_ITEMS, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
+                                                                rids_out, n, own, shift, gbase, status, meta, s_buf,
+                                                                s_wcnt, s_dstart, s_goff, s_scan, &s_help, help_after,
+                                                                s_abase, start_off);
   if (need != OS_NO_TILE)
-    os_help_loop<PAYLOAD, OS_NT, OS_ITEMS>(keys_in, ends_in, rids_in, keys_out, ends_out, rids_out, n, own,
-                                           need, shift, gbase, status, meta, s_buf, s_wcnt, s_dstart, s_goff,
-                                           s_scan, &s_help, help_after);
+    os_help_loop<PAYLOAD, OS_NT, OS_ITEMS, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out, rids_out, n, own,
+                                                   need, shift, gbase, status, meta, s_buf, s_wcnt, s_dstart,
+                                                   s_goff, s_scan, &s_help, help_after, s_abase, start_off);
 }
 
 }  // namespace giql

@@ -129,7 +129,8 @@ class HipEngine:
         out = {k: int(getattr(st, k)) for k in
                ("n_a", "n_b", "n_out", "n_irregular_a", "n_irregular_b", "workspace_bytes", "span",
                 "profiled")}
-        out["join_form"] = {0: "general", 1: "uniform_b", 2: "uniform_a"}.get(int(st.reserved) & 0xFF, "?")
+        out["join_form"] = {0: "general", 1: "uniform_b", 2: "uniform_a"}.get(int(st.reserved) & 0x0F, "?")
+        out["span_hist"] = bool(int(st.reserved) & 0x10)  # fixed-length side sorted from its raw columns
         out["sort_tile_order"] = (int(st.reserved) >> 8) & 0xFF
         out["sort_order_fallbacks"] = (int(st.reserved) >> 16) & 0x3FFF
         out["fused_fill"] = bool((int(st.reserved) >> 30) & 1)  # the last plan launched its own fill

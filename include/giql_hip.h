@@ -103,9 +103,10 @@ typedef struct giql_hip_stats {
   int32_t phase_launches[GIQL_PH_N];
   float total_ms;           /* sum of phase_ms                              */
   int32_t profiled;         /* 1 if phase_ms are valid                      */
-  int32_t reserved;         /* byte 0: INNER join form (0 = general two-class join,
+  int32_t reserved;         /* bits 0-3: INNER join form (0 = general two-class join,
                                1 / 2 = uniform-length form with B / A as the fixed-
-                               length side); byte 1: sort tile order in force (2 =
+                               length side); bit 4: that side was sorted straight from
+                               its raw columns (digit histogram in the span pass); byte 1: sort tile order in force (2 =
                                blockIdx order, 0 = ticket order); bits 16-29: calls
                                repeated in ticket order after a look-back timeout;
                                bit 30: the last plan launched its own fill

@@ -29,6 +29,16 @@ def eng():
     e.close()
 
 
+@pytest.fixture()
+def eng_fresh():
+    """A context of its own (tests of what a context remembers between plans)."""
+    from giql_amd.engine import HipEngine
+
+    e = HipEngine(0)
+    yield e
+    e.close()
+
+
 def dev(side: ora.Side):
     from giql_amd.engine import DeviceSide
 
@@ -422,6 +432,82 @@ def test_uniform_length_at_chromosome_edges(eng):
                  np.array([100, 1090, 100, 102, 100], np.int32))
     assert np.array_equal(gpu_inner(eng, a, b, 3), ora.sort_pairs(*ora.c_inner(a, b, "brute")))
     assert eng.stats()["join_form"] == "uniform_b"
+
+
+# ------------- histogram in the span pass: the fixed-length side sorted from its raw columns
+def test_span_histogram_form_runs_and_can_be_disabled(monkeypatch):
+    """Larger side fixed-length, coordinates >= 0, <= 32 chromosomes: no linearize pass for that
+    side (stats span_hist), first call (layout read back) and later calls (speculated) alike;
+    GIQL_HIP_NO_SPAN_HIST=1 gives the same pairs through the linearize pass."""
+    from giql_amd.engine import HipEngine
+
+    a = rand_side(91, 50_000, 24, 40_000_000, 1500)
+    b = uniform_side(92, 400_000, 24, 40_000_000, 150)
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    e = HipEngine(0)
+    try:
+        for _ in range(3):
+            assert np.array_equal(gpu_inner(e, a, b, 24), want)
+            st = e.stats()
+            assert st["join_form"] == "uniform_b" and st["span_hist"]
+    finally:
+        e.close()
+    monkeypatch.setenv("GIQL_HIP_NO_SPAN_HIST", "1")
+    e = HipEngine(0)
+    try:
+        assert np.array_equal(gpu_inner(e, a, b, 24), want)
+        assert e.stats()["join_form"] == "uniform_b" and not e.stats()["span_hist"]
+    finally:
+        e.close()
+
+
+def test_span_histogram_layout_misses_and_recovers(eng_fresh):
+    """The aligned layout is speculated on after the first plan; inputs it cannot hold -- a
+    coordinate below 0 (1-based start 0), buckets past 255 (INT32_MAX-scale coordinates on many
+    chromosomes), sorted input (wave-uniform high digits), a bad form guess -- re-plan and stay exact."""
+    e = eng_fresh
+    a = rand_side(93, 20_000, 8, 5_000_000, 800)
+    b = uniform_side(94, 150_000, 8, 5_000_000, 100)
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    assert np.array_equal(gpu_inner(e, a, b, 8), want) and e.stats()["span_hist"]
+    assert np.array_equal(gpu_inner(e, a, b, 8), want) and e.stats()["span_hist"]
+    # 1-based starts with a 0 among them: canonical -1, the aligned layout does not hold
+    b1 = ora.Side(b.chrom.copy(), b.start.copy(), b.end.copy(), start_off=-1, end_off=-1)  # 1-based half-open
+    b1.start[:7] = 0
+    b1.end[:7] = 100
+    want1 = ora.sort_pairs(*ora.c_inner(a, b1, "sweep"))
+    assert np.array_equal(gpu_inner(e, a, b1, 8), want1)
+    assert e.stats()["join_form"] == "uniform_b" and not e.stats()["span_hist"]
+    assert np.array_equal(gpu_inner(e, a, b1, 8), want1) and not e.stats()["span_hist"]
+    # huge coordinates on 8 chromosomes: 8 x 128 buckets do not fit 255
+    r = np.random.default_rng(95)
+    big = r.integers(2_000_000_000, 2_100_000_000, b.n).astype(np.int32)
+    b2 = ora.Side(b.chrom.copy(), big, big + np.int32(100))
+    a2 = ora.Side(a.chrom.copy(), (a.start // 4 + 2_000_000_000).astype(np.int32),
+                  (a.start // 4 + 2_000_000_000 + 5000).astype(np.int32))
+    try:
+        got = gpu_inner(e, a2, b2, 8)
+    except Exception as exc:  # the tight layout does not fit 32 bits either: the documented error
+        assert "span" in str(exc).lower()
+    else:
+        assert np.array_equal(got, ora.sort_pairs(*ora.c_inner(a2, b2, "sweep")))
+    # chromosome- and position-sorted fixed-length side (wave-uniform high digits)
+    order = np.lexsort((b.start, b.chrom))
+    bs = ora.Side(b.chrom[order], b.start[order], b.end[order])
+    e2_want = ora.sort_pairs(*ora.c_inner(a, bs, "sweep"))
+    assert np.array_equal(gpu_inner(e, a, bs, 8), e2_want)
+    assert np.array_equal(gpu_inner(e, a, bs, 8), e2_want)
+
+
+def test_span_histogram_tile_edges(eng_fresh):
+    """Row counts around the 8192-row sort tile and the span pass's 4-row unroll."""
+    e = eng_fresh
+    a = rand_side(96, 3000, 5, 300_000, 400)
+    for n in (1, 63, 64, 8191, 8192, 8193, 16384 + 5, 70_001):
+        b = uniform_side(97 + n, n, 5, 300_000, 36)
+        want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+        got = gpu_inner(e, a, b, 5)
+        assert np.array_equal(got, want), n
 
 
 # ------------------------------------------- BASELINE full size (cfg 4), properties

@@ -12,7 +12,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PHASE_OF = [("k_onesweep", "sort_scatter"), ("k_linearize", "linearize"), ("k_digit_offsets", "linearize"),
+PHASE_OF = [("k_onesweep", "sort_scatter"), ("k_linearize", "linearize"), ("k_digit_offsets", "linearize"), ("k_fold_top", "linearize"),
             ("k_init_minmax", "span"), ("k_chrom_minmax", "span"), ("k_chrom_offsets", "span"),
             ("k_range_count", "count"), ("k_count_partition", "count"), ("k_c1_count", "count"),
             ("k_scan_", "scan"), ("k_partition", "partition"), ("k_fill", "fill"), ("k_c1_emit", "fill")]
