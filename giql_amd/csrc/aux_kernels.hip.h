@@ -164,6 +164,33 @@ __global__ __launch_bounds__(256) void k_semi_flags(const u32* __restrict__ a_ke
   flag[a_rids[i]] = (hit != (anti != 0)) ? 1u : 0u;
 }
 
+// Fixed-length B (every row regular with canonical length L > 0): b.end = b.start + L, so
+//   a.start < b.end AND a.end > b.start  <=>  b.start in (a.start - L, a.end)
+// for ANY A row -- the literal predicate rewritten, no prefix max and no `end` payload on B:
+// an A row qualifies iff the sorted B starts hold a key in [a.start - L + 1, a.end).  Keys of
+// another chromosome cannot fall in that range (a B row ends inside its chromosome's span).
+__global__ __launch_bounds__(256) void k_semi_flags_uniform(const u32* __restrict__ a_keys,
+                                                             const u32* __restrict__ a_ends,
+                                                             const u32* __restrict__ a_rids, u32 n_a,
+                                                             const DevMeta* __restrict__ meta,
+                                                             const u32* __restrict__ b_keys, u32 n_b,
+                                                             i64 uni_len, int anti, u32* __restrict__ flag) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_a) return;
+  const u32 qs = a_keys[i], qe = a_ends[i];
+  bool hit = false;
+  if (n_b > 0 && qs < meta->sentinel) {
+    const i64 lo64 = (i64)qs - uni_len + 1;
+    const u32 lo_key = lo64 < 0 ? 0u : (u32)lo64;
+    if (qe > lo_key) {
+      const u32 lo = lower_bound_u32(b_keys, 0, n_b, lo_key);
+      // the range is short (a.len + L - 1 positions): the upper bound lies a few rows on
+      hit = lo < n_b && b_keys[lo] < qe;
+    }
+  }
+  flag[a_rids[i]] = (hit != (anti != 0)) ? 1u : 0u;
+}
+
 // rows_out[off[i]] = i for flagged rows (ascending row ids).
 __global__ __launch_bounds__(256) void k_compact(const u32* __restrict__ flag,
                                                   const u64* __restrict__ off, u32 n,
@@ -181,13 +208,21 @@ __global__ __launch_bounds__(256) void k_count_rows(
     const u32* __restrict__ a_keys, const u32* __restrict__ a_ends, const u32* __restrict__ a_rids,
     u32 n_a_total, SideView a, SideView b, const u32* __restrict__ b_keys_sorted,
     const u32* __restrict__ b_ends_sorted, u32 n_b_total, const u32* __restrict__ irr_b_list,
-    const DevMeta* __restrict__ meta, i64* __restrict__ counts_out) {
+    const DevMeta* __restrict__ meta, i64* __restrict__ counts_out, i64 uni_len) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_a_total - meta->irr_a) return;
   const u32 n_reg = n_b_total - meta->irr_b;
   const u32 qs = a_keys[i], qe = a_ends[i], r = a_rids[i];
   const u32 below = lower_bound_u32(b_keys_sorted, 0, n_reg, qe);  // b.start < a.end
-  const u32 done = upper_bound_u32(b_ends_sorted, 0, n_reg, qs);   // b.end <= a.start
+  u32 done;                                                        // b.end <= a.start
+  if (uni_len > 0) {
+    // fixed-length B: its sorted ends are its sorted starts + L, so no second sorted array:
+    // #{b.end <= a.start} = #{b.start <= a.start - L}
+    const i64 t = (i64)qs - uni_len;
+    done = t < 0 ? 0u : upper_bound_u32(b_keys_sorted, 0, n_reg, (u32)t);
+  } else {
+    done = upper_bound_u32(b_ends_sorted, 0, n_reg, qs);
+  }
   i64 cnt = (i64)below - (i64)done;
   const u32 m = meta->irr_b;
   if (m) {  // rare: literal predicate against the irregular B rows

@@ -120,6 +120,10 @@ struct giql_hip_ctx {
   int spec_form = 0;
   i64 spec_len = 0;
   int spec_misses = 0;
+  // per-row operators (SEMI / ANTI / COUNT): the fixed length of B seen by the previous call
+  // (0 = B was not fixed-length), speculated on like the INNER form
+  bool row_spec_valid = false;
+  i64 row_spec_len = 0;
   bool spec_aligned = false;  // ... and whether the aligned layout (histogram in the span pass) held
   bool no_span_hist = false;  // GIQL_HIP_NO_SPAN_HIST=1: always linearize the fixed-length side (A/B aid)
   int inject_timeout = 0;     // test hook: report one look-back timeout
@@ -516,6 +520,42 @@ static int with_order_fallback(giql_hip_ctx* ctx, F&& call) {
     rc = call();
   }
   return rc;
+}
+
+// Fixed-length B side of the per-row operators: the canonical length every B row has (all of
+// them regular), else 0.  From the span pass's length range.
+static inline i64 uniform_len_b(const DevMeta& m) {
+  return (m.len_min_b == m.len_max_b && m.len_max_b > 0) ? (i64)m.len_max_b : 0;
+}
+
+// Decide the form of a per-row operator after run_spans: a context that has run before assumes
+// the previous call's answer (no stream sync here) and the caller validates it with
+// row_form_settled() at the read-back the call ends with anyway; the first call reads the
+// lengths back.
+static int row_form_guess(giql_hip_ctx* ctx, hipStream_t st, i64& uni_len, bool& speculated) {
+  uni_len = 0;
+  speculated = false;
+  if (ctx->no_uniform) return GIQL_OK;
+  if (ctx->row_spec_valid) {
+    uni_len = ctx->row_spec_len;
+    speculated = true;
+    return GIQL_OK;
+  }
+  GIQL_TRY(read_meta(ctx, st));
+  uni_len = uniform_len_b(*ctx->h_meta);
+  return GIQL_OK;
+}
+
+// After the final read-back: remember the answer; false = the call assumed a fixed length that
+// B does not have (its result is wrong: repeat it; the general form is right on any input, so a
+// wrong "not fixed-length" guess only costs speed).
+static bool row_form_settled(giql_hip_ctx* ctx, i64 uni_len, bool speculated) {
+  if (ctx->no_uniform) return true;
+  const i64 actual = uniform_len_b(*ctx->h_meta);
+  const bool ok = !(speculated && uni_len != 0 && actual != uni_len);
+  ctx->row_spec_valid = ok;
+  ctx->row_spec_len = actual;
+  return ok;
 }
 
 // ================================================================= C ABI
@@ -1092,7 +1132,16 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   carve(ctx->arena);
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, nch, lb));
-  if (nb > 0) {
+  i64 uni_len = 0;
+  bool speculated = false;
+  if (nb > 0) GIQL_TRY(row_form_guess(ctx, st, uni_len, speculated));
+  if (nb > 0 && uni_len > 0) {
+    // fixed-length B: keys only (its `end` column is not read again), no prefix max
+    sbb.end[0] = sbb.end[1] = nullptr;
+    GIQL_TRY(run_linearize(ctx, st, *b, nch, lb, sbb.key[0], nullptr, dummy_irr, 1, 1, os.hist, os.gbase,
+                           nullptr, nullptr, /*skip_end=*/true));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status));
+  } else if (nb > 0) {
     // every B row keeps its real key: the prefix-max test is exact for any row
     GIQL_TRY(run_linearize(ctx, st, *b, nch, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist,
                            os.gbase));
@@ -1108,8 +1157,12 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status));
   {
     Phase ph(ctx, st, GIQL_PH_COUNT);
-    hipLaunchKernelGGL(k_semi_flags, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0],
-                       sa.rid[0], (u32)na, ctx->d_meta, sbb.key[0], pmax, (u32)nb, anti, flag);
+    if (nb > 0 && uni_len > 0)
+      hipLaunchKernelGGL(k_semi_flags_uniform, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0],
+                         sa.rid[0], (u32)na, ctx->d_meta, sbb.key[0], (u32)nb, uni_len, anti, flag);
+    else
+      hipLaunchKernelGGL(k_semi_flags, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0],
+                         sa.rid[0], (u32)na, ctx->d_meta, sbb.key[0], pmax, (u32)nb, anti, flag);
     GIQL_TRY(post_launch("semi flags"));
   }
   GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, flag, na, off, bsums, off + na));
@@ -1120,7 +1173,10 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
     GIQL_TRY(post_launch("compact"));
   }
   GIQL_TRY(read_meta(ctx, st));
+  if (nb > 0 && !row_form_settled(ctx, uni_len, speculated))  // B is not fixed-length after all
+    return giql_hip_semi_anti_dev_impl(ctx, a, b, n_chrom, anti, rows_out, n_out, stream);
   collect_spans(ctx);
+  ctx->stats.reserved = uni_len > 0 ? 1 : 0;  // form: fixed-length B or general
   *n_out = (int64_t)ctx->h_meta->n_out;
   ctx->stats.n_out = *n_out;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
@@ -1176,10 +1232,20 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
   carve(ctx->arena);
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
-  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sstart.key[0], send.key[0], irr_b_list, 1, 0,
-                         os.hist, os.gbase, os.hist_e, os.gbase_e));
-  GIQL_TRY(run_sort_onesweep(ctx, st, sstart, (u32)nb, os.gbase, os.status));
-  GIQL_TRY(run_sort_onesweep(ctx, st, send, (u32)nb, os.gbase_e, os.status));
+  i64 uni_len = 0;
+  bool speculated = false;
+  GIQL_TRY(row_form_guess(ctx, st, uni_len, speculated));
+  if (uni_len > 0) {
+    // fixed-length B: one sorted array (its sorted ends are its sorted starts + L)
+    GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sstart.key[0], nullptr, irr_b_list, 1, 0, os.hist,
+                           os.gbase, nullptr, nullptr, /*skip_end=*/true));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sstart, (u32)nb, os.gbase, os.status));
+  } else {
+    GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sstart.key[0], send.key[0], irr_b_list, 1, 0,
+                           os.hist, os.gbase, os.hist_e, os.gbase_e));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sstart, (u32)nb, os.gbase, os.status));
+    GIQL_TRY(run_sort_onesweep(ctx, st, send, (u32)nb, os.gbase_e, os.status));
+  }
   GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], irr_a_list, 0, 0, os.hist,
                          os.gbase));
   GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status));
@@ -1187,10 +1253,13 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
     Phase ph(ctx, st, GIQL_PH_COUNT);
     hipLaunchKernelGGL(k_count_rows, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0],
                        sa.rid[0], (u32)na, view_of(*a), view_of(*b), sstart.key[0], send.key[0], (u32)nb,
-                       irr_b_list, ctx->d_meta, counts_out);
+                       irr_b_list, ctx->d_meta, counts_out, uni_len);
     GIQL_TRY(post_launch("count rows"));
   }
   GIQL_TRY(read_meta(ctx, st));
+  if (!row_form_settled(ctx, uni_len, speculated))  // B is not fixed-length after all
+    return giql_hip_count_dev_impl(ctx, a, b, n_chrom, counts_out, stream);
+  ctx->stats.reserved = uni_len > 0 ? 1 : 0;
   ctx->stats.n_irregular_a = ctx->h_meta->irr_a;
   ctx->stats.n_irregular_b = ctx->h_meta->irr_b;
   if (ctx->h_meta->irr_a > 0) {

@@ -434,6 +434,67 @@ def test_uniform_length_at_chromosome_edges(eng):
     assert eng.stats()["join_form"] == "uniform_b"
 
 
+# ------------- per-row operators with a fixed-length B (no prefix max, one sorted array)
+def _row_ops_equal(e, a, b, nch, method="sweep"):
+    da, db = dev(a), dev(b)
+    assert np.array_equal(e.semi_join(da, db, nch).cpu().numpy(), ora.c_semi_anti(a, b, False))
+    form_semi = e.stats()["join_form"]
+    assert np.array_equal(e.anti_join(da, db, nch).cpu().numpy(), ora.c_semi_anti(a, b, True))
+    assert np.array_equal(e.count_overlaps(da, db, nch).cpu().numpy(), ora.c_count(a, b, method))
+    return form_semi, e.stats()["join_form"]
+
+
+def test_row_ops_fixed_length_b(eng_fresh):
+    """SEMI / ANTI / COUNT against fixed-length reads: the literal predicate rewritten as a range
+    of B starts; irregular A rows, all encodings of A, a closed-interval B (length + 1), rows at
+    chromosome edges, an A-only chromosome; repeated calls (first reads the form back, later
+    ones speculate on it)."""
+    e = eng_fresh
+    b = uniform_side(301, 200_000, 6, 3_000_000, 150)
+    for k, enc in enumerate(ora.ENCODING_OFFSETS):
+        a = rand_side(302 + k, 30_000, 7, 3_000_000, 900, min_len=-3, enc=enc)  # chrom 6 is A-only
+        assert _row_ops_equal(e, a, b, 7, "brute") == ("uniform_b", "uniform_b")
+    b.end_off = 1  # 0-based closed: canonical length 151
+    a = rand_side(310, 30_000, 6, 3_000_000, 900)
+    assert _row_ops_equal(e, a, b, 6) == ("uniform_b", "uniform_b")
+    # chromosome edges: ranges reaching below a chromosome's first key must not leak
+    a = ora.Side(np.array([0, 1, 1, 2, 2], np.int32), np.array([0, 0, 5, 0, 120], np.int32),
+                 np.array([10, 3, 9, 1000, 121], np.int32))
+    b = ora.Side(np.array([0, 0, 1, 1, 2], np.int32), np.array([0, 990, 0, 2, 0], np.int32),
+                 np.array([100, 1090, 100, 102, 100], np.int32))
+    assert _row_ops_equal(e, a, b, 3, "brute") == ("uniform_b", "uniform_b")
+
+
+def test_row_ops_form_guess_misses_and_recovers(eng_fresh):
+    """fixed-length B -> B with other lengths -> a different fixed length -> an irregular B row:
+    a wrong "fixed-length" guess repeats the call, a wrong "general" guess is merely slower (the
+    general form is exact on any input) and corrects itself on the next call; results stay exact."""
+    e = eng_fresh
+    a = rand_side(320, 40_000, 5, 2_000_000, 700)
+    b1 = uniform_side(321, 150_000, 5, 2_000_000, 100)
+    b2 = rand_side(322, 150_000, 5, 2_000_000, 300)
+    b3 = uniform_side(323, 150_000, 5, 2_000_000, 36)
+    b4 = uniform_side(324, 150_000, 5, 2_000_000, 36)
+    b4.end[77] = b4.start[77] - 2
+    for b, want in ((b1, "uniform_b"), (b1, "uniform_b"), (b2, "general"), (b2, "general"), (b3, "uniform_b"),
+                    (b4, "general"), (b1, "uniform_b")):
+        first, last = _row_ops_equal(e, a, b, 5)
+        assert last == want and first in (want, "general")
+
+
+def test_row_ops_fixed_length_can_be_disabled(monkeypatch):
+    from giql_amd.engine import HipEngine
+
+    monkeypatch.setenv("GIQL_HIP_NO_UNIFORM", "1")
+    e = HipEngine(0)
+    try:
+        a = rand_side(330, 20_000, 4, 1_000_000, 500)
+        b = uniform_side(331, 90_000, 4, 1_000_000, 150)
+        assert _row_ops_equal(e, a, b, 4) == ("general", "general")
+    finally:
+        e.close()
+
+
 # ------------- histogram in the span pass: the fixed-length side sorted from its raw columns
 def test_span_histogram_form_runs_and_can_be_disabled(monkeypatch):
     """Larger side fixed-length, coordinates >= 0, <= 32 chromosomes: no linearize pass for that

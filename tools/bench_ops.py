@@ -43,15 +43,21 @@ def main():
         for _ in range(args.warmup):
             fn()
         torch.cuda.synchronize()
-        eng.set_profiling(True)
+        # wall time with profiling OFF (an event pair costs the stream a few microseconds of idle
+        # time per phase: 0.1 ms and more on calls this short) ...
         times, phases = [], {}
         for _ in range(args.reps):
             t0 = time.perf_counter()
             out = fn()
             torch.cuda.synchronize()
             times.append((time.perf_counter() - t0) * 1e3)
+        # ... and the phase breakdown from separate profiled calls
+        eng.set_profiling(True)
+        for _ in range(2):
+            fn()
+            torch.cuda.synchronize()
             for k, v in eng.stats()["phase_ms"].items():
-                phases[k] = phases.get(k, 0.0) + v / args.reps
+                phases[k] = phases.get(k, 0.0) + v / 2
         eng.set_profiling(False)
         ms = statistics.median(times)
         n_out = int(out) if not hasattr(out, "shape") else int(out.shape[0])
