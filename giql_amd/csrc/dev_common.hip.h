@@ -41,11 +41,12 @@ struct DevMeta {
 // windows) meets in one L2.  A bijection on [0, n_blocks); the tail keeps its order.
 constexpr u32 XCD_GROUPS = 8;
 constexpr u32 XCD_GROUP = 8;
+template <u32 G = XCD_GROUP>
 __device__ __forceinline__ u32 xcd_tile_of_block(u32 b, u32 n_blocks) {
-  constexpr u32 SPAN = XCD_GROUPS * XCD_GROUP;
+  constexpr u32 SPAN = XCD_GROUPS * G;
   if (b >= (n_blocks / SPAN) * SPAN) return b;
   const u32 x = b % XCD_GROUPS, j = b / XCD_GROUPS;
-  return ((j / XCD_GROUP) * XCD_GROUPS + x) * XCD_GROUP + j % XCD_GROUP;
+  return ((j / G) * XCD_GROUPS + x) * G + j % G;
 }
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & (WAVE - 1); }

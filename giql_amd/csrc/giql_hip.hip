@@ -363,8 +363,10 @@ static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, 
 // Onesweep LSD sort (4 passes, one launch each); input and result in
 // buffer 0.  Payload of a sort = which of end / rid buffers the SortBufs carries.
 // status words of ONE pass: a {flag,count} word per (tile, digit) + the ticket word
+// ... + one word row per look-back group of tiles (k_onesweep finds it one row past the ticket's)
 static inline size_t os_pass_words(size_t n) {
-  return (size_t)cdiv(n ? n : 1, OS_MIN_TILE) * OS_BINS + 16;
+  const size_t tiles = cdiv(n ? n : 1, OS_MIN_TILE);
+  return (tiles + 1) * OS_BINS + (tiles / (GIQL_OS_LB_GROUP > 0 ? GIQL_OS_LB_GROUP : 1) + 2) * OS_BINS;
 }
 
 template <int NT, int ITEMS>
@@ -2076,5 +2078,16 @@ int giql_hip_nearest(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, 
 }
 
 void giql_hip_free_host(void* p) { free(p); }
+
+#if defined(GIQL_OS_TIMELINE)
+// diagnostic builds only (tools/os_timeline.py): the phase stamps of the last sort pass
+int giql_hip_debug_timeline(unsigned long long* out, int64_t n_words) {
+  const size_t cap = (size_t)OS_TL_TILES * 16;
+  const size_t n = (size_t)n_words < cap ? (size_t)n_words : cap;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_os_tl), n * sizeof(unsigned long long)));
+  return GIQL_OK;
+}
+#endif
 
 }  // extern "C"

@@ -29,7 +29,28 @@ constexpr u32 OS_FLAG_PREFIX = 2u << 30;
 constexpr u32 OS_VALUE_MASK = (1u << 30) - 1u;
 constexpr u32 OS_MAX_ROWS = (1u << 30) - 1u;
 constexpr u32 OS_NO_TILE = 0xFFFFFFFFu;
+#ifndef GIQL_OS_LB_WIDTH
+#define GIQL_OS_LB_WIDTH 4
+#endif
+constexpr int OS_LB_WIDTH = GIQL_OS_LB_WIDTH;  // status words polled per look-back round
+#ifndef GIQL_OS_LB_GROUP
+#define GIQL_OS_LB_GROUP 0  // tiles per look-back group (0 = the flat one-level walk; 8 measured slower)
+#endif
 constexpr u32 OS_HELP_AFTER = 1u << 11;  // look-back polls (a few ms, several whole passes) before a block computes a silent predecessor itself
+
+// Timeline build (-DGIQL_OS_TIMELINE, tools/os_timeline.py): thread 0 of every block stamps the
+// 100 MHz wall clock at the phase boundaries of its tile into g_os_tl[tile][k]; a diagnostic
+// aid only -- the product build compiles none of it.
+#if defined(GIQL_OS_TIMELINE)
+constexpr u32 OS_TL_TILES = 1u << 15;
+__device__ unsigned long long g_os_tl[OS_TL_TILES * 16];
+#define GIQL_TL(tile, k)                                                             \
+  do {                                                                               \
+    if (threadIdx.x == 0 && (tile) < OS_TL_TILES) g_os_tl[(size_t)(tile) * 16 + (k)] = wall_clock64(); \
+  } while (0)
+#else
+#define GIQL_TL(tile, k) do { } while (0)
+#endif
 
 // Stable in-wave rank of one item by its 8-bit digit.  For every digit bit b the
 // wave ballots the bit (m) and each lane ORs into `mis` the lanes whose bit differs
@@ -61,10 +82,13 @@ __device__ __forceinline__ void wave_match8(u32 d, u64 active, u32& below, u32& 
 // digit bin meet in THAT XCD's L2, which then writes whole lines back instead of two
 // partial lines per run (measured on 100M (key, end) rows: 0.471 -> 0.425 ms per pass).
 // Only speed depends on placement and dispatch order; progress does not (k_onesweep).
+#ifndef GIQL_OS_XCD_GROUP
+#define GIQL_OS_XCD_GROUP 8  // consecutive tiles that run side by side on one XCD
+#endif
 constexpr u32 OS_GROUPS = XCD_GROUPS;
-constexpr u32 OS_GROUP = XCD_GROUP;
+constexpr u32 OS_GROUP = GIQL_OS_XCD_GROUP;
 
-__device__ __forceinline__ u32 os_tile_of_ticket(u32 t, u32 n_tiles) { return xcd_tile_of_block(t, n_tiles); }
+__device__ __forceinline__ u32 os_tile_of_ticket(u32 t, u32 n_tiles) { return xcd_tile_of_block<OS_GROUP>(t, n_tiles); }
 
 // scatter store.  Kept temporal on purpose: the L2 merges the partial lines of adjacent
 // runs; a non-temporal hint took the random-key pass from 0.47 to 0.74 ms.
@@ -84,7 +108,7 @@ __device__ __forceinline__ u32 onesweep_tile(
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n_valid,
     u32 tile, u32 tile_base, int shift, const u32* __restrict__ gbase, u32* __restrict__ status,
     DevMeta* __restrict__ meta, u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff,
-    u32* s_scan, u32* s_help, u32 help_after, const u32* s_abase = nullptr, u32 start_off = 0) {
+    u32* s_scan, u32* s_help, u32 help_after, u32 n_total, const u32* s_abase = nullptr, u32 start_off = 0) {
   constexpr int OS_NW = OS_NT / WAVE;
   const u32 tid = threadIdx.x;
   const u32 lane = lane_id();
@@ -123,6 +147,11 @@ __device__ __forceinline__ u32 onesweep_tile(
     }
   }
 
+  GIQL_TL(tile, 1);  // key loads issued
+#if defined(GIQL_OS_TIMELINE)
+  __builtin_amdgcn_s_waitcnt(0);  // ... and arrived
+  GIQL_TL(tile, 2);
+#endif
   // stable rank inside the wave (peers = lanes with the same digit)
   u32 rank[OS_ITEMS];
   {
@@ -150,7 +179,9 @@ __device__ __forceinline__ u32 onesweep_tile(
       }
     }
   }
+  GIQL_TL(tile, 3);  // ranked
   __syncthreads();
+  GIQL_TL(tile, 4);  // every wave ranked
 
   // threads 0..255 own one digit each: wave bases, tile digit starts, look-back
   if (tid < OS_BINS) {
@@ -162,6 +193,7 @@ __device__ __forceinline__ u32 onesweep_tile(
       run += c;
     }
     const u32 count = run;
+    GIQL_TL(tile, 5);  // wave bases done
     // exclusive scan of the 256 digit counts (4 waves)
     const u32 incl = wave_incl_scan(count);
     if (lane == WAVE - 1) s_scan[w] = incl;
@@ -173,19 +205,145 @@ __device__ __forceinline__ u32 onesweep_tile(
       excl = tile * 32;
     } else
 #endif
+#if GIQL_OS_LB_GROUP > 0
+    {
+      // Two-level look-back.  512 tiles are in flight and the 64 of a dispatch group start
+      // together, so a flat walk crossed 24-32 aggregate-only predecessors before it met a
+      // prefix: 8 round trips of ~1 us, 8 us of a tile's 18.5 us life, a quarter of the pass
+      // (tools/os_timeline.py; polling MORE words per round only made it worse -- the
+      // agent-scope loads themselves are what is scarce).  Tiles are therefore grouped by
+      // OS_LB_GROUP consecutive ones (the 8 that the XCD-aware order runs side by side): a tile
+      // sums its EARLIER SIBLINGS' counts (<= 7 words, one round), the group's last tile
+      // publishes the group total, and the sum over earlier GROUPS is a walk over group words
+      // -- each worth 8 tiles -- that ends at the first group whose inclusive prefix is known.
+      constexpr u32 G = GIQL_OS_LB_GROUP;
+      const u32 m = tile / G, r = tile % G;
+      u32* gstatus = status + ((size_t)((n_total + OS_MIN_TILE - 1) / OS_MIN_TILE) + 1) * OS_BINS;
+      u32* gst = gstatus + (size_t)m * OS_BINS + tid;
+      __hip_atomic_store(st, OS_FLAG_AGG | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool abandoned = false;
+      u32 spins = 0;
+#if defined(GIQL_OS_TIMELINE)
+      u32 tl_polls = 0, tl_walked = 0;
+#endif
+      // 1. earlier siblings (they run beside this tile; all of them must have published)
+      u32 sib = 0;
+      if (r > 0) {
+        const u32* sst = status + (size_t)(m * G) * OS_BINS + tid;
+        for (;;) {
+#if defined(GIQL_OS_TIMELINE)
+          tl_polls++;
+#endif
+          u32 v[G - 1];
+#pragma unroll
+          for (u32 j = 0; j < G - 1; j++)
+            v[j] = j < r ? __hip_atomic_load(sst + (size_t)j * OS_BINS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                         : OS_FLAG_AGG;
+          u32 sum = 0, missing = G;
+#pragma unroll
+          for (u32 j = 0; j < G - 1; j++) {
+            if ((v[j] >> 30) == 0) missing = missing < j ? missing : j;
+            sum += v[j] & OS_VALUE_MASK;
+          }
+          if (missing == G) {
+            sib = sum;
+            break;
+          }
+          if (++spins > help_after) {
+            // a sibling has published nothing for too long: whatever the reason (its block may
+            // not even have been dispatched yet), this block computes it itself
+            atomicMin(s_help, m * G + missing);
+            abandoned = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      // 2. the group's last tile publishes the group total before anything else can wait
+      if (!abandoned && r == G - 1)
+        __hip_atomic_store(gst, OS_FLAG_AGG | ((sib + count) & OS_VALUE_MASK), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      // 3. earlier groups: OS_LB_WIDTH group words per round, nearest first
+      u32 gp = 0;
+      if (!abandoned && m > 0) {
+        u32 g = m;  // groups g-1, g-2, ... are still to be added
+        bool done = false;
+        spins = 0;
+        while (!done) {
+#if defined(GIQL_OS_TIMELINE)
+          tl_polls++;
+#endif
+          u32 v[OS_LB_WIDTH];
+#pragma unroll
+          for (int j = 0; j < OS_LB_WIDTH; j++) {
+            const u32 gj = g > (u32)j ? g - 1 - j : 0u;  // clamped; group 0 ends every walk
+            v[j] = __hip_atomic_load(gstatus + (size_t)gj * OS_BINS + tid, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+          }
+          int used = 0;  // consume in order while the words are ready
+#pragma unroll
+          for (int j = 0; j < OS_LB_WIDTH; j++) {
+            if (done || used != j) continue;
+            if (g <= (u32)j) {  // ran past group 0
+              done = true;
+              continue;
+            }
+            const u32 f = v[j] >> 30;
+            if (f == 0) continue;  // not published yet: re-poll from here
+            gp += v[j] & OS_VALUE_MASK;
+            used = j + 1;
+            if (f == 2u) done = true;  // an inclusive prefix: everything before it is in
+          }
+          g -= (u32)used;
+          if (!done && used == 0) {
+            if (++spins > help_after) {
+              atomicMin(s_help, (g - 1u) * G + (G - 1u));  // compute the silent group's publisher
+              abandoned = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (g == 0) done = true;
+        }
+#if defined(GIQL_OS_TIMELINE)
+        tl_walked = m - g;
+#endif
+      }
+      if (!abandoned) {
+        excl = gp + sib;
+        if (r == G - 1)
+          __hip_atomic_store(gst, OS_FLAG_PREFIX | ((gp + sib + count) & OS_VALUE_MASK), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+#if defined(GIQL_OS_TIMELINE)
+      if (tid == 0 && tile < OS_TL_TILES) {
+        g_os_tl[(size_t)tile * 16 + 12] = tl_polls;    // poll rounds of digit 0 (siblings + groups)
+        g_os_tl[(size_t)tile * 16 + 13] = tl_walked;   // group words consumed
+      }
+#endif
+    }
+#else
     if (tile == 0) {
       __hip_atomic_store(st, OS_FLAG_PREFIX | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       __hip_atomic_store(st, OS_FLAG_AGG | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // look back: the four nearest predecessors are polled together (four
-      // independent loads in flight), so the common 1-3 tile walk is ONE round trip
+      // look back: the OS_LB_WIDTH nearest predecessors are polled together (independent loads
+      // in flight).  The 64 tiles of a dispatch group start together and 512 tiles are in flight,
+      // so a walk crosses 24-32 aggregate-only tiles before it meets a prefix (measured,
+      // tools/os_timeline.py): at 4 per ~1 us round trip that was 8 us of a tile's 18.5 us life
       u32 t = tile;  // predecessors t-1, t-2, ...
       u32 spins = 0;
       bool done = false;
+#if defined(GIQL_OS_TIMELINE)
+      u32 tl_polls = 0;
+#endif
       while (!done) {
-        u32 v[4];
+#if defined(GIQL_OS_TIMELINE)
+        tl_polls++;
+#endif
+        u32 v[OS_LB_WIDTH];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < OS_LB_WIDTH; j++) {
           const u32 tj = t > (u32)j ? t - 1 - j : 0u;  // clamped; tile 0 always holds a PREFIX
           v[j] = __hip_atomic_load(status + (size_t)tj * OS_BINS + tid, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
@@ -193,7 +351,7 @@ __device__ __forceinline__ u32 onesweep_tile(
         // consume in order while the words are ready
         int used = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < OS_LB_WIDTH; j++) {
           if (done || used != j) continue;
           if (t <= (u32)j) {  // ran past tile 0 (its PREFIX ended the walk already)
             done = true;
@@ -220,11 +378,20 @@ __device__ __forceinline__ u32 onesweep_tile(
       if (done)  // not when the walk was abandoned for a helping round
         __hip_atomic_store(st, OS_FLAG_PREFIX | ((excl + count) & OS_VALUE_MASK), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+#if defined(GIQL_OS_TIMELINE)
+      if (tid == 0 && tile < OS_TL_TILES) {
+        g_os_tl[(size_t)tile * 16 + 12] = tl_polls;   // poll rounds of digit 0's walk
+        g_os_tl[(size_t)tile * 16 + 13] = tile - t;   // predecessors consumed
+      }
+#endif
     }
+#endif
     s_goff[tid] = gbase[tid] + excl;  // finished below once dstart is known
     s_dstart[tid] = incl - count;     // wave-local exclusive; wave base added below
+    GIQL_TL(tile, 6);  // look-back done
   }
   __syncthreads();
+  GIQL_TL(tile, 7);
   {
     const u32 help = *s_help;  // block-uniform; nothing of this tile has been written yet
     if (help != OS_NO_TILE) return help;
@@ -267,6 +434,7 @@ __device__ __forceinline__ u32 onesweep_tile(
     }
   }
 
+  GIQL_TL(tile, 8);  // positions known, payload loads issued
   // round 1: keys through LDS; remember each output slot's global destination
   u32 dst[OS_ITEMS];
 #pragma unroll
@@ -285,6 +453,7 @@ __device__ __forceinline__ u32 onesweep_tile(
       os_store(keys_out + dst[i], k);
     }
   }
+  GIQL_TL(tile, 9);  // key round: staged, stores issued
   if (PAYLOAD == 3) {
     // second payload array (rid) loaded while the end round runs
     u32 pay2[OS_ITEMS];
@@ -332,6 +501,11 @@ __device__ __forceinline__ u32 onesweep_tile(
       if (FULL || p < n_valid) os_store(out + dst[i], s_buf[p]);
     }
   }
+  GIQL_TL(tile, 10);  // every store issued
+#if defined(GIQL_OS_TIMELINE)
+  __builtin_amdgcn_s_waitcnt(0);
+  GIQL_TL(tile, 11);  // ... and acknowledged (wave 0's)
+#endif
   return OS_NO_TILE;
 }
 
@@ -362,11 +536,11 @@ __device__ __forceinline__ u32 os_run_tile(
     return onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, true, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
                                                                  rids_out, n_valid, tile, tile_base, shift, gbase,
                                                                  status, meta, s_buf, s_wcnt, s_dstart, s_goff,
-                                                                 s_scan, s_help, help_after, s_abase, start_off);
+                                                                 s_scan, s_help, help_after, n, s_abase, start_off);
   return onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, false, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
                                                                 rids_out, n_valid, tile, tile_base, shift, gbase,
                                                                 status, meta, s_buf, s_wcnt, s_dstart, s_goff,
-                                                                s_scan, s_help, help_after, s_abase, start_off);
+                                                                s_scan, s_help, help_after, n, s_abase, start_off);
 }
 
 // The cold path: compute the silent predecessor `need` (recursively the earliest silent
@@ -437,7 +611,7 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
   const u32 tid = threadIdx.x;
   if (KEYGEN && tid < 32) s_abase[tid] = abase[tid];
   if (tid == 0) {
-    s_tile = order == 2 ? xcd_tile_of_block(blockIdx.x, gridDim.x) : atomicAdd(ticket, 1u);
+    s_tile = order == 2 ? xcd_tile_of_block<OS_GROUP>(blockIdx.x, gridDim.x) : atomicAdd(ticket, 1u);
     s_help = OS_NO_TILE;
   }
 #pragma unroll
@@ -445,6 +619,7 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
   __syncthreads();
   const u32 own = s_tile;
   if (own * OS_TILE >= n) return;  // block-uniform (cannot happen: grid = n_tiles)
+  GIQL_TL(own, 0);  // block started, LDS counters zeroed
   const u32 need = os_run_tile<PAYLOAD, OS_NT, OS_ITEMS, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
                                                                 rids_out, n, own, shift, gbase, status, meta, s_buf,
                                                                 s_wcnt, s_dstart, s_goff, s_scan, &s_help, help_after,
