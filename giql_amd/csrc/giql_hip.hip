@@ -363,10 +363,8 @@ static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, 
 // Onesweep LSD sort (4 passes, one launch each); input and result in
 // buffer 0.  Payload of a sort = which of end / rid buffers the SortBufs carries.
 // status words of ONE pass: a {flag,count} word per (tile, digit) + the ticket word
-// ... + one word row per look-back group of tiles (k_onesweep finds it one row past the ticket's)
 static inline size_t os_pass_words(size_t n) {
-  const size_t tiles = cdiv(n ? n : 1, OS_MIN_TILE);
-  return (tiles + 1) * OS_BINS + (tiles / (GIQL_OS_LB_GROUP > 0 ? GIQL_OS_LB_GROUP : 1) + 2) * OS_BINS;
+  return (size_t)cdiv(n ? n : 1, OS_MIN_TILE) * OS_BINS + 16;
 }
 
 template <int NT, int ITEMS>

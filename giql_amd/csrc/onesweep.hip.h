@@ -33,8 +33,8 @@ constexpr u32 OS_NO_TILE = 0xFFFFFFFFu;
 #define GIQL_OS_LB_WIDTH 4
 #endif
 constexpr int OS_LB_WIDTH = GIQL_OS_LB_WIDTH;  // status words polled per look-back round
-#ifndef GIQL_OS_LB_GROUP
-#define GIQL_OS_LB_GROUP 0  // tiles per look-back group (0 = the flat one-level walk; 8 measured slower)
+#ifndef GIQL_OS_LATE_WALK
+#define GIQL_OS_LATE_WALK 1  // look-back walk after the key staging (0 = before, the older layout)
 #endif
 constexpr u32 OS_HELP_AFTER = 1u << 11;  // look-back polls (a few ms, several whole passes) before a block computes a silent predecessor itself
 
@@ -183,6 +183,149 @@ __device__ __forceinline__ u32 onesweep_tile(
   __syncthreads();
   GIQL_TL(tile, 4);  // every wave ranked
 
+#if GIQL_OS_LATE_WALK
+  // threads 0..255 own one digit each: wave bases, tile digit starts, and the tile's count
+  // published at once.  The look-back WALK comes later, after the keys are staged: a tile spends
+  // microseconds waiting for its predecessors (the 64 tiles of a dispatch group start together;
+  // tools/os_timeline.py), and the staging needs none of what the walk returns.
+  u32 lb_count = 0;
+  if (tid < OS_BINS) {
+    u32 run = 0;
+#pragma unroll
+    for (int k = 0; k < OS_NW; k++) {
+      const u32 c = s_wcnt[k][tid];
+      s_wcnt[k][tid] = run;
+      run += c;
+    }
+    const u32 count = run;
+    lb_count = count;
+    GIQL_TL(tile, 5);  // wave bases done
+    // exclusive scan of the 256 digit counts (4 waves)
+    const u32 incl = wave_incl_scan(count);
+    if (lane == WAVE - 1) s_scan[w] = incl;
+#if !(defined(GIQL_ABLATE) && GIQL_ABLATE == 1)
+    __hip_atomic_store(status + (size_t)tile * OS_BINS + tid, (tile == 0 ? OS_FLAG_PREFIX : OS_FLAG_AGG) | count,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    s_dstart[tid] = incl - count;  // wave-local exclusive; wave base added below
+  }
+  __syncthreads();
+  if (tid < OS_BINS) {
+    u32 wb = 0;
+#pragma unroll
+    for (int k = 0; k < OS_BINS / WAVE; k++)
+      if (k < (int)w) wb += s_scan[k];
+    s_dstart[tid] += wb;
+  }
+  __syncthreads();
+  GIQL_TL(tile, 6);
+
+  // in-tile sorted position of every item
+  u32 pos[OS_ITEMS];
+#pragma unroll
+  for (int i = 0; i < OS_ITEMS; i++) {
+    const u32 d = (key[i] >> shift) & 0xFFu;
+    pos[i] = s_dstart[d] + s_wcnt[w][d] + rank[i];
+  }
+  // first payload array: issue its loads now, they fly under the key round
+  u32 pay[OS_ITEMS];
+  if (PAYLOAD & 2) {
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      pay[i] = (FULL || r < n_valid) ? ein[r] : 0u;
+    }
+  } else if (PAYLOAD & 1) {
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      pay[i] = (FULL || r < n_valid) ? (rin ? rin[r] : tile_base + r) : 0u;
+    }
+  }
+  // keys into LDS in sorted order (the read-back below waits for the walk's barrier)
+#pragma unroll
+  for (int i = 0; i < OS_ITEMS; i++) {
+    const u32 r = wbase + i * WAVE + lane;
+    if (FULL || r < n_valid) s_buf[pos[i]] = key[i];
+  }
+  GIQL_TL(tile, 7);  // keys staged
+  if (tid < OS_BINS) {
+    u32 excl = 0;
+#if defined(GIQL_ABLATE) && GIQL_ABLATE == 1  // timing-only build: no look-back
+    excl = tile * 32;
+#else
+    if (tile != 0) {
+      // look back: the OS_LB_WIDTH nearest predecessors are polled together (independent loads
+      // in flight); polling more words per round is slower (the agent-scope loads themselves
+      // are what is scarce: 8 words 2 %, 16 words 37 % slower)
+      u32* st = status + (size_t)tile * OS_BINS + tid;
+      const u32 count = lb_count;
+      u32 t = tile;  // predecessors t-1, t-2, ...
+      u32 spins = 0;
+      bool done = false;
+#if defined(GIQL_OS_TIMELINE)
+      u32 tl_polls = 0;
+#endif
+      while (!done) {
+#if defined(GIQL_OS_TIMELINE)
+        tl_polls++;
+#endif
+        u32 v[OS_LB_WIDTH];
+#pragma unroll
+        for (int j = 0; j < OS_LB_WIDTH; j++) {
+          const u32 tj = t > (u32)j ? t - 1 - j : 0u;  // clamped; tile 0 always holds a PREFIX
+          v[j] = __hip_atomic_load(status + (size_t)tj * OS_BINS + tid, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // consume in order while the words are ready
+        int used = 0;
+#pragma unroll
+        for (int j = 0; j < OS_LB_WIDTH; j++) {
+          if (done || used != j) continue;
+          if (t <= (u32)j) {  // ran past tile 0 (its PREFIX ended the walk already)
+            done = true;
+            continue;
+          }
+          const u32 f = v[j] >> 30;
+          if (f == 0) continue;  // not published yet: re-poll from here
+          excl += v[j] & OS_VALUE_MASK;
+          used = j + 1;
+          if (f == 2u) done = true;
+        }
+        t -= (u32)used;
+        if (!done && used == 0) {
+          if (++spins > help_after) {
+            // predecessor t-1 has published nothing for too long: whatever the reason (its
+            // block may not even have been dispatched yet), this block computes it itself
+            atomicMin(s_help, t - 1u);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (t == 0) done = true;
+      }
+      if (done)  // not when the walk was abandoned for a helping round
+        __hip_atomic_store(st, OS_FLAG_PREFIX | ((excl + count) & OS_VALUE_MASK), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+#if defined(GIQL_OS_TIMELINE)
+      if (tid == 0 && tile < OS_TL_TILES) {
+        g_os_tl[(size_t)tile * 16 + 12] = tl_polls;   // poll rounds of digit 0's walk
+        g_os_tl[(size_t)tile * 16 + 13] = tile - t;   // predecessors consumed
+      }
+#endif
+    }
+#endif
+    s_goff[tid] = gbase[tid] + excl - s_dstart[tid];  // global dst = s_goff[d] + in-tile position
+  }
+  __syncthreads();
+  {
+    const u32 help = *s_help;  // block-uniform; nothing of this tile has been written yet
+    if (help != OS_NO_TILE) return help;
+  }
+#if defined(GIQL_ABLATE) && GIQL_ABLATE == 3  // timing-only build: no stores
+  if (key[0] != 0x12345u) return OS_NO_TILE;
+#endif
+#else
   // threads 0..255 own one digit each: wave bases, tile digit starts, look-back
   if (tid < OS_BINS) {
     u32 run = 0;
@@ -205,124 +348,6 @@ __device__ __forceinline__ u32 onesweep_tile(
       excl = tile * 32;
     } else
 #endif
-#if GIQL_OS_LB_GROUP > 0
-    {
-      // Two-level look-back.  512 tiles are in flight and the 64 of a dispatch group start
-      // together, so a flat walk crossed 24-32 aggregate-only predecessors before it met a
-      // prefix: 8 round trips of ~1 us, 8 us of a tile's 18.5 us life, a quarter of the pass
-      // (tools/os_timeline.py; polling MORE words per round only made it worse -- the
-      // agent-scope loads themselves are what is scarce).  Tiles are therefore grouped by
-      // OS_LB_GROUP consecutive ones (the 8 that the XCD-aware order runs side by side): a tile
-      // sums its EARLIER SIBLINGS' counts (<= 7 words, one round), the group's last tile
-      // publishes the group total, and the sum over earlier GROUPS is a walk over group words
-      // -- each worth 8 tiles -- that ends at the first group whose inclusive prefix is known.
-      constexpr u32 G = GIQL_OS_LB_GROUP;
-      const u32 m = tile / G, r = tile % G;
-      u32* gstatus = status + ((size_t)((n_total + OS_MIN_TILE - 1) / OS_MIN_TILE) + 1) * OS_BINS;
-      u32* gst = gstatus + (size_t)m * OS_BINS + tid;
-      __hip_atomic_store(st, OS_FLAG_AGG | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bool abandoned = false;
-      u32 spins = 0;
-#if defined(GIQL_OS_TIMELINE)
-      u32 tl_polls = 0, tl_walked = 0;
-#endif
-      // 1. earlier siblings (they run beside this tile; all of them must have published)
-      u32 sib = 0;
-      if (r > 0) {
-        const u32* sst = status + (size_t)(m * G) * OS_BINS + tid;
-        for (;;) {
-#if defined(GIQL_OS_TIMELINE)
-          tl_polls++;
-#endif
-          u32 v[G - 1];
-#pragma unroll
-          for (u32 j = 0; j < G - 1; j++)
-            v[j] = j < r ? __hip_atomic_load(sst + (size_t)j * OS_BINS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                         : OS_FLAG_AGG;
-          u32 sum = 0, missing = G;
-#pragma unroll
-          for (u32 j = 0; j < G - 1; j++) {
-            if ((v[j] >> 30) == 0) missing = missing < j ? missing : j;
-            sum += v[j] & OS_VALUE_MASK;
-          }
-          if (missing == G) {
-            sib = sum;
-            break;
-          }
-          if (++spins > help_after) {
-            // a sibling has published nothing for too long: whatever the reason (its block may
-            // not even have been dispatched yet), this block computes it itself
-            atomicMin(s_help, m * G + missing);
-            abandoned = true;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      // 2. the group's last tile publishes the group total before anything else can wait
-      if (!abandoned && r == G - 1)
-        __hip_atomic_store(gst, OS_FLAG_AGG | ((sib + count) & OS_VALUE_MASK), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      // 3. earlier groups: OS_LB_WIDTH group words per round, nearest first
-      u32 gp = 0;
-      if (!abandoned && m > 0) {
-        u32 g = m;  // groups g-1, g-2, ... are still to be added
-        bool done = false;
-        spins = 0;
-        while (!done) {
-#if defined(GIQL_OS_TIMELINE)
-          tl_polls++;
-#endif
-          u32 v[OS_LB_WIDTH];
-#pragma unroll
-          for (int j = 0; j < OS_LB_WIDTH; j++) {
-            const u32 gj = g > (u32)j ? g - 1 - j : 0u;  // clamped; group 0 ends every walk
-            v[j] = __hip_atomic_load(gstatus + (size_t)gj * OS_BINS + tid, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-          }
-          int used = 0;  // consume in order while the words are ready
-#pragma unroll
-          for (int j = 0; j < OS_LB_WIDTH; j++) {
-            if (done || used != j) continue;
-            if (g <= (u32)j) {  // ran past group 0
-              done = true;
-              continue;
-            }
-            const u32 f = v[j] >> 30;
-            if (f == 0) continue;  // not published yet: re-poll from here
-            gp += v[j] & OS_VALUE_MASK;
-            used = j + 1;
-            if (f == 2u) done = true;  // an inclusive prefix: everything before it is in
-          }
-          g -= (u32)used;
-          if (!done && used == 0) {
-            if (++spins > help_after) {
-              atomicMin(s_help, (g - 1u) * G + (G - 1u));  // compute the silent group's publisher
-              abandoned = true;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          if (g == 0) done = true;
-        }
-#if defined(GIQL_OS_TIMELINE)
-        tl_walked = m - g;
-#endif
-      }
-      if (!abandoned) {
-        excl = gp + sib;
-        if (r == G - 1)
-          __hip_atomic_store(gst, OS_FLAG_PREFIX | ((gp + sib + count) & OS_VALUE_MASK), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-      }
-#if defined(GIQL_OS_TIMELINE)
-      if (tid == 0 && tile < OS_TL_TILES) {
-        g_os_tl[(size_t)tile * 16 + 12] = tl_polls;    // poll rounds of digit 0 (siblings + groups)
-        g_os_tl[(size_t)tile * 16 + 13] = tl_walked;   // group words consumed
-      }
-#endif
-    }
-#else
     if (tile == 0) {
       __hip_atomic_store(st, OS_FLAG_PREFIX | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -385,7 +410,6 @@ __device__ __forceinline__ u32 onesweep_tile(
       }
 #endif
     }
-#endif
     s_goff[tid] = gbase[tid] + excl;  // finished below once dstart is known
     s_dstart[tid] = incl - count;     // wave-local exclusive; wave base added below
     GIQL_TL(tile, 6);  // look-back done
@@ -434,15 +458,18 @@ __device__ __forceinline__ u32 onesweep_tile(
     }
   }
 
+#endif
   GIQL_TL(tile, 8);  // positions known, payload loads issued
   // round 1: keys through LDS; remember each output slot's global destination
   u32 dst[OS_ITEMS];
+#if !GIQL_OS_LATE_WALK
 #pragma unroll
   for (int i = 0; i < OS_ITEMS; i++) {
     const u32 r = wbase + i * WAVE + lane;
     if (FULL || r < n_valid) s_buf[pos[i]] = key[i];
   }
   __syncthreads();
+#endif
 #pragma unroll
   for (int i = 0; i < OS_ITEMS; i++) {
     const u32 p = i * OS_NT + tid;
