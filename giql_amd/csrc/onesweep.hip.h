@@ -30,12 +30,13 @@ constexpr u32 OS_VALUE_MASK = (1u << 30) - 1u;
 constexpr u32 OS_MAX_ROWS = (1u << 30) - 1u;
 constexpr u32 OS_NO_TILE = 0xFFFFFFFFu;
 #ifndef GIQL_OS_LB_WIDTH
-#define GIQL_OS_LB_WIDTH 4
+#define GIQL_OS_LB_WIDTH 8
 #endif
 constexpr int OS_LB_WIDTH = GIQL_OS_LB_WIDTH;  // status words polled per look-back round
-#ifndef GIQL_OS_LATE_WALK
-#define GIQL_OS_LATE_WALK 1  // look-back walk after the key staging (0 = before, the older layout)
+#ifndef GIQL_OS_PRESTAGE
+#define GIQL_OS_PRESTAGE 1  // (key, one payload) sorts: both LDS rounds before the look-back walk
 #endif
+
 constexpr u32 OS_HELP_AFTER = 1u << 11;  // look-back polls (a few ms, several whole passes) before a block computes a silent predecessor itself
 
 // Timeline build (-DGIQL_OS_TIMELINE, tools/os_timeline.py): thread 0 of every block stamps the
@@ -183,7 +184,6 @@ __device__ __forceinline__ u32 onesweep_tile(
   __syncthreads();
   GIQL_TL(tile, 4);  // every wave ranked
 
-#if GIQL_OS_LATE_WALK
   // threads 0..255 own one digit each: wave bases, tile digit starts, and the tile's count
   // published at once.  The look-back WALK comes later, after the keys are staged: a tile spends
   // microseconds waiting for its predecessors (the 64 tiles of a dispatch group start together;
@@ -249,6 +249,31 @@ __device__ __forceinline__ u32 onesweep_tile(
     if (FULL || r < n_valid) s_buf[pos[i]] = key[i];
   }
   GIQL_TL(tile, 7);  // keys staged
+  // One payload array: ALL the LDS work comes before the walk -- sorted keys and payload end up
+  // in registers, and only the global stores are left once the walk has returned.
+  constexpr bool PRESTAGE = GIQL_OS_PRESTAGE && (PAYLOAD == 1 || PAYLOAD == 2);
+  u32 ks[PRESTAGE ? OS_ITEMS : 1], ps[PRESTAGE ? OS_ITEMS : 1];
+  if (PRESTAGE) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 p = i * OS_NT + tid;
+      ks[i] = (FULL || p < n_valid) ? s_buf[p] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      if (FULL || r < n_valid) s_buf[pos[i]] = pay[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 p = i * OS_NT + tid;
+      ps[i] = (FULL || p < n_valid) ? s_buf[p] : 0u;
+    }
+  }
+  GIQL_TL(tile, 8);  // every LDS round done (one-payload sorts)
   if (tid < OS_BINS) {
     u32 excl = 0;
 #if defined(GIQL_ABLATE) && GIQL_ABLATE == 1  // timing-only build: no look-back
@@ -256,8 +281,10 @@ __device__ __forceinline__ u32 onesweep_tile(
 #else
     if (tile != 0) {
       // look back: the OS_LB_WIDTH nearest predecessors are polled together (independent loads
-      // in flight); polling more words per round is slower (the agent-scope loads themselves
-      // are what is scarce: 8 words 2 %, 16 words 37 % slower)
+      // in flight).  The 64 tiles of a dispatch group start together, so a walk crosses ~25
+      // aggregate-only tiles (its distance from the group's first tile) before it meets a prefix.
+      // 8 words per round: 2 are 5 % slower, 4 are 1 % slower; 16 and 32 spill registers and
+      // were 37 % / 78 % slower when the walk still came before the staging.
       u32* st = status + (size_t)tile * OS_BINS + tid;
       const u32 count = lb_count;
       u32 t = tile;  // predecessors t-1, t-2, ...
@@ -317,6 +344,7 @@ __device__ __forceinline__ u32 onesweep_tile(
 #endif
     s_goff[tid] = gbase[tid] + excl - s_dstart[tid];  // global dst = s_goff[d] + in-tile position
   }
+  GIQL_TL(tile, 9);  // walk done (thread 0's digit)
   __syncthreads();
   {
     const u32 help = *s_help;  // block-uniform; nothing of this tile has been written yet
@@ -325,151 +353,26 @@ __device__ __forceinline__ u32 onesweep_tile(
 #if defined(GIQL_ABLATE) && GIQL_ABLATE == 3  // timing-only build: no stores
   if (key[0] != 0x12345u) return OS_NO_TILE;
 #endif
-#else
-  // threads 0..255 own one digit each: wave bases, tile digit starts, look-back
-  if (tid < OS_BINS) {
-    u32 run = 0;
-#pragma unroll
-    for (int k = 0; k < OS_NW; k++) {
-      const u32 c = s_wcnt[k][tid];
-      s_wcnt[k][tid] = run;
-      run += c;
-    }
-    const u32 count = run;
-    GIQL_TL(tile, 5);  // wave bases done
-    // exclusive scan of the 256 digit counts (4 waves)
-    const u32 incl = wave_incl_scan(count);
-    if (lane == WAVE - 1) s_scan[w] = incl;
-    // publish this tile's count before anything that could wait
-    u32* st = status + (size_t)tile * OS_BINS + tid;
-    u32 excl = 0;
-#if defined(GIQL_ABLATE) && GIQL_ABLATE == 1  // timing-only build: no look-back
-    if (true) {
-      excl = tile * 32;
-    } else
-#endif
-    if (tile == 0) {
-      __hip_atomic_store(st, OS_FLAG_PREFIX | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      __hip_atomic_store(st, OS_FLAG_AGG | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // look back: the OS_LB_WIDTH nearest predecessors are polled together (independent loads
-      // in flight).  The 64 tiles of a dispatch group start together and 512 tiles are in flight,
-      // so a walk crosses 24-32 aggregate-only tiles before it meets a prefix (measured,
-      // tools/os_timeline.py): at 4 per ~1 us round trip that was 8 us of a tile's 18.5 us life
-      u32 t = tile;  // predecessors t-1, t-2, ...
-      u32 spins = 0;
-      bool done = false;
-#if defined(GIQL_OS_TIMELINE)
-      u32 tl_polls = 0;
-#endif
-      while (!done) {
-#if defined(GIQL_OS_TIMELINE)
-        tl_polls++;
-#endif
-        u32 v[OS_LB_WIDTH];
-#pragma unroll
-        for (int j = 0; j < OS_LB_WIDTH; j++) {
-          const u32 tj = t > (u32)j ? t - 1 - j : 0u;  // clamped; tile 0 always holds a PREFIX
-          v[j] = __hip_atomic_load(status + (size_t)tj * OS_BINS + tid, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // consume in order while the words are ready
-        int used = 0;
-#pragma unroll
-        for (int j = 0; j < OS_LB_WIDTH; j++) {
-          if (done || used != j) continue;
-          if (t <= (u32)j) {  // ran past tile 0 (its PREFIX ended the walk already)
-            done = true;
-            continue;
-          }
-          const u32 f = v[j] >> 30;
-          if (f == 0) continue;  // not published yet: re-poll from here
-          excl += v[j] & OS_VALUE_MASK;
-          used = j + 1;
-          if (f == 2u) done = true;
-        }
-        t -= (u32)used;
-        if (!done && used == 0) {
-          if (++spins > help_after) {
-            // predecessor t-1 has published nothing for too long: whatever the reason (its
-            // block may not even have been dispatched yet), this block computes it itself
-            atomicMin(s_help, t - 1u);
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (t == 0) done = true;
-      }
-      if (done)  // not when the walk was abandoned for a helping round
-        __hip_atomic_store(st, OS_FLAG_PREFIX | ((excl + count) & OS_VALUE_MASK), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-#if defined(GIQL_OS_TIMELINE)
-      if (tid == 0 && tile < OS_TL_TILES) {
-        g_os_tl[(size_t)tile * 16 + 12] = tl_polls;   // poll rounds of digit 0's walk
-        g_os_tl[(size_t)tile * 16 + 13] = tile - t;   // predecessors consumed
-      }
-#endif
-    }
-    s_goff[tid] = gbase[tid] + excl;  // finished below once dstart is known
-    s_dstart[tid] = incl - count;     // wave-local exclusive; wave base added below
-    GIQL_TL(tile, 6);  // look-back done
-  }
-  __syncthreads();
-  GIQL_TL(tile, 7);
-  {
-    const u32 help = *s_help;  // block-uniform; nothing of this tile has been written yet
-    if (help != OS_NO_TILE) return help;
-  }
-  if (tid < OS_BINS) {
-    u32 wb = 0;
-#pragma unroll
-    for (int k = 0; k < OS_BINS / WAVE; k++)
-      if (k < (int)w) wb += s_scan[k];
-    const u32 dstart = s_dstart[tid] + wb;
-    s_dstart[tid] = dstart;
-    s_goff[tid] -= dstart;  // global dst = s_goff[d] + in-tile position
-  }
-  __syncthreads();
-
-  // in-tile sorted position of every item
-  u32 pos[OS_ITEMS];
-#pragma unroll
-  for (int i = 0; i < OS_ITEMS; i++) {
-    const u32 d = (key[i] >> shift) & 0xFFu;
-    pos[i] = s_dstart[d] + s_wcnt[w][d] + rank[i];
-  }
-
-#if defined(GIQL_ABLATE) && GIQL_ABLATE == 3  // timing-only build: no staging / stores
-  if (key[0] != 0x12345u) return;
-#endif
-  // first payload array: issue its loads now, they fly under the key round
-  u32 pay[OS_ITEMS];
-  if (PAYLOAD & 2) {
+  if (PRESTAGE) {
+    u32* pout = (PAYLOAD & 2) ? ends_out : rids_out;
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
-      const u32 r = wbase + i * WAVE + lane;
-      pay[i] = (FULL || r < n_valid) ? ein[r] : 0u;
+      const u32 p = i * OS_NT + tid;
+      if (FULL || p < n_valid) {
+        const u32 d = s_goff[(ks[i] >> shift) & 0xFFu] + p;
+        os_store(keys_out + d, ks[i]);
+        os_store(pout + d, ps[i]);
+      }
     }
-  } else if (PAYLOAD & 1) {
-#pragma unroll
-    for (int i = 0; i < OS_ITEMS; i++) {
-      const u32 r = wbase + i * WAVE + lane;
-      pay[i] = (FULL || r < n_valid) ? (rin ? rin[r] : tile_base + r) : 0u;
-    }
-  }
-
+    GIQL_TL(tile, 10);  // every store issued
+#if defined(GIQL_OS_TIMELINE)
+    __builtin_amdgcn_s_waitcnt(0);
+    GIQL_TL(tile, 11);  // ... and acknowledged (wave 0's)
 #endif
-  GIQL_TL(tile, 8);  // positions known, payload loads issued
-  // round 1: keys through LDS; remember each output slot's global destination
+    return OS_NO_TILE;
+  }
+  // keys out of LDS (staged above, before the walk); remember each output slot's global destination
   u32 dst[OS_ITEMS];
-#if !GIQL_OS_LATE_WALK
-#pragma unroll
-  for (int i = 0; i < OS_ITEMS; i++) {
-    const u32 r = wbase + i * WAVE + lane;
-    if (FULL || r < n_valid) s_buf[pos[i]] = key[i];
-  }
-  __syncthreads();
-#endif
 #pragma unroll
   for (int i = 0; i < OS_ITEMS; i++) {
     const u32 p = i * OS_NT + tid;

@@ -31,8 +31,8 @@ raw = buf.reshape(n_tiles, 16).astype(np.int64)[:-1]           # drop the partia
 t = raw[:, :12]
 us = (t - t[:, :1].min()) / 100.0                             # 100 MHz -> microseconds since the first block started
 names = ["start->loads issued", "loads arrive", "rank (wave 0)", "barrier: all waves ranked", "wave bases (16 LDS rmw)",
-         "scan + publish + look-back", "barrier", "positions + payload loads issued", "key round (LDS + stores)",
-         "payload round(s)", "drain (wave 0's stores acked)"]
+         "scan + publish + 2 barriers", "positions + key staging", "LDS rounds (keys, payload -> registers)",
+         "look-back walk (thread 0's digit)", "barrier + stores issued", "drain (wave 0's stores acked)"]
 out = {"tiles": int(t.shape[0]), "pass_us": round(float(us[:, 11].max()), 1)}
 d = np.diff(us, axis=1)
 out["phases_us_median_p90"] = {names[k]: [round(float(np.median(d[:, k])), 2), round(float(np.percentile(d[:, k], 90)), 2)]
