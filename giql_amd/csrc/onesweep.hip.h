@@ -133,6 +133,7 @@ __device__ __forceinline__ u32 onesweep_tile(
       cc[i] = ok ? (u32)cin[r] : 0u;
       key[i] = ok ? kin[r] : 0u;
     }
+    __syncthreads();  // the block's LDS is ready (counters zeroed, s_abase filled): see k_onesweep
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 r = wbase + i * WAVE + lane;
@@ -146,6 +147,7 @@ __device__ __forceinline__ u32 onesweep_tile(
       const bool ok = FULL || r < n_valid;
       key[i] = ok ? kin[r] : U32_MAX;
     }
+    __syncthreads();  // the block's LDS is ready (counters zeroed): the loads above fly meanwhile
   }
 
   GIQL_TL(tile, 1);  // key loads issued
@@ -541,13 +543,16 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
   const u32 tid = threadIdx.x;
   if (KEYGEN && tid < 32) s_abase[tid] = abase[tid];
   if (tid == 0) {
-    s_tile = order == 2 ? xcd_tile_of_block<OS_GROUP>(blockIdx.x, gridDim.x) : atomicAdd(ticket, 1u);
+    if (order != 2) s_tile = atomicAdd(ticket, 1u);
     s_help = OS_NO_TILE;
   }
 #pragma unroll
   for (int k = tid; k < OS_NW * OS_BINS; k += OS_NT) (&s_wcnt[0][0])[k] = 0;
-  __syncthreads();
-  const u32 own = s_tile;
+  // order 2: every thread knows its tile from blockIdx, so the tile's key loads are issued
+  // BEFORE the barrier that makes this LDS set-up visible (onesweep_tile holds that barrier,
+  // between issuing the loads and first using them): ~1 us per tile
+  if (order != 2) __syncthreads();
+  const u32 own = order == 2 ? xcd_tile_of_block<OS_GROUP>(blockIdx.x, gridDim.x) : s_tile;
   if (own * OS_TILE >= n) return;  // block-uniform (cannot happen: grid = n_tiles)
   GIQL_TL(own, 0);  // block started, LDS counters zeroed
   const u32 need = os_run_tile<PAYLOAD, OS_NT, OS_ITEMS, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
