@@ -1019,19 +1019,42 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
   u32 ql = part[bid + 1];
   if (ql >= nq) ql = nq - 1;
   const u32 nqt = ql - qf + 1;
-  const u64 first_delta = tile_start - off[qf];
-  const bool staged = nqt <= (u32)FILL_QCAP && first_delta < 0x7FFFFFFFull;
+  // The records of the tile's query rows are loaded in the SAME round trip as off[qf] (which
+  // decides whether the staged form applies): a tile starts with a chain of dependent global
+  // loads -- part, off[qf], the records -- and with two 1024-thread blocks per CU every
+  // microsecond of that chain is a slot standing idle (~15 us per tile).
+  constexpr int STAGE_IT = FILL_QCAP / FILL_NT;
+  const bool fits = nqt <= (u32)FILL_QCAP;
+  const u64 off_first = off[qf];
+  u64 ov[STAGE_IT];
+  u32 lv[STAGE_IT], rv[STAGE_IT];
+  if (fits) {
+#pragma unroll
+    for (int it = 0; it < STAGE_IT; it++) {
+      const u32 k = tid + it * FILL_NT;
+      const bool ok = k < nqt;
+      ov[it] = ok ? off[qf + k] : 0;
+      lv[it] = ok ? lo[qf + k] : 0;
+      rv[it] = ok ? q_rid[qf + k] : 0;
+    }
+  }
+  const u64 first_delta = tile_start - off_first;
+  const bool staged = fits && first_delta < 0x7FFFFFFFull;
   if (staged) {
-    for (u32 k = tid; k < nqt; k += FILL_NT) {
-      const u64 o = off[qf + k];
-      u32 r = 0;
-      if (o > tile_start) {
-        const u64 d = o - tile_start;
-        r = d > (u64)tile_len ? tile_len : (u32)d;
+#pragma unroll
+    for (int it = 0; it < STAGE_IT; it++) {
+      const u32 k = tid + it * FILL_NT;
+      if (k < nqt) {
+        const u64 o = ov[it];
+        u32 r = 0;
+        if (o > tile_start) {
+          const u64 d = o - tile_start;
+          r = d > (u64)tile_len ? tile_len : (u32)d;
+        }
+        s_rel[k] = r;
+        s_jbase[k] = lv[it] - (k == 0 ? (u32)(-(int)(u32)first_delta) : r);
+        s_qrid[k] = rv[it];
       }
-      s_rel[k] = r;
-      s_jbase[k] = lo[qf + k] - (k == 0 ? (u32)(-(int)(u32)first_delta) : r);
-      s_qrid[k] = q_rid[qf + k];
     }
     __syncthreads();
     if (tile_len == TILE)
