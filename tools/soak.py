@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Randomized differential soak of the HIP path against the C oracle (GPU box): one context for
+the whole run, so every form change (fixed-length / general, aligned / tight layout) also crosses
+the contexts' speculation.  usage: soak.py [seconds] [seed]"""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from giql_amd.engine import DeviceSide, HipEngine
+from oracle import pyoracle as ora
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.default_rng(seed)
+eng = HipEngine(0)
+ENC = list(ora.ENCODING_OFFSETS.values())
+
+
+def side(n, nch, span, fixed, irregular):
+    ch = rng.integers(0, nch, n).astype(np.int32)
+    if rng.random() < 0.3:
+        ch = np.sort(ch)
+    st = rng.integers(0, span, n).astype(np.int32)
+    ln = np.full(n, fixed, np.int32) if fixed else rng.integers(1, int(rng.integers(2, 3000)), n).astype(np.int32)
+    en = st + ln
+    if irregular and n:
+        bad = rng.integers(0, n, max(1, n // 500))
+        en[bad] = st[bad] - rng.integers(0, 3, bad.shape[0]).astype(np.int32)
+    so, eo = ENC[int(rng.integers(0, 4))] if rng.random() < 0.3 else (0, 0)
+    return ora.Side(ch, st, en, so, eo)
+
+
+def dev(s):
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.int32)).to("cuda:0")
+    return DeviceSide(t(s.chrom), t(s.start), t(s.end), s.start_off, s.end_off)
+
+
+t0, it, forms = time.time(), 0, {}
+while time.time() - t0 < budget:
+    nch = int(rng.choice([1, 3, 24, 31, 32, 33, 40]))
+    na = int(rng.choice([1, 77, 5000, 8192, 40_000, 150_000]))
+    nb = int(rng.choice([1, 64, 8193, 70_000, 300_000]))
+    span = int(rng.choice([2_000, 300_000, 50_000_000, 2_000_000_000 // max(nch, 1)]))
+    fixed_b = int(rng.choice([0, 0, 36, 150]))
+    fixed_a = int(rng.choice([0, 0, 0, 75]))
+    if na * nb * 3000.0 / (float(span) * nch) > 3e7:  # expected pairs (upper estimate): keep the oracle fast
+        continue
+    a = side(na, nch, span, fixed_a, rng.random() < 0.25)
+    b = side(nb, nch, span, fixed_b, rng.random() < 0.15)
+    da, db = dev(a), dev(b)
+    try:
+        ra, rb = eng.inner_join(da, db, nch)
+    except Exception as exc:
+        assert "span" in str(exc).lower(), exc   # 33+ chromosomes x 2e9 / n positions may not fit 32 bits
+        continue
+    st = eng.stats()
+    forms[(st["join_form"], st["span_hist"])] = forms.get((st["join_form"], st["span_hist"]), 0) + 1
+    got = ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy())
+    small = na * nb <= 4_000_000_000
+    want = ora.sort_pairs(*ora.c_inner(a, b, "brute" if small and (na * nb < 3e8) else "sweep"))
+    assert np.array_equal(got, want), ("inner", it, nch, na, nb, span, fixed_a, fixed_b)
+    assert np.array_equal(eng.semi_join(da, db, nch).cpu().numpy(), ora.c_semi_anti(a, b, False)), ("semi", it)
+    assert np.array_equal(eng.anti_join(da, db, nch).cpu().numpy(), ora.c_semi_anti(a, b, True)), ("anti", it)
+    assert np.array_equal(eng.count_overlaps(da, db, nch).cpu().numpy(),
+                          ora.c_count(a, b, "brute" if na * nb < 3e8 else "sweep")), ("count", it)
+    it += 1
+    if it % 10 == 0:
+        print(json.dumps({"iterations": it, "elapsed_s": round(time.time() - t0, 1)}), flush=True)
+print(json.dumps({"ok": True, "iterations": it, "seed": seed, "forms": {f"{k[0]}/{'span_hist' if k[1] else 'linearize'}": v
+                                                                      for k, v in forms.items()}}))
