@@ -5,9 +5,15 @@
 // Compared with the three-launch pass of radix_sort.hip.h this reads the keys
 // once per pass instead of twice and removes the tile-histogram scan:
 //   per pass:  read 12 B/row, write 12 B/row   (algorithmic: exactly that)
-// Tiles are 8192 rows (512 threads x 16) so a 256-bin scatter writes ~32-row
-// (128 B) runs per array; the three arrays are staged through ONE 32 KB LDS
-// buffer in turn, which keeps 2-3 blocks (16-24 waves) resident per CU.
+// Tiles are 8192 rows (1024 threads x 8) so a 256-bin scatter writes ~32-row
+// (128 B) runs per array; the arrays are staged through ONE 32 KB LDS buffer in
+// turn; two blocks (32 waves) are resident per CU.
+//
+// Order of a tile (what bounds it is the chain of look-backs, tools/os_timeline.py):
+//   key loads -> stable ranking (wave ballots) -> per-digit count PUBLISHED ->
+//   positions, keys (and a single payload) through LDS into registers in sorted
+//   order -> look-back walk (its wait overlaps all of the above in the predecessors)
+//   -> scatter stores.
 //
 // Inter-workgroup protocol (cdna_hip_programming.md G16, "granule" form): the
 // only cross-block data is one 32-bit status word per (tile, digit) holding
