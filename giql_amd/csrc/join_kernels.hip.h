@@ -179,16 +179,18 @@ __global__ __launch_bounds__(MM_NT) void k_chrom_minmax(const int* __restrict__ 
         const u64 act = __ballot(ok);
         if (act == 0) continue;
         const u32 d2 = (pos >> 16) & 0xFFu;
-        const u32 first = (u32)__ffsll((long long)act) - 1u;
-        const u32 d2f = (u32)__shfl((int)d2, (int)first, WAVE);
-        const u32 tbf = (u32)__shfl((int)tb, (int)first, WAVE);
+        // the rows of a wave are consecutive and the loop bound cuts a SUFFIX of lanes, so the
+        // first executing lane is valid whenever any lane is: readfirstlane (no LDS shuffle)
+        const u32 d2f = (u32)__builtin_amdgcn_readfirstlane((int)d2);
+        const u32 tbf = (u32)__builtin_amdgcn_readfirstlane((int)tb);
+        const bool leader = lane_id() == (u32)__ffsll((long long)act) - 1u;
         if (__ballot(ok && d2 == d2f) == act) {
-          if (lane_id() == first) atomicAdd(&s_hist[512 + d2f], (u32)__popcll(act));
+          if (leader) atomicAdd(&s_hist[512 + d2f], (u32)__popcll(act));
         } else if (ok) {
           atomicAdd(&s_hist[512 + d2], 1u);
         }
         if (__ballot(ok && tb == tbf) == act) {
-          if (lane_id() == first) atomicAdd(&s_top[tbf], (u32)__popcll(act));
+          if (leader) atomicAdd(&s_top[tbf], (u32)__popcll(act));
         } else if (ok) {
           atomicAdd(&s_top[tb], 1u);
         }
