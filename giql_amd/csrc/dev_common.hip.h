@@ -35,7 +35,7 @@ struct DevMeta {
 };
 
 // XCD-aware block -> tile map.  Workgroups are dealt round-robin to the 8 XCDs, each
-// with its own L2: inside groups of 64 blocks, block 8j + x takes tile
+// with its own L2: inside groups of 8 G blocks, block 8j + x takes tile
 // ((j / G) * 8 + x) * G + j % G, so G consecutive tiles run on one XCD at about the
 // same time and what neighbouring tiles share (adjacent output runs, overlapping input
 // windows) meets in one L2.  A bijection on [0, n_blocks); the tail keeps its order.

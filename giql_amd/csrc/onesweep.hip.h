@@ -82,15 +82,16 @@ __device__ __forceinline__ void wave_match8(u32 d, u64 active, u32& below, u32& 
 }
 
 // Tile order.  A block maps its blockIdx to a tile through the XCD-aware permutation of
-// dev_common.hip.h (inside groups of 64 blocks, block 8j + x takes tile
-// ((j / G) * 8 + x) * G + j % G).  Workgroups are dealt round-robin to the 8 XCDs, so
+// dev_common.hip.h (inside groups of 8 G blocks, block 8j + x takes tile
+// ((j / G) * 8 + x) * G + j % G; G = OS_GROUP).  Workgroups are dealt round-robin to the 8 XCDs, so
 // blocks x, x + 8, x + 16, ... -- and with them G CONSECUTIVE tiles -- land on one XCD
 // at about the same time: the adjacent ~128-byte runs those tiles write into every
 // digit bin meet in THAT XCD's L2, which then writes whole lines back instead of two
 // partial lines per run (measured on 100M (key, end) rows: 0.471 -> 0.425 ms per pass).
 // Only speed depends on placement and dispatch order; progress does not (k_onesweep).
 #ifndef GIQL_OS_XCD_GROUP
-#define GIQL_OS_XCD_GROUP 8  // consecutive tiles that run side by side on one XCD
+#define GIQL_OS_XCD_GROUP 16  // consecutive tiles that run side by side on one XCD (4 / 8 / 12 / 16 / 24 / 32:
+                              // sort 1.97 / 1.81 / 1.84 / 1.72 / 1.98 / 1.80 ms on the headline workload)
 #endif
 constexpr u32 OS_GROUPS = XCD_GROUPS;
 constexpr u32 OS_GROUP = GIQL_OS_XCD_GROUP;
