@@ -305,15 +305,16 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
   for (int k = 0; k < 2; k++) {
     const giql_side& s = *sides[k];
     if (s.n == 0) continue;
-    u32 grid = cdiv((u64)s.n, (u64)MM_NT * MM_ITEMS);
+    const bool with_hist = hist && k == hist_side;
+    u32 grid = cdiv((u64)s.n, (u64)(with_hist ? MM_NT_HIST : MM_NT) * MM_ITEMS);
     if (grid > (u32)MM_MAX_BLOCKS) grid = MM_MAX_BLOCKS;
     nblk[k] = (int)grid;
-    if (hist && k == hist_side)
-      hipLaunchKernelGGL((k_chrom_minmax<true>), dim3(grid), dim3(MM_NT), lds, st, s.chrom, s.start, s.end,
+    if (with_hist)
+      hipLaunchKernelGGL((k_chrom_minmax<true, MM_NT_HIST>), dim3(grid), dim3(MM_NT_HIST), lds, st, s.chrom, s.start, s.end,
                          (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
                          lb.len_part, s.start_off, hist_partial, lb.top_partial);
     else
-      hipLaunchKernelGGL((k_chrom_minmax<false>), dim3(grid), dim3(MM_NT), lds, st, s.chrom, s.start, s.end,
+      hipLaunchKernelGGL((k_chrom_minmax<false, MM_NT>), dim3(grid), dim3(MM_NT), lds, st, s.chrom, s.start, s.end,
                          (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
                          lb.len_part, 0, (u32*)nullptr, (u32*)nullptr);
   }
