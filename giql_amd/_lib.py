@@ -22,7 +22,7 @@ GIQL_ERR_STATE = -7
 
 PHASES = [
     "span", "linearize", "sort_hist", "sort_scan", "sort_scatter", "count", "scan",
-    "partition", "fill", "irregular", "aux",
+    "partition", "fill", "irregular", "aux", "sort_local",
 ]
 N_PHASES = 16
 
@@ -172,10 +172,6 @@ def load() -> ctypes.CDLL:
     L.giql_hip_segment_sum_dev.argtypes = [vp, vp, vp, i64, vp, i64, vp]
     L.giql_hip_cluster_dev.argtypes = [vp, P(CSide), i32, i64, vp, vp]
     L.giql_hip_merge_dev.argtypes = [vp, P(CSide), i32, i64, vp, vp, vp, vp, i64, P(i64), vp]
-    for name in SYMBOLS:
-        fn = getattr(L, name)
-        if fn.restype is ctypes.c_int and name not in ("giql_hip_abi_version",):
-            pass
     _lib = L
     return L
 

@@ -1,0 +1,276 @@
+// giql_amd/csrc/bucket_sort.hip.h -- last stage of the three-stage sort.
+//
+// The four-pass LSD sort (onesweep.hip.h) moves every row through HBM four times.  Here only
+// the two HIGH digits go through global scatter passes (bits 16-23, then 24-31): after them the
+// rows sharing key >> 16 -- a "bucket", a few thousand rows of a genome-scale table -- sit
+// contiguously, in input order.  The low 16 bits are then sorted bucket by bucket INSIDE LDS
+// (k_bucket_sort), read once and written once, in place: three trips through HBM instead of
+// four.  This is what the 160 KB of LDS per CU is for: a 4096-row bucket with its bin table
+// takes 32 KB, so four 512-thread blocks share a CU.
+//
+// Stable (ties keep their input order), like the onesweep passes, so a sort built from the two
+// stages is a stable sort by the full 32-bit key and can serve as one leg of a two-key sort.
+//
+// A bucket larger than BS_CAP rows (dense pile-ups; small spans) cannot be sorted here: the
+// block sets meta->status = GIQL_STATUS_RESORT and the host repeats the call with the four-pass
+// sort (and keeps using it on that context) -- the kernels downstream of a failed sort are
+// memory-safe on unsorted keys, exactly as they are for the context's other wrong guesses.
+#pragma once
+
+#include "dev_common.hip.h"
+#include "onesweep.hip.h"
+
+namespace giql {
+
+constexpr u32 BS_BUCKETS = 1u << 16;
+constexpr int BS_NT = 512;
+constexpr int BS_ITEMS = 8;
+constexpr int BS_NW = BS_NT / WAVE;
+constexpr u32 BS_CAP = BS_NT * BS_ITEMS;  // rows per bucket the LDS sort holds (12-bit local index)
+constexpr int GIQL_STATUS_RESORT = -100;  // internal: never crosses the C ABI
+
+// bnd[v] = first row of the top-16-sorted keys with key >= v << 16, v in [0, 65536]; the search
+// runs inside the top digit's row range, which the sort's own digit offsets give (gb3 = the 256
+// exclusive offsets of the bits 24-31 digit).
+__global__ __launch_bounds__(256) void k_bucket_bounds(const u32* __restrict__ keys, u32 n,
+                                                        const u32* __restrict__ gb3,
+                                                        u32* __restrict__ bnd) {
+  const u32 v = blockIdx.x * 256 + threadIdx.x;
+  if (v > BS_BUCKETS) return;
+  if (v == BS_BUCKETS) {
+    bnd[v] = n;
+    return;
+  }
+  const u32 d3 = v >> 8;
+  const u32 lo = gb3[d3];
+  const u32 hi = d3 == 255u ? n : gb3[d3 + 1];
+  bnd[v] = lower_bound_u32(keys, lo < n ? lo : n, hi < n ? hi : n, v << 16);
+}
+
+// One bucket per block, in place.  PAYLOAD bit 0: a rid array travels with the keys, bit 1: an
+// end array.
+//
+// What bounds this kernel before HBM does is the LDS: an access with a per-lane random address
+// costs ~10 cycles per wave instruction (bank conflicts), and a row has ~110 CU cycles per 64
+// rows to stay under the 0.29 ms that reading and writing 1.6 GB takes.  A ballot-ranked radix
+// round costs ~5 such accesses and ~60 VALU instructions per row and digit; binning + compare
+// loops ~11.  This form needs FOUR random accesses per row and no ranking at all:
+//
+//   Every row is ONE word {low 16 key bits : 16, row index inside the bucket : 12} -- distinct
+//   inside a bucket, so ascending word order IS the stable order.  The 16 key bits split into a
+//   bin (top 11 bits) and a sub-value (low 5 bits).  Each row makes ONE 64-bit LDS atomic add of
+//   {1 << sub : 32 | 1 : 32} on its bin's cell: the low half counts the bin's rows, the high
+//   half is the sum of one power of two per row -- a bitmap of the sub-values present as long as
+//   they are distinct, which popcount(high) == count tells exactly (equal powers carry, and a
+//   carry only ever lowers the popcount; carries leave through bit 63, never into the count).
+//   A block scan turns counts into bin starts, and a row of a bin with distinct sub-values has
+//   its final place from ONE read of its cell: start + popcount(bitmap below its sub-value).
+//   Rows of the other bins (equal 16-bit keys: ~3 % of random rows; pile-ups) gather in their
+//   bin's own output range by arrival order and count the smaller words there (the square of the
+//   bin's size, bounded by the bucket).  Low key halves (16-bit) and the payload then go through
+//   LDS by final place in one round and leave in row order.
+constexpr int BS_LOG_BINS = 11;
+constexpr int BS_SUB_BITS = 16 - BS_LOG_BINS;  // 5: the sub-values of a bin fit a 32-bit map
+#ifndef GIQL_BS_MIN_WAVES
+#define GIQL_BS_MIN_WAVES 8  // waves per SIMD the register allocation must allow (8 = 64 VGPRs: four blocks per CU)
+#endif
+
+// timing-only builds (-DGIQL_BS_ABLATE=k): the kernel stops after its k-th stage (results invalid)
+#if defined(GIQL_BS_ABLATE)
+#define GIQL_BS_STOP(k)                                        \
+  do {                                                         \
+    if (GIQL_BS_ABLATE == (k)) {                               \
+      u32 acc_ = 0;                                            \
+      for (int i_ = 0; i_ < R; i_++) acc_ += pk[i_] ^ pay[i_] ^ slot[i_]; \
+      if (acc_ == 0x12345u) kp[0] = acc_;                      \
+      return;                                                  \
+    }                                                          \
+  } while (0)
+#else
+#define GIQL_BS_STOP(k) do { } while (0)
+#endif
+
+constexpr u32 BS_CELL_START_MASK = 0x1FFFu;  // cell low half after the scan: start : 13 | count : 13 | ... | dup : 1
+constexpr u32 BS_CELL_DUP = 1u << 31;
+constexpr u32 BS_NB = 1u << BS_LOG_BINS;
+
+// The body for a bucket of (R - 1) * BS_NT < cnt <= R * BS_NT rows: row i * BS_NT + tid is item i
+// of thread tid, so every item but the last is a full round (no bounds predicates).
+template <int PAYLOAD, int R>
+__device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __restrict__ pp,
+                                                 u32* __restrict__ ep, u32 cnt, u32 v, u32* s_buf,
+                                                 u64* s_cell, u32* s_scan) {
+  constexpr int BIN_SHIFT = 12 + BS_SUB_BITS;
+  constexpr int PER = BS_NB / BS_NT;  // cells scanned per thread
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+#define GIQL_BS_OK(i, r) ((i) < R - 1 || (r) < cnt)
+  u32 pk[R], pay[R], slot[R];
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const u32 r = i * BS_NT + tid;
+    const bool ok = GIQL_BS_OK(i, r);
+    pk[i] = ok ? kp[r] : 0u;
+    pay[i] = (PAYLOAD && ok) ? pp[r] : 0u;  // used at the very end: the load flies under everything
+    slot[i] = 0;
+  }
+  // cells zeroed while the loads fly
+#pragma unroll
+  for (int k = 0; k < PER; k++) s_cell[tid + k * BS_NT] = 0;
+  __syncthreads();
+  GIQL_BS_STOP(1);  // loads + table zeroing
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const u32 r = i * BS_NT + tid;
+    if (GIQL_BS_OK(i, r)) {
+      pk[i] = ((pk[i] & 0xFFFFu) << 12) | r;
+      const u32 sub = (pk[i] >> 12) & 31u;
+      const u64 add = ((u64)(1u << sub) << 32) | 1ull;
+      slot[i] = (u32)atomicAdd((unsigned long long*)&s_cell[pk[i] >> BIN_SHIFT], (unsigned long long)add);
+    }
+  }
+  __syncthreads();
+  GIQL_BS_STOP(2);  // + binning atomics
+  {
+    // exclusive scan of the bin counts: PER consecutive cells per thread, DPP scan per wave, the
+    // wave totals through LDS (every thread adds up the waves below its own)
+    u32 c[PER], bm[PER], t = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const u64 cell = s_cell[tid * PER + k];
+      c[k] = (u32)cell;
+      bm[k] = (u32)(cell >> 32);
+      t += c[k];
+    }
+    const u32 incl = wave_incl_scan_add_u32(t);
+    if (lane == WAVE - 1) s_scan[w] = incl;
+    __syncthreads();
+    u32 ex = incl - t;
+#pragma unroll
+    for (int k = 0; k < BS_NW; k++)
+      if (k < (int)w) ex += s_scan[k];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      const u32 dup = (u32)__popc(bm[k]) != c[k] ? BS_CELL_DUP : 0u;
+      s_cell[tid * PER + k] = ((u64)bm[k] << 32) | (u64)(ex | (c[k] << 13) | dup);
+      ex += c[k];
+    }
+  }
+  __syncthreads();
+  GIQL_BS_STOP(3);  // + scan
+  bool any_dup = false;
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const u32 r = i * BS_NT + tid;
+    if (GIQL_BS_OK(i, r)) {
+      const u64 cell = s_cell[pk[i] >> BIN_SHIFT];
+      const u32 lo = (u32)cell, map = (u32)(cell >> 32);
+      const u32 start = lo & BS_CELL_START_MASK;
+      if (lo & BS_CELL_DUP) {
+        s_buf[start + slot[i]] = pk[i];  // gathered inside the bin's own output range
+        slot[i] = U32_MAX;               // place still to be found
+        any_dup = true;
+      } else {
+        const u32 sub = (pk[i] >> 12) & 31u;
+        slot[i] = start + (u32)__popc(map & ((1u << sub) - 1u));
+      }
+    }
+  }
+  __syncthreads();
+  GIQL_BS_STOP(4);  // + places of the rows with distinct keys
+  if (any_dup) {
+    // four words from the bin's start at once (independent loads: one LDS round trip per row
+    // instead of one per bin-mate), the rare longer bin in a loop
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      if (slot[i] == U32_MAX) {  // only rows can hold it
+        const u32 lo = (u32)s_cell[pk[i] >> BIN_SHIFT];
+        const u32 start = lo & BS_CELL_START_MASK, m = (lo >> 13) & BS_CELL_START_MASK;
+        const u32 x = pk[i];
+        const u32 w0 = s_buf[start], w1 = s_buf[start + 1], w2 = s_buf[start + 2], w3 = s_buf[start + 3];
+        u32 c = (u32)(w0 < x) + (u32)(m > 1u && w1 < x) + (u32)(m > 2u && w2 < x) + (u32)(m > 3u && w3 < x);
+        for (u32 j = 4; j < m; j++) c += (u32)(s_buf[start + j] < x);
+        slot[i] = start + c;
+      }
+    }
+  }
+  __syncthreads();  // every gathered bin has been read: s_buf and the cells are free
+  GIQL_BS_STOP(5);  // + places of the rows with equal keys
+  uint16_t* s_key16 = reinterpret_cast<uint16_t*>(s_cell);
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const u32 r = i * BS_NT + tid;
+    if (GIQL_BS_OK(i, r)) {
+      s_key16[slot[i]] = (uint16_t)(pk[i] >> 12);
+      if (PAYLOAD) s_buf[slot[i]] = pay[i];
+    }
+  }
+  __syncthreads();
+  GIQL_BS_STOP(6);  // + staging by final place (everything but the stores)
+  // keys: the high half is the bucket's number.  Every load of the block's rows completed before
+  // the barriers above, so the in-place stores cannot overtake a load.
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const u32 r = i * BS_NT + tid;
+    if (GIQL_BS_OK(i, r)) {
+      kp[r] = (v << 16) | (u32)s_key16[r];
+      if (PAYLOAD) pp[r] = s_buf[r];
+    }
+  }
+  if (PAYLOAD == 3) {
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const u32 r = i * BS_NT + tid;
+      pay[i] = GIQL_BS_OK(i, r) ? ep[r] : 0u;
+    }
+    __syncthreads();  // the rid round has left s_buf
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const u32 r = i * BS_NT + tid;
+      if (GIQL_BS_OK(i, r)) s_buf[slot[i]] = pay[i];
+    }
+    __syncthreads();  // every `end` of the bucket is in LDS: the in-place stores may start
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const u32 r = i * BS_NT + tid;
+      if (GIQL_BS_OK(i, r)) ep[r] = s_buf[r];
+    }
+  }
+#undef GIQL_BS_OK
+}
+
+template <int PAYLOAD>
+__global__ __launch_bounds__(BS_NT, GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* __restrict__ keys, u32* __restrict__ ends,
+                                                           u32* __restrict__ rids,
+                                                           const u32* __restrict__ bnd,
+                                                           DevMeta* __restrict__ meta) {
+  static_assert(BS_NB % BS_NT == 0, "bins must be a multiple of the block size");
+  static_assert(BS_NB * sizeof(u64) >= BS_CAP * sizeof(uint16_t), "the cell table doubles as the 16-bit key stage");
+  static_assert(BS_SUB_BITS == 5, "one 32-bit map of sub-values per bin");
+  __shared__ u32 s_buf[BS_CAP + 4];  // + 4: the four-wide read of a gathered bin may run past the last row
+  __shared__ u64 s_cell[BS_NB];  // {sub-value map : 32 | count : 32}, after the scan {map | dup, count, start}
+  __shared__ u32 s_scan[BS_NW];
+  const u32 v = blockIdx.x;
+  const u32 b0 = bnd[v];
+  const u32 cnt = bnd[v + 1] - b0;
+  if (cnt < 2u) return;  // block-uniform
+  if (cnt > BS_CAP) {
+    if (threadIdx.x == 0) meta->status = GIQL_STATUS_RESORT;
+    return;
+  }
+  u32* kp = keys + b0;
+  // the payload that rides along in registers: rid when there is one, else end
+  u32* pp = (PAYLOAD & 1) ? rids + b0 : ((PAYLOAD & 2) ? ends + b0 : nullptr);
+  u32* ep = (PAYLOAD == 3) ? ends + b0 : nullptr;  // a second payload array takes a round of its own
+  switch ((cnt + BS_NT - 1) / BS_NT) {  // rows per thread: 1..BS_ITEMS, block-uniform
+    case 1: bucket_sort_body<PAYLOAD, 1>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
+    case 2: bucket_sort_body<PAYLOAD, 2>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
+    case 3: bucket_sort_body<PAYLOAD, 3>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
+    case 4: bucket_sort_body<PAYLOAD, 4>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
+    case 5: bucket_sort_body<PAYLOAD, 5>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
+    case 6: bucket_sort_body<PAYLOAD, 6>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
+    case 7: bucket_sort_body<PAYLOAD, 7>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
+    default: bucket_sort_body<PAYLOAD, 8>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
+  }
+}
+
+}  // namespace giql

@@ -20,6 +20,7 @@
 #include "dev_common.hip.h"
 #include "join_kernels.hip.h"
 #include "onesweep.hip.h"
+#include "bucket_sort.hip.h"
 #include "radix_sort.hip.h"
 #include "scan.hip.h"
 
@@ -128,6 +129,14 @@ struct giql_hip_ctx {
   bool no_span_hist = false;  // GIQL_HIP_NO_SPAN_HIST=1: always linearize the fixed-length side (A/B aid)
   int inject_timeout = 0;     // test hook: report one look-back timeout
   int order_fallbacks = 0;    // calls repeated in the ticket order after a timeout
+  // three-stage sort (two global passes on bits 16-31 + the in-LDS bucket sort, bucket_sort.hip.h)
+  // for sides of at least local_min_rows rows (smaller sides have too few rows per bucket to pay for a block each); switched off for good on a context once a bucket
+  // turned out larger than the LDS sort holds (GIQL_HIP_NO_LOCAL_SORT=1: never)
+  bool local_sort = true;
+  u64 local_min_rows = 1u << 25;
+  int local_resorts = 0;      // calls repeated with the four-pass sort
+  bool last_sort_local = false;  // the call in flight sorted at least one side in three stages
+  u32* bucket_bnd = nullptr;  // [BS_BUCKETS + 1] bucket boundaries of the sort in flight
 
   // profiling
   int profiling = 0;          // 0 off, 1 every phase, 2 only the sort passes (the dominant kernel)
@@ -207,6 +216,7 @@ struct Phase {
 
 static void reset_stats(giql_hip_ctx* ctx) {
   memset(&ctx->stats, 0, sizeof(ctx->stats));
+  ctx->last_sort_local = false;
   ctx->spans.clear();
   ctx->ev_used = 0;
 }
@@ -394,37 +404,69 @@ static void launch_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, int
 // keygen (with abase): the first pass builds the keys from that side's raw (chrom, start)
 // columns instead of reading sb.key[0] (k_onesweep<.., KEYGEN>; (key, rid) sorts, default
 // block shape only).
+// Sides of ctx->local_min_rows rows and more take the three-stage form: global passes on bits
+// 16-23 and 24-31 only, then every 16-bit bucket sorted on its low bits inside LDS, in place
+// (bucket_sort.hip.h) -- three trips through HBM instead of four.
+static inline bool sort_is_local(const giql_hip_ctx* ctx, size_t n) {
+  return ctx->local_sort && ctx->bucket_bnd && ctx->os_variant == 0 && n >= ctx->local_min_rows;
+}
+
 static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
                              const u32* gbase, u32* status, bool keep_rids = false,
                              const giql_side* keygen = nullptr, const u32* abase = nullptr) {
   if (n == 0) return GIQL_OK;
+  const bool local = sort_is_local(ctx, n);
+  if (local) ctx->last_sort_local = true;
+  const int n_pass = local ? 2 : 4;
+  const int first_digit = local ? 2 : 0;
   const size_t per_pass = os_pass_words(n);
-  HIP_TRY(hipMemsetAsync(status, 0, 4 * per_pass * sizeof(u32), st));
-  // one event pair around the four passes (an event record between two launches costs the
-  // stream ~8 us of idle time; the per-launch time is phase time / launches)
-  Phase ph(ctx, st, GIQL_PH_SORT_SCATTER, 4);
-  for (int pass = 0; pass < 4; pass++) {
-    const int src = pass & 1, dst = src ^ 1;
-    u32* stat = status + pass * per_pass;
-    const bool first = pass == 0 && !keep_rids;
-    const u32* gb = gbase + pass * OS_BINS;
-    if (pass == 0 && keygen) {
-      const u32 grid = cdiv(n, 1024 * 8);
-      u32* claim = stat + (size_t)cdiv(n, OS_MIN_TILE) * OS_BINS;
-      hipLaunchKernelGGL((k_onesweep<1, 1024, 8, true>), dim3(grid), dim3(1024), 0, st,
-                         reinterpret_cast<const u32*>(keygen->start), reinterpret_cast<const u32*>(keygen->chrom),
-                         (const u32*)nullptr, sb.key[dst], (u32*)nullptr, sb.rid[dst], n, 0, gb, stat, claim,
-                         ctx->d_meta, ctx->os_order, ctx->os_help_after, abase, (u32)keygen->start_off);
-      continue;
+  HIP_TRY(hipMemsetAsync(status, 0, n_pass * per_pass * sizeof(u32), st));
+  {
+    // one event pair around the passes (an event record between two launches costs the
+    // stream ~8 us of idle time; the per-launch time is phase time / launches)
+    Phase ph(ctx, st, GIQL_PH_SORT_SCATTER, n_pass);
+    for (int pass = 0; pass < n_pass; pass++) {
+      const int src = pass & 1, dst = src ^ 1;
+      const int digit = first_digit + pass;
+      u32* stat = status + pass * per_pass;
+      const bool first = pass == 0 && !keep_rids;
+      const u32* gb = gbase + digit * OS_BINS;
+      if (pass == 0 && keygen) {
+        const u32 grid = cdiv(n, 1024 * 8);
+        u32* claim = stat + (size_t)cdiv(n, OS_MIN_TILE) * OS_BINS;
+        hipLaunchKernelGGL((k_onesweep<1, 1024, 8, true>), dim3(grid), dim3(1024), 0, st,
+                           reinterpret_cast<const u32*>(keygen->start), reinterpret_cast<const u32*>(keygen->chrom),
+                           (const u32*)nullptr, sb.key[dst], (u32*)nullptr, sb.rid[dst], n, digit * 8, gb, stat, claim,
+                           ctx->d_meta, ctx->os_order, ctx->os_help_after, abase, (u32)keygen->start_off);
+        continue;
+      }
+      switch (ctx->os_variant) {  // block-shape sweep (tools/os_variants.py); default 1024 x 8
+        case 1: launch_onesweep<512, 8>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
+        case 2: launch_onesweep<512, 16>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
+        case 3: launch_onesweep<256, 16>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
+        case 4: launch_onesweep<1024, 4>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
+        case 5: case 7: launch_onesweep<1024, 12>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
+        default: launch_onesweep<1024, 8>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
+      }
     }
-    switch (ctx->os_variant) {  // block-shape sweep (tools/os_variants.py); default 1024 x 8
-      case 1: launch_onesweep<512, 8>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
-      case 2: launch_onesweep<512, 16>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
-      case 3: launch_onesweep<256, 16>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
-      case 4: launch_onesweep<1024, 4>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
-      case 5: case 7: launch_onesweep<1024, 12>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
-      default: launch_onesweep<1024, 8>(ctx, st, sb, src, dst, first, n, pass * 8, gb, stat, ctx->d_meta); break;
+  }
+  if (local) {
+    // the rows are back in buffer 0, ordered by key >> 16: bucket boundaries, then one block per bucket
+    Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 2);
+    hipLaunchKernelGGL(k_bucket_bounds, dim3(cdiv((u64)BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
+                       gbase + 3 * OS_BINS, ctx->bucket_bnd);
+    const int mode = (sb.rid[0] ? 1 : 0) | (sb.end[0] ? 2 : 0);
+#define GIQL_BS_LAUNCH(M)                                                                              \
+  hipLaunchKernelGGL((k_bucket_sort<M>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0],              \
+                     sb.end[0] ? sb.end[0] : (u32*)nullptr, sb.rid[0] ? sb.rid[0] : (u32*)nullptr,      \
+                     ctx->bucket_bnd, ctx->d_meta)
+    switch (mode) {
+      case 0: GIQL_BS_LAUNCH(0); break;
+      case 1: GIQL_BS_LAUNCH(1); break;
+      case 2: GIQL_BS_LAUNCH(2); break;
+      default: GIQL_BS_LAUNCH(3); break;
     }
+#undef GIQL_BS_LAUNCH
   }
   return post_launch("onesweep sort");
 }
@@ -479,6 +521,8 @@ static int read_meta(giql_hip_ctx* ctx, hipStream_t st) {
     ctx->inject_timeout = 0;
     status = ctx->h_meta->status = GIQL_ERR_HIP;
   }
+  if (status == GIQL_STATUS_RESORT)  // internal: with_order_fallback repeats the call with the four-pass sort
+    return set_err(GIQL_STATUS_RESORT, "a 16-bit key bucket holds more than %u rows", BS_CAP);
   if (status == GIQL_ERR_HIP)
     return set_err(GIQL_ERR_HIP, "onesweep look-back timed out (tile order %d)", ctx->os_order);
   if (status == GIQL_ERR_CHROM)
@@ -515,6 +559,12 @@ static void sort_sizes(Carver& c, size_t n, SortBufs& sb, bool payload) {
 template <typename F>
 static int with_order_fallback(giql_hip_ctx* ctx, F&& call) {
   int rc = call();
+  if (rc == GIQL_STATUS_RESORT && ctx && ctx->local_sort) {
+    // a bucket too large for the in-LDS stage (bucket_sort.hip.h): this table wants the four-pass sort
+    ctx->local_sort = false;
+    ctx->local_resorts++;
+    rc = call();
+  }
   if (rc == GIQL_ERR_HIP && ctx && ctx->os_order != 0 && ctx->h_meta && ctx->h_meta->status == GIQL_ERR_HIP) {
     ctx->os_order = 0;
     ctx->order_fallbacks++;
@@ -600,6 +650,10 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->no_uniform = u && atoi(u) != 0;
     const char* nh = getenv("GIQL_HIP_NO_SPAN_HIST");
     ctx->no_span_hist = nh && atoi(nh) != 0;
+    const char* nl = getenv("GIQL_HIP_NO_LOCAL_SORT");
+    if (nl && atoi(nl) != 0) ctx->local_sort = false;
+    const char* lm = getenv("GIQL_HIP_LOCAL_MIN_ROWS");
+    if (lm) ctx->local_min_rows = strtoull(lm, nullptr, 10);
   }
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   {
@@ -610,6 +664,7 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
   hipError_t e = hipMalloc((void**)&ctx->d_meta, sizeof(DevMeta));
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_meta, sizeof(DevMeta), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_scratch64, 64);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_bnd, ((size_t)BS_BUCKETS + 16) * sizeof(u32));
   if (e != hipSuccess) {
     giql_hip_destroy(ctx);
     return set_err(GIQL_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e));
@@ -627,6 +682,7 @@ int giql_hip_destroy(giql_hip_ctx* ctx) {
   if (ctx->part) (void)hipFree(ctx->part);
   if (ctx->d_meta) (void)hipFree(ctx->d_meta);
   if (ctx->d_scratch64) (void)hipFree(ctx->d_scratch64);
+  if (ctx->bucket_bnd) (void)hipFree(ctx->bucket_bnd);
   if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
   delete ctx;
   return GIQL_OK;
@@ -653,8 +709,10 @@ int giql_hip_get_stats(giql_hip_ctx* ctx, giql_hip_stats* out) {
   }
   ctx->stats.workspace_bytes = (int64_t)ctx->arena_cap;
   *out = ctx->stats;
-  // byte 0: join form; byte 1: sort tile order in force; bytes 2-3: order fallbacks so far
-  out->reserved = (ctx->stats.reserved & 0xFF) | ((ctx->os_order & 0xFF) << 8) |
+  // byte 0: join form (+ bit 5: a side was sorted in three stages, bit 6: this context fell back to
+  // the four-pass sort for good); byte 1: sort tile order in force; bytes 2-3: order fallbacks so far
+  out->reserved = (ctx->stats.reserved & 0x1F) | (ctx->last_sort_local ? 0x20 : 0) |
+                  (ctx->local_resorts ? 0x40 : 0) | ((ctx->os_order & 0xFF) << 8) |
                   ((ctx->order_fallbacks & 0x3FFF) << 16) | (ctx->fuse_done ? (1 << 30) : 0);
   return GIQL_OK;
 }
@@ -852,12 +910,12 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
         {
           Phase ph(ctx, st, GIQL_PH_PARTITION);
           hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt_cap + 1, 256)), dim3(256), 0, st, S.off2,
-                             (u32)nqr, (u64)0, T2, nt_cap, ctx->part, (const u64*)(S.off2 + nqr));
+                             (u32)nqr, (u64)0, T2, nt_cap, ctx->part, (const u64*)(S.off2 + nqr), ctx->fuse_cap);
         }
         {
           Phase ph(ctx, st, GIQL_PH_FILL);
           hipLaunchKernelGGL((k_fill<FILL_ITEMS_C2>), dim3(nt_cap), dim3(FILL_NT), 0, st, S.off2, S.lo2, qrid,
-                             (u32)nqr, srid, ctx->part, (u64)0, (u64)0, rq, rs, (const u64*)(S.off2 + nqr));
+                             (u32)nqr, srid, ctx->part, (u64)0, (u64)0, rq, rs, (const u64*)(S.off2 + nqr), ctx->fuse_cap);
         }
         GIQL_TRY(post_launch("fused fill"));
         fused = true;

@@ -855,12 +855,14 @@ constexpr int FILL_QCAP = 4 * FILL_NT;  // query records staged per output tile 
 // exactly `tile` pairs.  part[t] = last query q (relative to q_base) whose
 // offset is <= out_base + t*tile;  part[n_tiles] = nq - 1.
 // n_out_dev (optional): the number of outputs is read from the device and n_tiles is
-// only an upper bound (a fill launched before the host has learned the count).
+// only an upper bound (a fill launched before the host has learned the count); a count above
+// `cap` (the caller's buffers) means that early fill is void: nothing is partitioned.
 __global__ void k_partition(const u64* __restrict__ off, u32 nq, u64 out_base, u32 tile,
                             u32 n_tiles, u32* __restrict__ part,
-                            const u64* __restrict__ n_out_dev = nullptr) {
+                            const u64* __restrict__ n_out_dev = nullptr, u64 cap = ~0ull) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (n_out_dev) {
+    if (*n_out_dev > cap) return;
     const u64 nt = (*n_out_dev + tile - 1) / tile;
     n_tiles = nt < (u64)n_tiles ? (u32)nt : n_tiles;
   }
@@ -999,11 +1001,13 @@ __global__ __launch_bounds__(FILL_NT) void k_fill(
     const u64* __restrict__ off, const u32* __restrict__ lo, const u32* __restrict__ q_rid, u32 nq,
     const u32* __restrict__ s_rid, const u32* __restrict__ part, u64 out_base, u64 n_out,
     int32_t* __restrict__ row_q, int32_t* __restrict__ row_s,
-    const u64* __restrict__ n_out_dev = nullptr) {
+    const u64* __restrict__ n_out_dev = nullptr, u64 cap = ~0ull) {
   constexpr u32 TILE = FILL_NT * ITEMS;
   if (n_out_dev) {  // launched with an upper-bound grid before the host knew the count
     n_out = *n_out_dev;
-    if ((u64)blockIdx.x * TILE >= n_out) return;
+    // more pairs than the caller's buffers hold: the early fill is discarded by the host
+    // (GIQL_ERR_CAPACITY), and its last tile would store past the end -- write nothing
+    if (n_out > cap || (u64)blockIdx.x * TILE >= n_out) return;
   }
   __shared__ u32 s_rel[FILL_QCAP];  // unsigned relative starts; [0] unused by searches
   // lo[k] - rel0[k] (mod 2^32), rel0 = the relative start with its true (<= 0) value for row 0:

@@ -89,6 +89,7 @@ enum {
   GIQL_PH_FILL = 8,      /* pair materialisation                            */
   GIQL_PH_IRREGULAR = 9, /* literal-predicate path for end<=start rows      */
   GIQL_PH_AUX = 10,      /* prefix-max / compaction / nearest kernels       */
+  GIQL_PH_SORT_LOCAL = 11, /* three-stage sort: bucket bounds + in-LDS bucket sort */
   GIQL_PH_N = 16
 };
 
@@ -106,7 +107,10 @@ typedef struct giql_hip_stats {
   int32_t reserved;         /* bits 0-3: INNER join form (0 = general two-class join,
                                1 / 2 = uniform-length form with B / A as the fixed-
                                length side); bit 4: that side was sorted straight from
-                               its raw columns (digit histogram in the span pass); byte 1: sort tile order in force (2 =
+                               its raw columns (digit histogram in the span pass); bit 5: a side
+                               was sorted in three stages (two global passes + the in-LDS
+                               bucket sort); bit 6: the context fell back to the four-pass
+                               sort (a bucket too large for LDS); byte 1: sort tile order in force (2 =
                                blockIdx order, 0 = ticket order); bits 16-29: calls
                                repeated in ticket order after a look-back timeout;
                                bit 30: the last plan launched its own fill

@@ -1039,3 +1039,36 @@ def test_fused_inner_join_into_caller_buffers():
         assert run(empty, b1, 16).shape[0] == 0
     finally:
         e.close()
+
+
+def test_fused_fill_never_writes_past_a_short_buffer():
+    # the fill launched inside the plan has a grid bounded by the capacity but learns the pair
+    # count on the device: with more pairs than capacity it must write NOTHING past the buffers
+    # (its last tile would otherwise overrun by up to a whole tile), and the call must report
+    # GIQL_ERR_CAPACITY with the plan still valid
+    from giql_amd._lib import GIQL_ERR_CAPACITY, GiqlHipError
+    from giql_amd.engine import HipEngine
+
+    e = HipEngine(0)
+    try:
+        a, b = rand_side(311, 20_000, 4, 1_500_000, 700), uniform_side(312, 150_000, 4, 1_500_000, 120)
+        want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+        n = want.shape[0]
+        big = torch.empty((2, n + 64), dtype=torch.int32, device="cuda")
+        assert e.inner_join_into(dev(a), dev(b), 4, big[0], big[1]) == n   # first plan (nothing fused yet)
+        assert e.inner_join_into(dev(a), dev(b), 4, big[0], big[1]) == n   # fused: the guesses hold
+        guard = 40_000                                                      # > two fill tiles
+        for cap in (n // 3 + 17, 1000, n - 1):                              # none a multiple of the 16384-pair tile
+            buf = torch.full((2 * (cap + guard),), -7, dtype=torch.int32, device="cuda")
+            ra, rb = buf[:cap], buf[cap + guard:2 * cap + guard]
+            with pytest.raises(GiqlHipError) as ei:
+                e.inner_join_into(dev(a), dev(b), 4, ra, rb)
+            assert ei.value.code == GIQL_ERR_CAPACITY and e.last_pairs == n
+            torch.cuda.synchronize()
+            assert bool((buf[cap:cap + guard] == -7).all()) and bool((buf[2 * cap + guard:] == -7).all())
+        ra = torch.empty(n, dtype=torch.int32, device="cuda")
+        rb = torch.empty_like(ra)
+        e.inner_fill(ra, rb)                                                # the plan is still valid
+        assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), want)
+    finally:
+        e.close()

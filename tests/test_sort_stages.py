@@ -1,0 +1,159 @@
+"""The three-stage sort (two global onesweep passes on key bits 16-31 + the in-LDS bucket sort of
+``giql_amd/csrc/bucket_sort.hip.h``) against the oracle -- needs a GPU.
+
+Production contexts take that form for sides of 32M rows and more; here
+``GIQL_HIP_LOCAL_MIN_ROWS=1`` forces it at every size so that small inputs exercise it: empty and
+one-row buckets, buckets at both ends of the key axis, ties, every payload shape (keys only /
++rid / +end / both), the two-key sorts that rely on stability, and the fall-back to the four-pass
+sort when a bucket is too large for LDS.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as ora
+from test_gpu_parity import dev, rand_side, uniform_side
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture()
+def eng_local(monkeypatch):
+    from giql_amd.engine import HipEngine
+
+    monkeypatch.setenv("GIQL_HIP_LOCAL_MIN_ROWS", "1")
+    e = HipEngine(0)
+    monkeypatch.delenv("GIQL_HIP_LOCAL_MIN_ROWS")
+    yield e
+    e.close()
+
+
+def _inner(e, a, b, nch):
+    ra, rb = e.inner_join(dev(a), dev(b), nch)
+    return ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy())
+
+
+def _all_ops(e, a, b, nch, nearest=True):
+    assert np.array_equal(_inner(e, a, b, nch), ora.sort_pairs(*ora.c_inner(a, b, "sweep")))
+    st = e.stats()
+    assert np.array_equal(e.semi_join(dev(a), dev(b), nch).cpu().numpy(), ora.c_semi_anti(a, b, False))
+    assert np.array_equal(e.anti_join(dev(a), dev(b), nch).cpu().numpy(), ora.c_semi_anti(a, b, True))
+    assert np.array_equal(e.count_overlaps(dev(a), dev(b), nch).cpu().numpy(), ora.c_count(a, b, "sweep"))
+    if nearest:
+        idx, dist = e.nearest(dev(a), dev(b), nch)
+        oi, od = ora.c_nearest_k1(a, b, method="sweep")
+        assert np.array_equal(dist.cpu().numpy(), od)
+        j = idx.cpu().numpy()
+        ok = j >= 0
+        assert np.array_equal(ok, oi >= 0)
+        assert np.array_equal(b.start[j[ok]], b.start[oi[ok]]) and np.array_equal(b.end[j[ok]], b.end[oi[ok]])
+        raw = ora.Side(a.chrom, a.start, a.end)
+        assert np.array_equal(e.cluster(dev(raw), nch, 25).cpu().numpy(), ora.c_cluster(raw, 25))
+    return st
+
+
+@pytest.mark.parametrize("na,nb,nch,ms,ml", [
+    (1, 1, 1, 10, 5),
+    (63, 65, 2, 500, 60),
+    (5000, 300_000, 24, 200_000_000, 500),      # ~100 rows per 65536-bp bucket
+    (200_000, 150_000, 24, 50_000_000, 3000),
+    (40_000, 700_000, 3, 40_000_000, 400),      # ~380 rows per bucket, 3 chromosomes
+    (300_000, 300_000, 1, 6_000_000, 300),      # ~3300 rows per bucket: near the LDS capacity
+])
+def test_three_stage_sort_every_operator(eng_local, na, nb, nch, ms, ml):
+    a = rand_side(700 + na, na, nch, ms, ml)
+    b = rand_side(800 + nb, nb, nch, ms, ml)
+    st = _all_ops(eng_local, a, b, nch)
+    assert st["sort_local"] and not st["sort_resorted"]
+
+
+def test_three_stage_sort_uniform_forms_and_keygen(eng_local):
+    # fixed-length reads: the big side is sorted straight from its raw columns (KEYGEN first pass,
+    # now on bits 16-23), twice so that the second call runs fully speculated and fused
+    a = rand_side(901, 60_000, 6, 30_000_000, 900)
+    b = uniform_side(902, 900_000, 6, 30_000_000, 150)
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    for _ in range(3):
+        assert np.array_equal(_inner(eng_local, a, b, 6), want)
+        st = eng_local.stats()
+        assert st["join_form"] == "uniform_b" and st["sort_local"]
+    assert st["span_hist"]
+    want2 = ora.sort_pairs(*ora.c_inner(b, a, "sweep"))
+    assert np.array_equal(_inner(eng_local, b, a, 6), want2)
+    assert eng_local.stats()["join_form"] == "uniform_a"
+    _all_ops(eng_local, a, b, 6, nearest=False)
+
+
+def test_three_stage_sort_irregular_rows_encodings_and_extremes(eng_local):
+    encs = list(ora.ENCODING_OFFSETS)
+    for seed in range(6):
+        a = rand_side(1100 + seed, 30_000, 5, 90_000_000, 2000, min_len=-3, enc=encs[seed % 4])
+        b = rand_side(1200 + seed, 80_000, 5, 90_000_000, 700, min_len=-3 if seed % 2 else 1, enc=encs[(seed + 1) % 4])
+        assert np.array_equal(_inner(eng_local, a, b, 5), ora.sort_pairs(*ora.c_inner(a, b, "sweep")))
+        assert np.array_equal(eng_local.count_overlaps(dev(a), dev(b), 5).cpu().numpy(), ora.c_count(a, b, "sweep"))
+    # keys in the first and the last bucket of the 32-bit axis
+    top = 2_147_483_000
+    s = np.array([0, 1, 65535, 65536, top - 50, top - 10, top - 10], np.int32)
+    a = ora.Side(np.zeros(7, np.int32), s, s + np.int32(40))
+    b = ora.Side(np.zeros(7, np.int32), s[::-1].copy(), s[::-1] + np.int32(25))
+    _all_ops(eng_local, a, b, 1)
+
+
+def test_three_stage_sort_is_stable_for_the_two_key_sorts(eng_local):
+    # pile-ups (long runs of equal starts) put NEAREST and group_rows on their two-sort plan: sort by
+    # end, then STABLY by start -- every stage of the second sort has to keep the order of ties
+    rng = np.random.default_rng(77)
+    n = 120_000
+    st = (rng.integers(0, 400, n) * 50_000).astype(np.int32)        # 400 distinct starts, ~300 rows each
+    b = ora.Side(np.zeros(n, np.int32), st, st + rng.integers(1, 3000, n).astype(np.int32))
+    qs = rng.integers(0, 20_000_000, 50_000).astype(np.int32)
+    a = ora.Side(np.zeros(50_000, np.int32), qs, qs + rng.integers(1, 500, 50_000).astype(np.int32))
+    for _ in range(2):  # the first call discovers the pile-ups and switches plans
+        idx, dist = eng_local.nearest(dev(a), dev(b), 1)
+        oi, od = ora.c_nearest_k1(a, b, method="sweep")
+        assert np.array_equal(dist.cpu().numpy(), od)
+        j = idx.cpu().numpy()
+        assert np.array_equal(b.start[j], b.start[oi]) and np.array_equal(b.end[j], b.end[oi])
+    gid, rep = eng_local.group_rows(dev(b), 1)
+    assert rep.shape[0] == len({(int(x), int(y)) for x, y in zip(b.start, b.end)})
+    assert eng_local.stats()["sort_local"]
+
+
+def test_oversized_bucket_falls_back_to_the_four_pass_sort(eng_local):
+    # 60,000 rows inside ONE 65536-bp bucket: the in-LDS stage cannot hold it; the call is repeated
+    # with the four-pass sort, stays exact, and the context keeps that sort afterwards
+    a = rand_side(1301, 20_000, 1, 60_000, 300)
+    b = rand_side(1302, 60_000, 1, 60_000, 300)
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    assert np.array_equal(_inner(eng_local, a, b, 1), want)
+    st = eng_local.stats()
+    assert st["sort_resorted"] and not st["sort_local"]
+    assert np.array_equal(eng_local.semi_join(dev(a), dev(b), 1).cpu().numpy(), ora.c_semi_anti(a, b, False))
+    assert np.array_equal(_inner(eng_local, a, b, 1), want)
+    assert not eng_local.stats()["sort_local"]
+
+
+def test_row_operators_recover_from_an_oversized_bucket(eng_local):
+    # same, discovered by a per-row operator first (its read-back is the only one of the call)
+    a = rand_side(1311, 20_000, 1, 60_000, 300)
+    b = rand_side(1312, 50_000, 1, 60_000, 300)
+    assert np.array_equal(eng_local.count_overlaps(dev(a), dev(b), 1).cpu().numpy(), ora.c_count(a, b, "sweep"))
+    assert eng_local.stats()["sort_resorted"]
+    idx, dist = eng_local.nearest(dev(a), dev(b), 1)
+    assert np.array_equal(dist.cpu().numpy(), ora.c_nearest_k1(a, b, method="sweep")[1])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_three_stage_randomized_sweep(eng_local, seed):
+    r = np.random.default_rng(3000 + seed)
+    encs = list(ora.ENCODING_OFFSETS)
+    n_chrom = int(r.integers(1, 30))
+    max_start = int(r.choice([2_000, 400_000, 80_000_000]))
+    max_len = int(r.choice([3, 80, 5_000]))
+    min_len = -3 if seed % 2 else 1
+    na, nb = (int(r.choice([0, 1, 65, 700, 9_000, 120_000])) for _ in range(2))
+    a = rand_side(7000 + seed, na, n_chrom, max_start, max_len + 1, min_len=min_len, enc=encs[int(r.integers(0, 4))])
+    b = rand_side(8000 + seed, nb, n_chrom, max_start, max_len + 1, min_len=min_len, enc=encs[int(r.integers(0, 4))])
+    _all_ops(eng_local, a, b, n_chrom, nearest=min_len >= 0)
