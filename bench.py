@@ -250,6 +250,13 @@ def main() -> None:
     eng = HipEngine(dev_index)
     out_cap = 0
     out = None
+
+    def alloc_out(n):
+        """Caller-owned output: row_a / row_b, 5 % head-room, each row a 2 MiB multiple long."""
+        cap = (int(n * 1.05) + 1024 + (1 << 19) - 1) >> 19 << 19
+        if os.environ.get("GIQL_BENCH_OUT", "split") == "joint":   # probe: both rows in ONE allocation
+            return cap, torch.empty((2, cap), dtype=torch.int32, device=dev)
+        return cap, (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev))
     # shard-local row index -> global row id: ranks own disjoint chromosome sets and the
     # global table is "rows of lower ranks first", so the map is one offset per side
     # (giql_amd.distributed.sharded_inner_join handles arbitrary row sets with the take kernel)
@@ -284,6 +291,10 @@ def main() -> None:
             send = xg.send_block(max(counts))
             ra, rb = send[0, :n], send[1, :n]
             eng.inner_fill(ra, rb)
+        elif out is not None and os.environ.get("GIQL_BENCH_NO_FUSE"):
+            n = eng.inner_plan(a, b, n_chrom)
+            ra, rb = out[0][:n], out[1][:n]
+            eng.inner_fill(ra, rb)
         elif out is not None:
             # one C-ABI call into the buffers of the previous step (plan + fill, no stream sync
             # between them when the context's guesses hold); a larger result re-allocates
@@ -294,15 +305,13 @@ def main() -> None:
                     raise
                 n = eng.last_pairs
                 out = None
-                out_cap = int(n * 1.05) + 1024
-                out = torch.empty((2, out_cap), dtype=torch.int32, device=dev)
-                eng.inner_fill(out[0, :n], out[1, :n])
-            ra, rb = out[0, :n], out[1, :n]
+                out_cap, out = alloc_out(n)
+                eng.inner_fill(out[0][:n], out[1][:n])
+            ra, rb = out[0][:n], out[1][:n]
         else:
             n = eng.inner_plan(a, b, n_chrom)
-            out_cap = int(n * 1.05) + 1024
-            out = torch.empty((2, out_cap), dtype=torch.int32, device=dev)
-            ra, rb = out[0, :n], out[1, :n]
+            out_cap, out = alloc_out(n)
+            ra, rb = out[0][:n], out[1][:n]
             eng.inner_fill(ra, rb)
         last_pairs[0] = (ra, rb)
         if ev:

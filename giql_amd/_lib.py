@@ -37,6 +37,7 @@ SYMBOLS = [
     "giql_hip_take_dev", "giql_hip_take_utf8_plan_dev", "giql_hip_take_utf8_fill_dev",
     "giql_hip_select_dev", "giql_hip_mark_dev", "giql_hip_cluster_dev", "giql_hip_merge_dev",
     "giql_hip_group_rows_dev", "giql_hip_segment_sum_dev", "giql_hip_inner_join_dev",
+    "giql_hip_inner_plan_export_dev", "giql_hip_fill_from_plan_dev", "giql_hip_copy_probe_dev",
 ]
 
 
@@ -171,6 +172,9 @@ def load() -> ctypes.CDLL:
     L.giql_hip_group_rows_dev.argtypes = [vp, P(CSide), i32, vp, vp, P(i64), vp]
     L.giql_hip_segment_sum_dev.argtypes = [vp, vp, vp, i64, vp, i64, vp]
     L.giql_hip_cluster_dev.argtypes = [vp, P(CSide), i32, i64, vp, vp]
+    L.giql_hip_inner_plan_export_dev.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, P(i32), P(i64), P(i64), vp]
+    L.giql_hip_fill_from_plan_dev.argtypes = [vp, vp, vp, vp, i64, vp, i64, vp, vp, i64, i64, vp, P(i64)]
+    L.giql_hip_copy_probe_dev.argtypes = [vp, vp, vp, i64, i32, vp, P(ctypes.c_double)]
     L.giql_hip_merge_dev.argtypes = [vp, P(CSide), i32, i64, vp, vp, vp, vp, i64, P(i64), vp]
     _lib = L
     return L

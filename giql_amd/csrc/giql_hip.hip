@@ -87,6 +87,7 @@ struct InnerState {
   u64* c1_base = nullptr;  // class-1 output base per block
   u32* wlo2 = nullptr;
   u32* lo2 = nullptr;    // class-2 first matching B index per A row
+  u32* cnt2 = nullptr;   // ... and the number of matches (kept for giql_hip_inner_plan_export_dev)
   u64* off2 = nullptr;   // class-2 exclusive output offsets
   // uniform-length form: 0 = general two-class join; 1 = B is uniform (queries =
   // A rows); 2 = A is uniform (queries = B rows)
@@ -137,6 +138,8 @@ struct giql_hip_ctx {
   int local_resorts = 0;      // calls repeated with the four-pass sort
   bool last_sort_local = false;  // the call in flight sorted at least one side in three stages
   u32* bucket_bnd = nullptr;  // [BS_BUCKETS + 1] bucket boundaries of the sort in flight
+  char* xplan = nullptr;      // scratch of giql_hip_fill_from_plan_dev (offsets + scan partials), grown on demand
+  size_t xplan_cap = 0;
 
   // profiling
   int profiling = 0;          // 0 off, 1 every phase, 2 only the sort passes (the dominant kernel)
@@ -186,6 +189,7 @@ static int ensure_arena(giql_hip_ctx* ctx, size_t bytes, hipStream_t stream) {
     return set_err(GIQL_ERR_NOMEM, "hipMalloc(%zu bytes) for the workspace failed: %s", want,
                    hipGetErrorString(e));
   ctx->arena_cap = want;
+  if (getenv("GIQL_HIP_DEBUG_ADDR")) fprintf(stderr, "[giql_hip] arena %p + %zu bytes\n", (void*)ctx->arena, want);
   return GIQL_OK;
 }
 
@@ -295,6 +299,8 @@ struct LinBufs {
   u32* top_partial = nullptr;  // [LIN_HIST_REPLICAS][MM_HIST_CHROMS][256]
 };
 
+static inline bool sort_is_local(const giql_hip_ctx* ctx, size_t n);
+
 // hist_side = 0 / 1 (with hist_partial and lb.abase / lb.top_partial): that side's span pass
 // also counts the digits of its aligned keys (k_chrom_minmax<true>) and the chromosome bases
 // are laid out 2^24-aligned when they fit (meta->aligned_ok).
@@ -319,12 +325,16 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
     u32 grid = cdiv((u64)s.n, (u64)(with_hist ? MM_NT_HIST : MM_NT) * MM_ITEMS);
     if (grid > (u32)MM_MAX_BLOCKS) grid = MM_MAX_BLOCKS;
     nblk[k] = (int)grid;
-    if (with_hist)
-      hipLaunchKernelGGL((k_chrom_minmax<true, MM_NT_HIST>), dim3(grid), dim3(MM_NT_HIST), lds, st, s.chrom, s.start, s.end,
+    if (with_hist && sort_is_local(ctx, (size_t)s.n))  // the low digits are sorted in LDS: not counted
+      hipLaunchKernelGGL((k_chrom_minmax<2, MM_NT_HIST>), dim3(grid), dim3(MM_NT_HIST), lds, st, s.chrom, s.start, s.end,
+                         (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
+                         lb.len_part, s.start_off, hist_partial, lb.top_partial);
+    else if (with_hist)
+      hipLaunchKernelGGL((k_chrom_minmax<1, MM_NT_HIST>), dim3(grid), dim3(MM_NT_HIST), lds, st, s.chrom, s.start, s.end,
                          (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
                          lb.len_part, s.start_off, hist_partial, lb.top_partial);
     else
-      hipLaunchKernelGGL((k_chrom_minmax<false, MM_NT>), dim3(grid), dim3(MM_NT), lds, st, s.chrom, s.start, s.end,
+      hipLaunchKernelGGL((k_chrom_minmax<0, MM_NT>), dim3(grid), dim3(MM_NT), lds, st, s.chrom, s.start, s.end,
                          (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
                          lb.len_part, 0, (u32*)nullptr, (u32*)nullptr);
   }
@@ -683,6 +693,7 @@ int giql_hip_destroy(giql_hip_ctx* ctx) {
   if (ctx->d_meta) (void)hipFree(ctx->d_meta);
   if (ctx->d_scratch64) (void)hipFree(ctx->d_scratch64);
   if (ctx->bucket_bnd) (void)hipFree(ctx->bucket_bnd);
+  if (ctx->xplan) (void)hipFree(ctx->xplan);
   if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
   delete ctx;
   return GIQL_OK;
@@ -780,6 +791,7 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     const size_t nq2 = ctx->no_uniform ? na : n_max;  // the uniform form may query the other side
     S.wlo2 = c.take<u32>((size_t)cdiv(nq2, TQ2) + 2);
     cnt2 = c.take<u32>(nq2);
+    S.cnt2 = cnt2;
     S.lo2 = c.take<u32>(nq2);
     S.off2 = c.take<u64>(nq2 + 1);
     ctx->irr_a_list = c.take<u32>(na);
@@ -1779,6 +1791,164 @@ int giql_hip_pairs_checksum_dev(giql_hip_ctx* ctx, const int32_t* row_a, const i
   return GIQL_OK;
 }
 
+
+// ------------------------------------------- compact plan (multi-GPU exchange)
+// The uniform-length plan IS a compact description of the result: per query row its id, the
+// first matching position in the other side's sorted order and the number of matches, plus
+// that side's row ids in sorted order -- 12 B per query row + 4 B per row instead of 8 B per
+// pair (65 MB instead of 400 MB per rank at BASELINE config 4 on 8 GPUs).  Ranks exchange THAT
+// and every receiver expands it with the same partition + fill kernels the local join uses.
+__global__ __launch_bounds__(256) void k_plan_export(const u32* __restrict__ q_rid, const u32* __restrict__ lo,
+                                                      const u32* __restrict__ cnt, u32 n_q,
+                                                      const u32* __restrict__ s_rid, u32 n_s, u32 q_add, u32 s_add,
+                                                      int32_t* __restrict__ q_rid_out, u32* __restrict__ lo_out,
+                                                      u32* __restrict__ cnt_out, int32_t* __restrict__ s_rid_out) {
+  const u64 stride = (u64)gridDim.x * 256;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < (u64)n_q + n_s; i += stride) {
+    if (i < n_q) {
+      q_rid_out[i] = (int32_t)(q_rid[i] + q_add);
+      lo_out[i] = lo[i];
+      cnt_out[i] = cnt[i];
+    } else {
+      const u64 j = i - n_q;
+      s_rid_out[j] = (int32_t)(s_rid[j] + s_add);
+    }
+  }
+}
+
+int giql_hip_inner_plan_export_dev(giql_hip_ctx* ctx, int32_t* q_rid_out, uint32_t* lo_out, uint32_t* cnt_out,
+                                   int32_t* s_rid_out, int64_t q_capacity, int64_t s_capacity,
+                                   int32_t rid_add_a, int32_t rid_add_b, int32_t* query_is_a, int64_t* n_q,
+                                   int64_t* n_s, void* stream) {
+  if (!ctx || !query_is_a || !n_q || !n_s) return set_err(GIQL_ERR_INVALID, "NULL argument");
+  if (!ctx->planned) return set_err(GIQL_ERR_STATE, "plan export without a successful inner_plan");
+  InnerState& S = ctx->inner;
+  const bool empty = ctx->n_reg + ctx->n_irr == 0;
+  if (!empty && (S.uniform == 0 || ctx->n_irr != 0 || ctx->n_c1 != 0))
+    return set_err(GIQL_ERR_STATE, "the last plan is not in the compact single-range form "
+                                   "(general two-class join or irregular rows): exchange the pairs instead");
+  const bool q_is_a = S.uniform != 2;
+  *query_is_a = q_is_a ? 1 : 0;
+  *n_q = empty ? 0 : (q_is_a ? ctx->n_a : ctx->n_b);
+  *n_s = empty ? 0 : (q_is_a ? ctx->n_b : ctx->n_a);
+  if (empty) return GIQL_OK;
+  if (*n_q > q_capacity || *n_s > s_capacity)
+    return set_err(GIQL_ERR_CAPACITY, "plan export needs %lld query rows and %lld sorted rows", (long long)*n_q,
+                   (long long)*n_s);
+  if (!q_rid_out || !lo_out || !cnt_out || !s_rid_out) return set_err(GIQL_ERR_INVALID, "NULL output");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const u32* qrid = q_is_a ? S.sa.rid[0] : S.sb.rid[0];
+  const u32* srid = q_is_a ? S.sb.rid[0] : S.sa.rid[0];
+  u32 grid = cdiv((u64)(*n_q + *n_s), 256 * 8);
+  if (grid > GIQL_STREAM_GRID) grid = GIQL_STREAM_GRID;
+  hipLaunchKernelGGL(k_plan_export, dim3(grid), dim3(256), 0, st, qrid, S.lo2, S.cnt2, (u32)*n_q, srid, (u32)*n_s,
+                     (u32)(q_is_a ? rid_add_a : rid_add_b), (u32)(q_is_a ? rid_add_b : rid_add_a), q_rid_out,
+                     lo_out, cnt_out, s_rid_out);
+  return post_launch("plan export");
+}
+
+int giql_hip_fill_from_plan_dev(giql_hip_ctx* ctx, const int32_t* q_rid, const uint32_t* lo, const uint32_t* cnt,
+                                int64_t n_q, const int32_t* s_rid, int64_t n_s, int32_t* row_q, int32_t* row_s,
+                                int64_t capacity, int64_t n_pairs_expected, void* stream, int64_t* n_pairs) {
+  if (!ctx || !n_pairs) return set_err(GIQL_ERR_INVALID, "ctx/n_pairs is NULL");
+  if (n_q < 0 || n_q > 0x7FFFFFF0ll || n_s < 0 || n_s > 0x7FFFFFF0ll || capacity < 0)
+    return set_err(GIQL_ERR_INVALID, "bad sizes");
+  *n_pairs = 0;
+  if (n_q == 0 || n_s == 0) return GIQL_OK;
+  if (!q_rid || !lo || !cnt || !s_rid) return set_err(GIQL_ERR_INVALID, "NULL plan array");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  constexpr u32 T2 = FILL_NT * FILL_ITEMS_C2;
+  // scratch: exclusive u64 offsets [n_q + 1], scan partials, partition array for `capacity` pairs
+  const u64 nt_cap = ((u64)capacity + T2 - 1) / T2;
+  if (nt_cap > 0x7FFFFFF0ull) return set_err(GIQL_ERR_INVALID, "output too large");
+  u64* off = nullptr;
+  u64* bsums = nullptr;
+  u32* part = nullptr;
+  auto carve = [&](char* base) {
+    Carver c{base};
+    off = c.take<u64>((size_t)n_q + 1);
+    bsums = c.take<u64>(cdiv((u64)n_q, SCAN_TILE) + 2);
+    part = c.take<u32>((size_t)nt_cap + 2);
+    return c.off;
+  };
+  const size_t need = carve(nullptr);
+  if (need > ctx->xplan_cap) {
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ctx->xplan) HIP_TRY(hipFree(ctx->xplan));
+    ctx->xplan = nullptr;
+    ctx->xplan_cap = 0;
+    const size_t want = align_up(need + need / 8, (size_t)1 << 20);
+    hipError_t e = hipMalloc((void**)&ctx->xplan, want);
+    if (e != hipSuccess) return set_err(GIQL_ERR_NOMEM, "hipMalloc(%zu bytes) for the plan scratch failed", want);
+    ctx->xplan_cap = want;
+  }
+  carve(ctx->xplan);
+  GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt, (u64)n_q, off, bsums, off + n_q));
+  u64 total = 0;
+  if (n_pairs_expected >= 0) {
+    total = (u64)n_pairs_expected;  // the caller knows it (all-gathered counts): no read-back, no stream sync
+  } else {
+    HIP_TRY(hipMemcpyAsync(&total, off + n_q, sizeof(u64), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  *n_pairs = (int64_t)total;
+  if (total == 0) return GIQL_OK;
+  if (total > (u64)capacity)
+    return set_err(GIQL_ERR_CAPACITY, "capacity %lld < %llu pairs", (long long)capacity, (unsigned long long)total);
+  if (!row_q || !row_s) return set_err(GIQL_ERR_INVALID, "row_q/row_s is NULL");
+  const u32 nt = (u32)((total + T2 - 1) / T2);
+  {
+    Phase ph(ctx, st, GIQL_PH_PARTITION);
+    hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt + 1, 256)), dim3(256), 0, st, off, (u32)n_q, (u64)0, T2, nt,
+                       part, (const u64*)(off + n_q), (u64)capacity);
+  }
+  {
+    // the pair count is read on the device (off[n_q]): a wrong n_pairs_expected cannot overrun
+    Phase ph(ctx, st, GIQL_PH_FILL);
+    hipLaunchKernelGGL((k_fill<FILL_ITEMS_C2>), dim3(nt), dim3(FILL_NT), 0, st, off, lo,
+                       reinterpret_cast<const u32*>(q_rid), (u32)n_q, reinterpret_cast<const u32*>(s_rid), part,
+                       (u64)0, (u64)0, row_q, row_s, (const u64*)(off + n_q), (u64)capacity);
+  }
+  return post_launch("fill from plan");
+}
+
+// ------------------------------------------------------------ copy probe
+// The box's own streaming-copy rate with THIS library's access pattern (16 B per lane, grid-
+// stride): the yardstick bench.py reports next to the 8 TB/s peak.
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, u64 n16) {
+  const u64 stride = (u64)gridDim.x * 256;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
+int giql_hip_copy_probe_dev(giql_hip_ctx* ctx, const void* src, void* dst, int64_t bytes, int32_t reps,
+                            void* stream, double* gbytes_per_s) {
+  if (!ctx || !src || !dst || !gbytes_per_s || bytes < 16 || reps < 1) return set_err(GIQL_ERR_INVALID, "bad arguments");
+  if (((uintptr_t)src | (uintptr_t)dst) & 15) return set_err(GIQL_ERR_INVALID, "buffers must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const u64 n16 = (u64)bytes / 16;
+  const u32 grid = (u32)ctx->n_cu * 8;  // one resident wave of 256-thread blocks
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n16);  // warm-up
+  (void)hipEventRecord(e0, st);
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n16);
+  (void)hipEventRecord(e1, st);
+  hipError_t e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return set_err(GIQL_ERR_HIP, "copy probe failed: %s", hipGetErrorString(e));
+  GIQL_TRY(post_launch("copy probe"));
+  *gbytes_per_s = ms > 0.f ? 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e6) : 0.0;
+  return GIQL_OK;
+}
+
 // ------------------------------------------------ projection (Arrow take)
 int giql_hip_take_dev(giql_hip_ctx* ctx, const void* const* cols, const int32_t* elem_bytes,
                       int32_t n_cols, int64_t n_rows, const int32_t* idx, int64_t n,
@@ -2019,6 +2189,13 @@ static int upload_side(const giql_side* h, DevSide& d) {
   return GIQL_OK;
 }
 
+// pinned host memory for library-owned outputs (released by giql_hip_free_host)
+static void* host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
 struct DevBuf {
   void* p = nullptr;
   ~DevBuf() {
@@ -2039,28 +2216,33 @@ int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, in
   int64_t n = 0;
   GIQL_TRY(giql_hip_inner_plan_dev(ctx, &da.s, &db.s, n_chrom, nullptr, &n));
   *n_pairs = n;
-  int32_t* ha = (int32_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
-  int32_t* hb = (int32_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+  // library-owned host outputs are PINNED (the D2H copy of the pairs runs at link speed, not
+  // through a pageable bounce buffer); giql_hip_free_host releases them
+  int32_t* ha = (int32_t*)host_alloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+  int32_t* hb = (int32_t*)host_alloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
   if (!ha || !hb) {
-    free(ha);
-    free(hb);
+    giql_hip_free_host(ha);
+    giql_hip_free_host(hb);
     return set_err(GIQL_ERR_NOMEM, "out of host memory for %lld pairs", (long long)n);
   }
   if (n > 0) {
     DevBuf out;
-    hipError_t e = hipMalloc(&out.p, 2 * (size_t)n * sizeof(int32_t));
+    // row_b starts on a 2 MiB boundary of its own: a row that begins in the middle of a cache
+    // line makes every 256-byte wave store of the fill touch three lines instead of two
+    const size_t stride = align_up((size_t)n, (size_t)1 << 19);
+    hipError_t e = hipMalloc(&out.p, 2 * stride * sizeof(int32_t));
     int rc = GIQL_OK;
     if (e != hipSuccess) rc = set_err(GIQL_ERR_NOMEM, "hipMalloc for %lld pairs failed", (long long)n);
     int32_t* d_a = (int32_t*)out.p;
-    int32_t* d_b = d_a + n;
+    int32_t* d_b = d_a + stride;
     if (rc == GIQL_OK) rc = giql_hip_inner_fill_dev(ctx, d_a, d_b, n, nullptr);
     if (rc == GIQL_OK && hipMemcpy(ha, d_a, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
       rc = set_err(GIQL_ERR_HIP, "D2H copy of row_a failed");
     if (rc == GIQL_OK && hipMemcpy(hb, d_b, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
       rc = set_err(GIQL_ERR_HIP, "D2H copy of row_b failed");
     if (rc != GIQL_OK) {
-      free(ha);
-      free(hb);
+      giql_hip_free_host(ha);
+      giql_hip_free_host(hb);
       return rc;
     }
   }
@@ -2084,10 +2266,10 @@ int giql_hip_semi_anti(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b
   HIP_TRY(hipMalloc(&out.p, (na ? na : 1) * sizeof(int32_t)));
   int64_t n = 0;
   GIQL_TRY(giql_hip_semi_anti_dev(ctx, &da.s, &db.s, n_chrom, anti, (int32_t*)out.p, &n, nullptr));
-  int32_t* h = (int32_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+  int32_t* h = (int32_t*)host_alloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
   if (!h) return set_err(GIQL_ERR_NOMEM, "out of host memory");
   if (n > 0 && hipMemcpy(h, out.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
-    free(h);
+    giql_hip_free_host(h);
     return set_err(GIQL_ERR_HIP, "D2H copy failed");
   }
   *n_out = n;
@@ -2134,7 +2316,9 @@ int giql_hip_nearest(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, 
   return GIQL_OK;
 }
 
-void giql_hip_free_host(void* p) { free(p); }
+void giql_hip_free_host(void* p) {
+  if (p) (void)hipHostFree(p);
+}
 
 #if defined(GIQL_OS_TIMELINE)
 // diagnostic builds only (tools/os_timeline.py): the phase stamps of the last sort pass

@@ -80,7 +80,10 @@ constexpr int MM_TOP_WORDS = MM_HIST_CHROMS * 256;
 // Per-chromosome min/max of the raw coordinates (both columns).  LDS-privatised
 // atomics; a per-thread run cache keeps chromosome-sorted input (the common BED
 // case) from serialising on one LDS address.
-template <bool HIST, int NT>
+// HIST: 0 = min/max and lengths only; 1 = also the four digit histograms; 2 = only the two high
+// digits (the three-stage sort scatters on bits 16-31 only: its low bits are sorted in LDS, and the
+// two per-row LDS atomics of the low digits are what bounds this pass).
+template <int HIST, int NT>
 __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chrom,
                                                          const int* __restrict__ start,
                                                          const int* __restrict__ end, i64 n,
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
         const bool ok = okv[u];
         const u32 pos = (u32)(sv[u] + start_off);
         const u32 tb = ((u32)cv[u] & (MM_HIST_CHROMS - 1)) * 256u + (pos >> 24);
-        if (ok) {
+        if (HIST == 1 && ok) {
           atomicAdd(&s_hist[pos & 0xFFu], 1u);
           atomicAdd(&s_hist[256 + ((pos >> 8) & 0xFFu)], 1u);
         }
@@ -990,8 +993,13 @@ __device__ __forceinline__ void fill_wave(const u32* s_rel, const u32* s_jbase,
   for (int it = 0; it < NWIN; it++) {
     const u32 p_rel = p_w0 + it * WAVE + lane;
     if (FULL || p_rel < tile_len) {
+#if defined(GIQL_FILL_STORE_NT)  // probe: non-temporal output stores
+      __builtin_nontemporal_store((int32_t)qr[it], rq + p_rel);
+      __builtin_nontemporal_store((int32_t)sr[it], rs + p_rel);
+#else
       rq[p_rel] = (int32_t)qr[it];
       rs[p_rel] = (int32_t)sr[it];
+#endif
     }
   }
 }

@@ -35,8 +35,13 @@
  *     sides (the reference compares VARCHAR values).
  *   - "_dev" entry points take DEVICE pointers and a hipStream_t (as void*; NULL
  *     = the default stream); results stay on the device.  The host-buffer entry
- *     points stage H2D/D2H themselves and return malloc'ed host arrays that the
- *     caller releases with giql_hip_free_host().
+ *     points stage H2D/D2H themselves and return PINNED host arrays
+ *     (hipHostMalloc: the D2H copy runs at link speed) that the caller releases
+ *     with giql_hip_free_host() -- not with free().
+ *   - caller-owned DEVICE outputs (row_a / row_b of the fill) should start on a
+ *     128-byte boundary each: the fill stores 256 bytes per wave instruction, and a
+ *     row that begins inside a cache line makes every store touch three lines
+ *     instead of two (measured 0.73-0.80 -> 0.70 ms on the 404M-pair fill).
  *   - Output order is unspecified (as upstream); pairs are a
  *     multiset (bag semantics).
  */
@@ -303,6 +308,43 @@ void giql_hip_free_host(void* p);
 int giql_hip_pairs_checksum_dev(giql_hip_ctx* ctx, const int32_t* row_a,
                                 const int32_t* row_b, int64_t n, void* stream,
                                 uint64_t* out);
+
+/* ---- compact plan: the multi-GPU exchange ------------
+ * Replaces the reference's UNION ALL over per-chromosome branches
+ * (src/giql/expanders/_per_chrom.py:46-74) across devices.  After a successful
+ * giql_hip_inner_plan_dev in the single-range (uniform-length) form with no
+ * irregular rows, the plan is a compact description of the pairs: per query
+ * row {row id, first matching position, match count} + the other side's row ids
+ * in sorted order.  Export copies it into caller buffers, adding rid_add_a /
+ * rid_add_b to the A / B row ids on the way (shard-local -> global ids);
+ * *query_is_a tells which side the query rows are.  GIQL_ERR_STATE when the
+ * last plan has another form (the caller then exchanges the pairs themselves),
+ * GIQL_ERR_CAPACITY (with *n_q / *n_s set) when a buffer is short. */
+int giql_hip_inner_plan_export_dev(giql_hip_ctx* ctx, int32_t* q_rid_out,
+                                   uint32_t* lo_out, uint32_t* cnt_out,
+                                   int32_t* s_rid_out, int64_t q_capacity,
+                                   int64_t s_capacity, int32_t rid_add_a,
+                                   int32_t rid_add_b, int32_t* query_is_a,
+                                   int64_t* n_q, int64_t* n_s, void* stream);
+/* Expand a compact plan (possibly another device's) into index pairs: pair k of
+ * query row i is (q_rid[i], s_rid[lo[i] + k]), k < cnt[i]; row_q receives the
+ * query side's ids.  n_pairs_expected >= 0: the caller knows the pair count
+ * (e.g. from an all-gather of counts) and no read-back / stream sync happens;
+ * -1: the count is read back.  The kernels take the count from the device
+ * either way, so a wrong expectation cannot overrun `capacity`. */
+int giql_hip_fill_from_plan_dev(giql_hip_ctx* ctx, const int32_t* q_rid,
+                                const uint32_t* lo, const uint32_t* cnt,
+                                int64_t n_q, const int32_t* s_rid, int64_t n_s,
+                                int32_t* row_q, int32_t* row_s, int64_t capacity,
+                                int64_t n_pairs_expected, void* stream,
+                                int64_t* n_pairs);
+
+/* Streaming-copy rate of this device with the library's access pattern (16 B
+ * per lane), bytes read + written per second / 1e9: the measured yardstick
+ * bench.py reports next to the 8 TB/s HBM peak. */
+int giql_hip_copy_probe_dev(giql_hip_ctx* ctx, const void* src, void* dst,
+                            int64_t bytes, int32_t reps, void* stream,
+                            double* gbytes_per_s);
 
 #ifdef __cplusplus
 }
