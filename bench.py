@@ -1,34 +1,40 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the INTERSECTS hot path on MI355X.
+"""bench.py -- the INTERSECTS hot path on MI355X, one JSON line per run.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
-A *step* is one full pass of the hot path (plan: linearise + sort + count + scan;
-fill: pair materialisation) over one batch of synthetic input already resident in
-HBM.  Workload (BASELINE.json configs[3], SURVEY.md §8(d) cfg 4): 10M peaks x
-100M reads, 24 chromosomes with hg38 lengths, int32 columns, unsorted rows.
+A *step* is one full pass of the hot path over one batch of synthetic input already resident
+in HBM.  The default workload is BASELINE.json configs[3] (cfg 4): 10M
+peaks x 100M reads, 24 chromosomes with hg38 lengths, int32 columns, unsorted rows, INNER join
+-> (row_a, row_b) index pairs.  ``--workload`` selects the other BASELINE configs (1M x 1M single
+chromosome, SEMI / ANTI / COUNT 1M x 10M, NEAREST 10M x 10M) on the same contract.
 
-N > 1: launched as ``python -m torch.distributed.run --nproc-per-node N ...``;
-chromosomes are LPT-packed onto the ranks (giql_amd.shard), every rank joins its
-own chromosomes, then the pair counts are all-gathered and the index pairs are
-gathered with one RCCL all-gather (padded to the largest shard).  Total work is
-fixed as N grows ("strong" scaling).
+N > 1 (default workload): one rank per GPU.  ``python bench.py --gpus N`` without WORLD_SIZE in the
+environment starts ``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a child
+process -- before anything touches the GPU -- and relays rank 0's JSON line and the exit code;
+under torch.distributed.run it is a rank.  Chromosomes are LPT-packed onto the ranks
+(giql_amd.shard), every rank plans its own chromosomes with no data-path collective, then ONE
+exchange: an all-gather of the per-rank sizes, one RCCL all-gather of the COMPACT plan (per query
+row {row id, first match, match count} + the other side's sorted row ids, 65 MB per rank instead of
+400 MB of pairs at N = 8), and every rank expands the gathered plan into the global pairs.  Total
+work is fixed as N grows ("strong" scaling).
 
-Prints ONE JSON line on rank 0 (see the task contract): metric / value / unit,
-plus ``roofline`` for the dominant kernel (algorithmic bytes per launch over the
-hipEvent-measured average launch time) and ``cpu_baseline`` (the oracle's
-OpenMP sort-merge port timed on the host cores, bounded sample).
+The line carries ``roofline`` (dominant kernel: algorithmic bytes per launch, as accounted by
+the host code that issues the launches, over the hipEvent-measured launch time of the timed
+steps) and ``cpu_baseline`` (the reference's DuckDB path when ``import duckdb`` works on the box,
+else the oracle's OpenMP sort-merge port), which is also the run's parity check.
 """
 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -36,10 +42,25 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+HG38 = "hg38"
 WORKLOADS = {
-    # name: (n_a, kind_a, seed_a, n_b, kind_b, seed_b)
-    "cfg4_10Mx100M_24chrom": (10_000_000, "peaks", 5, 100_000_000, "reads", 6),
-    "cfg4_small_1Mx10M_24chrom": (1_000_000, "peaks", 5, 10_000_000, "reads", 6),
+    # name: op, (n_a, kind_a, seed_a), (n_b, kind_b, seed_b), genome (HG38 or a single-chromosome length)
+    "cfg4_10Mx100M_24chrom": ("inner", (10_000_000, "peaks", 5), (100_000_000, "reads", 6), HG38),
+    "cfg4_small_1Mx10M_24chrom": ("inner", (1_000_000, "peaks", 5), (10_000_000, "reads", 6), HG38),
+    "cfg2_sparse_1Mx1M_1chrom": ("inner", (1_000_000, "peaks", 1), (1_000_000, "peaks", 2), 248_956_422),
+    "cfg2_dense_1Mx1M_1chrom": ("inner", (1_000_000, "peaks", 1), (1_000_000, "peaks", 2), 10_000_000),
+    "cfg3_semi_1Mx10M_24chrom": ("semi", (1_000_000, "peaks", 3), (10_000_000, "reads", 4), HG38),
+    "cfg3_anti_1Mx10M_24chrom": ("anti", (1_000_000, "peaks", 3), (10_000_000, "reads", 4), HG38),
+    "cfg3_count_1Mx10M_24chrom": ("count", (1_000_000, "peaks", 3), (10_000_000, "reads", 4), HG38),
+    "cfg5_nearest_10Mx10M_24chrom": ("nearest", (10_000_000, "peaks", 7), (10_000_000, "peaks", 8), HG38),
+}
+DEFAULT_WORKLOAD = "cfg4_10Mx100M_24chrom"
+METRIC = {
+    "inner": ("overlap-pairs/sec, {a}x{b} INTERSECTS inner join", "pairs/s"),
+    "semi": ("input rows/sec, {a}x{b} INTERSECTS SEMI join", "rows/s"),
+    "anti": ("input rows/sec, {a}x{b} INTERSECTS ANTI join", "rows/s"),
+    "count": ("input rows/sec, {a}x{b} count_overlaps", "rows/s"),
+    "nearest": ("input rows/sec, {a}x{b} NEAREST k=1", "rows/s"),
 }
 
 
@@ -48,28 +69,63 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--workload", default="cfg4_10Mx100M_24chrom", choices=sorted(WORKLOADS))
+    p.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the general-form / end-to-end / copy-probe legs that follow the timed region")
+    p.add_argument("--exchange", default="plan", choices=["plan", "pairs", "none"],
+                   help="N>1: what the ranks all-gather -- the compact plan (default), the expanded pairs, nothing")
+    p.add_argument("--no-gather", action="store_true", help="same as --exchange none (compute-only scaling)")
     p.add_argument("--force-exchange", action="store_true", help=argparse.SUPPRESS)
-    p.add_argument("--no-gather", action="store_true",
-                   help="N>1: skip the final RCCL gather of the pairs (compute-only scaling)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                   help="N>1 exchange backend; 'gloo' is a rehearsal mode for boxes with fewer "
-                        "GPUs than ranks (ranks share GPUs, pairs are exchanged through host memory)")
+                   help="N>1 exchange backend; 'gloo' is a rehearsal mode for boxes with fewer GPUs than ranks "
+                        "(ranks share GPUs, the exchange runs through host memory)")
     p.add_argument("--cpu-sample-chroms", default="18,19,20,21",
-                   help="chromosome ids of the bounded cpu_baseline sample")
-    return p.parse_args()
+                   help="chromosome ids of the bounded cpu_baseline probe")
+    p.add_argument("--master-port", type=int, default=29531)
+    a = p.parse_args()
+    if a.no_gather:
+        a.exchange = "none"
+    return a
 
 
-def phase_bytes(phase: str, n_a: int, n_b: int, n_out: int, form: str = "general", span_hist: bool = False) -> float:
-    """Algorithmic (minimal) HBM bytes moved by ALL launches of one phase per step.
+def self_launch(args) -> None:
+    """``python bench.py --gpus N`` (N > 1) outside torch.distributed.run: start the N ranks as a
+    child process and relay its output and exit code.  Nothing in THIS process has touched the GPU
+    (no torch import yet), and it never execs."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env)
+    sys.exit(proc.returncode)
 
-    DESIGN.md §3 states each figure: read every input of the kernel once, write
-    every output once, nothing else.  In the uniform-length forms the fixed-length
-    side is sorted as (key, rid) -- 8 B/row -- and there is no class-1 stage.  With
-    ``span_hist`` (the digit histogram taken in the span pass) that side has no linearize pass
-    and its first sort pass reads (chrom, start) -- 8 B/row -- instead of the 4-byte key.
-    """
+
+# --------------------------------------------------------------------------- bytes
+def sort_bytes_model(sorts, local_min_rows=1 << 25):
+    """Algorithmic bytes of the sort launches, mirroring the host code's own accounting
+    (run_sort_onesweep in giql_amd/csrc/giql_hip.hip): ``sorts`` = [(rows, payload_arrays, keygen)].
+    A pass reads the key and the payload arrays it carries and writes them, 4 B each; the first
+    pass synthesises the row ids instead of reading them; a KEYGEN first pass reads (chrom, start);
+    sides of ``local_min_rows`` and more take two global passes + the in-LDS bucket sort.
+    Returns (global passes, bucket sort) bytes."""
+    scatter = local = 0.0
+    for n, payload, keygen in sorts:
+        w = 1 + payload
+        n_pass = 2 if n >= local_min_rows else 4
+        first_in = 2 if keygen else w - (1 if payload else 0)   # the rid array is not read by a first pass
+        scatter += 4.0 * n * ((first_in + w) + (n_pass - 1) * 2 * w)
+        if n >= local_min_rows:
+            local += 8.0 * n * w
+    return scatter, local
+
+
+def inner_phase_bytes(n_a, n_b, n_out, form, span_hist, stats_bytes=None):
+    """Algorithmic (minimal) HBM bytes of every phase of one INNER join: read every input of a
+    kernel once, write every output once (DESIGN.md section 3 states each figure).  The sort
+    phases take the library's own accounting (``stats.phase_bytes``) when it is there."""
     n = n_a + n_b
     if form == "uniform_b":
         n_q, n_u = n_a, n_b
@@ -78,143 +134,196 @@ def phase_bytes(phase: str, n_a: int, n_b: int, n_out: int, form: str = "general
     else:
         n_q = n_u = 0
     if form == "general":
-        sort = 24.0 * n * 4                      # 4 passes x (read + write key,end,rid)
-        lin = 12.0 * n + 8.0 * n                 # read 3 cols, write key + end
+        sc, lo = sort_bytes_model([(n_a, 2, False), (n_b, 2, False)])
+        lin = 12.0 * n + 8.0 * n                       # read 3 columns, write key + end
         count = (8.0 * n_b + 4.0 * n_a) + (8.0 * n_a + 4.0 * n_b + 8.0 * n_a)
         scan = 12.0 * n_a
         fill = 8.0 * n_out + 12.0 * n_b + 4.0 * n_a + 16.0 * n_a + 4.0 * n_b
     else:
-        sort = (24.0 * n_q + 16.0 * n_u) * 4     # the uniform side carries (key, rid)
-        lin = 12.0 * n + 8.0 * n_q + 4.0 * n_u
-        if span_hist:
-            sort += 4.0 * n_u
-            lin = 12.0 * n_q + 8.0 * n_q
-        count = 8.0 * n_q + 4.0 * n_u + 8.0 * n_q
+        sc, lo = sort_bytes_model([(n_q, 2, False), (n_u, 1, span_hist)])
+        lin = (12.0 + 8.0) * n_q + (0.0 if span_hist else 8.0 * n_u + 4.0 * n_u)
+        count = 8.0 * n_q + 4.0 * n_u + 8.0 * n_q      # query (key, end) + the other side's keys -> lo, cnt
         scan = 12.0 * n_q
-        fill = 8.0 * n_out + 16.0 * n_q + 4.0 * n_u
-    return {
-        "span": 12.0 * n,       # chrom, start, end once
-        "linearize": lin,
-        "sort_hist": 4.0 * n * 4,
-        "sort_scan": 0.0,
-        "sort_scatter": sort,
-        "count": count,
-        "scan": scan,
-        "partition": 0.0,
-        "fill": fill,
-        "irregular": 0.0,
-        "aux": 0.0,
-    }[phase]
+        fill = 8.0 * n_out + 16.0 * n_q + 4.0 * n_u    # pairs + {off, lo, rid} per query row + sorted rids
+    out = {"span": 12.0 * n, "linearize": lin, "sort_scatter": sc, "sort_local": lo, "count": count,
+           "scan": scan, "partition": 0.0, "fill": fill}
+    for k in ("sort_scatter", "sort_local"):
+        if stats_bytes and stats_bytes.get(k):
+            out[k] = float(stats_bytes[k])
+    return out
 
 
-def pmc_traffic(workload: str, form: str, phase: str, launches: int):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/pmc_traffic.json; rocprofv3 cannot run inside the timed process).
-    None when no counter run exists for this workload / join form."""
+def op_bytes(op, n_a, n_b, n_out):
+    """the operator-level algorithmic bytes."""
+    base = 12.0 * (n_a + n_b)
+    return base + {"inner": 8.0 * n_out, "semi": 4.0 * n_out, "anti": 4.0 * n_out, "count": 8.0 * n_a,
+                   "nearest": 8.0 * n_a}[op]
+
+
+def csrc_hash() -> str:
+    """Hash of the kernel sources: what ties a committed PMC run to the code that is timed here."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "giql_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload, form, phase, launches):
+    """HBM bytes per launch of a phase from the committed PMC passes (profiles/pmc_traffic.json;
+    rocprofv3 cannot run inside the timed process).  None unless the file was collected on THIS
+    kernel source (its csrc_hash) for this workload / join form."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
+        if t.get("csrc_hash") != csrc_hash():
+            return None
         return round(t[workload][form][phase] / max(launches, 1))
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, TypeError):
         return None
 
 
-def run_cpu_baseline(args, n_a, kind_a, seed_a, n_b, kind_b, seed_b):
-    """Time the oracle's OpenMP sort-merge port on a bounded sample of the workload.
+# ---------------------------------------------------------------------------- inputs
+def make_inputs(wl, chroms=None):
+    from giql_amd import synth
 
-    A probe on four small chromosomes estimates the rate; the reported sample is
-    the largest prefix of chromosomes (by id) whose estimated time stays under
-    ~20 s -- the whole workload when the host is fast enough.
-    """
+    op, (n_a, kind_a, seed_a), (n_b, kind_b, seed_b), genome = WORKLOADS[wl]
+    if genome == HG38:
+        a = synth.make_table(n_a, seed_a, kind_a, chroms=chroms)
+        b = synth.make_table(n_b, seed_b, kind_b, chroms=chroms)
+        n_chrom = len(synth.HG38_LENGTHS)
+    else:
+        a = synth.make_single_chrom(n_a, seed_a, kind_a, genome)
+        b = synth.make_single_chrom(n_b, seed_b, kind_b, genome)
+        n_chrom = 1
+    return op, a, b, n_chrom
+
+
+def short(n):
+    return f"{n // 1_000_000}M" if n % 1_000_000 == 0 else str(n)
+
+
+# ----------------------------------------------------------------------- CPU baseline
+def duckdb_baseline(op, a, b, n_chrom, names):
+    """The reference's own CPU path, when the box has DuckDB: the IEJoin SQL the reference emits
+    for ``SELECT a.rid, b.rid FROM peaks a JOIN reads b ON a.interval INTERSECTS b.interval``
+    (reconstructed from src/giql/expanders/intersects_duckdb.py:1283-1400 and
+    _per_chrom.py:46-74), executed on all host cores.  Returns None when ``import duckdb`` fails."""
+    try:
+        import duckdb  # noqa: F401
+        import numpy as np
+        import pyarrow as pa
+    except Exception:
+        return None
+    try:
+        if op != "inner":
+            return {"error": "the DuckDB leg is wired for the INNER join only"}
+        con = duckdb.connect()
+
+        def table(cols):
+            c, s, e = cols
+            return pa.table({"chrom": pa.array(np.asarray(names, dtype=object)[c], pa.string()), "start": pa.array(s),
+                             "end": pa.array(e), "rid": pa.array(np.arange(len(c), dtype=np.int32))})
+        con.register("peaks", table(a))
+        con.register("reads", table(b))
+        var = "__giql_iejoin_bench"
+        branch = ("'SELECT a.\"rid\" AS __giql_p0, b.\"rid\" AS __giql_p1 FROM (SELECT * FROM peaks WHERE \"chrom\" = ' || "
+                  "'''' || replace(chrom, '''', '''''') || '''' || ') a JOIN (SELECT * FROM reads WHERE \"chrom\" = ' || "
+                  "'''' || replace(chrom, '''', '''''') || '''' || ') b ON a.\"start\" < b.\"end\" AND a.\"end\" > b.\"start\"'")
+        set_sql = (f"SET VARIABLE {var} = COALESCE((SELECT string_agg({branch}, ' UNION ALL ') FROM "
+                   "(SELECT DISTINCT \"chrom\" AS chrom FROM peaks INTERSECT SELECT DISTINCT \"chrom\" AS chrom FROM reads)), "
+                   "'SELECT a.\"rid\" AS __giql_p0, b.\"rid\" AS __giql_p1 FROM peaks a, reads b WHERE FALSE')")
+        t0 = time.perf_counter()
+        con.execute(set_sql)
+        res = con.execute(f"SELECT __giql_p0 AS ra, __giql_p1 AS rb FROM query(getvariable('{var}')) AS w").fetch_arrow_table()
+        dt = time.perf_counter() - t0
+        ra = res.column("ra").to_numpy().astype(np.int32)
+        rb = res.column("rb").to_numpy().astype(np.int32)
+        threads = con.execute("SELECT current_setting('threads')").fetchone()[0]
+        return {"seconds": dt, "row_a": ra, "row_b": rb, "threads": int(threads), "version": duckdb.__version__}
+    except Exception as exc:  # never let the optional leg take the bench down
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
+
+def cpu_baseline_inner(args, wl, n_chrom):
+    """Bounded CPU leg of an INNER workload + the data for the parity line.  DuckDB (the reference's
+    path) when importable, else the oracle's OpenMP sort-merge port; a probe on four small
+    chromosomes sizes the sample (the whole workload when the host does it in ~20 s)."""
     from giql_amd import synth
     from oracle import pyoracle as ora
 
+    op, (n_a, kind_a, seed_a), (n_b, kind_b, seed_b), genome = WORKLOADS[wl]
     threads = ora.max_threads()
+    names = synth.HG38_NAMES if genome == HG38 else ["chr1"]
+    out = {"unit": "pairs/s", "host_cpu_count": os.cpu_count()}
 
-    n_chrom_all = len(synth.HG38_LENGTHS)
-    checksum = [None]
+    def tables(chroms):
+        if genome != HG38:
+            return make_inputs(wl)[1:3]
+        return (synth.make_table(n_a, seed_a, kind_a, chroms=chroms), synth.make_table(n_b, seed_b, kind_b, chroms=chroms))
 
-    def run(chroms):
-        sel = None if len(chroms) == n_chrom_all else chroms  # None = the GPU run's row order
-        sa = synth.make_table(n_a, seed_a, kind_a, chroms=sel)
-        sb = synth.make_table(n_b, seed_b, kind_b, chroms=sel)
-        oa, ob = ora.Side(*sa), ora.Side(*sb)
+    def port(chroms):
+        a, b = tables(chroms)
+        oa, ob = ora.Side(*a), ora.Side(*b)
         t1 = time.perf_counter()
         ra, rb = ora.c_inner(oa, ob, "sweep", threads=threads)
-        dt = time.perf_counter() - t1
-        # whole workload only: the same order-independent 64-bit checksum as
-        # giql_hip_pairs_checksum_dev, for the parity line (outside the timing)
-        checksum[0] = ora.c_pairs_checksum(ra, rb) if len(chroms) == n_chrom_all else None
-        return oa.n, ob.n, int(ra.shape[0]), dt
+        return oa.n, ob.n, ra, rb, time.perf_counter() - t1
 
-    probe = [int(c) for c in args.cpu_sample_chroms.split(",") if c != ""]
-    pa_, pb_, pp, pt = run(probe)
-    rows_total = synth.rows_per_chrom(n_a, seed_a) + synth.rows_per_chrom(n_b, seed_b)
-    rate = (pa_ + pb_) / max(pt, 1e-3)                    # rows/s on the probe
-    budget_rows = rate * 20.0
-    chroms, acc = [], 0
-    for c in range(len(rows_total)):
-        if acc + rows_total[c] > budget_rows and chroms:
-            break
-        chroms.append(c)
-        acc += int(rows_total[c])
-    sa_n, sb_n, sp, st_ = run(chroms)
-    whole = len(chroms) == len(rows_total)
-    return {
-        "value": round(sp / st_, 1),
-        "unit": "pairs/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": (("the whole workload" if whole else f"chromosome ids 0..{chroms[-1]} of the same workload")
-                   + f": {sa_n} x {sb_n} rows -> {sp} pairs in {st_:.2f} s "
-                   "(oracle OpenMP sort-merge port, not DuckDB: duckdb is not installed on the box)"),
-        "host_cpu_count": os.cpu_count(),
-        # popped by main() into the "parity" entry (SURVEY.md 8d: parity check in the same run)
-        "pairs": sp if whole else None,
-        "pairs_checksum": checksum[0] if whole else None,
-    }
-
-
-def measured_copy_gbs(dev, mb: int = 1600, reps: int = 5):
-    """Device-to-device copy bandwidth of this GPU in GB/s (bytes read + written)."""
-    import torch
-
-    try:
-        n = mb * (1 << 20) // 4
-        x = torch.empty(n, dtype=torch.int32, device=dev)
-        y = torch.empty_like(x)
-        x.fill_(1)
-        y.copy_(x)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(dev)
-        e0.record()
-        for _ in range(reps):
-            y.copy_(x)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / reps
-        return round(2 * n * 4 / ms / 1e6, 1) if ms > 0 else None
-    except RuntimeError:  # not enough free HBM next to the workload
-        return None
+    if genome == HG38:
+        probe = [int(c) for c in args.cpu_sample_chroms.split(",") if c != ""]
+        pa_, pb_, _pra, _prb, pt = port(probe)
+        rows_total = synth.rows_per_chrom(n_a, seed_a) + synth.rows_per_chrom(n_b, seed_b)
+        budget_rows = (pa_ + pb_) / max(pt, 1e-3) * 20.0
+        chroms, acc = [], 0
+        for c in range(len(rows_total)):
+            if acc + rows_total[c] > budget_rows and chroms:
+                break
+            chroms.append(c)
+            acc += int(rows_total[c])
+        whole = len(chroms) == len(rows_total)
+        sel = None if whole else chroms
+    else:
+        whole, sel, chroms = True, None, [0]
+    sa_n, sb_n, ra, rb, st_ = port(sel)
+    sample = ("the whole workload" if whole else f"chromosome ids 0..{chroms[-1]} of the same workload")
+    out.update({"value": round(ra.shape[0] / st_, 1), "cores": threads, "kind": "port",
+                "sample": f"{sample}: {sa_n} x {sb_n} rows -> {ra.shape[0]} pairs in {st_:.2f} s (oracle OpenMP "
+                          "sort-merge port, not DuckDB: duckdb is not installed on the box)"})
+    parity_ref = (int(ra.shape[0]), ora.c_pairs_checksum(ra, rb)) if whole else None
+    # the reference's real path, when the box has it: same sample, same inputs
+    a, b = tables(sel)
+    dd = duckdb_baseline(op, a, b, n_chrom, names)
+    if dd is not None and "error" not in dd:
+        ok = (int(dd["row_a"].shape[0]) == int(ra.shape[0])
+              and ora.c_pairs_checksum(dd["row_a"], dd["row_b"]) == ora.c_pairs_checksum(ra, rb))
+        out.update({"value": round(dd["row_a"].shape[0] / dd["seconds"], 1), "cores": dd["threads"], "kind": "reference",
+                    "sample": f"{sample}: {sa_n} x {sb_n} rows -> {dd['row_a'].shape[0]} pairs in {dd['seconds']:.2f} s "
+                              f"(DuckDB {dd['version']} IEJoin SQL of the reference, {dd['threads']} threads)",
+                    "port_value": round(ra.shape[0] / st_, 1), "duckdb_equals_port": bool(ok)})
+    elif dd is not None:
+        out["duckdb_probe"] = dd["error"]
+    return out, parity_ref
 
 
-def main() -> None:
-    args = parse_args()
+# ------------------------------------------------------------------------ the INNER run
+def run_inner(args):
     import torch
     import torch.distributed as dist
 
     from giql_amd import shard, synth
-    from giql_amd._lib import GIQL_ERR_CAPACITY, GiqlHipError
+    from giql_amd._lib import GIQL_ERR_CAPACITY, GIQL_ERR_STATE, GiqlHipError
     from giql_amd.engine import DeviceSide, HipEngine
 
+    wl = args.workload
+    op, (n_a, kind_a, seed_a), (n_b, kind_b, seed_b), genome = WORKLOADS[wl]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    # --force-exchange: run the N>1 exchange code (process group, counts, take into the send
-    # block, all-gather) with a single rank -- the only way to drive it over RCCL on a 1-GPU box
+    if world > 1 and genome != HG38:
+        raise SystemExit("the single-chromosome workloads run on one GPU (giql_amd.distributed splits a dominant "
+                         "chromosome by row ranges; bench.py shards whole chromosomes)")
     distributed = world > 1 or args.force_exchange
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
@@ -222,7 +331,7 @@ def main() -> None:
     xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the exchange happens
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
@@ -230,73 +339,59 @@ def main() -> None:
         else:
             dist.init_process_group("gloo")
 
-    n_a, kind_a, seed_a, n_b, kind_b, seed_b = WORKLOADS[args.workload]
-    n_chrom = len(synth.HG38_LENGTHS)
-
-    # ---- shard: chromosomes -> ranks (LPT on expected rows); N=1 keeps all 24
-    rows_a = synth.rows_per_chrom(n_a, seed_a)
-    rows_b = synth.rows_per_chrom(n_b, seed_b)
-    assign = shard.lpt_assign((rows_a + rows_b).tolist(), world)
-    my_chroms = [c for c in range(n_chrom) if assign[c] == rank]
-
+    # ---- shard: chromosomes -> ranks (LPT on expected rows); N = 1 keeps everything
+    my_chroms = None
+    if genome == HG38 and world > 1:
+        rows = synth.rows_per_chrom(n_a, seed_a) + synth.rows_per_chrom(n_b, seed_b)
+        assign = shard.lpt_assign(rows.tolist(), world)
+        my_chroms = [c for c in range(len(synth.HG38_LENGTHS)) if assign[c] == rank]
     t0 = time.time()
-    ac, as_, ae = synth.make_table(n_a, seed_a, kind_a, chroms=None if world == 1 else my_chroms)
-    bc, bs, be = synth.make_table(n_b, seed_b, kind_b, chroms=None if world == 1 else my_chroms)
+    _op, ha, hb, n_chrom = make_inputs(wl, my_chroms)
     gen_s = time.time() - t0
-    a = DeviceSide.from_numpy(ac, as_, ae, device=dev)
-    b = DeviceSide.from_numpy(bc, bs, be, device=dev)
+    a = DeviceSide.from_numpy(*ha, device=dev)
+    b = DeviceSide.from_numpy(*hb, device=dev)
     loc_na, loc_nb = a.n, b.n
-
     eng = HipEngine(dev_index)
-    out_cap = 0
-    out = None
 
-    def alloc_out(n):
-        """Caller-owned output: row_a / row_b, 5 % head-room, each row a 2 MiB multiple long."""
-        cap = (int(n * 1.05) + 1024 + (1 << 19) - 1) >> 19 << 19
-        if os.environ.get("GIQL_BENCH_OUT", "split") == "joint":   # probe: both rows in ONE allocation
-            return cap, torch.empty((2, cap), dtype=torch.int32, device=dev)
-        return cap, (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev))
-    # shard-local row index -> global row id: ranks own disjoint chromosome sets and the
-    # global table is "rows of lower ranks first", so the map is one offset per side
-    # (giql_amd.distributed.sharded_inner_join handles arbitrary row sets with the take kernel)
+    # shard-local row index -> global row id: ranks own disjoint chromosome sets and the global table
+    # is "rows of lower ranks first", so the map is one offset per side (giql_amd.distributed handles
+    # arbitrary row sets with the take kernel)
     base_a = base_b = 0
+    D = None
     if distributed:
         from giql_amd import distributed as D
 
-        sizes = torch.tensor([loc_na, loc_nb], dtype=torch.int64, device=xdev)
+        sizes_t = torch.tensor([loc_na, loc_nb], dtype=torch.int64, device=xdev)
         all_sizes = torch.empty((world, 2), dtype=torch.int64, device=xdev)
-        dist.all_gather_into_tensor(all_sizes.view(-1), sizes)
+        dist.all_gather_into_tensor(all_sizes.view(-1), sizes_t)
         base_a, base_b = (int(x) for x in all_sizes[:rank].sum(0).tolist()) if rank else (0, 0)
+    exchange = args.exchange if distributed else "none"
+    xplan = D.PlanGather(xdev) if exchange == "plan" else None
+    xpairs = D.PairGather(xdev) if exchange in ("plan", "pairs") else None   # "plan" falls back to it
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if distributed else None
+    split_ms = [0.0, 0.0, 0.0]  # [local join, exchange, expansion] summed over the timed steps
+    used = {"plan": 0, "pairs": 0}
 
-    xg = D.PairGather(xdev) if distributed and not args.no_gather else None
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if distributed else None
-    split_ms = [0.0, 0.0]  # [local join, exchange] summed over the timed steps
+    out = None
+    gout = None  # the gathered global pairs (every rank holds all of them)
 
-    phase_ms = {}
-    phase_launches = {}
+    def alloc_out(n):
+        """Caller-owned output rows, 5 % head-room, each a 2 MiB multiple long (a row that starts
+        inside a cache line makes every 256-byte wave store of the fill touch three lines)."""
+        cap = (int(n * 1.05) + 1024 + (1 << 19) - 1) >> 19 << 19
+        if os.environ.get("GIQL_BENCH_OUT", "split") == "joint":   # probe: both rows in ONE allocation
+            return torch.empty((2, cap), dtype=torch.int32, device=dev)
+        return (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev))
+
+    phase_ms, phase_launches = {}, {}
     last_stats = [None]
-    last_pairs = [None]  # views of the last step's (row_a, row_b), for the parity line
+    last_pairs = [None]
 
-    def step(collect=False):
-        """One pass of the hot path; returns this rank's pair count."""
-        nonlocal out, out_cap
-        if ev:
-            ev[0].record()
-        if xg is not None and xdev == dev:
-            # the path's one exchange step starts inside the join: the counts are all-gathered
-            # after the plan, then the fill writes straight into the send block of the all-gather
-            n = eng.inner_plan(a, b, n_chrom)
-            counts = xg.counts(n)
-            send = xg.send_block(max(counts))
-            ra, rb = send[0, :n], send[1, :n]
-            eng.inner_fill(ra, rb)
-        elif out is not None and os.environ.get("GIQL_BENCH_NO_FUSE"):
-            n = eng.inner_plan(a, b, n_chrom)
-            ra, rb = out[0][:n], out[1][:n]
-            eng.inner_fill(ra, rb)
-        elif out is not None:
-            # one C-ABI call into the buffers of the previous step (plan + fill, no stream sync
+    def local_join():
+        """One pass of the hot path over this rank's rows into `out`; returns the pair count."""
+        nonlocal out
+        if out is not None and not os.environ.get("GIQL_BENCH_NO_FUSE"):
+            # ONE C-ABI call into the buffers of the previous step (plan + fill, no stream sync
             # between them when the context's guesses hold); a larger result re-allocates
             try:
                 n = eng.inner_join_into(a, b, n_chrom, out[0], out[1])
@@ -305,41 +400,110 @@ def main() -> None:
                     raise
                 n = eng.last_pairs
                 out = None
-                out_cap, out = alloc_out(n)
+                out = alloc_out(n)
                 eng.inner_fill(out[0][:n], out[1][:n])
-            ra, rb = out[0][:n], out[1][:n]
         else:
             n = eng.inner_plan(a, b, n_chrom)
-            out_cap, out = alloc_out(n)
-            ra, rb = out[0][:n], out[1][:n]
-            eng.inner_fill(ra, rb)
-        last_pairs[0] = (ra, rb)
+            if out is None or out[0].shape[0] < n:
+                out = None
+                out = alloc_out(n)
+            eng.inner_fill(out[0][:n], out[1][:n])
+        return n
+
+    def step(collect=False):
+        nonlocal gout
+        sizes = None
+        n = 0
         if ev:
-            ev[1].record()
-        if collect:  # the join's phase times, before anything else touches the engine
-            st = eng.stats()
-            last_stats[0] = st
-            for k, v in st["phase_ms"].items():
-                phase_ms[k] = phase_ms.get(k, 0.0) + v
-            for k, v in st["phase_launches"].items():
-                phase_launches[k] = phase_launches.get(k, 0) + v
-        if xg is not None:
+            ev[0].record()
+        if exchange == "plan":
+            # the plan is the compact description of this rank's pairs: export it with GLOBAL row
+            # ids straight into the send block, all-gather, expand every rank's block locally
+            n = eng.inner_plan(a, b, n_chrom)
+            try:
+                q_is_a, n_q, n_s = eng.plan_sizes()
+            except GiqlHipError as exc:
+                if exc.code != GIQL_ERR_STATE:
+                    raise
+                q_is_a, n_q, n_s = True, -1, -1   # no compact form on this rank: everybody falls back
+            sizes = xplan.sizes(n, n_q, n_s, q_is_a)
+        if exchange == "plan" and D.PlanGather.compact(sizes):
+            used["plan"] += 1
+            views = xplan.send_views(sizes)
             if xdev == dev:
+                eng.plan_export(*views, rid_add_a=base_a, rid_add_b=base_b)
+            else:  # gloo rehearsal: through host memory
+                tmp = [torch.empty(v.shape[0], dtype=torch.int32, device=dev) for v in views]
+                eng.plan_export(*tmp, rid_add_a=base_a, rid_add_b=base_b)
+                for v, t_ in zip(views, tmp):
+                    v.copy_(t_)
+            if collect:
+                last_stats[0] = eng.stats()
+            if ev:
+                ev[1].record()
+            blocks = xplan.all_gather(sizes)
+            if ev:
+                ev[2].record()
+            total = sum(s[0] for s in sizes)
+            if gout is None or gout[0].shape[0] < total:
+                gout = None
+                gout = alloc_out(total)
+            o = 0
+            for (q_r, lo_r, cnt_r, s_r), (n_r, _q, _s, qa_r) in zip(blocks, sizes):
+                if n_r == 0:
+                    continue
+                if xdev != dev:
+                    q_r, lo_r, cnt_r, s_r = (t_.to(dev) for t_ in (q_r, lo_r, cnt_r, s_r))
+                rq, rs = (gout[0], gout[1]) if qa_r else (gout[1], gout[0])
+                eng.fill_from_plan(q_r, lo_r, cnt_r, s_r, rq[o:o + n_r], rs[o:o + n_r], n_pairs_expected=n_r)
+                o += n_r
+            last_pairs[0] = (gout[0][:total], gout[1][:total])
+        elif exchange in ("plan", "pairs"):
+            used["pairs"] += 1
+            if exchange == "pairs":
+                n = eng.inner_plan(a, b, n_chrom)
+            counts = xpairs.counts(n)
+            send = xpairs.send_block(max(counts))
+            if xdev == dev:
+                ra, rb = send[0, :n], send[1, :n]
+                eng.inner_fill(ra, rb)       # straight into the send block of the all-gather
                 if base_a:
-                    ra.add_(base_a)  # local -> global row ids, in place in the send block
+                    ra.add_(base_a)          # local -> global row ids, in place
                 if base_b:
                     rb.add_(base_b)
-            else:  # gloo rehearsal: the exchange runs through host memory
-                counts = xg.counts(n)
-                send = xg.send_block(max(counts))
+            else:
+                ra = torch.empty(n, dtype=torch.int32, device=dev)
+                rb = torch.empty(n, dtype=torch.int32, device=dev)
+                eng.inner_fill(ra, rb)
                 send[0, :n] = (ra + base_a).to(xdev)
                 send[1, :n] = (rb + base_b).to(xdev)
-            xg.all_gather(counts)
+            if collect:
+                last_stats[0] = eng.stats()
+            if ev:
+                ev[1].record()
+            last_pairs[0] = xpairs.all_gather(counts)
+            if ev:
+                ev[2].record()
+        else:
+            n = local_join()
+            last_pairs[0] = (out[0][:n], out[1][:n])
+            if collect:
+                last_stats[0] = eng.stats()
+            if ev:
+                ev[1].record()
+                ev[2].record()
+        if collect and last_stats[0] is not None:
+            st_ = last_stats[0]
+            for k, v in st_["phase_ms"].items():
+                phase_ms[k] = phase_ms.get(k, 0.0) + v
+            for k, v in st_["phase_launches"].items():
+                phase_launches[k] = phase_launches.get(k, 0) + v
         if ev:
-            ev[2].record()
-            ev[2].synchronize()
+            ev[3].record()
+            ev[3].synchronize()
             split_ms[0] += ev[0].elapsed_time(ev[1])
             split_ms[1] += ev[1].elapsed_time(ev[2])
+            split_ms[2] += ev[2].elapsed_time(ev[3])
         return n
 
     def sync_all():
@@ -348,29 +512,33 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # Warm-up steps run with hipEvent pairs around EVERY phase: they give the phase table.
-    # The timed steps keep events only around the dominant kernel's launches (the sort passes),
-    # which is what the roofline object is computed from: every event pair costs the launch
-    # stream a few microseconds of idle time, ~0.1 ms per step with all nine phases timed.
+    # Warm-up steps run with hipEvent pairs around EVERY phase: they give the phase table.  The timed
+    # steps keep events only around the dominant kernel's launches (the global sort passes), which is
+    # what the roofline object is computed from: every event pair costs the launch stream a few
+    # microseconds of idle time, ~0.1 ms per step with all the phases timed.
     eng.set_profiling(True)
     for _ in range(args.warmup):
         step(collect=True)
-    # the LAST warm-up step's phases (the first one also pays for the arena's first touch)
-    warm_phase_ms = dict(last_stats[0]["phase_ms"]) if args.warmup and last_stats[0] else {}
+    warm = last_stats[0] if args.warmup else None
+    warm_phase_ms = dict(warm["phase_ms"]) if warm else {}
     light = bool(warm_phase_ms)
     phase_ms.clear()
     phase_launches.clear()
     eng.set_profiling(2 if light else True)
     sync_all()
-    split_ms[0] = split_ms[1] = 0.0
+    split_ms[0] = split_ms[1] = split_ms[2] = 0.0
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     n_local = 0
-    for _ in range(args.steps):
+    step_ev[0].record()
+    for k in range(args.steps):
         n_local = step(collect=True)
+        step_ev[k + 1].record()
     sync_all()
-    st = last_stats[0]
     elapsed = time.perf_counter() - t0
+    st = last_stats[0]
     eng.set_profiling(False)
+    step_ms = [step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps)]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
     tot = torch.tensor([n_local, loc_na, loc_nb], dtype=torch.int64, device=xdev)
@@ -380,99 +548,299 @@ def main() -> None:
     elapsed = float(t.item())
     n_pairs, tot_na, tot_nb = (int(x) for x in tot.tolist())
 
-    # ---- rank 0: roofline of the dominant kernel + CPU baseline + the JSON line
+    # per-rank view of a step (outside the timed region): local join, exchange, expansion, HBM fraction
+    per_step_ms = {k: v / args.steps for k, v in phase_ms.items()}
+    if light:
+        per_step_ms = {**warm_phase_ms, "sort_scatter": per_step_ms.get("sort_scatter", 0.0)}
+    if exchange == "plan":   # the expansion's scan / partition / fill are timed by `expand_ms`, not as join phases
+        per_step_ms = {k: v for k, v in per_step_ms.items() if k not in ("scan", "partition", "fill") or not used["plan"]}
+    device_ms = sum(per_step_ms.values())
+    mine = {"rank": rank, "rows_a": loc_na, "rows_b": loc_nb, "pairs": n_local,
+            "join_device_ms": round(device_ms, 3),
+            "hbm_frac": round(op_bytes("inner", loc_na, loc_nb, n_local) / max(device_ms * 1e-3, 1e-9) / 1e9 / HBM_PEAK_GBS, 4)}
+    if distributed:
+        mine.update({"local_join_ms": round(split_ms[0] / args.steps, 3), "exchange_ms": round(split_ms[1] / args.steps, 3),
+                     "expand_ms": round(split_ms[2] / args.steps, 3)})
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    else:
+        per_rank = [mine]
+
+    line = None
     if rank == 0:
-        per_step_ms = {k: v / args.steps for k, v in phase_ms.items()}
         per_step_launches = {k: v // args.steps for k, v in phase_launches.items()}
-        if light:  # the other phases were timed in the warm-up steps only
-            per_step_ms = {**warm_phase_ms, "sort_scatter": per_step_ms.get("sort_scatter", 0.0)}
-        # the sort passes are the path's dominant kernel; they are the phase timed in the timed steps
-        dom = "sort_scatter" if light else max(per_step_ms, key=lambda k: per_step_ms[k])
-        dom_ms = per_step_ms[dom]
-        dom_launches = max(per_step_launches[dom], 1)
-        dom_bytes = phase_bytes(dom, loc_na, loc_nb, n_local, st["join_form"], st.get("span_hist", False))
-        achieved = (dom_bytes / dom_launches) / (dom_ms / dom_launches * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        join_bytes = 12.0 * (loc_na + loc_nb) + 8.0 * n_local
-        device_ms = sum(per_step_ms.values())
-        copy_gbs = measured_copy_gbs(dev)
+        form, span_hist = st["join_form"], bool(st.get("span_hist", False))
+        pbytes = inner_phase_bytes(loc_na, loc_nb, n_local, form, span_hist, st.get("phase_bytes"))
+        dom = "sort_scatter"   # the phase timed in the timed steps: the global sort passes (k_onesweep)
+        dom_ms = per_step_ms.get(dom, 0.0)
+        dom_launches = max(per_step_launches.get(dom, 0), 1)
+        dom_bytes = pbytes[dom]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        join_bytes = op_bytes("inner", loc_na, loc_nb, n_local)
+        warm_launches = warm["phase_launches"] if warm else {}
+        kernels = {}
+        for k, ms in per_step_ms.items():
+            if ms <= 0:
+                continue
+            bts = pbytes.get(k, 0.0)
+            kernels[k] = {"ms": round(ms, 3), "launches": int(warm_launches.get(k, per_step_launches.get(k, 0))),
+                          "algorithmic_GB": round(bts / 1e9, 4),
+                          "achieved_GBps": round(bts / (ms * 1e-3) / 1e9, 1) if bts else None,
+                          "frac": round(bts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if bts else None}
         roofline = {
             "bound": "hbm",
-            "kernel": dom,
+            "kernel": "k_onesweep (phase sort_scatter: the global radix passes of both sides)",
             "launches_per_step": dom_launches,
             "avg_launch_ms": round(dom_ms / dom_launches, 4),
-            "algorithmic_bytes_per_launch": dom_bytes / dom_launches,
+            "algorithmic_bytes_per_launch": round(dom_bytes / dom_launches),
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            # this box's own streaming-copy rate (read + written bytes of a 1.6 GB d2d copy,
-            # SURVEY.md 8d) and the kernel's fraction of THAT; "frac" stays against the 8 TB/s peak
-            "measured_copy": copy_gbs,
-            "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
-            # the PMC passes were collected on the whole workload on one GPU
-            "traffic": pmc_traffic(args.workload, st["join_form"], dom, dom_launches) if world == 1 else None,
+            "traffic": pmc_traffic(wl, form, dom, dom_launches) if world == 1 else None,
+            "bytes_source": ("giql_hip_stats.phase_bytes (accounted by the host code that issues the passes)"
+                             if (st.get("phase_bytes") or {}).get(dom) else "bench.sort_bytes_model"),
             "whole_join": {
                 "algorithmic_bytes": join_bytes,
                 "device_ms": round(device_ms, 3),
                 "achieved": round(join_bytes / (device_ms * 1e-3) / 1e9, 1) if device_ms > 0 else 0.0,
                 "frac": round(join_bytes / (device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms > 0 else 0.0,
             },
-            "phase_ms": {k: round(v, 3) for k, v in per_step_ms.items() if v > 0},
-            "phase_ms_source": ("sort_scatter: hipEvents in the timed steps; other phases: hipEvents in the "
-                                "warm-up steps (the timed steps record events around the sort passes only)"
+            "kernels": kernels,
+            "phase_ms_source": ("sort_scatter: hipEvents in the timed steps; other phases: hipEvents in the last warm-up "
+                                "step (the timed steps record events around the global sort passes only)"
                                 if light else "hipEvents in the timed steps"),
         }
 
         cpu_baseline = None
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only (the other ranks would idle in the barrier)
-            cpu_baseline = run_cpu_baseline(args, n_a, kind_a, seed_a, n_b, kind_b, seed_b)
-            cpu_sum = cpu_baseline.pop("pairs_checksum", None)
-            cpu_pairs = cpu_baseline.pop("pairs", None)
-            if world == 1 and cpu_sum is not None and last_pairs[0] is not None:
-                gpu_sum = eng.pairs_checksum(*last_pairs[0])
-                cpu_baseline["parity"] = {"pairs_equal": cpu_pairs == n_pairs, "multiset_checksum_equal": gpu_sum == cpu_sum,
-                                          "checked": "all %d pairs of the last timed step" % n_pairs}
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
+            cpu_baseline, ref = cpu_baseline_inner(args, wl, n_chrom)
+            if ref is not None and last_pairs[0] is not None:
+                pa_, pb_ = last_pairs[0] if not isinstance(last_pairs[0], list) else (
+                    torch.cat([x[0] for x in last_pairs[0]]), torch.cat([x[1] for x in last_pairs[0]]))
+                gpu_sum = eng.pairs_checksum(pa_, pb_)
+                cpu_baseline["parity"] = {"pairs_equal": ref[0] == n_pairs, "multiset_checksum_equal": gpu_sum == ref[1],
+                                          "checked": "all %d pairs of the last timed step against the CPU leg" % n_pairs}
 
+        extras = {}
+        if world == 1 and not distributed and not args.no_extras:
+            extras = inner_extras(eng, dev_index, a, b, ha, hb, n_chrom, n_local, alloc_out, join_bytes)
+
+        metric, unit = METRIC["inner"]
         value = n_pairs * args.steps / elapsed
         line = {
-            "metric": "overlap-pairs/sec, 10Mx100M INTERSECTS inner join",
+            "metric": metric.format(a=short(tot_na), b=short(tot_nb)),
             "value": round(value, 1),
-            "unit": "pairs/s",
+            "unit": unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step_median": round(statistics.median(step_ms), 3) if step_ms else None,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
             "config": {
-                "workload": args.workload,
+                "workload": wl,
                 "n_a": tot_na, "n_b": tot_nb, "n_chrom": n_chrom, "pairs_per_step": n_pairs,
-                "parallelism": f"chrom-shard x{world}" + ("" if world == 1 or args.no_gather else
-                                                            (" + rccl all-gather of pairs" if args.backend == "nccl"
-                                                             else " + gloo (rehearsal) all-gather of pairs")),
+                "parallelism": f"chrom-shard x{world}" + ("" if not distributed else {
+                    "plan": f" + {args.backend} all-gather of the compact plan, expanded on every rank",
+                    "pairs": f" + {args.backend} all-gather of the pairs", "none": ", no gather"}[exchange]),
                 "inputs": "resident in HBM before the timed region",
-                "join_form": st["join_form"],
-                "span_hist": bool(st.get("span_hist", False)),
+                "join_form": form,
+                "span_hist": span_hist,
+                "sort": ("two global passes + in-LDS bucket sort for sides >= 32M rows" if st.get("sort_local")
+                         else "four global passes"),
             },
-            "hbm_algorithmic_GBps": round((12.0 * (tot_na + tot_nb) + 8.0 * n_pairs) * args.steps / elapsed / 1e9, 1),
+            "hbm_algorithmic_GBps": round(op_bytes("inner", tot_na, tot_nb, n_pairs) * args.steps / elapsed / 1e9, 1),
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "sort_order_fallbacks": st.get("sort_order_fallbacks", 0),
+            "sort_resorted": bool(st.get("sort_resorted", False)),
+            "per_rank": per_rank,
             "gen_seconds": round(gen_s, 1),
         }
+        line.update(extras)
         if distributed:
-            # rank 0's view of where a step goes: its own shard's join vs the one
-            # exchange (global ids + all-gather of every rank's pairs)
-            line["rank0_local_join_ms"] = round(split_ms[0] / args.steps, 3)
-            line["rank0_exchange_ms"] = round(split_ms[1] / args.steps, 3)
-        print(json.dumps(line), flush=True)
-
+            line["exchange"] = {"mode": exchange, "steps_compact": used["plan"], "steps_expanded": used["pairs"],
+                                "bytes_per_rank": (xplan.bytes_per_rank() if used["plan"] else None)}
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+    return line
+
+
+def inner_extras(eng, dev_index, a, b, ha, hb, n_chrom, n_pairs, alloc_out, join_bytes):
+    """Legs that follow the timed region at N = 1: the general two-class form on the same inputs (a
+    second context under GIQL_HIP_NO_UNIFORM=1), the PCIe-inclusive end-to-end time through the
+    host-buffer entry point, and this box's measured copy rate with the library's own copy kernel."""
+    import torch
+
+    from giql_amd.engine import HipEngine
+
+    out = {}
+    try:
+        out["measured_copy_GBps"] = round(eng.copy_probe(), 1)
+    except Exception as exc:  # e.g. not enough free HBM next to the workload
+        out["measured_copy_GBps"] = None
+        out["measured_copy_error"] = str(exc)[:200]
+    uniform_sum = None
+    try:
+        os.environ["GIQL_HIP_NO_UNIFORM"] = "1"
+        g = HipEngine(dev_index)
+    finally:
+        del os.environ["GIQL_HIP_NO_UNIFORM"]
+    try:
+        buf = alloc_out(n_pairs)
+        n = eng.inner_plan(a, b, n_chrom)
+        eng.inner_fill(buf[0][:n], buf[1][:n])
+        uniform_sum = eng.pairs_checksum(buf[0][:n], buf[1][:n])
+        g.set_profiling(True)
+        for _ in range(2):
+            n = g.inner_plan(a, b, n_chrom)
+            g.inner_fill(buf[0][:n], buf[1][:n])
+        phases = g.stats()["phase_ms"]
+        g.set_profiling(False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            n = g.inner_plan(a, b, n_chrom)
+            g.inner_fill(buf[0][:n], buf[1][:n])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        dms = sum(phases.values())
+        out["general_form"] = {"ms_per_step": round(ms, 3), "pairs": n, "join_form": g.stats()["join_form"],
+                               "device_ms": round(dms, 3),
+                               "whole_join_frac": round(join_bytes / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dms > 0 else None,
+                               "pairs_equal_default_form": n == n_pairs,
+                               "checksum_equal_default_form": g.pairs_checksum(buf[0][:n], buf[1][:n]) == uniform_sum}
+        del buf
+    finally:
+        g.close()
+    # host Arrow buffers in, host index pairs out (H2D of 12 B/row, join, D2H of 8 B/pair into pinned memory)
+    try:
+        ms, n = eng.inner_join_host_timed(ha, hb, n_chrom)
+        out["t_e2e_ms"] = round(ms, 1)
+        out["t_e2e_note"] = ("giql_hip_inner: pageable host columns -> device, join, pairs -> pinned host memory "
+                             "(allocations included); never the headline value")
+    except Exception as exc:
+        out["t_e2e_ms"] = None
+        out["t_e2e_error"] = str(exc)[:200]
+    return out
+
+
+# ---------------------------------------------------------------------- the row operators
+def run_rowop(args):
+    import numpy as np
+    import torch
+
+    from giql_amd.engine import DeviceSide, HipEngine
+
+    wl = args.workload
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1:
+        raise SystemExit("the SEMI / ANTI / COUNT / NEAREST workloads run on one GPU in bench.py")
+    t0 = time.time()
+    op, ha, hb, n_chrom = make_inputs(wl)
+    gen_s = time.time() - t0
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    a = DeviceSide.from_numpy(*ha, device=dev)
+    b = DeviceSide.from_numpy(*hb, device=dev)
+    eng = HipEngine(0)
+    fn = {"semi": lambda: eng.semi_join(a, b, n_chrom), "anti": lambda: eng.anti_join(a, b, n_chrom),
+          "count": lambda: eng.count_overlaps(a, b, n_chrom), "nearest": lambda: eng.nearest(a, b, n_chrom)}[op]
+    eng.set_profiling(True)
+    res = None
+    for _ in range(max(args.warmup, 1)):
+        res = fn()
+    torch.cuda.synchronize(dev)
+    st = eng.stats()
+    phases = {k: v for k, v in st["phase_ms"].items() if v > 0}
+    eng.set_profiling(False)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = fn()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    n_out = int((res[0] if isinstance(res, tuple) else res).shape[0])
+    device_ms = sum(phases.values())
+    alg = op_bytes(op, a.n, b.n, n_out)
+    dom = max(phases, key=lambda k: phases[k]) if phases else None
+    dom_bytes = (st.get("phase_bytes") or {}).get(dom, 0) if dom else 0
+    roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                "whole_operator": {"algorithmic_bytes": alg, "device_ms": round(device_ms, 3),
+                                   "achieved": round(alg / (device_ms * 1e-3) / 1e9, 1) if device_ms else 0.0,
+                                   "frac": round(alg / (device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms else 0.0},
+                "phase_ms": {k: round(v, 3) for k, v in phases.items()},
+                "phase_launches": {k: v for k, v in st["phase_launches"].items() if v},
+                "phase_ms_source": "hipEvents in the last warm-up call (the timed calls run without events)"}
+    if dom and dom_bytes:
+        launches = max(st["phase_launches"].get(dom, 1), 1)
+        ach = dom_bytes / (phases[dom] * 1e-3) / 1e9
+        roofline.update({"kernel": f"phase {dom}", "launches_per_step": launches,
+                         "avg_launch_ms": round(phases[dom] / launches, 4),
+                         "algorithmic_bytes_per_launch": round(dom_bytes / launches),
+                         "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                         "bytes_source": "giql_hip_stats.phase_bytes"})
+    else:  # the dominant phase has no byte accounting: the operator-level figure of SURVEY.md 8(d)
+        w = roofline["whole_operator"]
+        roofline.update({"kernel": f"whole operator (dominant phase: {dom})", "achieved": w["achieved"], "frac": w["frac"]})
+
+    cpu_baseline = None
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle as ora
+
+        oa, ob = ora.Side(*ha), ora.Side(*hb)
+        threads = ora.max_threads()
+        t1 = time.perf_counter()
+        if op in ("semi", "anti"):
+            want = ora.c_semi_anti(oa, ob, op == "anti", threads=threads)
+            dt = time.perf_counter() - t1
+            equal = bool(np.array_equal(res.cpu().numpy(), want))
+        elif op == "count":
+            want = ora.c_count(oa, ob, "sweep", threads=threads)
+            dt = time.perf_counter() - t1
+            equal = bool(np.array_equal(res.cpu().numpy(), want))
+        else:
+            wi, wd = ora.c_nearest_k1(oa, ob, method="sweep", threads=threads)
+            dt = time.perf_counter() - t1
+            j = res[0].cpu().numpy()
+            ok = j >= 0
+            equal = bool(np.array_equal(res[1].cpu().numpy(), wd) and np.array_equal(ok, wi >= 0)
+                         and np.array_equal(hb[1][j[ok]], hb[1][wi[ok]]) and np.array_equal(hb[2][j[ok]], hb[2][wi[ok]]))
+        cpu_baseline = {"value": round((a.n + b.n) / dt, 1), "unit": "rows/s", "cores": threads, "kind": "port",
+                        "sample": f"the whole workload: {a.n} x {b.n} rows in {dt:.2f} s (oracle OpenMP sweep, not DuckDB)",
+                        "host_cpu_count": os.cpu_count(),
+                        "parity": {"equal": equal, "checked": "every output row of the last timed call (NEAREST: distances, "
+                                                                "presence and the matched (start, end); ids are tie-ambiguous)"}}
+    metric, unit = METRIC[op]
+    line = {
+        "metric": metric.format(a=short(a.n), b=short(b.n)),
+        "value": round((a.n + b.n) * args.steps / elapsed, 1),
+        "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": wl, "n_a": a.n, "n_b": b.n, "n_chrom": n_chrom, "rows_out": n_out,
+                   "inputs": "resident in HBM before the timed region", "form": st.get("join_form")},
+        "hbm_algorithmic_GBps": round(alg * args.steps / elapsed / 1e9, 1),
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "gen_seconds": round(gen_s, 1),
+    }
+    eng.close()
+    return line
+
+
+def main() -> None:
+    args = parse_args()
+    self_launch(args)
+    op = WORKLOADS[args.workload][0]
+    line = run_inner(args) if op == "inner" else run_rowop(args)
+    if line is not None:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -79,6 +79,7 @@ class CStats(ctypes.Structure):
         ("span", ctypes.c_int64),
         ("phase_ms", ctypes.c_float * N_PHASES),
         ("phase_launches", ctypes.c_int32 * N_PHASES),
+        ("phase_bytes", ctypes.c_int64 * N_PHASES),
         ("total_ms", ctypes.c_float),
         ("profiled", ctypes.c_int32),
         ("reserved", ctypes.c_int32),

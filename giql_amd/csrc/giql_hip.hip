@@ -441,6 +441,13 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
       u32* stat = status + pass * per_pass;
       const bool first = pass == 0 && !keep_rids;
       const u32* gb = gbase + digit * OS_BINS;
+      {
+        // algorithmic bytes of this pass: every array it reads + every array it writes, 4 B per row
+        // (KEYGEN reads chrom + start instead of the key; a first pass synthesises the row ids)
+        const int w_out = 1 + (sb.rid[0] ? 1 : 0) + (sb.end[0] ? 1 : 0);
+        const int w_in = (pass == 0 && keygen) ? 2 : 1 + ((sb.rid[0] && !first) ? 1 : 0) + (sb.end[0] ? 1 : 0);
+        ctx->stats.phase_bytes[GIQL_PH_SORT_SCATTER] += (int64_t)4 * (w_in + w_out) * n;
+      }
       if (pass == 0 && keygen) {
         const u32 grid = cdiv(n, 1024 * 8);
         u32* claim = stat + (size_t)cdiv(n, OS_MIN_TILE) * OS_BINS;
@@ -463,6 +470,8 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
   if (local) {
     // the rows are back in buffer 0, ordered by key >> 16: bucket boundaries, then one block per bucket
     Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 2);
+    ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] +=
+        (int64_t)8 * (1 + (sb.rid[0] ? 1 : 0) + (sb.end[0] ? 1 : 0)) * n;  // every array read once, written once
     hipLaunchKernelGGL(k_bucket_bounds, dim3(cdiv((u64)BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
                        gbase + 3 * OS_BINS, ctx->bucket_bnd);
     const int mode = (sb.rid[0] ? 1 : 0) | (sb.end[0] ? 2 : 0);

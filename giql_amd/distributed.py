@@ -206,3 +206,128 @@ def hip_local_join(engine):
         return engine.inner_join(a, b, n_chrom)
 
     return run
+
+
+class PlanGather:
+    """The exchange step in its COMPACT form: instead of the expanded pairs (8 B per pair), ranks
+    all-gather the plan that describes them -- per query row ``{row id, first matching position,
+    match count}`` plus the other side's row ids in sorted order (12 B per query row + 4 B per
+    row: ~65 MB instead of ~400 MB per rank at BASELINE config 4 on 8 GPUs) -- and every receiver
+    expands each rank's block locally (``giql_hip_fill_from_plan_dev`` on GPUs).
+
+        xg = PlanGather(device)
+        sizes = xg.sizes(n_pairs, n_q, n_s, query_is_a)     # collective 1: four int64 per rank
+        q_rid, lo, cnt, s_rid = xg.send_views(sizes)        # int32 views into the send block
+        ... write the plan with GLOBAL row ids (giql_hip_inner_plan_export_dev) ...
+        blocks = xg.all_gather(sizes)                        # collective 2: one padded all-gather
+        for (q_rid_r, lo_r, cnt_r, s_rid_r), (n_pairs_r, _, _, q_is_a_r) in zip(blocks, sizes): expand
+
+    A rank whose plan has no compact form reports ``n_q = -1``; :meth:`compact` is then False on
+    every rank and the callers exchange the expanded pairs (:class:`PairGather`) instead.
+    """
+
+    def __init__(self, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.group = group
+        self.device = torch.device(device)
+        self.world = dist.get_world_size(group)
+        self._q = self._s = -1
+        self._send = None
+        self._recv = None
+        self._mine = torch.zeros(4, dtype=torch.int64, device=self.device)
+        self._all = torch.zeros((self.world, 4), dtype=torch.int64, device=self.device)
+
+    def sizes(self, n_pairs: int, n_q: int, n_s: int, query_is_a: bool):
+        import torch
+        import torch.distributed as dist
+
+        self._mine.copy_(torch.tensor([int(n_pairs), int(n_q), int(n_s), 1 if query_is_a else 0], dtype=torch.int64))
+        dist.all_gather_into_tensor(self._all.view(-1), self._mine, group=self.group)
+        return [tuple(int(x) for x in row) for row in self._all.tolist()]
+
+    @staticmethod
+    def compact(sizes) -> bool:
+        return all(s[1] >= 0 for s in sizes)
+
+    def _ensure(self, sizes):
+        import torch
+
+        q = max((s[1] for s in sizes), default=0)
+        s_ = max((s[2] for s in sizes), default=0)
+        if q > self._q or s_ > self._s:
+            self._send = self._recv = None
+            self._q = (int(q * 1.02) + 1024 + 63) // 64 * 64
+            self._s = (int(s_ * 1.02) + 1024 + 63) // 64 * 64
+            block = 3 * self._q + self._s
+            self._send = torch.empty(block, dtype=torch.int32, device=self.device)
+            self._recv = torch.empty((self.world, block), dtype=torch.int32, device=self.device)
+
+    def _views(self, block, n_q, n_s):
+        q = self._q
+        return block[:n_q], block[q:q + n_q], block[2 * q:2 * q + n_q], block[3 * q:3 * q + n_s]
+
+    def send_views(self, sizes, rank=None):
+        import torch.distributed as dist
+
+        self._ensure(sizes)
+        r = dist.get_rank(self.group) if rank is None else rank
+        return self._views(self._send, sizes[r][1], sizes[r][2])
+
+    def all_gather(self, sizes):
+        import torch.distributed as dist
+
+        self._ensure(sizes)
+        dist.all_gather_into_tensor(self._recv.view(-1), self._send, group=self.group)
+        return [self._views(self._recv[r], s[1], s[2]) for r, s in enumerate(sizes)]
+
+    def bytes_per_rank(self) -> int:
+        return 4 * (3 * self._q + self._s) if self._send is not None else 0
+
+
+def sharded_inner_join_compact(a, b, n_chrom: int, local_plan: Callable, expand: Callable, *, device=None,
+                               group=None):
+    """:func:`sharded_inner_join` with the compact exchange.
+
+    ``local_plan(chrom_a, start_a, end_a, offs_a, chrom_b, ..., n_chrom)`` plans this rank's
+    shard and returns ``None`` (no compact form) or ``(query_is_a, q_rid, lo, cnt, s_rid,
+    n_pairs)`` with shard-LOCAL row ids (torch int32 / int64-convertible tensors);
+    ``expand(q_rid, lo, cnt, s_rid, n_pairs)`` turns one plan block into ``(row_q, row_s)``.
+    Returns global ``(row_a, row_b)``, every rank the whole result.
+    """
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    ca, sa, ea = (np.asarray(x) for x in a[:3])
+    cb, sb, eb = (np.asarray(x) for x in b[:3])
+    offs_a = tuple(a[3:5]) if len(a) >= 5 else (0, 0)
+    offs_b = tuple(b[3:5]) if len(b) >= 5 else (0, 0)
+    ia, ib = unit_rows(ca, cb, n_chrom, world, rank)
+    plan = local_plan(ca[ia], sa[ia], ea[ia], offs_a, cb[ib], sb[ib], eb[ib], offs_b, n_chrom)
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    xg = PlanGather(dev, group=group)
+    if plan is None:
+        sizes = xg.sizes(0, -1, -1, True)
+    else:
+        q_is_a, q_rid, lo, cnt, s_rid, n_pairs = plan
+        sizes = xg.sizes(n_pairs, int(q_rid.shape[0]), int(s_rid.shape[0]), q_is_a)
+    if not xg.compact(sizes):
+        return None  # the caller falls back to the expanded exchange (collectively: every rank sees the same sizes)
+    q_rid_v, lo_v, cnt_v, s_rid_v = xg.send_views(sizes)
+    map_q, map_s = (ia, ib) if q_is_a else (ib, ia)
+    q_rid_v.copy_(torch.from_numpy(map_q.astype(np.int32)).to(dev)[q_rid.to(dev).long()])   # local -> global ids
+    s_rid_v.copy_(torch.from_numpy(map_s.astype(np.int32)).to(dev)[s_rid.to(dev).long()])
+    lo_v.copy_(lo.to(dev).to(torch.int32))
+    cnt_v.copy_(cnt.to(dev).to(torch.int32))
+    out_a, out_b = [], []
+    for (q_r, lo_r, cnt_r, s_r), (n_r, _nq, _ns, qa_r) in zip(xg.all_gather(sizes), sizes):
+        if n_r == 0:
+            continue
+        row_q, row_s = expand(q_r, lo_r, cnt_r, s_r, n_r)
+        out_a.append(row_q if qa_r else row_s)
+        out_b.append(row_s if qa_r else row_q)
+    z = torch.empty(0, dtype=torch.int32, device=dev)
+    return (torch.cat(out_a) if out_a else z), (torch.cat(out_b) if out_b else z.clone())

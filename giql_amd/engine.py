@@ -139,6 +139,7 @@ class HipEngine:
         out["total_ms"] = float(st.total_ms)
         out["phase_ms"] = {name: float(st.phase_ms[i]) for i, name in enumerate(_lib.PHASES)}
         out["phase_launches"] = {name: int(st.phase_launches[i]) for i, name in enumerate(_lib.PHASES)}
+        out["phase_bytes"] = {name: int(st.phase_bytes[i]) for i, name in enumerate(_lib.PHASES)}
         return out
 
     def _check_sides(self, a: DeviceSide, b: DeviceSide) -> None:
@@ -573,3 +574,105 @@ class HipEngine:
             self._h, row_a.data_ptr() if n else None, row_b.data_ptr() if n else None, n,
             self._stream(), ctypes.byref(h)))
         return int(h.value)
+
+    # ------------------------------------------ compact plan (multi-GPU exchange)
+    def plan_export(self, q_rid, lo, cnt, s_rid, rid_add_a: int = 0, rid_add_b: int = 0):
+        """Copy the last plan's compact form into caller tensors (``q_rid`` / ``lo`` / ``cnt`` of
+        at least n_q int32 elements, ``s_rid`` of at least n_s), adding the two offsets to the A /
+        B row ids; returns ``(query_is_a, n_q, n_s)``.  ``GIQL_ERR_STATE`` when the plan is not in
+        the single-range form (exchange the pairs instead)."""
+        qa, nq, ns = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        qcap = min(int(q_rid.shape[0]), int(lo.shape[0]), int(cnt.shape[0]))
+        scap = int(s_rid.shape[0])
+        _lib.check(self._L.giql_hip_inner_plan_export_dev(
+            self._h, q_rid.data_ptr() if qcap else None, lo.data_ptr() if qcap else None,
+            cnt.data_ptr() if qcap else None, s_rid.data_ptr() if scap else None, qcap, scap,
+            int(rid_add_a), int(rid_add_b), ctypes.byref(qa), ctypes.byref(nq), ctypes.byref(ns), self._stream()))
+        return bool(qa.value), int(nq.value), int(ns.value)
+
+    def plan_sizes(self):
+        """``(query_is_a, n_q, n_s)`` of the last plan's compact form without copying anything
+        (the export call with empty buffers reports the sizes with ``GIQL_ERR_CAPACITY``)."""
+        qa, nq, ns = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        rc = self._L.giql_hip_inner_plan_export_dev(self._h, None, None, None, None, 0, 0, 0, 0, ctypes.byref(qa),
+                                                    ctypes.byref(nq), ctypes.byref(ns), self._stream())
+        if rc not in (_lib.GIQL_OK, _lib.GIQL_ERR_CAPACITY):
+            _lib.check(rc)
+        return bool(qa.value), int(nq.value), int(ns.value)
+
+    def fill_from_plan(self, q_rid, lo, cnt, s_rid, row_q, row_s, n_pairs_expected: int = -1) -> int:
+        """Expand a compact plan (this device's or another's) into ``row_q`` / ``row_s``; returns
+        the pair count."""
+        n = ctypes.c_int64(0)
+        nq, ns = int(q_rid.shape[0]), int(s_rid.shape[0])
+        cap = min(int(row_q.shape[0]), int(row_s.shape[0]))
+        _lib.check(self._L.giql_hip_fill_from_plan_dev(
+            self._h, q_rid.data_ptr() if nq else None, lo.data_ptr() if nq else None, cnt.data_ptr() if nq else None,
+            nq, s_rid.data_ptr() if ns else None, ns, row_q.data_ptr() if cap else None,
+            row_s.data_ptr() if cap else None, cap, int(n_pairs_expected), self._stream(), ctypes.byref(n)))
+        return int(n.value)
+
+    # --------------------------------------------------------- host-buffer join
+    def inner_join_host(self, a_cols, b_cols, n_chrom: int, offs_a=(0, 0), offs_b=(0, 0)):
+        """``giql_hip_inner``: host (numpy int32) columns in, host index pairs out -- the
+        PCIe-inclusive path (H2D of the six columns, join, D2H of the pairs into pinned memory).
+        Returns two numpy arrays (copies; the library's buffers are released)."""
+        import numpy as np
+
+        def cside(cols, offs):
+            c, s, e = (np.ascontiguousarray(x, np.int32) for x in cols)
+            cs = _lib.CSide(c.ctypes.data, s.ctypes.data, e.ctypes.data, int(c.shape[0]), int(offs[0]), int(offs[1]))
+            return cs, (c, s, e)
+
+        ca, keep_a = cside(a_cols, offs_a)
+        cb, keep_b = cside(b_cols, offs_b)
+        n = ctypes.c_int64(0)
+        pa, pb = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(self._L.giql_hip_inner(self._h, ctypes.byref(ca), ctypes.byref(cb), int(n_chrom),
+                                          ctypes.byref(n), ctypes.byref(pa), ctypes.byref(pb)))
+        try:
+            m = int(n.value)
+            ra = np.ctypeslib.as_array(ctypes.cast(pa, ctypes.POINTER(ctypes.c_int32)), shape=(max(m, 1),))[:m].copy()
+            rb = np.ctypeslib.as_array(ctypes.cast(pb, ctypes.POINTER(ctypes.c_int32)), shape=(max(m, 1),))[:m].copy()
+        finally:
+            self._L.giql_hip_free_host(pa)
+            self._L.giql_hip_free_host(pb)
+        del keep_a, keep_b
+        return ra, rb
+
+    def inner_join_host_timed(self, a_cols, b_cols, n_chrom: int):
+        """Wall time (ms) and pair count of one ``giql_hip_inner`` call; the pinned results are
+        released without being copied (bench.py's t_e2e)."""
+        import time
+
+        import numpy as np
+
+        def cside(cols):
+            c, s, e = (np.ascontiguousarray(x, np.int32) for x in cols)
+            return _lib.CSide(c.ctypes.data, s.ctypes.data, e.ctypes.data, int(c.shape[0]), 0, 0), (c, s, e)
+
+        ca, keep_a = cside(a_cols)
+        cb, keep_b = cside(b_cols)
+        n = ctypes.c_int64(0)
+        pa, pb = ctypes.c_void_p(), ctypes.c_void_p()
+        t0 = time.perf_counter()
+        rc = self._L.giql_hip_inner(self._h, ctypes.byref(ca), ctypes.byref(cb), int(n_chrom), ctypes.byref(n),
+                                    ctypes.byref(pa), ctypes.byref(pb))
+        ms = (time.perf_counter() - t0) * 1e3
+        self._L.giql_hip_free_host(pa)
+        self._L.giql_hip_free_host(pb)
+        _lib.check(rc)
+        del keep_a, keep_b
+        return ms, int(n.value)
+
+    # ---------------------------------------------------------------- copy probe
+    def copy_probe(self, nbytes: int = 1600 << 20, reps: int = 5) -> float:
+        """GB/s (read + written) of a 16-byte-per-lane copy of ``nbytes`` on this device."""
+        torch = _torch()
+        src = torch.empty(nbytes // 4, dtype=torch.int32, device=self.device)
+        dst = torch.empty_like(src)
+        src.fill_(1)
+        g = ctypes.c_double(0.0)
+        _lib.check(self._L.giql_hip_copy_probe_dev(self._h, src.data_ptr(), dst.data_ptr(), int(src.numel()) * 4,
+                                                   int(reps), self._stream(), ctypes.byref(g)))
+        return float(g.value)

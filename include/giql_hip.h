@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define GIQL_HIP_ABI_VERSION 1
+#define GIQL_HIP_ABI_VERSION 2  /* 2: giql_hip_stats.phase_bytes, pinned host outputs, plan export */
 
 enum {
   GIQL_OK = 0,
@@ -107,6 +107,10 @@ typedef struct giql_hip_stats {
   int64_t span;             /* linearised coordinate span                   */
   float phase_ms[GIQL_PH_N];
   int32_t phase_launches[GIQL_PH_N];
+  int64_t phase_bytes[GIQL_PH_N]; /* ALGORITHMIC bytes of the phase's launches (read every input
+                               of a kernel once + write every output once), accounted by the
+                               host code that issues them for the sort phases (SORT_SCATTER,
+                               SORT_LOCAL); 0 = not accounted */
   float total_ms;           /* sum of phase_ms                              */
   int32_t profiled;         /* 1 if phase_ms are valid                      */
   int32_t reserved;         /* bits 0-3: INNER join form (0 = general two-class join,

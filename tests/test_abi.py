@@ -13,6 +13,7 @@ import pytest
 from giql_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "giql_hip.h")
 
 
 def _declared_symbols():
@@ -36,11 +37,37 @@ def test_abi_version_matches_header():
     assert _lib.load().giql_hip_abi_version() == want
 
 
-def test_struct_layout_matches_header():
-    # giql_side: 3 pointers + int64 + 2 int32
-    assert ctypes.sizeof(_lib.CSide) == 3 * 8 + 8 + 2 * 4
-    # giql_hip_stats: 7 int64 + 16 float + 16 int32 + float + 2 int32 (+pad)
-    assert ctypes.sizeof(_lib.CStats) == 7 * 8 + 16 * 4 + 16 * 4 + 4 + 2 * 4 + 4
+def test_struct_layout_matches_header(tmp_path):
+    """ctypes mirrors vs the REAL C layout: a probe compiled from include/giql_hip.h prints
+    sizeof / offsetof, field by field."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    fields = {
+        "giql_side": (_lib.CSide, ["chrom", "start", "end", "n", "start_off", "end_off"]),
+        "giql_hip_stats": (_lib.CStats, ["n_a", "n_out", "workspace_bytes", "span", "phase_ms", "phase_launches",
+                                         "phase_bytes", "total_ms", "profiled", "reserved"]),
+        "giql_operand": (_lib.COperand, ["side", "type", "data", "valid", "lit_i", "lit_f", "lit_is_float"]),
+        "giql_pred": (_lib.CPred, ["lhs", "rhs", "op"]),
+    }
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{HEADER}"', "int main(void) {"]
+    for name, (_cls, fs) in fields.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for f in fs:
+            lines.append(f'  printf("{name}.{f} %zu\\n", offsetof({name}, {f}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run([gcc, "-o", str(exe), str(src)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, (cls, fs) in fields.items():
+        assert ctypes.sizeof(cls) == int(got[name]), name
+        for f in fs:
+            assert getattr(cls, f).offset == int(got[f"{name}.{f}"]), f"{name}.{f}"
+    assert len(_lib.PHASES) <= _lib.N_PHASES == int(re.search(r"GIQL_PH_N = (\d+)", open(HEADER).read()).group(1))
 
 
 def test_product_has_no_cpu_fallback():

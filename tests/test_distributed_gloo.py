@@ -87,6 +87,100 @@ def _worker(rank, world, port, out_dir, skew=False):
         dist.destroy_process_group()
 
 
+def _uniform_tables(seed=11, skew=False):
+    """A: free lengths; B: fixed-length reads (the shape whose plan has a compact form)."""
+    r = np.random.default_rng(seed)
+    def chroms(n, nch):
+        ch = r.integers(0, nch, n).astype(np.int32)
+        if skew:
+            ch[r.random(n) < 0.8] = 2
+        return ch
+    ca, cb = chroms(3000, 7), chroms(9000, 6)
+    sa = r.integers(0, 150_000, 3000).astype(np.int32)
+    sb = r.integers(0, 150_000, 9000).astype(np.int32)
+    return (ca, sa, sa + r.integers(1, 900, 3000).astype(np.int32)), (cb, sb, sb + np.int32(150))
+
+
+def _np_plan(ca, sa, ea, offs_a, cb, sb, eb, offs_b, n_chrom):
+    """numpy stand-in for giql_hip_inner_plan_dev + giql_hip_inner_plan_export_dev on a shard whose
+    B rows all have one length L: b overlaps a  <=>  b.start in [a.start - L + 1, a.end)."""
+    if len(cb) == 0 or len(ca) == 0:
+        z = torch.zeros(0, dtype=torch.int32)
+        return True, z, z.clone(), z.clone(), z.clone(), 0
+    lens = np.unique(eb.astype(np.int64) - sb)
+    if lens.shape[0] != 1 or lens[0] <= 0:
+        return None
+    big = np.int64(1) << 33
+    kb = cb.astype(np.int64) * big + sb
+    order = np.argsort(kb, kind="stable")
+    ks = kb[order]
+    lo = np.searchsorted(ks, ca.astype(np.int64) * big + sa - lens[0] + 1, "left")
+    hi = np.searchsorted(ks, ca.astype(np.int64) * big + ea, "left")
+    cnt = np.maximum(hi - lo, 0)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.int32))
+    return True, t(np.arange(len(ca))), t(lo), t(cnt), t(order), int(cnt.sum())
+
+
+def _np_expand(q_rid, lo, cnt, s_rid, n_pairs):
+    """numpy stand-in for giql_hip_fill_from_plan_dev."""
+    c = cnt.numpy().astype(np.int64)
+    row_q = np.repeat(q_rid.numpy(), c)
+    start = np.repeat(lo.numpy().astype(np.int64), c)
+    within = np.arange(int(c.sum())) - np.repeat(np.cumsum(c) - c, c)
+    row_s = s_rid.numpy()[start + within]
+    assert row_q.shape[0] == n_pairs
+    return torch.from_numpy(row_q.astype(np.int32)), torch.from_numpy(row_s.astype(np.int32))
+
+
+def _compact_worker(rank, world, port, out_dir, skew=False):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from giql_amd import distributed as D
+
+        a, b = _uniform_tables(skew=skew)
+        res = D.sharded_inner_join_compact(a, b, 7, _np_plan, _np_expand)
+        assert res is not None
+        np.save(os.path.join(out_dir, f"cpairs_{rank}.npy"), np.stack([res[0].numpy(), res[1].numpy()]))
+        # a shard without a compact form on ONE rank makes every rank fall back, collectively
+        def plan_or_none(*args):
+            return None if rank == world - 1 else _np_plan(*args)
+        assert D.sharded_inner_join_compact(a, b, 7, plan_or_none, _np_expand) is None
+        # the buffered exchange itself: ragged blocks, two steps with growing sizes, an empty rank
+        xg = D.PlanGather("cpu")
+        for step_no in (1, 4):
+            nq, ns = (rank + 1) * step_no, (0 if rank == 1 else 5 * step_no + rank)
+            sizes = xg.sizes(nq * 2, nq, ns, rank % 2 == 0)
+            assert sizes == [((r + 1) * step_no * 2, (r + 1) * step_no, 0 if r == 1 else 5 * step_no + r, int(r % 2 == 0))
+                             for r in range(world)]
+            assert D.PlanGather.compact(sizes)
+            q, lo, cnt, srid = xg.send_views(sizes)
+            q.fill_(rank); lo.fill_(10 + rank); cnt.fill_(2); srid.fill_(100 + rank)
+            for r, (q_r, lo_r, cnt_r, s_r) in enumerate(xg.all_gather(sizes)):
+                assert q_r.tolist() == [r] * sizes[r][1] and lo_r.tolist() == [10 + r] * sizes[r][1]
+                assert cnt_r.tolist() == [2] * sizes[r][1] and s_r.tolist() == [100 + r] * sizes[r][2]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,skew", [(2, False), (3, False), (2, True), (3, True)])
+def test_compact_plan_exchange_matches_single_process(tmp_path, world, skew):
+    """The compact exchange (plan blocks all-gathered, expanded by every receiver) returns the same
+    global pair set on every rank as one process joining everything -- bit-exact ids."""
+    from oracle import pyoracle as ora
+
+    port = _free_port()
+    mp.spawn(_compact_worker, args=(world, port, str(tmp_path), skew), nprocs=world, join=True)
+    a, b = _uniform_tables(skew=skew)
+    want = ora.sort_pairs(*ora.c_inner(ora.Side(*a), ora.Side(*b), "sweep", threads=2))
+    assert want.shape[0] > 1000
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"cpairs_{r}.npy"))
+        assert np.array_equal(ora.sort_pairs(got[0], got[1]), want), r
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_join_matches_single_process(tmp_path, world):
     from oracle import pyoracle as ora
