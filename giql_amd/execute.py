@@ -14,7 +14,7 @@ from __future__ import annotations
 import numpy as np
 
 from .engine import ENCODING_OFFSETS, DeviceSide, HipEngine
-from .plan import JoinPlan, PlanSide, is_plan_string
+from .plan import JoinPlan, PlanSide, Projection, is_plan_string
 from .transpile import build_plan
 
 _ENGINES: dict[int, HipEngine] = {}
@@ -560,15 +560,19 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
     except ImportError:  # pragma: no cover
         pa = None
     taken: dict = {}
+    # columns to materialise: the projection (incl. the hidden "__giql_*" carriers of ORDER BY / GROUP BY
+    # keys) + one carrier per aggregate argument
+    wanted = list(plan.projection) + [Projection(a.side, a.column, f"__giql_a{i}")
+                                      for i, a in enumerate(plan.aggregates) if a.side in ("l", "r")]
     if pa is not None and device_projection and all(isinstance(t, pa.Table) for t in (lt, rt)):
         for s, tbl in (("l", lt), ("r", rt)):
-            want = [p.column for p in plan.projection if p.side == s]
-            if want:
+            want = [p.column for p in wanted if p.side == s]
+            if want and s in idx:
                 taken[s] = _device_take(tbl, want, idx[s], eng)
     idx_h = {s: v.cpu().numpy() for s, v in idx.items() if s not in taken}
 
     names, cols = [], []
-    for p in plan.projection:
+    for p in wanted:
         names.append(p.name)
         if p.side == "distance":
             cols.append(extra["distance"])
@@ -579,7 +583,51 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
     if pa is None:  # pragma: no cover
         return dict(zip(names, cols))
     arrays = [c if isinstance(c, (pa.Array, pa.ChunkedArray)) else pa.array(c) for c in cols]
+    if not arrays:   # e.g. SELECT COUNT(*): no column to carry, only the row count
+        n_rows = int(next(iter(idx.values())).shape[0])
+        names, arrays = ["__giql_rows"], [pa.nulls(n_rows, pa.int8())]
     out = pa.Table.from_arrays(arrays, names=names)
+    return _finish_outer(out, plan)
+
+
+_PA_AGG = {"COUNT": "count", "SUM": "sum", "MIN": "min", "MAX": "max", "AVG": "mean"}
+
+
+def _finish_outer(out, plan: JoinPlan):
+    """The clauses that ride on the reference's outer SELECT wrapper (intersects_duckdb.py:1336-1400):
+    aggregates / GROUP BY, DISTINCT, ORDER BY, OFFSET / LIMIT -- finished here on the projected Arrow
+    table with pyarrow compute on the HOST (a first version: the join, the residual filters and the
+    column gathers ran on the GPU; these operate on the already-reduced result)."""
+    import pyarrow as pa
+
+    if plan.aggregates:
+        cols = {}
+        # one aggregate at a time keeps the produced column names unambiguous
+        keys = list(plan.group_by)
+        base = None
+        for i, a in enumerate(plan.aggregates):
+            if a.side == "*":
+                spec, produced = ([], "count_all"), "count_all"
+            else:
+                fn = "count_distinct" if (a.distinct and a.func == "COUNT") else _PA_AGG[a.func]
+                spec, produced = (f"__giql_a{i}", fn), f"__giql_a{i}_{fn}"
+            res = out.group_by(keys, use_threads=False).aggregate([spec])   # use_threads=False: stable group order
+            if base is None:
+                base = res
+                for k in keys:
+                    cols[k] = res.column(k)
+            cols[a.name] = res.column(produced)
+        order = list(plan.output) if plan.output else list(cols)
+        keep = [n for n in order if n in cols] + [n for n in cols if n not in order]
+        out = pa.Table.from_arrays([cols[n] for n in keep], names=keep)
+    visible = [n for n in out.column_names if not n.startswith("__giql_")]
     if plan.distinct:
-        out = out.group_by(names, use_threads=False).aggregate([])
-    return out
+        if plan.order_by and any(n not in visible for n, _ in plan.order_by):
+            raise ValueError("ORDER BY a column that DISTINCT does not keep")
+        out = out.select(visible).group_by(visible, use_threads=False).aggregate([])
+    if plan.order_by:
+        out = out.sort_by([(n, "descending" if desc else "ascending") for n, desc in plan.order_by])
+    if plan.offset is not None or plan.limit is not None:
+        start = plan.offset or 0
+        out = out.slice(start, plan.limit) if plan.limit is not None else out.slice(start)
+    return out.select([n for n in out.column_names if not n.startswith("__giql_")])

@@ -64,6 +64,19 @@ class Residual:
 
 
 @dataclass(frozen=True)
+class Aggregate:
+    """A plain aggregate of the outer SELECT (``FUNC([DISTINCT] <col>)`` or ``COUNT(*)``), computed
+    over the join's rows per ``group_by`` key (the reference rebuilds these over its wrapper
+    relation, intersects_duckdb.py:1402-1644)."""
+
+    func: str      # COUNT SUM MIN MAX AVG
+    side: str      # "l" / "r", or "*" for COUNT(*)
+    column: str
+    name: str      # output column name
+    distinct: bool = False
+
+
+@dataclass(frozen=True)
 class JoinPlan:
     kind: str
     left: PlanSide
@@ -79,6 +92,14 @@ class JoinPlan:
     distance: int = 0
     stranded: bool = False
     strand_col: str | None = None
+    # the clauses that ride on the reference's outer SELECT wrapper (intersects_duckdb.py:1336-1400),
+    # finished on the projected table: projection columns named "__giql_*" are carried for them only
+    aggregates: tuple[Aggregate, ...] = field(default_factory=tuple)
+    group_by: tuple[str, ...] = field(default_factory=tuple)       # output names of the key columns
+    order_by: tuple[tuple[str, bool], ...] = field(default_factory=tuple)   # (output name, descending)
+    limit: int | None = None
+    offset: int | None = None
+    output: tuple[str, ...] = field(default_factory=tuple)         # final column names in SELECT order (grouped plans)
 
     def __post_init__(self) -> None:
         if self.kind not in KINDS:
@@ -88,6 +109,8 @@ class JoinPlan:
         d = asdict(self)
         d["projection"] = [asdict(p) for p in self.projection]
         d["residuals"] = [asdict(r) for r in self.residuals]
+        d["aggregates"] = [asdict(a) for a in self.aggregates]
+        d["order_by"] = [list(o) for o in self.order_by]
         return PLAN_PREFIX + json.dumps(d, sort_keys=True, separators=(",", ":"))
 
     @classmethod
@@ -103,7 +126,10 @@ class JoinPlan:
             max_distance=d.get("max_distance"), signed=d.get("signed", False),
             residuals=tuple(Residual(r["clause"], Operand(**r["lhs"]), r["op"], Operand(**r["rhs"]))
                             for r in d.get("residuals", ())),
-            distance=d.get("distance", 0), stranded=d.get("stranded", False), strand_col=d.get("strand_col"))
+            distance=d.get("distance", 0), stranded=d.get("stranded", False), strand_col=d.get("strand_col"),
+            aggregates=tuple(Aggregate(**a) for a in d.get("aggregates", ())),
+            group_by=tuple(d.get("group_by", ())), order_by=tuple((o[0], bool(o[1])) for o in d.get("order_by", ())),
+            limit=d.get("limit"), offset=d.get("offset"), output=tuple(d.get("output", ())))
 
 
 def is_plan_string(text) -> bool:

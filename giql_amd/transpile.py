@@ -35,11 +35,13 @@ import re
 from dataclasses import dataclass
 
 from .plan import JoinPlan, Operand, PlanSide, Projection, Residual
+from .shape import AGG_FUNCS, ColRef as _ColRef, HipDeclined, JoinShape, OrderKey, SelItem, TableRef as _TableRef
+from .shape import decline as _decline
+from .shape import genomic_col as _genomic_col
+from .shape import lower_join_shape, resolve_projection
+from .shape import norm as _norm
+from .shape import table_side as _table_side
 from .table import Table, Tables, build_tables
-
-
-class HipDeclined(ValueError):
-    """Valid GIQL that the hip dialect does not execute (reference: decline)."""
 
 
 # ------------------------------------------------------------------- tokens
@@ -98,28 +100,7 @@ def _tokenize(sql: str) -> list[Tok]:
     return out
 
 
-def _norm(name: str, quoted: bool = False) -> str:
-    # unquoted identifiers are case-insensitive (intersects_duckdb.py:119-128)
-    return name if quoted else name.casefold()
-
-
 # ------------------------------------------------------------------- parser
-@dataclass
-class _ColRef:
-    table: str | None
-    table_quoted: bool
-    column: str
-    star: bool = False
-    count: bool = False  # COUNT(<this column>)
-
-
-@dataclass
-class _TableRef:
-    name: str
-    alias: str
-    alias_quoted: bool
-
-
 class _Parser:
     def __init__(self, sql: str):
         self.toks = _tokenize(sql)
@@ -283,50 +264,47 @@ def _parse_conjunction(p: _Parser, allow_literal: bool = False):
 _UNSUPPORTED_TAIL = ("GROUP", "ORDER", "HAVING", "LIMIT", "OFFSET", "UNION")
 
 
-def _decline(reason: str) -> HipDeclined:
-    return HipDeclined(
-        f"{reason}: this query shape is valid GIQL but is not executed by dialect='hip' "
-        "(the reference declines it to the naive overlap predicate); transpile it with "
-        "giql.transpile(...) for a SQL engine instead")
-
-
-def _table_side(ref: _TableRef, tables: Tables) -> PlanSide:
-    t = tables.get(ref.name)
-    if t is None:
-        # an unregistered table uses default column names, like the naive plan
-        # (intersects_duckdb.py:1179-1188)
-        t = Table(ref.name)
-    return PlanSide(table=ref.name, alias=_norm(ref.alias, ref.alias_quoted),
-                    chrom_col=t.chrom_col, start_col=t.start_col, end_col=t.end_col,
-                    coordinate_system=t.coordinate_system, interval_type=t.interval_type)
-
-
-def _genomic_col(name: str, tables: Tables) -> str:
-    t = tables.get(name)
-    return t.genomic_col if t is not None else "interval"
-
-
-def _parse_projection(p: _Parser) -> list[tuple[_ColRef, str | None]]:
-    """SELECT list: qualified columns, plus at most the count_overlaps aggregate
-    ``COUNT(<right col>) AS <alias>`` (returned as a _ColRef with ``count=True``)."""
-    items: list[tuple[_ColRef, str | None]] = []
+def _parse_projection(p: _Parser) -> list[SelItem]:
+    """SELECT list: qualified columns and plain aggregates ``FUNC([DISTINCT] <col>)`` / ``COUNT(*)``
+    (the projections ``_resolve_projections`` can rebuild, intersects_duckdb.py:1402-1644); every
+    other expression declines (#204, #205)."""
+    items: list[SelItem] = []
     while True:
         if p.peek().kind == "kw" and not p.at_kw("FROM"):
             raise _decline(f"projection starting with {p.peek().text}")
         if p.peek().kind in ("num", "str") or p.at_punct("("):
             raise _decline("expression in the SELECT list")
-        is_count = (p.peek().kind == "id" and not p.peek().quoted and p.peek().text.upper() == "COUNT"
-                    and p.peek(1).kind == "punct" and p.peek(1).text == "(")
-        if is_count:
+        t = p.peek()
+        is_call = t.kind == "id" and not t.quoted and p.peek(1).kind == "punct" and p.peek(1).text == "("
+        func = None
+        distinct = False
+        if is_call:
+            func = t.text.upper()
+            if func not in AGG_FUNCS:
+                raise _decline("function call in the SELECT list")
             p.next()
             p.next()
             if p.at_kw("DISTINCT"):
-                raise _decline("COUNT(DISTINCT ...)")
+                p.next()
+                distinct = True
             if p.at_punct("*"):
-                raise _decline("COUNT(*)")  # _match_count_overlaps wants COUNT(<right col>)
-            ref = p.colref()
+                p.next()
+                ref = None
+                if func != "COUNT" or distinct:
+                    raise _decline(f"{func}(*)")
+            else:
+                if p.peek().kind != "id":
+                    raise _decline("aggregate over an expression")
+                ref = p.colref()
+                if ref.star:
+                    raise _decline("star inside an aggregate")   # COUNT(a.*), #204
+                if p.peek().kind == "punct" and p.peek().text in "+-/*=<>(":
+                    raise _decline("aggregate over an expression")
             p.expect_punct(")")
-            ref.count = True
+            if p.peek().kind == "id" and not p.peek().quoted and p.peek().text.upper() in ("OVER", "FILTER"):
+                raise _decline("window aggregate / FILTER clause")
+            if ref is not None and func == "COUNT" and not distinct:
+                ref.count = True
         else:
             ref = p.colref()
             if p.at_punct("("):
@@ -339,113 +317,12 @@ def _parse_projection(p: _Parser) -> list[tuple[_ColRef, str | None]]:
             alias = p.next().text
         elif p.peek().kind == "id":
             alias = p.next().text
-        items.append((ref, alias))
+        items.append(SelItem(ref, alias, func, distinct))
         if p.at_punct(","):
             p.next()
             continue
         break
     return items
-
-
-def _resolve_projection(items, left: PlanSide, right: PlanSide, left_only: bool,
-                        distance_alias: str | None = None) -> tuple[Projection, ...]:
-    out = []
-    for ref, alias in items:
-        if ref.count:
-            raise _decline("COUNT(...) outside the count_overlaps LEFT JOIN ... GROUP BY shape")
-        if ref.star:
-            # schema-less star enumeration would narrow the result (#202)
-            raise _decline("star projection")
-        if ref.table is None:
-            raise ValueError(
-                f"Unqualified column {ref.column!r} in the SELECT list: the hip join path has no "
-                "live schema to attribute it to a side; qualify it with a table alias")
-        q = _norm(ref.table, ref.table_quoted)
-        name = alias or ref.column
-        if q == left.alias:
-            out.append(Projection("l", ref.column, name))
-        elif q == right.alias:
-            if left_only:
-                raise ValueError(
-                    f"Column {ref.table}.{ref.column} references the right side of a SEMI/ANTI "
-                    "join, which is out of scope in the SELECT list")
-            if distance_alias is not None and ref.column == "distance":
-                out.append(Projection("distance", "distance", name))
-            else:
-                out.append(Projection("r", ref.column, name))
-        else:
-            raise ValueError(f"Unknown table qualifier {ref.table!r} in the SELECT list")
-    return tuple(out)
-
-
-def _resolve_residual(clause: str, term, left: PlanSide, right: PlanSide, kind: str) -> Residual:
-    """Bind a comparison's operands to the two sides; qualifier mistakes are user
-    errors, as in ``_validate_extra_qualifiers`` (intersects_duckdb.py:914-959)."""
-    _, lhs, op, rhs = term
-
-    def bind(o) -> Operand:
-        if o[0] == "lit":
-            v = o[1]
-            return Operand("str" if isinstance(v, str) else ("float" if isinstance(v, float) else "int"), v)
-        ref: _ColRef = o[1]
-        if ref.star:
-            raise _decline("star in a join condition")
-        if ref.table is None:
-            raise ValueError(
-                f"dialect='hip' cannot inline the extra predicate: column {ref.column!r} must be "
-                f"qualified with {left.alias!r} or {right.alias!r}")
-        q = _norm(ref.table, ref.table_quoted)
-        if q == left.alias:
-            return Operand("l", ref.column)
-        if q == right.alias:
-            if kind in ("SEMI", "ANTI") and clause == "where":
-                raise ValueError(f"{kind} join: the WHERE clause cannot reference the right side "
-                                 f"({ref.table}.{ref.column})")
-            return Operand("r", ref.column)
-        raise ValueError(f"dialect='hip' cannot inline the extra predicate: unknown table qualifier "
-                         f"{ref.table!r}; expected {left.alias!r} or {right.alias!r}")
-
-    a, b = bind(lhs), bind(rhs)
-    if a.kind not in ("l", "r") and b.kind not in ("l", "r"):
-        raise _decline("constant predicate in the join condition")
-    return Residual(clause, a, op, b)
-
-
-def _resolve_count_projection(items, group_cols, left: PlanSide, right: PlanSide):
-    """The count_overlaps projection: left key columns + ONE aliased COUNT(<right col>);
-    GROUP BY must be exactly the projected left columns (intersects_duckdb.py:484-539)."""
-    out = []
-    n_count = 0
-    keys = set()
-    for ref, alias in items:
-        if ref.star or ref.table is None:
-            raise _decline("count_overlaps projection that is not a qualified column")
-        q = _norm(ref.table, ref.table_quoted)
-        if ref.count:
-            n_count += 1
-            if q != right.alias:
-                raise _decline("COUNT over a left-side column")
-            if not alias:
-                raise _decline("count_overlaps COUNT without an alias")
-            out.append(Projection("count", ref.column, alias))
-        else:
-            if q != left.alias:
-                raise _decline("count_overlaps key from the right side")
-            keys.add(ref.column)
-            out.append(Projection("l", ref.column, alias or ref.column))
-    if n_count != 1 or not keys:
-        raise _decline("count_overlaps needs left key columns and exactly one COUNT")
-    gkeys = set()
-    for g in group_cols:
-        if g.table is None or _norm(g.table, g.table_quoted) != left.alias:
-            raise _decline("GROUP BY column that is not a left-side qualified column")
-        gkeys.add(g.column)
-    if gkeys != keys:
-        raise _decline("GROUP BY keys differ from the projected left columns")
-    names = [p.name for p in out]
-    if len(set(names)) != len(names):
-        raise _decline("duplicate output names in count_overlaps")
-    return tuple(out)
 
 
 def _parse_nearest(p: _Parser, tables: Tables, from_ref: _TableRef):
@@ -882,6 +759,7 @@ def _lower(giql: str, tables, want_sql: bool):
     nearest = None
     join_ref = None
     on_seen = False
+    using: list[str] = []
     if p.at_punct(","):
         p.next()
         join_ref = p.table_ref()
@@ -892,12 +770,12 @@ def _lower(giql: str, tables, want_sql: bool):
             side = p.next().text
             if p.at_kw("SEMI", "ANTI"):
                 kind = p.next().text
-            elif side == "LEFT" and any(ref.count for ref, _ in items):
-                # count_overlaps: LEFT [OUTER] JOIN ... COUNT(b.col) ... GROUP BY left keys
-                # (_match_count_overlaps, intersects_duckdb.py:432-548)
+            elif side == "LEFT":
+                # count_overlaps (LEFT [OUTER] JOIN ... COUNT(b.col) ... GROUP BY left keys) is decided
+                # by the gate (_match_count_overlaps, intersects_duckdb.py:432-548)
                 if p.at_kw("OUTER"):
                     p.next()
-                kind = "COUNT"
+                kind = "LEFT"
             else:
                 raise _decline(f"{side} outer join")  # intersects_duckdb.py:661-662
         elif p.at_kw("INNER", "CROSS", "SEMI", "ANTI"):
@@ -914,92 +792,93 @@ def _lower(giql: str, tables, want_sql: bool):
         else:
             join_ref = p.table_ref()
             if p.at_kw("USING"):
-                raise _decline("JOIN ... USING")
+                p.next()
+                p.expect_punct("(")
+                while True:
+                    using.append(p.ident().text)
+                    if p.at_punct(","):
+                        p.next()
+                        continue
+                    break
+                p.expect_punct(")")
             if p.at_kw("ON"):
                 p.next()
                 on_seen = True
 
-    left = _table_side(from_ref, tbls)
-    right = _table_side(join_ref, tbls)
-
     if kind == "NEAREST":
+        left = _table_side(from_ref, tbls)
+        right = _table_side(join_ref, tbls)
         if p.peek().kind != "end" and not p.at_punct(";"):
             raise _decline("extra clauses after NEAREST")
         if left.alias == right.alias:
             raise _decline("same alias on both sides")
-        proj = _resolve_projection(items, left, right, False, distance_alias=right.alias)
+        proj = resolve_projection(items, left, right, False, distance_alias=right.alias)
         return JoinPlan("NEAREST", left, right, proj, distinct, 1, nearest[0], nearest[1])
 
-    if kind == "COUNT" and not on_seen:
-        raise _decline("count_overlaps without an ON clause")
-    on_terms, where_terms = [], []
+    shape = JoinShape(items=items, from_ref=from_ref, join_ref=join_ref, kind=kind, on_seen=on_seen, using=using,
+                      distinct=distinct)
     if on_seen:
         if p.peek().kind not in ("id", "num", "str") and not p.at_punct("-"):
             raise _decline("join condition other than INTERSECTS / simple comparisons")
-        on_terms = _parse_conjunction(p)
-    elif kind in ("SEMI", "ANTI"):
-        raise _decline("SEMI/ANTI join with its INTERSECTS outside ON")  # #201
+        shape.on_terms = _parse_conjunction(p)
     if p.at_kw("WHERE"):
         p.next()
-        where_terms = _parse_conjunction(p)
-    n_int = sum(t[0] == "intersects" for t in on_terms + where_terms)
-    if n_int == 0:
-        raise _decline("join without an INTERSECTS predicate")
-    if n_int > 1:
-        raise _decline("more than one INTERSECTS")
-    if kind in ("SEMI", "ANTI") and not any(t[0] == "intersects" for t in on_terms):
-        raise _decline("SEMI/ANTI join with its INTERSECTS outside ON")  # #201
-    _, lhs, rhs = [t for t in on_terms + where_terms if t[0] == "intersects"][0]
-    cmp_terms = [("on", t) for t in on_terms if t[0] == "cmp"] + [("where", t) for t in where_terms if t[0] == "cmp"]
-    if kind == "COUNT" and (cmp_terms or where_terms):
-        raise _decline("count_overlaps with predicates beside the INTERSECTS")  # bare ON only (:432-548)
-    group_cols: list[_ColRef] = []
-    if kind == "COUNT":
-        if not p.at_kw("GROUP"):
-            raise _decline("count_overlaps without GROUP BY")
+        shape.where_terms = _parse_conjunction(p)
+    # the clauses the reference lets ride on its outer SELECT wrapper (intersects_duckdb.py:1336-1400)
+    if p.at_kw("GROUP"):
         p.next()
         p.expect_kw("BY")
         while True:
             if p.peek().kind != "id":
                 raise _decline("GROUP BY expression")
-            group_cols.append(p.colref())
+            shape.group_by.append(p.colref())
+            if p.at_punct("(") or (p.peek().kind == "punct" and p.peek().text in "+-/*"):
+                raise _decline("GROUP BY expression")
             if p.at_punct(","):
                 p.next()
                 continue
             break
+    if p.at_kw("HAVING"):
+        raise _decline("HAVING clause")
+    if p.at_kw("ORDER"):
+        p.next()
+        p.expect_kw("BY")
+        while True:
+            if p.peek().kind != "id":
+                raise _decline("ORDER BY expression")
+            ref = p.colref()
+            if p.at_punct("(") or (p.peek().kind == "punct" and p.peek().text in "+-/*"):
+                raise _decline("ORDER BY expression")
+            desc = False
+            if p.peek().kind == "id" and not p.peek().quoted and p.peek().text.upper() in ("ASC", "DESC"):
+                desc = p.next().text.upper() == "DESC"
+            if p.peek().kind == "id" and not p.peek().quoted and p.peek().text.upper() == "NULLS":
+                raise _decline("ORDER BY ... NULLS FIRST/LAST")
+            shape.order_by.append(OrderKey(ref, desc))
+            if p.at_punct(","):
+                p.next()
+                continue
+            break
+    for clause in ("LIMIT", "OFFSET"):
+        if p.at_kw(clause):
+            p.next()
+            t = p.next()
+            if t.kind != "num" or "." in t.text:
+                raise _decline(f"{clause} that is not an integer literal")
+            setattr(shape, clause.lower(), int(t.text))
+    if p.at_kw("LIMIT") and shape.limit is None:   # OFFSET n LIMIT m
+        p.next()
+        t = p.next()
+        if t.kind != "num" or "." in t.text:
+            raise _decline("LIMIT that is not an integer literal")
+        shape.limit = int(t.text)
     if p.peek().kind == "kw" and p.peek().text in _CLAUSE_END:
         raise _decline(f"{p.peek().text} clause")
     if p.at_punct(","):
         raise _decline("a third table")
     if p.peek().kind != "end" and not p.at_punct(";"):
         raise _decline(f"trailing input near {p.peek().text!r}")
-
-    for side_ref in (lhs, rhs):
-        if side_ref.table is None or side_ref.star:
-            raise _decline("INTERSECTS operand that is not a table-qualified column")
-    la, ra = _norm(lhs.table, lhs.table_quoted), _norm(rhs.table, rhs.table_quoted)
-    if left.alias == right.alias:
-        raise _decline("same alias on both sides")
-    if left.table == right.table:
-        raise _decline("self-join")
-    # FROM-side orientation swap (intersects_duckdb.py:359-410)
-    if la == left.alias and ra == right.alias:
-        l_col, r_col = lhs.column, rhs.column
-    elif ra == left.alias and la == right.alias:
-        l_col, r_col = rhs.column, lhs.column
-    else:
-        raise _decline("INTERSECTS operands that do not name the two joined tables")
-    if l_col != _genomic_col(left.table, tbls) or r_col != _genomic_col(right.table, tbls):
-        raise ValueError(
-            f"INTERSECTS operands must be the tables' genomic columns "
-            f"({_genomic_col(left.table, tbls)!r} / {_genomic_col(right.table, tbls)!r})")
-    if kind == "COUNT":
-        if distinct:
-            raise _decline("DISTINCT with count_overlaps")
-        return JoinPlan("COUNT", left, right, _resolve_count_projection(items, group_cols, left, right))
-    proj = _resolve_projection(items, left, right, kind in ("SEMI", "ANTI"))
-    residuals = tuple(_resolve_residual(clause, t, left, right, kind) for clause, t in cmp_terms)
-    return JoinPlan(kind, left, right, proj, distinct, residuals=residuals)
+    return lower_join_shape(shape, tbls)
 
 
 def _render(toks: list[Tok]) -> str:

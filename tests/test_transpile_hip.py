@@ -100,11 +100,9 @@ def test_case_insensitive_aliases():
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval WHERE a.score IN (1, 2)",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.interval INTERSECTS b.interval",
     "SELECT a.start FROM peaks a JOIN genes b ON a.score > 5",
-    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval ORDER BY a.start",
-    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval LIMIT 5",
-    "SELECT COUNT(*) FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
     "SELECT a.start + 1 FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
-    "SELECT a.start FROM peaks a JOIN genes b USING (chrom)",
+    "SELECT a.start FROM peaks a JOIN genes b USING (chrom)",                      # USING without any INTERSECTS
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval HAVING COUNT(*) > 1",
     "SELECT a.start FROM peaks a SEMI JOIN genes b ON TRUE WHERE a.interval INTERSECTS b.interval",
     "SELECT a.start FROM peaks a, genes b, exons c WHERE a.interval INTERSECTS b.interval",
     "WITH x AS (SELECT 1) SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
@@ -261,13 +259,21 @@ def test_count_overlaps_shape_engages_the_path():
     "SELECT a.chrom, COUNT(a.start) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom",
     "SELECT a.chrom, b.start, COUNT(b.chrom) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval "
     "GROUP BY a.chrom",
-    "SELECT a.chrom, COUNT(b.chrom) AS n FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom",
     "SELECT a.chrom, COUNT(b.chrom) AS n FROM peaks a LEFT JOIN genes b ON a.interval INTERSECTS b.interval "
     "GROUP BY a.chrom HAVING COUNT(b.chrom) > 1",
 ])
 def test_count_overlaps_lookalikes_decline(query):
     with pytest.raises(HipDeclined):
         build_plan(query, ["peaks", "genes"])
+
+
+def test_inner_join_with_count_is_a_grouped_inner_join_not_count_overlaps():
+    # an INNER join drops the zero-overlap keys, so this is the plain aggregate over the join's rows
+    # (intersects_duckdb.py:1402-1644), not the zero-filling count_overlaps shape (:432-548)
+    plan = build_plan("SELECT a.chrom, COUNT(b.chrom) AS n FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval "
+                      "GROUP BY a.chrom", ["peaks", "genes"])
+    assert plan.kind == "INNER" and plan.group_by == ("chrom",)
+    assert [(a.func, a.side, a.column, a.name) for a in plan.aggregates] == [("COUNT", "r", "chrom", "n")]
 
 
 def test_nearest_plan():

@@ -12,7 +12,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PHASE_OF = [("k_onesweep", "sort_scatter"), ("k_linearize", "linearize"), ("k_digit_offsets", "linearize"), ("k_fold_top", "linearize"),
+PHASE_OF = [("k_onesweep", "sort_scatter"), ("k_bucket_sort", "sort_local"), ("k_bucket_bounds", "sort_local"), ("k_linearize", "linearize"), ("k_digit_offsets", "linearize"), ("k_fold_top", "linearize"),
             ("k_init_minmax", "span"), ("k_chrom_minmax", "span"), ("k_chrom_offsets", "span"),
             ("k_range_count", "count"), ("k_count_partition", "count"), ("k_c1_count", "count"),
             ("k_scan_", "scan"), ("k_partition", "partition"), ("k_fill", "fill"), ("k_c1_emit", "fill")]
@@ -65,6 +65,19 @@ def main() -> None:
     workload = re.search(r'"workload": "([A-Za-z0-9_]+)"', bench)
     path = os.path.join(prof, "pmc_traffic.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
+    sys.path.insert(0, ROOT)
+    import subprocess
+
+    import bench  # csrc_hash(): ties these counters to the kernel sources they were collected on
+
+    if data.get("csrc_hash") != bench.csrc_hash():
+        data = {}  # counters of older kernels say nothing about these
+    data["csrc_hash"] = bench.csrc_hash()
+    try:
+        data["commit"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                        text=True).stdout.strip()
+    except OSError:
+        data["commit"] = None
     data["source"] = (f"profiles/{tag}_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                       "FETCH_SIZE doubled per MI355X_MICROARCH.md)")
     data.setdefault(workload.group(1), {})[form.group(1)] = {k: round(v) for k, v in per_phase.items()}
