@@ -82,6 +82,9 @@ def parse_args():
                         "(ranks share GPUs, the exchange runs through host memory)")
     p.add_argument("--cpu-sample-chroms", default="18,19,20,21",
                    help="chromosome ids of the bounded cpu_baseline probe")
+    p.add_argument("--verify", action="store_true",
+                   help="N>1: rank 0 also runs the CPU leg on the WHOLE workload after the timed region and checks the "
+                        "gathered result against it (count + multiset checksum); the other ranks wait")
     p.add_argument("--master-port", type=int, default=29531)
     a = p.parse_args()
     if a.no_gather:
@@ -441,22 +444,31 @@ def run_inner(args):
                 last_stats[0] = eng.stats()
             if ev:
                 ev[1].record()
-            blocks = xplan.all_gather(sizes)
-            if ev:
-                ev[2].record()
             total = sum(s[0] for s in sizes)
             if gout is None or gout[0].shape[0] < total:
                 gout = None
                 gout = alloc_out(total)
-            o = 0
-            for (q_r, lo_r, cnt_r, s_r), (n_r, _q, _s, qa_r) in zip(blocks, sizes):
+            offs = [sum(s[0] for s in sizes[:r]) for r in range(world)]
+
+            def expand(r, blk):
+                n_r, _q, _s, qa_r = sizes[r]
                 if n_r == 0:
-                    continue
-                if xdev != dev:
-                    q_r, lo_r, cnt_r, s_r = (t_.to(dev) for t_ in (q_r, lo_r, cnt_r, s_r))
+                    return
+                q_r, lo_r, cnt_r, s_r = (t_.to(dev) for t_ in blk) if xdev != dev else blk
                 rq, rs = (gout[0], gout[1]) if qa_r else (gout[1], gout[0])
-                eng.fill_from_plan(q_r, lo_r, cnt_r, s_r, rq[o:o + n_r], rs[o:o + n_r], n_pairs_expected=n_r)
-                o += n_r
+                eng.fill_from_plan(q_r, lo_r, cnt_r, s_r, rq[offs[r]:offs[r] + n_r], rs[offs[r]:offs[r] + n_r],
+                                   n_pairs_expected=n_r)
+
+            # the all-gather runs on RCCL's own stream; this rank's OWN block is expanded meanwhile, straight
+            # from the send block (it needs nothing from the wire)
+            work = xplan.all_gather_async(sizes)
+            expand(rank, views)
+            blocks = work()
+            if ev:
+                ev[2].record()
+            for r, blk in enumerate(blocks):
+                if r != rank:
+                    expand(r, blk)
             last_pairs[0] = (gout[0][:total], gout[1][:total])
         elif exchange in ("plan", "pairs"):
             used["pairs"] += 1
@@ -613,7 +625,8 @@ def run_inner(args):
         }
 
         cpu_baseline = None
-        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
+        if (not args.no_cpu_baseline and world == 1) or (args.verify and exchange in ("plan", "pairs")):
+            # rank 0 at N = 1 (the contract); at N > 1 only on request (--verify), as the gathered result's check
             cpu_baseline, ref = cpu_baseline_inner(args, wl, n_chrom)
             if ref is not None and last_pairs[0] is not None:
                 pa_, pb_ = last_pairs[0] if not isinstance(last_pairs[0], list) else (

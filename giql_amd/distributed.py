@@ -282,6 +282,20 @@ class PlanGather:
         dist.all_gather_into_tensor(self._recv.view(-1), self._send, group=self.group)
         return [self._views(self._recv[r], s[1], s[2]) for r, s in enumerate(sizes)]
 
+    def all_gather_async(self, sizes):
+        """Start the all-gather without blocking the caller's stream; returns a function that waits for
+        it (the current stream then waits for the collective) and yields the per-rank views."""
+        import torch.distributed as dist
+
+        self._ensure(sizes)
+        work = dist.all_gather_into_tensor(self._recv.view(-1), self._send, group=self.group, async_op=True)
+
+        def wait():
+            work.wait()
+            return [self._views(self._recv[r], s[1], s[2]) for r, s in enumerate(sizes)]
+
+        return wait
+
     def bytes_per_rank(self) -> int:
         return 4 * (3 * self._q + self._s) if self._send is not None else 0
 

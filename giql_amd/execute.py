@@ -81,10 +81,21 @@ def encode_chroms(col_a, col_b):
         if (ia.size and ia.min() < 0) or (ib.size and ib.min() < 0):
             raise ValueError("integer chrom ids must be non-negative")
         n = int(max(ia.max() if ia.size else -1, ib.max() if ib.size else -1)) + 1
+        if n > 4096 and n > 4 * (ia.size + ib.size):
+            # sparse ids (one large id would size every per-chromosome array by it): remap to dense codes
+            dictionary, inverse = np.unique(np.concatenate([ia, ib]), return_inverse=True)
+            inverse = inverse.astype(np.int32)
+            return (np.ascontiguousarray(inverse[: ia.size]), np.ascontiguousarray(inverse[ia.size:]),
+                    dictionary.tolist())
         return ia, ib, list(range(n))
     both = np.concatenate([a.astype(object), b.astype(object)])
-    if both.size and any(v is None for v in both[: min(both.size, 1)]):
-        raise ValueError("chrom contains NULLs: not supported by dialect='hip'")
+    # SQL NULL never matches (and the reference never joins NULL chroms): every element is checked, not
+    # the first -- a later None would otherwise become the string 'None' in the shared dictionary and
+    # NULL-chrom rows of the two sides would join each other
+    if both.size:
+        null = np.fromiter((v is None or (isinstance(v, float) and v != v) for v in both), dtype=bool, count=both.size)
+        if null.any():
+            raise ValueError("chrom contains NULLs: not supported by dialect='hip'")
     dictionary, inverse = np.unique(both.astype(str), return_inverse=True)
     inverse = inverse.astype(np.int32)
     return (np.ascontiguousarray(inverse[: a.size]), np.ascontiguousarray(inverse[a.size:]),

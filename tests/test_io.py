@@ -28,3 +28,27 @@ def test_read_bed3_custom_names_and_empty(tmp_path):
     e = tmp_path / "empty.bed"
     e.write_text("# nothing\n")
     assert read_bed(str(e)).num_rows == 0
+
+
+def test_encode_chroms_rejects_a_null_anywhere_and_remaps_sparse_ids():
+    import numpy as np
+    import pytest
+
+    from giql_amd.execute import encode_chroms
+
+    a = np.array(["chr1", "chr2", "chr1"], dtype=object)
+    ia, ib, d = encode_chroms(a, np.array(["chr2", "chrX"], dtype=object))
+    assert d == ["chr1", "chr2", "chrX"] and ia.tolist() == [0, 1, 0] and ib.tolist() == [1, 2]
+    for bad in (None, float("nan")):
+        b = np.array(["chr2", "chrX", bad, "chr1"], dtype=object)   # NOT the first element
+        with pytest.raises(ValueError, match="NULL"):
+            encode_chroms(a, b)
+        with pytest.raises(ValueError, match="NULL"):
+            encode_chroms(b, a)
+    # dense integer ids pass through; one huge id is remapped instead of sizing the per-chromosome arrays
+    ia, ib, d = encode_chroms(np.array([0, 3, 1]), np.array([2, 3]))
+    assert ia.tolist() == [0, 3, 1] and len(d) == 4
+    ia, ib, d = encode_chroms(np.array([5, 2_000_000_000, 5]), np.array([7, 5]))
+    assert d == [5, 7, 2_000_000_000] and ia.tolist() == [0, 2, 0] and ib.tolist() == [1, 0]
+    with pytest.raises(ValueError, match="non-negative"):
+        encode_chroms(np.array([-1, 2]), np.array([1]))
