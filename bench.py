@@ -250,7 +250,7 @@ def duckdb_baseline(op, a, b, n_chrom, names):
         return {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
 
-def cpu_baseline_inner(args, wl, n_chrom):
+def cpu_baseline_inner(args, wl, n_chrom, rank_chroms=None):
     """Bounded CPU leg of an INNER workload + the data for the parity line.  DuckDB (the reference's
     path) when importable, else the oracle's OpenMP sort-merge port; a probe on four small
     chromosomes sizes the sample (the whole workload when the host does it in ~20 s)."""
@@ -265,6 +265,15 @@ def cpu_baseline_inner(args, wl, n_chrom):
     def tables(chroms):
         if genome != HG38:
             return make_inputs(wl)[1:3]
+        if chroms is None and rank_chroms is not None:
+            # N > 1: the global table is "the rows of lower ranks first" -- the same numbering the ranks'
+            # global row ids use -- so the reference is the concatenation of the ranks' shards
+            import numpy as np
+
+            parts_a = [synth.make_table(n_a, seed_a, kind_a, chroms=c) for c in rank_chroms]
+            parts_b = [synth.make_table(n_b, seed_b, kind_b, chroms=c) for c in rank_chroms]
+            return (tuple(np.concatenate([p[k] for p in parts_a]) for k in range(3)),
+                    tuple(np.concatenate([p[k] for p in parts_b]) for k in range(3)))
         return (synth.make_table(n_a, seed_a, kind_a, chroms=chroms), synth.make_table(n_b, seed_b, kind_b, chroms=chroms))
 
     def port(chroms):
@@ -344,6 +353,7 @@ def run_inner(args):
 
     # ---- shard: chromosomes -> ranks (LPT on expected rows); N = 1 keeps everything
     my_chroms = None
+    assign = None
     if genome == HG38 and world > 1:
         rows = synth.rows_per_chrom(n_a, seed_a) + synth.rows_per_chrom(n_b, seed_b)
         assign = shard.lpt_assign(rows.tolist(), world)
@@ -627,11 +637,14 @@ def run_inner(args):
         cpu_baseline = None
         if (not args.no_cpu_baseline and world == 1) or (args.verify and exchange in ("plan", "pairs")):
             # rank 0 at N = 1 (the contract); at N > 1 only on request (--verify), as the gathered result's check
-            cpu_baseline, ref = cpu_baseline_inner(args, wl, n_chrom)
+            layout = ([[c for c in range(n_chrom) if assign[c] == r] for r in range(world)]
+                      if world > 1 and genome == HG38 else None)
+            cpu_baseline, ref = cpu_baseline_inner(args, wl, n_chrom, layout)
             if ref is not None and last_pairs[0] is not None:
                 pa_, pb_ = last_pairs[0] if not isinstance(last_pairs[0], list) else (
                     torch.cat([x[0] for x in last_pairs[0]]), torch.cat([x[1] for x in last_pairs[0]]))
-                gpu_sum = eng.pairs_checksum(pa_, pb_)
+                # (the gloo rehearsal gathers the pairs in HOST memory: the checksum kernel wants them on the device)
+                gpu_sum = eng.pairs_checksum(pa_.to(dev).contiguous(), pb_.to(dev).contiguous())
                 cpu_baseline["parity"] = {"pairs_equal": ref[0] == n_pairs, "multiset_checksum_equal": gpu_sum == ref[1],
                                           "checked": "all %d pairs of the last timed step against the CPU leg" % n_pairs}
 

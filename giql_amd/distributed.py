@@ -145,7 +145,7 @@ class PairGather:
 
         if m > self._m:
             self._send = self._recv = None
-            cap = int(m * 1.05) + 1024
+            cap = (int(m * 1.05) + 1024 + 1023) // 1024 * 1024   # row 1 starts on a 4 KiB boundary (aligned fill stores)
             self._send = torch.empty((2, cap), dtype=torch.int32, device=self.device)
             self._recv = torch.empty((self.world, 2, cap), dtype=torch.int32, device=self.device)
             self._m = cap

@@ -142,6 +142,20 @@ class HipEngine:
         out["phase_bytes"] = {name: int(st.phase_bytes[i]) for i, name in enumerate(_lib.PHASES)}
         return out
 
+    def _dev_ptr(self, t, what: str, dtype=None):
+        """Device pointer of a tensor argument, or None for an empty one.  Anything that does not live
+        on THIS engine's device is refused here: a host pointer handed to a kernel is a GPU memory
+        fault, not an exception."""
+        if t is None or int(t.numel()) == 0:
+            return None
+        if not t.is_cuda or t.device != self.device:
+            raise ValueError(f"{what} lives on {t.device}, the engine on {self.device}")
+        if not t.is_contiguous():
+            raise ValueError(f"{what} must be contiguous")
+        if dtype is not None and t.dtype != dtype:
+            raise ValueError(f"{what} must be {dtype}, got {t.dtype}")
+        return t.data_ptr()
+
     def _check_sides(self, a: DeviceSide, b: DeviceSide) -> None:
         for s in (a, b):
             if s.n and s.device != self.device:
@@ -158,9 +172,10 @@ class HipEngine:
         return int(n.value)
 
     def inner_fill(self, row_a, row_b) -> None:
-        cap = int(row_a.shape[0])
+        torch = _torch()
+        cap = min(int(row_a.shape[0]), int(row_b.shape[0]))
         _lib.check(self._L.giql_hip_inner_fill_dev(
-            self._h, row_a.data_ptr() if cap else None, row_b.data_ptr() if cap else None, cap,
+            self._h, self._dev_ptr(row_a, "row_a", torch.int32), self._dev_ptr(row_b, "row_b", torch.int32), cap,
             self._stream()))
 
     def inner_join_into(self, a: DeviceSide, b: DeviceSide, n_chrom: int, row_a, row_b) -> int:
@@ -172,9 +187,10 @@ class HipEngine:
         cap = min(int(row_a.shape[0]), int(row_b.shape[0]))
         n = ctypes.c_int64(0)
         self.last_pairs = None
+        torch = _torch()
         rc = self._L.giql_hip_inner_join_dev(
-            self._h, a.c_struct(), b.c_struct(), int(n_chrom), row_a.data_ptr() if cap else None,
-            row_b.data_ptr() if cap else None, cap, self._stream(), ctypes.byref(n))
+            self._h, a.c_struct(), b.c_struct(), int(n_chrom), self._dev_ptr(row_a, "row_a", torch.int32),
+            self._dev_ptr(row_b, "row_b", torch.int32), cap, self._stream(), ctypes.byref(n))
         self.last_pairs = int(n.value)
         _lib.check(rc)
         return int(n.value)
@@ -568,10 +584,11 @@ class HipEngine:
 
     # --------------------------------------------------------------- checksum
     def pairs_checksum(self, row_a, row_b) -> int:
+        torch = _torch()
         h = ctypes.c_uint64(0)
-        n = int(row_a.shape[0])
+        n = min(int(row_a.shape[0]), int(row_b.shape[0]))
         _lib.check(self._L.giql_hip_pairs_checksum_dev(
-            self._h, row_a.data_ptr() if n else None, row_b.data_ptr() if n else None, n,
+            self._h, self._dev_ptr(row_a, "row_a", torch.int32), self._dev_ptr(row_b, "row_b", torch.int32), n,
             self._stream(), ctypes.byref(h)))
         return int(h.value)
 
@@ -584,9 +601,10 @@ class HipEngine:
         qa, nq, ns = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
         qcap = min(int(q_rid.shape[0]), int(lo.shape[0]), int(cnt.shape[0]))
         scap = int(s_rid.shape[0])
+        torch = _torch()
         _lib.check(self._L.giql_hip_inner_plan_export_dev(
-            self._h, q_rid.data_ptr() if qcap else None, lo.data_ptr() if qcap else None,
-            cnt.data_ptr() if qcap else None, s_rid.data_ptr() if scap else None, qcap, scap,
+            self._h, self._dev_ptr(q_rid, "q_rid", torch.int32), self._dev_ptr(lo, "lo", torch.int32),
+            self._dev_ptr(cnt, "cnt", torch.int32), self._dev_ptr(s_rid, "s_rid", torch.int32), qcap, scap,
             int(rid_add_a), int(rid_add_b), ctypes.byref(qa), ctypes.byref(nq), ctypes.byref(ns), self._stream()))
         return bool(qa.value), int(nq.value), int(ns.value)
 
@@ -606,10 +624,12 @@ class HipEngine:
         n = ctypes.c_int64(0)
         nq, ns = int(q_rid.shape[0]), int(s_rid.shape[0])
         cap = min(int(row_q.shape[0]), int(row_s.shape[0]))
+        torch = _torch()
+        i32 = torch.int32
         _lib.check(self._L.giql_hip_fill_from_plan_dev(
-            self._h, q_rid.data_ptr() if nq else None, lo.data_ptr() if nq else None, cnt.data_ptr() if nq else None,
-            nq, s_rid.data_ptr() if ns else None, ns, row_q.data_ptr() if cap else None,
-            row_s.data_ptr() if cap else None, cap, int(n_pairs_expected), self._stream(), ctypes.byref(n)))
+            self._h, self._dev_ptr(q_rid, "q_rid", i32), self._dev_ptr(lo, "lo", i32), self._dev_ptr(cnt, "cnt", i32),
+            nq, self._dev_ptr(s_rid, "s_rid", i32), ns, self._dev_ptr(row_q, "row_q", i32),
+            self._dev_ptr(row_s, "row_s", i32), cap, int(n_pairs_expected), self._stream(), ctypes.byref(n)))
         return int(n.value)
 
     # --------------------------------------------------------- host-buffer join
