@@ -11,10 +11,14 @@
 // Stable (ties keep their input order), like the onesweep passes, so a sort built from the two
 // stages is a stable sort by the full 32-bit key and can serve as one leg of a two-key sort.
 //
-// A bucket larger than BS_CAP rows (dense pile-ups; small spans) cannot be sorted here: the
-// block sets meta->status = GIQL_STATUS_RESORT and the host repeats the call with the four-pass
-// sort (and keeps using it on that context) -- the kernels downstream of a failed sort are
-// memory-safe on unsorted keys, exactly as they are for the context's other wrong guesses.
+// A bucket larger than BS_CAP rows (pile-ups: real read tables have windows far denser than the
+// average) does not fit the LDS form; its block sorts it with a small two-pass LSD radix sort
+// through the sort's OTHER ping-pong buffer instead (bucket_sort_big: tile by tile, stable, ~10x
+// the cost per row -- paid by the hot buckets only).  Past BS_BIG_MAX rows in one bucket (a table
+// squeezed into a few 65536-wide windows) that serial form would dominate: the block sets
+// meta->status = GIQL_STATUS_RESORT and the host repeats the call with the four-pass sort (and
+// keeps using it on that context) -- the kernels downstream of a failed sort are memory-safe on
+// unsorted keys, exactly as they are for the context's other wrong guesses.
 #pragma once
 
 #include "dev_common.hip.h"
@@ -28,6 +32,10 @@ constexpr int BS_ITEMS = 8;
 constexpr int BS_NW = BS_NT / WAVE;
 constexpr u32 BS_CAP = BS_NT * BS_ITEMS;  // rows per bucket the LDS sort holds (12-bit local index)
 constexpr int GIQL_STATUS_RESORT = -100;  // internal: never crosses the C ABI
+#ifndef GIQL_BS_BIG_MAX
+#define GIQL_BS_BIG_MAX (1u << 18)
+#endif
+constexpr u32 BS_BIG_MAX = GIQL_BS_BIG_MAX;  // rows of one bucket the in-block global-memory sort takes
 
 // bnd[v] = first row of the top-16-sorted keys with key >= v << 16, v in [0, 65536]; the search
 // runs inside the top digit's row range, which the sort's own digit offsets give (gb3 = the 256
@@ -238,11 +246,103 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
 #undef GIQL_BS_OK
 }
 
+
+// A bucket of BS_CAP < cnt <= BS_BIG_MAX rows: stable LSD radix sort on the low 16 key bits by ONE
+// block, two 8-bit passes, buffer 0 -> buffer 1 -> buffer 0 (the bucket's own row range in both:
+// no other block touches it).  Per pass: a digit histogram of the whole bucket (LDS atomics), its
+// scan, then the tiles of BS_CAP rows in order -- each ranked stably inside the tile (wave ballots
+// + per-wave digit counters, as the global passes do) on top of the running per-digit base.
+template <int PAYLOAD>
+__device__ __forceinline__ void bucket_sort_big(u32* __restrict__ k0, u32* __restrict__ e0, u32* __restrict__ r0,
+                                             u32* __restrict__ k1, u32* __restrict__ e1, u32* __restrict__ r1,
+                                             u32 cnt, u32* s_wcnt /* [BS_NW][256] */, u32* s_base /* [256] */,
+                                             u32* s_scan /* [BS_NW] */) {
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  for (int p = 0; p < 2; p++) {
+    const int shift = 8 * p;
+    u32* ks = p ? k1 : k0;
+    u32* kd = p ? k0 : k1;
+    u32* es = p ? e1 : e0;
+    u32* ed = p ? e0 : e1;
+    u32* rs = p ? r1 : r0;
+    u32* rd = p ? r0 : r1;
+    __syncthreads();
+    if (tid < OS_BINS) s_base[tid] = 0;
+    __syncthreads();
+    for (u32 i = tid; i < cnt; i += BS_NT) atomicAdd(&s_base[(ks[i] >> shift) & 0xFFu], 1u);
+    __syncthreads();
+    if (tid < OS_BINS) {  // exclusive scan of the 256 counts (4 waves)
+      const u32 c = s_base[tid];
+      const u32 incl = wave_incl_scan_add_u32(c);
+      if (lane == WAVE - 1) s_scan[w] = incl;
+      s_base[tid] = incl - c;
+    }
+    __syncthreads();
+    if (tid < OS_BINS) {
+      u32 wb = 0;
+      for (int k = 0; k < OS_BINS / WAVE; k++)
+        if (k < (int)w) wb += s_scan[k];
+      s_base[tid] += wb;
+    }
+    for (u32 t0 = 0; t0 < cnt; t0 += BS_CAP) {
+      __syncthreads();  // the previous tile's bases are final; its counters are free
+      for (int k = tid; k < BS_NW * OS_BINS; k += BS_NT) s_wcnt[k] = 0;
+      __syncthreads();
+      // wave-striped: item i of lane l of wave w is row t0 + w * (BS_ITEMS * 64) + i * 64 + l
+      u32 key[BS_ITEMS], rank[BS_ITEMS];
+      u32* wc = s_wcnt + w * OS_BINS;
+#pragma unroll
+      for (int i = 0; i < BS_ITEMS; i++) {
+        const u32 r = t0 + w * (BS_ITEMS * WAVE) + i * WAVE + lane;
+        const bool ok = r < cnt;
+        key[i] = ok ? ks[r] : 0u;
+        const u32 d = (key[i] >> shift) & 0xFFu;
+        const u64 active = __ballot(ok);
+        u32 below, total;
+        wave_match8(d, active, below, total);
+        rank[i] = 0;
+        if (ok) {
+          const u32 pre = wc[d];
+          rank[i] = pre + below;
+          if (below == 0) wc[d] = pre + total;  // the peers have read `pre` (one wave, in-order LDS)
+        }
+      }
+      __syncthreads();
+      u32 tile_count = 0;
+      if (tid < OS_BINS) {  // per-wave counts -> exclusive bases across the waves of this tile
+        u32 run = 0;
+#pragma unroll
+        for (int k = 0; k < BS_NW; k++) {
+          const u32 c = s_wcnt[k * OS_BINS + tid];
+          s_wcnt[k * OS_BINS + tid] = run;
+          run += c;
+        }
+        tile_count = run;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < BS_ITEMS; i++) {
+        const u32 r = t0 + w * (BS_ITEMS * WAVE) + i * WAVE + lane;
+        if (r < cnt) {
+          const u32 d = (key[i] >> shift) & 0xFFu;
+          const u32 pos = s_base[d] + wc[d] + rank[i];
+          kd[pos] = key[i];
+          if (PAYLOAD & 1) rd[pos] = rs[r];
+          if (PAYLOAD & 2) ed[pos] = es[r];
+        }
+      }
+      __syncthreads();
+      if (tid < OS_BINS) s_base[tid] += tile_count;
+    }
+  }
+}
+
 template <int PAYLOAD>
 __global__ __launch_bounds__(BS_NT, GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* __restrict__ keys, u32* __restrict__ ends,
                                                            u32* __restrict__ rids,
                                                            const u32* __restrict__ bnd,
-                                                           DevMeta* __restrict__ meta) {
+                                                           DevMeta* __restrict__ meta,
+                                                           u32* __restrict__ big_list) {
   static_assert(BS_NB % BS_NT == 0, "bins must be a multiple of the block size");
   static_assert(BS_NB * sizeof(u64) >= BS_CAP * sizeof(uint16_t), "the cell table doubles as the 16-bit key stage");
   static_assert(BS_SUB_BITS == 5, "one 32-bit map of sub-values per bin");
@@ -254,7 +354,14 @@ __global__ __launch_bounds__(BS_NT, GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* _
   const u32 cnt = bnd[v + 1] - b0;
   if (cnt < 2u) return;  // block-uniform
   if (cnt > BS_CAP) {
-    if (threadIdx.x == 0) meta->status = GIQL_STATUS_RESORT;
+    // too large for LDS: queued for k_bucket_sort_big (a launch of its own keeps this kernel free of
+    // the big path's registers and scratch frame); past BS_BIG_MAX the whole call is repeated
+    if (threadIdx.x == 0) {
+      if (cnt > BS_BIG_MAX || !big_list)
+        meta->status = GIQL_STATUS_RESORT;
+      else
+        big_list[1 + atomicAdd(&big_list[0], 1u)] = v;
+    }
     return;
   }
   u32* kp = keys + b0;
@@ -270,6 +377,28 @@ __global__ __launch_bounds__(BS_NT, GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* _
     case 6: bucket_sort_body<PAYLOAD, 6>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
     case 7: bucket_sort_body<PAYLOAD, 7>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
     default: bucket_sort_body<PAYLOAD, 8>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
+  }
+}
+
+// The buckets k_bucket_sort queued (big_list[0] = how many): one block each, grid-stride.
+template <int PAYLOAD>
+__global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ keys, u32* __restrict__ ends,
+                                                            u32* __restrict__ rids, u32* __restrict__ keys1,
+                                                            u32* __restrict__ ends1, u32* __restrict__ rids1,
+                                                            const u32* __restrict__ bnd,
+                                                            const u32* __restrict__ big_list) {
+  __shared__ u32 s_wcnt[BS_NW * OS_BINS];
+  __shared__ u32 s_base[OS_BINS];
+  __shared__ u32 s_scan[BS_NW];
+  const u32 n_big = big_list[0];
+  for (u32 i = blockIdx.x; i < n_big; i += gridDim.x) {
+    const u32 v = big_list[1 + i];
+    const u32 b0 = bnd[v];
+    const u32 cnt = bnd[v + 1] - b0;
+    bucket_sort_big<PAYLOAD>(keys + b0, (PAYLOAD & 2) ? ends + b0 : nullptr, (PAYLOAD & 1) ? rids + b0 : nullptr,
+                             keys1 + b0, (PAYLOAD & 2) ? ends1 + b0 : nullptr, (PAYLOAD & 1) ? rids1 + b0 : nullptr, cnt,
+                             s_wcnt, s_base, s_scan);
+    __syncthreads();
   }
 }
 

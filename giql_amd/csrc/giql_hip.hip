@@ -138,6 +138,7 @@ struct giql_hip_ctx {
   int local_resorts = 0;      // calls repeated with the four-pass sort
   bool last_sort_local = false;  // the call in flight sorted at least one side in three stages
   u32* bucket_bnd = nullptr;  // [BS_BUCKETS + 1] bucket boundaries of the sort in flight
+  u32* bucket_big = nullptr;  // [1 + BS_BUCKETS] buckets too large for LDS, queued for k_bucket_sort_big ([0] = count)
   char* xplan = nullptr;      // scratch of giql_hip_fill_from_plan_dev (offsets + scan partials), grown on demand
   size_t xplan_cap = 0;
 
@@ -469,7 +470,8 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
   }
   if (local) {
     // the rows are back in buffer 0, ordered by key >> 16: bucket boundaries, then one block per bucket
-    Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 2);
+    HIP_TRY(hipMemsetAsync(ctx->bucket_big, 0, sizeof(u32), st));
+    Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 3);
     ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] +=
         (int64_t)8 * (1 + (sb.rid[0] ? 1 : 0) + (sb.end[0] ? 1 : 0)) * n;  // every array read once, written once
     hipLaunchKernelGGL(k_bucket_bounds, dim3(cdiv((u64)BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
@@ -478,7 +480,11 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
 #define GIQL_BS_LAUNCH(M)                                                                              \
   hipLaunchKernelGGL((k_bucket_sort<M>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0],              \
                      sb.end[0] ? sb.end[0] : (u32*)nullptr, sb.rid[0] ? sb.rid[0] : (u32*)nullptr,      \
-                     ctx->bucket_bnd, ctx->d_meta)
+                     ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big);                                   \
+  hipLaunchKernelGGL((k_bucket_sort_big<M>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0],           \
+                     sb.end[0] ? sb.end[0] : (u32*)nullptr, sb.rid[0] ? sb.rid[0] : (u32*)nullptr,      \
+                     sb.key[1], sb.end[0] ? sb.end[1] : (u32*)nullptr, sb.rid[0] ? sb.rid[1] : (u32*)nullptr, \
+                     ctx->bucket_bnd, ctx->bucket_big)
     switch (mode) {
       case 0: GIQL_BS_LAUNCH(0); break;
       case 1: GIQL_BS_LAUNCH(1); break;
@@ -684,6 +690,7 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_meta, sizeof(DevMeta), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_scratch64, 64);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_bnd, ((size_t)BS_BUCKETS + 16) * sizeof(u32));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_big, ((size_t)BS_BUCKETS + 16) * sizeof(u32));
   if (e != hipSuccess) {
     giql_hip_destroy(ctx);
     return set_err(GIQL_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e));
@@ -702,6 +709,7 @@ int giql_hip_destroy(giql_hip_ctx* ctx) {
   if (ctx->d_meta) (void)hipFree(ctx->d_meta);
   if (ctx->d_scratch64) (void)hipFree(ctx->d_scratch64);
   if (ctx->bucket_bnd) (void)hipFree(ctx->bucket_bnd);
+  if (ctx->bucket_big) (void)hipFree(ctx->bucket_big);
   if (ctx->xplan) (void)hipFree(ctx->xplan);
   if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
   delete ctx;

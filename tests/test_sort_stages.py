@@ -121,24 +121,54 @@ def test_three_stage_sort_is_stable_for_the_two_key_sorts(eng_local):
     assert eng_local.stats()["sort_local"]
 
 
+def test_buckets_larger_than_lds_are_sorted_by_their_block_through_the_other_buffer(eng_local):
+    # pile-ups: 4096 < rows <= 2^18 in one 65536-wide bucket take the in-block two-pass radix sort
+    # (bucket_sort_big) -- every payload shape (INNER general: key + end + rid; fixed-length B: key + rid;
+    # COUNT: keys only; SEMI general: key + end), next to ordinary buckets, without any fall-back
+    rng = np.random.default_rng(91)
+    def side(n_hot, n_rest, fixed=None):
+        st = np.concatenate([rng.integers(1_000_000, 1_060_000, n_hot), rng.integers(0, 30_000_000, n_rest)]).astype(np.int32)
+        ln = np.full(st.shape[0], fixed, np.int32) if fixed else rng.integers(1, 400, st.shape[0]).astype(np.int32)
+        perm = rng.permutation(st.shape[0])
+        return ora.Side(np.zeros(st.shape[0], np.int32), st[perm], (st + ln)[perm])
+    a, b = side(9_000, 20_000), side(70_000, 150_000)
+    st = _all_ops(eng_local, a, b, 1)
+    assert st["sort_local"] and not st["sort_resorted"]
+    bu = side(70_000, 150_000, fixed=150)
+    st = _all_ops(eng_local, a, bu, 1, nearest=False)
+    assert st["sort_local"] and not st["sort_resorted"] and st["join_form"] == "uniform_b"
+    # ties inside a big bucket keep their order: NEAREST's two-sort plan over 300-row pile-ups
+    n = 90_000
+    s2 = (rng.integers(0, 300, n) * 200).astype(np.int32)               # all inside one bucket
+    b2 = ora.Side(np.zeros(n, np.int32), s2, s2 + rng.integers(1, 3000, n).astype(np.int32))
+    for _ in range(2):
+        idx, dist = eng_local.nearest(dev(a), dev(b2), 1)
+        oi, od = ora.c_nearest_k1(a, b2, method="sweep")
+        assert np.array_equal(dist.cpu().numpy(), od)
+        j = idx.cpu().numpy()
+        assert np.array_equal(b2.start[j], b2.start[oi]) and np.array_equal(b2.end[j], b2.end[oi])
+    assert not eng_local.stats()["sort_resorted"]
+
+
 def test_oversized_bucket_falls_back_to_the_four_pass_sort(eng_local):
-    # 60,000 rows inside ONE 65536-bp bucket: the in-LDS stage cannot hold it; the call is repeated
+    # 300,000 rows inside ONE 65536-wide bucket (more than the in-block sort takes): the call is repeated
     # with the four-pass sort, stays exact, and the context keeps that sort afterwards
     a = rand_side(1301, 20_000, 1, 60_000, 300)
-    b = rand_side(1302, 60_000, 1, 60_000, 300)
-    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
-    assert np.array_equal(_inner(eng_local, a, b, 1), want)
+    b = rand_side(1302, 300_000, 1, 60_000, 300)
+    want_n = int(ora.c_count(a, b, "sweep").sum())
+    ra, rb = eng_local.inner_join(dev(a), dev(b), 1)
+    assert int(ra.shape[0]) == want_n
+    assert eng_local.pairs_checksum(ra, rb) == ora.c_pairs_checksum(*ora.c_inner(a, b, "sweep"))
     st = eng_local.stats()
     assert st["sort_resorted"] and not st["sort_local"]
     assert np.array_equal(eng_local.semi_join(dev(a), dev(b), 1).cpu().numpy(), ora.c_semi_anti(a, b, False))
-    assert np.array_equal(_inner(eng_local, a, b, 1), want)
     assert not eng_local.stats()["sort_local"]
 
 
 def test_row_operators_recover_from_an_oversized_bucket(eng_local):
     # same, discovered by a per-row operator first (its read-back is the only one of the call)
     a = rand_side(1311, 20_000, 1, 60_000, 300)
-    b = rand_side(1312, 50_000, 1, 60_000, 300)
+    b = rand_side(1312, 300_000, 1, 60_000, 300)
     assert np.array_equal(eng_local.count_overlaps(dev(a), dev(b), 1).cpu().numpy(), ora.c_count(a, b, "sweep"))
     assert eng_local.stats()["sort_resorted"]
     idx, dist = eng_local.nearest(dev(a), dev(b), 1)
