@@ -38,6 +38,7 @@ SYMBOLS = [
     "giql_hip_select_dev", "giql_hip_mark_dev", "giql_hip_cluster_dev", "giql_hip_merge_dev",
     "giql_hip_group_rows_dev", "giql_hip_segment_sum_dev", "giql_hip_inner_join_dev",
     "giql_hip_inner_plan_export_dev", "giql_hip_fill_from_plan_dev", "giql_hip_copy_probe_dev",
+    "giql_hip_nearest_k_dev",
 ]
 
 
@@ -157,6 +158,7 @@ def load() -> ctypes.CDLL:
     L.giql_hip_semi_anti_dev.argtypes = [vp, P(CSide), P(CSide), i32, ctypes.c_int, vp, P(i64), vp]
     L.giql_hip_count_dev.argtypes = [vp, P(CSide), P(CSide), i32, vp, vp]
     L.giql_hip_nearest_dev.argtypes = [vp, P(CSide), P(CSide), i32, ctypes.c_int, i64, vp, vp, vp]
+    L.giql_hip_nearest_k_dev.argtypes = [vp, P(CSide), P(CSide), i32, i32, ctypes.c_int, i64, vp, vp, vp]
     L.giql_hip_chrom_spans_dev.argtypes = [vp, P(CSide), P(CSide), i32, vp, vp]
     L.giql_hip_inner.argtypes = [vp, P(CSide), P(CSide), i32, P(i64), P(vp), P(vp)]
     L.giql_hip_semi_anti.argtypes = [vp, P(CSide), P(CSide), i32, ctypes.c_int, P(i64), P(vp)]

@@ -438,6 +438,105 @@ __global__ __launch_bounds__(256) void k_nearest_unpack(const NearestRec* __rest
   dist_out[i] = v.dist;
 }
 
+
+// ------------------------------------------------------------ NEAREST k > 1
+// The k nearest B rows of every A row in the reference's order ABS(distance), start, end
+// (nearest.py:387-396) from TWO sorted views of B on the linear axis:
+//   by (start, end) with the prefix max of the ends: the overlapping rows (distance 0) are the
+//     rows i in [first i with pmax > a.start, lower_bound(start, a.end)) whose end exceeds a.start,
+//     already in (start, end) order; the downstream rows (start >= a.end, distance start - a.end + 1)
+//     follow from that lower bound on, nearest first, ties by (start, end) -- the order itself;
+//   by (end, start): the upstream rows (end <= a.start, distance a.start - end + 1) lie below
+//     upper_bound(end, a.start), nearest last -- walked backwards RUN by run of equal ends, each
+//     run forwards (equal ends = equal distances: ascending start).
+// Upstream wins a tie of distances against downstream (its start is smaller).  A row that is both
+// (zero-length a and b on one point) is downstream, as the distance CASE's first matching arm says
+// (_distance.py:67-87).  One thread per A row (rows sorted by start: neighbouring lanes walk
+// neighbouring ranges); results go out as k 16-byte records per row, by row id.
+constexpr int NEAREST_K_MAX = 64;
+
+__global__ __launch_bounds__(256) void k_nearest_k(
+    const u32* __restrict__ a_keys, const u32* __restrict__ a_ends, const u32* __restrict__ a_rids, u32 n_a,
+    int n_chrom, const u32* __restrict__ chrom_first, const u32* __restrict__ chrom_lo,
+    const u32* __restrict__ chrom_lo_e, const u32* __restrict__ b_keys, const u32* __restrict__ b_ends,
+    const u32* __restrict__ b_pmax, const u32* __restrict__ b_rids, const u32* __restrict__ e_ends,
+    const u32* __restrict__ e_starts, const u32* __restrict__ e_rids, u32 n_b, int k, int is_signed,
+    i64 max_distance, NearestRec* __restrict__ rec_out, DevMeta* __restrict__ meta) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_a) return;
+  const u32 sentinel = meta->sentinel;
+  const u32 qs = a_keys[i], qe = a_ends[i], r = a_rids[i];
+  NearestRec* out = rec_out + (size_t)r * (size_t)k;
+  int emitted = 0;
+  if (n_b > 0 && qs < sentinel) {
+    if (qe < qs && meta->status == 0) meta->status = -1;  // NEAREST needs start <= end
+    const u32 c = upper_bound_u32(chrom_first, 0, (u32)n_chrom + 1, qs) - 1;
+    const u32 blo = chrom_lo[c], bhi = chrom_lo[c + 1];
+    const u32 elo = chrom_lo_e[c], ehi = chrom_lo_e[c + 1];
+    if (bhi > blo) {
+      const u32 hi = lower_bound_u32(b_keys, blo, bhi, qe);  // rows [blo, hi) start before a.end
+      if (hi > blo && b_pmax[hi - 1] > qs) {
+        for (u32 j = gallop_back_upper_u32(b_pmax, blo, hi, qs); j < hi && emitted < k; j++) {
+          if (b_ends[j] > qs) {
+            NearestRec rec;
+            rec.dist = 0;
+            rec.idx = (int32_t)b_rids[j];
+            rec.pad = 0;
+            out[emitted++] = rec;
+          }
+        }
+      }
+      u32 dn = hi;
+      // upstream cursor: the run [run_lo, run_hi) of equal ends being emitted, `cur` inside it
+      u32 run_lo = upper_bound_u32(e_ends, elo, ehi, qs), run_hi = run_lo, cur = run_lo;
+      while (emitted < k) {
+        // next upstream candidate (skipping rows that are downstream by the CASE's first arm)
+        bool has_up = false;
+        u32 up_e = 0;
+        while (true) {
+          if (cur == run_hi) {
+            if (run_lo == elo) break;
+            const u32 last = run_lo - 1;
+            const u32 e = e_ends[last];
+            run_hi = run_lo;
+            run_lo = lower_bound_u32(e_ends, elo, last + 1, e);
+            cur = run_lo;
+          }
+          if (e_starts[cur] < qe) {
+            has_up = true;
+            up_e = e_ends[cur];
+            break;
+          }
+          cur++;
+        }
+        const bool has_dn = dn < bhi;
+        if (!has_up && !has_dn) break;
+        const i64 up_d = has_up ? (i64)qs - (i64)up_e + 1 : 0;
+        const i64 dn_d = has_dn ? (i64)b_keys[dn] - (i64)qe + 1 : 0;
+        const bool take_up = has_up && (!has_dn || up_d <= dn_d);
+        const i64 d = take_up ? up_d : dn_d;
+        if (max_distance >= 0 && d > max_distance) break;  // every later candidate is at least as far
+        NearestRec rec;
+        rec.dist = take_up ? (is_signed ? -d : d) : d;
+        rec.idx = (int32_t)(take_up ? e_rids[cur] : b_rids[dn]);
+        rec.pad = 0;
+        out[emitted++] = rec;
+        if (take_up)
+          cur++;
+        else
+          dn++;
+      }
+    }
+  }
+  for (int t = emitted; t < k; t++) {
+    NearestRec rec;
+    rec.dist = 0;
+    rec.idx = -1;
+    rec.pad = 0;
+    out[t] = rec;
+  }
+}
+
 // NEAREST needs start <= end on the B side too.
 __global__ __launch_bounds__(256) void k_check_not_inverted(SideView s, DevMeta* __restrict__ meta) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;

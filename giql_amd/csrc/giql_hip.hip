@@ -1470,6 +1470,108 @@ int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side*
   return with_order_fallback(ctx, [&] { return giql_hip_nearest_dev_impl(ctx, a, b, n_chrom, is_signed, max_distance, idx_b_out, dist_out, stream); });
 }
 
+
+// ------------------------------------------------------------ NEAREST k > 1
+static int giql_hip_nearest_k_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
+                                       int32_t k, int is_signed, int64_t max_distance, int32_t* idx_b_out,
+                                       int64_t* dist_out, void* stream) {
+  if (!ctx) return set_err(GIQL_ERR_INVALID, "ctx is NULL");
+  GIQL_TRY(check_side(a, "a"));
+  GIQL_TRY(check_side(b, "b"));
+  if (n_chrom < 0) return set_err(GIQL_ERR_INVALID, "n_chrom < 0");
+  if (k < 1 || k > NEAREST_K_MAX) return set_err(GIQL_ERR_INVALID, "k=%d outside [1, %d]", k, NEAREST_K_MAX);
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  ctx->planned = false;
+  reset_stats(ctx);
+  ctx->stats.n_a = a->n;
+  ctx->stats.n_b = b->n;
+  if (a->n == 0) return GIQL_OK;
+  if (!idx_b_out || !dist_out) return set_err(GIQL_ERR_INVALID, "idx_b_out/dist_out is NULL");
+  const size_t na = (size_t)a->n, nb = (size_t)b->n;
+  if (na > OS_MAX_ROWS || nb > OS_MAX_ROWS) return set_err(GIQL_ERR_INVALID, "side larger than 2^30 rows");
+  if (na * (size_t)k > 0x7FFFFFF0ull) return set_err(GIQL_ERR_INVALID, "n_a * k does not fit 31 bits");
+  if (nb == 0 || n_chrom == 0) {
+    HIP_TRY(hipMemsetAsync(idx_b_out, 0xFF, na * k * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(dist_out, 0, na * k * sizeof(int64_t), st));
+    return GIQL_OK;
+  }
+  LinBufs lb;
+  SortBufs sa, sbb, se;
+  OsScratch os;
+  u32 *pmax = nullptr, *bmax = nullptr, *dummy_irr = nullptr, *chrom_lo = nullptr, *chrom_lo_e = nullptr;
+  NearestRec* recs = nullptr;
+  auto carve = [&](char* base) {
+    Carver c{base};
+    common_sizes(c, n_chrom, lb);
+    sort_sizes(c, na, sa, true);
+    sort_sizes(c, nb, sbb, true);
+    sort_sizes(c, nb, se, true);   // the (end, start) order: key = end, "end" payload = start
+    os_scratch_sizes(c, na > nb ? na : nb, os);
+    recs = c.take<NearestRec>(na * (size_t)k);
+    pmax = c.take<u32>(nb);
+    bmax = c.take<u32>(cdiv(nb, PM_TILE) + 1);
+    chrom_lo = c.take<u32>((size_t)n_chrom + 2);
+    chrom_lo_e = c.take<u32>((size_t)n_chrom + 2);
+    dummy_irr = c.take<u32>(16);
+    return c.off;
+  };
+  GIQL_TRY(ensure_arena(ctx, carve(nullptr), st));
+  carve(ctx->arena);
+
+  GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
+  // B by (start, end): the stable two-sort form (by end, then stably by start); its digit histograms
+  // of the starts AND of the ends come out of one linearize pass
+  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist, os.gbase,
+                         os.hist_e, os.gbase_e));
+  {
+    Phase ph(ctx, st, GIQL_PH_AUX);
+    hipLaunchKernelGGL(k_check_not_inverted, dim3(cdiv(nb, 256)), dim3(256), 0, st, view_of(*b), ctx->d_meta);
+  }
+  {
+    SortBufs by_end = sbb;
+    for (int i = 0; i < 2; i++) {
+      by_end.key[i] = sbb.end[i];
+      by_end.end[i] = sbb.key[i];
+    }
+    GIQL_TRY(run_sort_onesweep(ctx, st, by_end, (u32)nb, os.gbase_e, os.status));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, /*keep_rids=*/true));
+  }
+  GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
+  // B by (end, start): the (start, end) order, stably re-sorted by end
+  HIP_TRY(hipMemcpyAsync(se.key[0], sbb.end[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(se.end[0], sbb.key[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(se.rid[0], sbb.rid[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
+  GIQL_TRY(run_sort_onesweep(ctx, st, se, (u32)nb, os.gbase_e, os.status, /*keep_rids=*/true));
+  GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist, os.gbase));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status));
+  {
+    Phase ph(ctx, st, GIQL_PH_COUNT, 4);
+    hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st, lb.chrom_first, n_chrom,
+                       sbb.key[0], (u32)nb, chrom_lo);
+    hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st, lb.chrom_first, n_chrom,
+                       se.key[0], (u32)nb, chrom_lo_e);
+    hipLaunchKernelGGL(k_nearest_k, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0], sa.rid[0], (u32)na,
+                       n_chrom, lb.chrom_first, chrom_lo, chrom_lo_e, sbb.key[0], sbb.end[0], pmax, sbb.rid[0],
+                       se.key[0], se.end[0], se.rid[0], (u32)nb, (int)k, is_signed, (i64)max_distance, recs,
+                       ctx->d_meta);
+    hipLaunchKernelGGL(k_nearest_unpack, dim3(cdiv(na * (size_t)k, 256)), dim3(256), 0, st, recs, (u32)(na * (size_t)k),
+                       idx_b_out, (i64*)dist_out);
+    GIQL_TRY(post_launch("nearest k"));
+  }
+  GIQL_TRY(read_meta(ctx, st));
+  collect_spans(ctx);
+  ctx->stats.n_out = a->n * (int64_t)k;
+  ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+  return GIQL_OK;
+}
+
+int giql_hip_nearest_k_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom, int32_t k,
+                           int is_signed, int64_t max_distance, int32_t* idx_b_out, int64_t* dist_out,
+                           void* stream) {
+  return with_order_fallback(ctx, [&] { return giql_hip_nearest_k_dev_impl(ctx, a, b, n_chrom, k, is_signed, max_distance, idx_b_out, dist_out, stream); });
+}
+
 // ---------------------------------------------------------- CLUSTER / MERGE
 // Shared front half: keys + ends on the linear axis, sorted by start, inclusive
 // prefix max of the ends, new-cluster flags and their exclusive scan.

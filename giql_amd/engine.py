@@ -351,6 +351,20 @@ class HipEngine:
             idx.data_ptr() if a.n else None, dist.data_ptr() if a.n else None, self._stream()))
         return idx, dist
 
+    def nearest_k(self, a: DeviceSide, b: DeviceSide, n_chrom: int, k: int, signed: bool = False, max_distance=None):
+        """NEAREST k >= 1: ``(idx_b [n_a, k] int32, distance [n_a, k] int64)`` per A row in the reference's
+        order ABS(distance), start, end; unused slots idx_b = -1 (``giql_hip_nearest_k_dev``)."""
+        torch = _torch()
+        self._check_sides(a, b)
+        k = int(k)
+        idx = torch.full((a.n, k), -1, dtype=torch.int32, device=self.device)
+        dist = torch.zeros((a.n, k), dtype=torch.int64, device=self.device)
+        md = -1 if max_distance is None else int(max_distance)
+        _lib.check(self._L.giql_hip_nearest_k_dev(
+            self._h, a.c_struct(), b.c_struct(), int(n_chrom), k, int(bool(signed)), md,
+            idx.data_ptr() if a.n else None, dist.data_ptr() if a.n else None, self._stream()))
+        return idx, dist
+
     # ------------------------------------------------ GROUP BY interval + SUM
     def group_rows(self, s: DeviceSide, n_chrom: int):
         """Rows with identical (chrom, raw start, raw end) share a group: returns

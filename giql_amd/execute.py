@@ -63,6 +63,18 @@ def _to_numpy(col, what: str) -> np.ndarray:
     return np.asarray(col)
 
 
+def _to_numpy_obj(col) -> np.ndarray:
+    """A column as a numpy object array with None for NULL (strings / strands)."""
+    try:
+        import pyarrow as pa
+
+        if isinstance(col, (pa.ChunkedArray, pa.Array)):
+            return np.array(col.to_pylist(), dtype=object)
+    except ImportError:  # pragma: no cover
+        pass
+    return np.asarray(col, dtype=object)
+
+
 def _int32_column(col, what: str) -> np.ndarray:
     x = _to_numpy(col, what)
     if x.dtype.kind not in "iu":
@@ -531,6 +543,28 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
     lt, rt = tables[plan.left.table], tables[plan.right.table]
     ia, ib, dictionary = encode_chroms(_column(lt, plan.left.chrom_col), _column(rt, plan.right.chrom_col))
     n_chrom = len(dictionary)
+    strand_sign = None
+    if plan.kind == "NEAREST" and plan.stranded:
+        # stranded := true: a target row matches only on the reference row's strand (nearest.py:313-333),
+        # so (chrom, strand) is the partition; the distance of a '-' reference row flips its sign
+        # (_distance.py:88-117).  A NULL strand never equals anything: those rows get partitions of their own.
+        ls, rs = (plan.strand_col or "strand,strand").split(",")
+
+        def codes(col, null_code):
+            v = np.asarray(_to_numpy_obj(col), dtype=object)
+            out = np.full(v.shape[0], null_code, np.int32)
+            out[v == "+"] = 0
+            out[v == "-"] = 1
+            bad = ~np.isin(out, (0, 1)) & np.array([x is not None for x in v], dtype=bool)
+            if bad.any():
+                raise ValueError("stranded NEAREST: strands other than '+' / '-' (the reference yields a NULL "
+                                 "distance for '.' / '?') are not supported by dialect='hip'")
+            return out
+        ca, cb = codes(_column(lt, ls), 2), codes(_column(rt, rs), 3)
+        ia = (ia.astype(np.int64) * 4 + ca).astype(np.int32)
+        ib = (ib.astype(np.int64) * 4 + cb).astype(np.int32)
+        n_chrom *= 4
+        strand_sign = np.where(ca == 1, -1, 1).astype(np.int64)
     a = _device_side(lt, plan.left, ia, eng)
     b = _device_side(rt, plan.right, ib, eng)
 
@@ -554,13 +588,22 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
             return rows.cpu().numpy()
         idx = {"l": rows}
         extra = {}
-    else:  # NEAREST k=1: A rows whose chromosome has no target row yield no row
+    else:  # NEAREST: A rows whose chromosome (and strand) has no target row yield no row
         import torch
 
-        ib_dev, dist = eng.nearest(a, b, n_chrom, signed=plan.signed, max_distance=plan.max_distance)
-        keep = torch.nonzero(ib_dev >= 0).flatten().to(torch.int32)
-        ib_keep = ib_dev[keep.long()].contiguous()
-        dn = dist[keep.long()].cpu().numpy()
+        if plan.k == 1:
+            ib_dev, dist = eng.nearest(a, b, n_chrom, signed=plan.signed, max_distance=plan.max_distance)
+            keep = torch.nonzero(ib_dev >= 0).flatten().to(torch.int32)
+            ib_keep = ib_dev[keep.long()].contiguous()
+            dn = dist[keep.long()].cpu().numpy()
+        else:  # up to k rows per A row, in the reference's order ABS(distance), start, end (nearest.py:387-396)
+            ib_k, dist_k = eng.nearest_k(a, b, n_chrom, plan.k, signed=plan.signed, max_distance=plan.max_distance)
+            hit = torch.nonzero(ib_k >= 0)
+            keep = hit[:, 0].to(torch.int32).contiguous()
+            ib_keep = ib_k[hit[:, 0], hit[:, 1]].contiguous()
+            dn = dist_k[hit[:, 0], hit[:, 1]].cpu().numpy()
+        if strand_sign is not None:
+            dn = dn * strand_sign[keep.cpu().numpy()]
         if return_indices:
             return keep.cpu().numpy(), ib_keep.cpu().numpy(), dn
         idx = {"l": keep, "r": ib_keep}

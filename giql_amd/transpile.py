@@ -371,12 +371,13 @@ def _parse_nearest(p: _Parser, tables: Tables, from_ref: _TableRef):
     if ref.column != _genomic_col(from_ref.name, tables):
         raise ValueError(f"{ref.table}.{ref.column} is not the genomic column of {from_ref.name}")
     k = int(args.get("k", 1))
-    if k != 1:
-        raise _decline("NEAREST with k != 1")
-    if args.get("stranded"):
-        raise _decline("stranded NEAREST")
+    if k < 1:
+        raise ValueError("NEAREST k must be a positive integer")
+    if k > 64:
+        raise _decline("NEAREST with k > 64")   # giql_hip_nearest_k_dev keeps k records per row
     md = args.get("max_distance")
-    return _TableRef(target.text, alias, aq), (None if md is None else int(md)), bool(args.get("signed", False))
+    return (_TableRef(target.text, alias, aq), (None if md is None else int(md)), bool(args.get("signed", False)), k,
+            bool(args.get("stranded", False)))
 
 
 def _literal_range_sql(p: _Parser, proj_text: str, from_ref: _TableRef, tables: Tables) -> str:
@@ -786,8 +787,8 @@ def _lower(giql: str, tables, want_sql: bool):
         p.next()
         if p.at_kw("LATERAL"):
             p.next()
-            join_ref, max_distance, signed = _parse_nearest(p, tbls, from_ref)
-            nearest = (max_distance, signed)
+            join_ref, max_distance, signed, k_near, stranded = _parse_nearest(p, tbls, from_ref)
+            nearest = (max_distance, signed, k_near, stranded)
             kind = "NEAREST"
         else:
             join_ref = p.table_ref()
@@ -813,7 +814,18 @@ def _lower(giql: str, tables, want_sql: bool):
         if left.alias == right.alias:
             raise _decline("same alias on both sides")
         proj = resolve_projection(items, left, right, False, distance_alias=right.alias)
-        return JoinPlan("NEAREST", left, right, proj, distinct, 1, nearest[0], nearest[1])
+        strand_col = None
+        if nearest[3]:
+            # stranded := true matches targets on the reference row's strand (nearest.py:313-333); both
+            # tables need a strand column, the TARGET's name is what the reference reads (output_table.strand_col)
+            lt_, rt_ = tbls.get(from_ref.name), tbls.get(join_ref.name)
+            ls = lt_.strand_col if lt_ is not None else "strand"
+            rs = rt_.strand_col if rt_ is not None else "strand"
+            if not ls or not rs:
+                raise _decline("stranded NEAREST over a table without a strand column")
+            strand_col = f"{ls},{rs}"
+        return JoinPlan("NEAREST", left, right, proj, distinct, nearest[2], nearest[0], nearest[1],
+                        stranded=nearest[3], strand_col=strand_col)
 
     shape = JoinShape(items=items, from_ref=from_ref, join_ref=join_ref, kind=kind, on_seen=on_seen, using=using,
                       distinct=distinct)

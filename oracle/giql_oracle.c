@@ -150,6 +150,57 @@ int ora_nearest_k1_brute(const ora_side* a, const ora_side* b, int is_signed,
   return ORA_OK;
 }
 
+
+/* NEAREST k >= 1, brute force: for every A row the k best B rows of its chromosome under
+ * ORDER BY ABS(distance), start, end LIMIT k (src/giql/expanders/nearest.py:336-397,
+ * _distance.py:67-87), kept by insertion into a k-slot list.  idx_b / dist are [n_a * k]
+ * row-major; unused slots -1 / 0.  Rows tied on (|d|, start, end) keep the lower row id. */
+int ora_nearest_k_brute(const ora_side* a, const ora_side* b, int32_t k, int is_signed,
+                        int64_t max_distance, int threads, int32_t* idx_b, int64_t* dist) {
+  if (k < 1) return ORA_EINVAL;
+  (void)threads;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads > 0 ? threads : 1)
+  for (int64_t i = 0; i < a->n; i++) {
+    const int64_t as = cs_of(a, i), ae = ce_of(a, i);
+    const int32_t ac = a->chrom[i];
+    int32_t* bi = idx_b + i * k;
+    int64_t* bd = dist + i * k;
+    int n = 0;
+    for (int64_t j = 0; j < b->n; j++) {
+      if (b->chrom[j] != ac) continue;
+      const int64_t bs = cs_of(b, j), be = ce_of(b, j);
+      const int64_t d = distance_case(as, ae, bs, be, is_signed);
+      const int64_t ad = iabs64(d);
+      if (max_distance >= 0 && ad > max_distance) continue;
+      /* position of (ad, bs, be) among the kept ones; equal keys go after (stable by row id) */
+      int pos = n;
+      while (pos > 0) {
+        const int64_t j2 = bi[pos - 1];
+        const int64_t ad2 = iabs64(bd[pos - 1]);
+        const int64_t bs2 = cs_of(b, j2), be2 = ce_of(b, j2);
+        if (ad < ad2 || (ad == ad2 && (bs < bs2 || (bs == bs2 && be < be2))))
+          pos--;
+        else
+          break;
+      }
+      if (pos >= k) continue;
+      const int last = n < k ? n : k - 1;
+      for (int t = last; t > pos; t--) {
+        bi[t] = bi[t - 1];
+        bd[t] = bd[t - 1];
+      }
+      bi[pos] = (int32_t)j;
+      bd[pos] = d;
+      if (n < k) n++;
+    }
+    for (int t = n; t < k; t++) {
+      bi[t] = -1;
+      bd[t] = 0;
+    }
+  }
+  return ORA_OK;
+}
+
 /* --------------------------------------------------- per-chromosome index */
 typedef struct {
   int32_t n_chrom;  /* max chrom id + 1 over both sides */

@@ -66,6 +66,9 @@ int ora_semi_anti(const ora_side* a, const ora_side* b, int anti, int n_threads,
  * Ties: |distance|, then b.start, then b.end, then lowest row id. */
 int ora_nearest_k1_brute(const ora_side* a, const ora_side* b, int is_signed,
                          int64_t max_distance, int32_t* idx_b, int64_t* dist);
+/* NEAREST k >= 1 by brute force (nearest.py:336-397): [n_a * k] row-major outputs. */
+int ora_nearest_k_brute(const ora_side* a, const ora_side* b, int32_t k, int is_signed,
+                        int64_t max_distance, int threads, int32_t* idx_b, int64_t* dist);
 int ora_nearest_k1_sweep(const ora_side* a, const ora_side* b, int is_signed,
                          int64_t max_distance, int n_threads, int32_t* idx_b,
                          int64_t* dist);

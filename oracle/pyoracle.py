@@ -178,6 +178,8 @@ def lib() -> ctypes.CDLL:
                                     P(ctypes.c_int64), P(ctypes.c_void_p)]
         L.ora_nearest_k1_brute.argtypes = [P(_CSide), P(_CSide), ctypes.c_int, ctypes.c_int64,
                                            ctypes.c_void_p, ctypes.c_void_p]
+        L.ora_nearest_k_brute.argtypes = [P(_CSide), P(_CSide), ctypes.c_int32, ctypes.c_int, ctypes.c_int64,
+                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.ora_nearest_k1_sweep.argtypes = [P(_CSide), P(_CSide), ctypes.c_int, ctypes.c_int64,
                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.ora_cluster.argtypes = [P(_CSide), ctypes.c_int64, ctypes.c_void_p]
@@ -263,6 +265,38 @@ def c_nearest_k1(a: Side, b: Side, signed=False, max_distance=None, method="swee
                                     idx.ctypes.data, dist.ctypes.data)
     if rc:
         raise RuntimeError(f"oracle nearest failed rc={rc}")
+    return idx, dist
+
+
+def py_nearest_k(a: Side, b: Side, k: int, signed=False, max_distance=None):
+    """NEAREST k >= 1 in pure Python: per A row the list of (idx_b, distance) under
+    ``ORDER BY ABS(distance), start, end LIMIT k`` (nearest.py:336-397)."""
+    out = []
+    acs, ace, bcs, bce = a.cs, a.ce, b.cs, b.ce
+    for i in range(a.n):
+        cand = []
+        for j in range(b.n):
+            if b.chrom[j] != a.chrom[i]:
+                continue
+            d = py_distance(int(acs[i]), int(ace[i]), int(bcs[j]), int(bce[j]), signed)
+            if max_distance is not None and abs(d) > max_distance:
+                continue
+            cand.append((abs(d), int(bcs[j]), int(bce[j]), j, d))
+        cand.sort()
+        out.append([(j, d) for _, _, _, j, d in cand[:k]])
+    return out
+
+
+def c_nearest_k(a: Side, b: Side, k: int, signed=False, max_distance=None, threads: int | None = None):
+    """C brute force of NEAREST k: ``(idx_b [n_a, k] int32, distance [n_a, k] int64)``, -1 / 0 = no row."""
+    L = lib()
+    idx = np.full((a.n, k), -1, np.int32)
+    dist = np.zeros((a.n, k), np.int64)
+    md = -1 if max_distance is None else int(max_distance)
+    rc = L.ora_nearest_k_brute(_cside(a), _cside(b), int(k), int(bool(signed)), md, threads or max_threads(),
+                               idx.ctypes.data, dist.ctypes.data)
+    if rc:
+        raise RuntimeError(f"oracle nearest k failed rc={rc}")
     return idx, dist
 
 

@@ -519,3 +519,31 @@ def test_outer_clauses_against_brute_force(peaks_genes):
     far = {"peaks": tables["peaks"], "genes": make_table([("chr9", 1, 2, "g", 1, "+")])}
     out = execute(transpile(f"SELECT COUNT(*) AS n, SUM(b.score) AS t {J}", ["peaks", "genes"], dialect="hip"), far)
     assert out.to_pylist() == [{"n": 0, "t": None}]
+
+
+# --------------------------------------------------- NEAREST k > 1 and stranded (reference known answers)
+def test_nearest_k2_and_stranded_reference_known_answers():
+    X = "CROSS JOIN LATERAL NEAREST(genes, reference := a.interval"
+    # tests/integration/datafusion/test_cross_target_oracle.py:293-324
+    t = {"peaks": make_table([("chr1", 200, 300, "p", 0, "+")]),
+         "genes": make_table([("chr1", 1000, 1100, "g1", 0, "+"), ("chr1", 50, 60, "g2", 0, "+"),
+                              ("chr1", 280, 290, "g3", 0, "+"), ("chr1", 310, 320, "g4", 0, "+")])}
+    out = execute(transpile(f"SELECT a.start AS a_start, b.start AS b_start FROM peaks a {X}, k := 2) b", ["peaks", "genes"],
+                            dialect="hip"), t)
+    assert [(d["a_start"], d["b_start"]) for d in out.to_pylist()] == [(200, 280), (200, 310)]
+    # :398-424 -- the same-strand gene wins although the opposite-strand one is nearer
+    t = {"peaks": make_table([("chr1", 200, 300, "p", 0, "+")]),
+         "genes": make_table([("chr1", 280, 290, "g1", 0, "+"), ("chr1", 250, 260, "g2", 0, "-")])}
+    q = f"SELECT a.start AS a_start, b.start AS b_start FROM peaks a {X}, k := 1, stranded := true) b"
+    assert [(d["a_start"], d["b_start"]) for d in execute(transpile(q, ["peaks", "genes"], dialect="hip"), t).to_pylist()] == [(200, 280)]
+    # :482-520 -- co-located opposite-strand reference rows keep their own strand's nearest
+    t["peaks"] = make_table([("chr1", 200, 300, "p1", 0, "+"), ("chr1", 200, 300, "p2", 0, "-")])
+    q = f"SELECT a.strand AS a_strand, b.start AS b_start FROM peaks a {X}, k := 1, stranded := true) b"
+    assert rows_of(execute(transpile(q, ["peaks", "genes"], dialect="hip"), t)) == [("+", 280), ("-", 250)]
+    # signed + stranded: a '-' reference flips the sign (_distance.py:88-117): upstream of a '-' row is positive
+    q = f"SELECT a.name, b.name AS g, b.distance AS d FROM peaks a {X}, k := 2, stranded := true, signed := true) b"
+    t["genes"] = make_table([("chr1", 100, 150, "gm", 0, "-"), ("chr1", 400, 450, "gp", 0, "+"), ("chr1", 350, 360, "gm2", 0, "-")])
+    assert rows_of(execute(transpile(q, ["peaks", "genes"], dialect="hip"), t)) == [("p1", "gp", 101), ("p2", "gm", 51), ("p2", "gm2", -51)]
+    with pytest.raises(ValueError, match="strands other than"):
+        t["genes"] = make_table([("chr1", 100, 150, "g", 0, ".")])
+        execute(transpile(q, ["peaks", "genes"], dialect="hip"), t)

@@ -1,0 +1,89 @@
+"""NEAREST k >= 1 and ``stranded := true`` through the C ABI against the sqlite-minted golden vectors
+(tests/golden/nearest_k.json: the reference's distance CASE + ORDER BY ABS(distance), start, end LIMIT k)
+and the oracle's brute force -- needs a GPU."""
+
+import numpy as np
+import pytest
+
+import _golden as G
+from oracle import pyoracle as ora
+from test_gpu_parity import dev, rand_side
+from test_oracle_golden import fold_strand
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+CASES = G.load("nearest_k.json")["cases"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from giql_amd.engine import HipEngine
+
+    e = HipEngine(0)
+    yield e
+    e.close()
+
+
+def _triples(idx, dist, b, sign=None):
+    """Per A row the (distance, start, end) of its neighbours: what the reference orders by (row ids are
+    ambiguous on exact ties, nearest.py:366-372)."""
+    out = []
+    for i in range(idx.shape[0]):
+        s = 1 if sign is None else int(sign[i])
+        out.append([(int(dist[i, t]) * s, int(b.start[idx[i, t]]), int(b.end[idx[i, t]])) for t in range(idx.shape[1]) if idx[i, t] >= 0])
+    return out
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_nearest_k_golden(eng, case):
+    a, b, sign = fold_strand(case)
+    n_chrom = int(max(a.chrom.max(initial=-1), b.chrom.max(initial=-1))) + 1
+    idx, dist = eng.nearest_k(dev(a), dev(b), max(n_chrom, 1), case["k"], signed=case["signed"], max_distance=case["max_distance"])
+    got = _triples(idx.cpu().numpy(), dist.cpu().numpy(), b, sign)
+    assert got == [[(w[3], w[1], w[2]) for w in want] for want in case["expected"]]
+
+
+@pytest.mark.parametrize("k,signed,md", [(1, False, None), (2, True, None), (3, False, 500), (8, True, 90), (64, False, None)])
+def test_nearest_k_random_vs_brute_force(eng, k, signed, md):
+    for seed, (na, nb, nch, ms, ml, min_len) in enumerate([
+            (3000, 4000, 5, 2_000_000, 900, 0),      # sparse: mostly gaps
+            (2000, 6000, 3, 60_000, 400, 0),         # dense: many overlaps per row, zero-length rows
+            (1500, 5000, 2, 3_000, 40, 0),           # pile-ups: long runs of equal starts AND equal ends
+            (500, 7, 4, 100_000, 100, 1),            # fewer targets than k
+    ]):
+        a = rand_side(100 + seed, na, nch, ms, ml + 1, min_len=min_len)
+        b = rand_side(200 + seed, nb, nch, ms, ml + 1, min_len=min_len)
+        idx, dist = eng.nearest_k(dev(a), dev(b), nch, k, signed=signed, max_distance=md)
+        wi, wd = ora.c_nearest_k(a, b, k, signed=signed, max_distance=md)
+        assert _triples(idx.cpu().numpy(), dist.cpu().numpy(), b) == _triples(wi, wd, b), (seed, k)
+        assert np.array_equal(idx.cpu().numpy() >= 0, wi >= 0)
+    # k = 1 is the dedicated kernel's answer
+    i1, d1 = eng.nearest(dev(a), dev(b), nch, signed=signed, max_distance=md)
+    ik, dk = eng.nearest_k(dev(a), dev(b), nch, 1, signed=signed, max_distance=md)
+    assert np.array_equal(d1.cpu().numpy(), dk.cpu().numpy()[:, 0]) and np.array_equal(i1.cpu().numpy() >= 0, ik.cpu().numpy()[:, 0] >= 0)
+
+
+def test_nearest_k_edge_cases(eng):
+    empty = ora.Side(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    a = rand_side(7, 100, 3, 10_000, 50)
+    idx, dist = eng.nearest_k(dev(a), dev(empty), 3, 4)
+    assert (idx.cpu().numpy() == -1).all() and idx.shape == (100, 4)
+    assert eng.nearest_k(dev(empty), dev(a), 3, 4)[0].shape == (0, 4)
+    # targets on another chromosome only: no row (CROSS JOIN LATERAL of an empty set)
+    b = ora.Side(np.full(10, 2, np.int32), np.arange(10, dtype=np.int32) * 10, np.arange(10, dtype=np.int32) * 10 + 5)
+    a0 = ora.Side(np.zeros(3, np.int32), np.array([5, 50, 500], np.int32), np.array([6, 60, 600], np.int32))
+    assert (eng.nearest_k(dev(a0), dev(b), 3, 2)[0].cpu().numpy() == -1).all()
+    # zero-length reference and target on one point: downstream by the CASE's first matching arm (+1, also signed)
+    z = ora.Side(np.zeros(1, np.int32), np.array([100], np.int32), np.array([100], np.int32))
+    idx, dist = eng.nearest_k(dev(z), dev(z), 1, 2, signed=True)
+    assert dist.cpu().numpy().tolist() == [[1, 0]] and idx.cpu().numpy().tolist() == [[0, -1]]
+    from giql_amd._lib import GiqlHipError
+    with pytest.raises(GiqlHipError):
+        eng.nearest_k(dev(a), dev(a), 3, 65)
+    with pytest.raises(GiqlHipError):
+        eng.nearest_k(dev(a), dev(a), 3, 0)
+    inv = ora.Side(np.zeros(2, np.int32), np.array([10, 50], np.int32), np.array([5, 60], np.int32))
+    with pytest.raises(GiqlHipError):
+        eng.nearest_k(dev(a), dev(inv), 3, 2)

@@ -138,3 +138,34 @@ def test_cluster_merge_golden(case):
     G.check_cluster_case(case, ora.c_cluster(side, d), list(zip(c, s, e, n)))
     if side.n <= 80:
         G.check_cluster_case(case, ora.py_cluster(side, d), ora.py_merge(side, d))
+
+
+# ------------------------------------------------------- NEAREST k > 1 / stranded
+NEAREST_K = G.load("nearest_k.json")["cases"]
+
+
+def fold_strand(case):
+    """``stranded := true``: a target row matches only on the reference row's strand
+    (nearest.py:313-333), i.e. (chrom, strand) is the partition; the distance takes the sign flip of a
+    '-' reference (_distance.py:88-117).  Returns (a, b, sign per A row)."""
+    chroms = sorted({r[0] for r in case["a"]} | {r[0] for r in case["b"]})
+    cid = {c: i for i, c in enumerate(chroms)}
+
+    def side(rows):
+        part = [cid[r[0]] * 2 + (1 if (case["stranded"] and r[3] == "-") else 0) for r in rows]
+        return ora.Side(np.array(part, np.int32).reshape(-1), np.array([r[1] for r in rows], np.int32).reshape(-1),
+                        np.array([r[2] for r in rows], np.int32).reshape(-1))
+    sign = np.array([-1 if (case["stranded"] and r[3] == "-") else 1 for r in case["a"]], np.int64)
+    return side(case["a"]), side(case["b"]), sign
+
+
+@pytest.mark.parametrize("case", NEAREST_K, ids=lambda c: c["name"])
+def test_oracle_nearest_k_matches_the_references_sql(case):
+    a, b, sign = fold_strand(case)
+    k = case["k"]
+    idx, dist = ora.c_nearest_k(a, b, k, signed=case["signed"], max_distance=case["max_distance"])
+    py = ora.py_nearest_k(a, b, k, signed=case["signed"], max_distance=case["max_distance"])
+    for i, want in enumerate(case["expected"]):
+        got = [(int(dist[i, t]) * int(sign[i]), int(b.start[idx[i, t]]), int(b.end[idx[i, t]])) for t in range(k) if idx[i, t] >= 0]
+        assert got == [(w[3], w[1], w[2]) for w in want], (case["name"], i)
+        assert [(d * int(sign[i]), int(b.start[j]), int(b.end[j])) for j, d in py[i]] == got

@@ -107,7 +107,7 @@ def test_case_insensitive_aliases():
     "SELECT a.start FROM peaks a, genes b, exons c WHERE a.interval INTERSECTS b.interval",
     "WITH x AS (SELECT 1) SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS 'chr1:1-10'",
-    "SELECT a.start FROM peaks a CROSS JOIN LATERAL NEAREST(genes, reference := a.interval, k := 2) b",
+    "SELECT a.start FROM peaks a CROSS JOIN LATERAL NEAREST(genes, reference := a.interval, k := 65) b",
 ])
 def test_valid_but_unsupported_shapes_decline(query):
     with pytest.raises(HipDeclined):
@@ -298,3 +298,19 @@ def test_plugin_module_is_import_guarded():
     from giql_amd import plugin
 
     assert plugin.HAVE_GIQL in (True, False)  # importing never raises without giql/sqlglot
+
+
+def test_nearest_k_and_stranded_lower_to_the_plan():
+    plan = build_plan("SELECT a.start, b.start AS g, b.distance FROM peaks a CROSS JOIN LATERAL "
+                      "NEAREST(genes, reference := a.interval, k := 3, stranded := true, signed := true, max_distance := 500) b",
+                      ["peaks", "genes"])
+    assert (plan.kind, plan.k, plan.stranded, plan.signed, plan.max_distance, plan.strand_col) == \
+        ("NEAREST", 3, True, True, 500, "strand,strand")
+    from giql_amd.plan import JoinPlan
+    assert JoinPlan.from_string(plan.to_string()) == plan
+    from giql_amd.table import Table
+    with pytest.raises(HipDeclined):     # no strand column to match on
+        build_plan("SELECT a.start FROM peaks a CROSS JOIN LATERAL NEAREST(genes, reference := a.interval, stranded := true) b",
+                   [Table("peaks", strand_col=None), "genes"])
+    with pytest.raises(ValueError, match="positive"):
+        build_plan("SELECT a.start FROM peaks a CROSS JOIN LATERAL NEAREST(genes, reference := a.interval, k := 0) b", ["peaks", "genes"])
