@@ -114,23 +114,9 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
   int cur = -1, mn = INT_MAX, mx = INT_MIN;
   int lmn = INT_MAX, lmx = 0;  // canonical length range (0 as soon as a row is irregular)
   bool bad = false;
-  const i64 stride = (i64)gridDim.x * NT;
-  for (i64 i0 = (i64)blockIdx.x * NT + threadIdx.x; i0 < n; i0 += 4 * stride) {
-    int cv[4], sv[4], ev[4];
-    bool okv[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {  // 12 loads in flight per thread
-      const i64 i = i0 + u * stride;
-      okv[u] = i < n;
-      cv[u] = okv[u] ? chrom[i] : 0;
-      sv[u] = okv[u] ? start[i] : 0;
-      ev[u] = okv[u] ? end[i] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (!okv[u]) continue;
-      const int c = cv[u];
-      const int s = sv[u], e = ev[u];
+  // One row: length range, per-chromosome min/max through the run cache, digit counts.
+  auto row = [&](const int c, const int s, const int e, const bool ok) {
+    if (ok) {
       // canonical length, saturated to int range; rows with len <= 0 are irregular
       if (e > s) {
         const u32 d = (u32)e - (u32)s;  // exact for e > s
@@ -148,42 +134,45 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
       }
       if (c < 0 || c >= n_chrom) {
         bad = true;
-        continue;
-      }
-      if (c != cur) {
+      } else {
+        if (c != cur) {
 #if defined(GIQL_MM_ABLATE)  // timing-only build: (almost) no LDS atomics
-        if (cur >= 0 && (i0 & 0xFF) == 0) {
+          if (cur >= 0 && (s & 0xFF) == 0) {
 #else
-        if (cur >= 0) {
+          if (cur >= 0) {
 #endif
-          atomicMin(&lmin[cur], mn);
-          atomicMax(&lmax[cur], mx);
+            // (two explicit branches: through the generic `lmin` pointer these compile to FLAT atomics)
+            if (use_lds) {
+              atomicMin(&mm_lds[cur], mn);
+              atomicMax(&mm_lds[n_chrom + cur], mx);
+            } else {
+              atomicMin(&gmin[cur], mn);
+              atomicMax(&gmax[cur], mx);
+            }
+          }
+          cur = c;
+          mn = INT_MAX;
+          mx = INT_MIN;
         }
-        cur = c;
-        mn = INT_MAX;
-        mx = INT_MIN;
+        const int lo = s < e ? s : e, hi = s < e ? e : s;
+        mn = lo < mn ? lo : mn;
+        mx = hi > mx ? hi : mx;
       }
-      const int lo = s < e ? s : e, hi = s < e ? e : s;
-      mn = lo < mn ? lo : mn;
-      mx = hi > mx ? hi : mx;
     }
     if (HIST) {
       // n_chrom <= MM_HIST_CHROMS here (host); a bad id (flagged above) is masked into range
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const bool ok = okv[u];
-        const u32 pos = (u32)(sv[u] + start_off);
-        const u32 tb = ((u32)cv[u] & (MM_HIST_CHROMS - 1)) * 256u + (pos >> 24);
-        if (HIST == 1 && ok) {
-          atomicAdd(&s_hist[pos & 0xFFu], 1u);
-          atomicAdd(&s_hist[256 + ((pos >> 8) & 0xFFu)], 1u);
-        }
-        // chromosome- and position-sorted input makes the two high digits wave-uniform:
-        // one add per wave instead of 64 serialised ones on the same LDS word
-        const u64 act = __ballot(ok);
-        if (act == 0) continue;
+      const u32 pos = (u32)(s + start_off);
+      const u32 tb = ((u32)c & (MM_HIST_CHROMS - 1)) * 256u + (pos >> 24);
+      if (HIST == 1 && ok) {
+        atomicAdd(&s_hist[pos & 0xFFu], 1u);
+        atomicAdd(&s_hist[256 + ((pos >> 8) & 0xFFu)], 1u);
+      }
+      // chromosome- and position-sorted input makes the two high digits wave-uniform:
+      // one add per wave instead of 64 serialised ones on the same LDS word
+      const u64 act = __ballot(ok);
+      if (act != 0) {
         const u32 d2 = (pos >> 16) & 0xFFu;
-        // the rows of a wave are consecutive and the loop bound cuts a SUFFIX of lanes, so the
+        // the rows of a wave are consecutive and the bound cuts a SUFFIX of lanes, so the
         // first executing lane is valid whenever any lane is: readfirstlane (no LDS shuffle)
         const u32 d2f = (u32)__builtin_amdgcn_readfirstlane((int)d2);
         const u32 tbf = (u32)__builtin_amdgcn_readfirstlane((int)tb);
@@ -199,6 +188,34 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
           atomicAdd(&s_top[tb], 1u);
         }
       }
+    }
+  };
+  // Tiles of 4 * NT consecutive rows, grid-stride: row u * NT + tid of a tile is item u of thread
+  // tid.  Every tile but the last is full, so its twelve loads are issued back to back with no
+  // bounds predicate (the predicated form branched around every single load).
+  constexpr u32 TILE = 4u * NT;
+  const u64 n_full = (u64)n / TILE;
+  for (u64 t = blockIdx.x; t < n_full; t += gridDim.x) {
+    const int* cp = chrom + t * TILE + threadIdx.x;
+    const int* sp = start + t * TILE + threadIdx.x;
+    const int* ep = end + t * TILE + threadIdx.x;
+    int cv[4], sv[4], ev[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      cv[u] = cp[u * NT];
+      sv[u] = sp[u * NT];
+      ev[u] = ep[u * NT];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) row(cv[u], sv[u], ev[u], true);
+  }
+  if (blockIdx.x == (u32)(n_full % gridDim.x)) {  // the ragged tail: one block
+    const u64 base = n_full * TILE;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const u64 i = base + (u64)u * NT + threadIdx.x;
+      const bool ok = i < (u64)n;
+      row(ok ? chrom[i] : 0, ok ? start[i] : 0, ok ? end[i] : 0, ok);
     }
   }
   if (HIST) {
@@ -216,8 +233,13 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
     }
   }
   if (cur >= 0) {
-    atomicMin(&lmin[cur], mn);
-    atomicMax(&lmax[cur], mx);
+    if (use_lds) {
+      atomicMin(&mm_lds[cur], mn);
+      atomicMax(&mm_lds[n_chrom + cur], mx);
+    } else {
+      atomicMin(&gmin[cur], mn);
+      atomicMax(&gmax[cur], mx);
+    }
   }
   if (bad) meta->status = -4;  // GIQL_ERR_CHROM
   {
