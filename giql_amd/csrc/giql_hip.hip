@@ -133,6 +133,7 @@ struct giql_hip_ctx {
   // three-stage sort (two global passes on bits 16-31 + the in-LDS bucket sort, bucket_sort.hip.h)
   // for sides of at least local_min_rows rows (smaller sides have too few rows per bucket to pay for a block each); switched off for good on a context once a bucket
   // turned out larger than the LDS sort holds (GIQL_HIP_NO_LOCAL_SORT=1: never)
+  bool no_skip_digit = false;  // GIQL_HIP_NO_SKIP_DIGIT=1: query sides are sorted on every digit
   bool local_sort = true;
   u64 local_min_rows = 1u << 25;
   int local_resorts = 0;      // calls repeated with the four-pass sort
@@ -422,14 +423,20 @@ static inline bool sort_is_local(const giql_hip_ctx* ctx, size_t n) {
   return ctx->local_sort && ctx->bucket_bnd && ctx->os_variant == 0 && n >= ctx->local_min_rows;
 }
 
+// skip_digits = 1 (four-pass form only): the lowest digit is left unsorted -- rows come out ordered
+// by key >> 8 and the result is left in buffer 0 by swapping the ping-pong pointers.  For QUERY
+// sides whose order only serves locality (neighbouring rows search neighbouring ranges): three
+// passes instead of four.
 static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
                              const u32* gbase, u32* status, bool keep_rids = false,
-                             const giql_side* keygen = nullptr, const u32* abase = nullptr) {
+                             const giql_side* keygen = nullptr, const u32* abase = nullptr,
+                             int skip_digits = 0) {
   if (n == 0) return GIQL_OK;
   const bool local = sort_is_local(ctx, n);
   if (local) ctx->last_sort_local = true;
-  const int n_pass = local ? 2 : 4;
-  const int first_digit = local ? 2 : 0;
+  if (local || ctx->no_skip_digit) skip_digits = 0;
+  const int n_pass = local ? 2 : 4 - skip_digits;
+  const int first_digit = local ? 2 : skip_digits;
   const size_t per_pass = os_pass_words(n);
   HIP_TRY(hipMemsetAsync(status, 0, n_pass * per_pass * sizeof(u32), st));
   {
@@ -467,6 +474,12 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
         default: launch_onesweep<1024, 8>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
       }
     }
+  }
+  if (n_pass & 1) {  // an odd number of passes ends in buffer 1: make that "buffer 0"
+    u32* t;
+    t = sb.key[0], sb.key[0] = sb.key[1], sb.key[1] = t;
+    t = sb.end[0], sb.end[0] = sb.end[1], sb.end[1] = t;
+    t = sb.rid[0], sb.rid[0] = sb.rid[1], sb.rid[1] = t;
   }
   if (local) {
     // the rows are back in buffer 0, ordered by key >> 16: bucket boundaries, then one block per bucket
@@ -675,6 +688,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->no_uniform = u && atoi(u) != 0;
     const char* nh = getenv("GIQL_HIP_NO_SPAN_HIST");
     ctx->no_span_hist = nh && atoi(nh) != 0;
+    const char* nsd = getenv("GIQL_HIP_NO_SKIP_DIGIT");
+    ctx->no_skip_digit = nsd && atoi(nsd) != 0;
     const char* nl = getenv("GIQL_HIP_NO_LOCAL_SORT");
     if (nl && atoi(nl) != 0) ctx->local_sort = false;
     const char* lm = getenv("GIQL_HIP_LOCAL_MIN_ROWS");
@@ -859,6 +874,7 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     }
   };
   bool speculated = false;
+  bool coarse_q = false;  // the query side was sorted without its lowest digit (a guess: no irregular rows)
   if (onesweep && !ctx->no_uniform) {
     if (ctx->spec_valid) {
       S.uniform = ctx->spec_form;
@@ -901,7 +917,14 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
                              q_is_a ? hist_b : hist_a, q_is_a ? gbase_b : gbase_a, nullptr, nullptr,
                              /*skip_end=*/true));  // uniform => no irregular row: `end` is not read
     }
-    GIQL_TRY(run_sort_onesweep(ctx, st, sq, (u32)nqr, q_is_a ? gbase_a : gbase_b, os_status));
+    // The query side's order only serves locality (its bounds are searched per row, its pairs are laid
+    // out by the scan), so its lowest digit stays unsorted: three passes.  Irregular rows would break
+    // that (their sentinel keys must end up LAST, after every row of the top 256-key block): taken
+    // only on the context's guess that there are none, validated with the other guesses below.
+    const int q_skip = (speculated && ctx->last_no_irr && !ctx->no_skip_digit && !sort_is_local(ctx, nqr)) ? 1 : 0;
+    coarse_q = q_skip != 0;
+    GIQL_TRY(run_sort_onesweep(ctx, st, sq, (u32)nqr, q_is_a ? gbase_a : gbase_b, os_status, false, nullptr, nullptr,
+                               q_skip));
     GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, os_status, false,
                                keygen ? &us_ : nullptr, lb.abase));
     constexpr u32 TQ = RC_NT * RC_ITEMS_C2;
@@ -913,7 +936,7 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
       const i64 lo_off = 1 - uni_len;  // u.start in [q.start - L + 1, q.end)
       hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt2 + 1, 256)), dim3(256), 0, st,
                          sq.key[0], (u32)nqr, irr_q, su.key[0], (u32)nu, irr_u, lo_off, TQ, S.nt2,
-                         S.wlo2);
+                         S.wlo2, coarse_q ? 0xFFFFFF00u : 0xFFFFFFFFu);
       hipLaunchKernelGGL((k_range_count<RC_ITEMS_C2, RC_LDS_CAP>), dim3(S.nt2), dim3(RC_NT), 0, st,
                          sq.key[0], sq.end[0], (u32)nqr, irr_q, su.key[0], (u32)nu, irr_u, lo_off,
                          S.wlo2, S.lo2, cnt2);
@@ -1001,7 +1024,8 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     i64 len;
     decide(*ctx->h_meta, form, len);
     const bool aligned_now = ctx->h_meta->aligned_ok != 0;
-    if (speculated && (form != S.uniform || len != uni_len || (want_hist && !aligned_now))) {
+    const bool coarse_wrong = coarse_q && ctx->h_meta->irr_a + ctx->h_meta->irr_b > 0;
+    if (speculated && (form != S.uniform || len != uni_len || (want_hist && !aligned_now) || coarse_wrong)) {
       ctx->spec_valid = false;  // wrong guess: plan again from the numbers just read
       ctx->spec_misses++;
       ctx->fuse_done = false;
@@ -1242,7 +1266,8 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
     GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
   }
   GIQL_TRY(run_linearize(ctx, st, *a, nch, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist, os.gbase));
-  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, false, nullptr, nullptr,
+                             /*skip_digits=*/1));  // the query side's order only serves locality; every row keeps its real key here
   {
     Phase ph(ctx, st, GIQL_PH_COUNT);
     if (nb > 0 && uni_len > 0)
@@ -1440,7 +1465,8 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
   GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
   GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist,
                          os.gbase));
-  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, false, nullptr, nullptr,
+                             /*skip_digits=*/1));  // the query side's order only serves locality; every row keeps its real key here
   {
     Phase ph(ctx, st, GIQL_PH_COUNT, 3);
     hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st,
@@ -1544,7 +1570,8 @@ static int giql_hip_nearest_k_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   HIP_TRY(hipMemcpyAsync(se.rid[0], sbb.rid[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
   GIQL_TRY(run_sort_onesweep(ctx, st, se, (u32)nb, os.gbase_e, os.status, /*keep_rids=*/true));
   GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist, os.gbase));
-  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status));
+  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, false, nullptr, nullptr,
+                             /*skip_digits=*/1));  // the query side's order only serves locality; every row keeps its real key here
   {
     Phase ph(ctx, st, GIQL_PH_COUNT, 4);
     hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st, lb.chrom_first, n_chrom,

@@ -585,16 +585,19 @@ __device__ __forceinline__ u32 shift_key(u32 k, i64 off) {
 // w_lo[t] = first S index a query of tile t can match = lower_bound(S, first
 // query start + lo_off); w_lo[n_tiles] = |S|.  One thread per tile: the count
 // kernel then starts with its S window known (no serial per-block search).
+// key_mask: the queries may be ordered by their high key bits only (a query side sorted without
+// its lowest digit, run_sort_onesweep skip_digits): every query of tile t then has a key >= the
+// tile's first key with the unordered bits cleared, and that is where the window starts.
 __global__ void k_count_partition(const u32* __restrict__ qs, u32 nq_total,
                                   const u32* __restrict__ irr_q, const u32* __restrict__ ss,
                                   u32 ns_total, const u32* __restrict__ irr_s, i64 lo_off, u32 tq,
-                                  u32 n_tiles, u32* __restrict__ w_lo) {
+                                  u32 n_tiles, u32* __restrict__ w_lo, u32 key_mask = 0xFFFFFFFFu) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t > n_tiles) return;
   const u32 nq = nq_total - *irr_q;
   const u32 ns = ns_total - *irr_s;
   const u64 q = (u64)t * tq;
-  w_lo[t] = (t < n_tiles && q < nq) ? lower_bound_u32(ss, 0, ns, shift_key(qs[q], lo_off)) : ns;
+  w_lo[t] = (t < n_tiles && q < nq) ? lower_bound_u32(ss, 0, ns, shift_key(qs[q] & key_mask, lo_off)) : ns;
 }
 
 // Shared by the count / emit kernels: the block's S window [w0, w0 + len) staged
