@@ -114,3 +114,33 @@ def test_config2_1m_x_1m_single_chromosome_full_result(monkeypatch, genome, env)
         assert np.array_equal(e.count_overlaps(dev(a), dev(b), 1).cpu().numpy(), counts)
     finally:
         e.close()
+
+
+def test_skewed_reads_hot_windows_take_the_big_bucket_path(monkeypatch):
+    # real read tables are far from uniform: 40M fixed-length reads, a fifth of them piled into 200 hot
+    # 20-kb windows (~40K rows in each of those 16-bit buckets), against 2M peaks.  The three-stage sort
+    # keeps its form (the hot buckets go through bucket_sort_big), nothing falls back, results exact.
+    rng = np.random.default_rng(42)
+    n_b, n_hot, n_a = 40_000_000, 8_000_000, 2_000_000
+    lengths = synth.HG38_LENGTHS
+    bc, bs, be = synth.make_table(n_b - n_hot, 11, "reads")
+    hot_c = rng.integers(0, 24, 200)
+    hot_s = (rng.random(200) * (lengths[hot_c] - 100_000)).astype(np.int64)
+    pick = rng.integers(0, 200, n_hot)
+    hs = (hot_s[pick] + rng.integers(0, 20_000, n_hot)).astype(np.int32)
+    b = ora.Side(np.concatenate([bc, hot_c[pick].astype(np.int32)]), np.concatenate([bs, hs]), np.concatenate([be, hs + np.int32(150)]))
+    a = ora.Side(*synth.make_table(n_a, 12, "peaks"))
+    ra, rb = ora.c_inner(a, b, "sweep")
+    want_n, want_sum = int(ra.shape[0]), ora.c_pairs_checksum(ra, rb)
+    del ra, rb
+    e = _engine(monkeypatch)
+    try:
+        for _ in range(2):
+            ga, gb = e.inner_join(dev(a), dev(b), 24)
+            st = e.stats()
+            assert int(ga.shape[0]) == want_n and e.pairs_checksum(ga, gb) == want_sum
+            assert st["sort_local"] and not st["sort_resorted"] and st["join_form"] == "uniform_b"
+            del ga, gb
+        assert np.array_equal(e.count_overlaps(dev(a), dev(b), 24).cpu().numpy(), ora.c_count(a, b, "sweep"))
+    finally:
+        e.close()
