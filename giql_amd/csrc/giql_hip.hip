@@ -133,6 +133,11 @@ struct giql_hip_ctx {
   // three-stage sort (two global passes on bits 16-31 + the in-LDS bucket sort, bucket_sort.hip.h)
   // for sides of at least local_min_rows rows (smaller sides have too few rows per bucket to pay for a block each); switched off for good on a context once a bucket
   // turned out larger than the LDS sort holds (GIQL_HIP_NO_LOCAL_SORT=1: never)
+  // second stream: the smaller side's linearize + sort run beside the larger side's when that side is
+  // small enough to be latency-bound (a chain of ~10 short launches); GIQL_HIP_NO_OVERLAP=1: never
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  u64 overlap_max_rows = 4u << 20;
   bool no_skip_digit = false;  // GIQL_HIP_NO_SKIP_DIGIT=1: query sides are sorted on every digit
   bool local_sort = true;
   u64 local_min_rows = 1u << 25;
@@ -590,6 +595,39 @@ static void sort_sizes(Carver& c, size_t n, SortBufs& sb, bool payload) {
   }
 }
 
+// Fork / join of the context's second stream.  A side of a few million rows is a chain of ~10 launches
+// of 10-40 us each that do not fill the GPU (look-back latency, not bandwidth, bounds them): run beside
+// the other side's chain it costs almost nothing.  Work given to stream() is ordered after everything
+// already on the caller's stream; join() orders the caller's stream after it.  A call that returns
+// early (an error) synchronises the second stream in the destructor, so no kernel outlives the arena.
+struct SideChain {
+  giql_hip_ctx* ctx;
+  hipStream_t main;
+  bool active = false, joined = false;
+  // n_small / n_large: rows of the side given to the second stream / of the side that stays.  BOTH must
+  // be small: beside a sort of many tiles the look-back chains of the two kernels delay each other
+  // (measured: SEMI 1M x 10M 0.38 -> 0.50 ms with the 1M side beside the 10M one; 1M x 1M 0.38 -> 0.34).
+  SideChain(giql_hip_ctx* c, hipStream_t m, size_t n_small, size_t n_large) : ctx(c), main(m) {
+    if (!c->side_stream || n_small == 0 || n_small > c->overlap_max_rows || n_large > c->overlap_max_rows) return;
+    if (sort_is_local(c, n_small)) return;  // the bucket sort's boundary / queue buffers are one per context
+    if (hipEventRecord(c->ev_fork, m) != hipSuccess) return;
+    if (hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) return;
+    active = true;
+  }
+  hipStream_t stream() const { return active ? ctx->side_stream : main; }
+  int join() {
+    if (active && !joined) {
+      joined = true;
+      HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side_stream));
+      HIP_TRY(hipStreamWaitEvent(main, ctx->ev_join, 0));
+    }
+    return GIQL_OK;
+  }
+  ~SideChain() {
+    if (active && !joined) (void)hipStreamSynchronize(ctx->side_stream);
+  }
+};
+
 // Belt and braces around the sort: its look-back makes progress whatever the dispatch
 // order (blocks compute silent predecessors themselves, k_onesweep), so a timeout status
 // is never expected; should one be reported all the same, the call is repeated ONCE in
@@ -704,6 +742,15 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
   hipError_t e = hipMalloc((void**)&ctx->d_meta, sizeof(DevMeta));
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_meta, sizeof(DevMeta), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_scratch64, 64);
+  {
+    const char* no = getenv("GIQL_HIP_NO_OVERLAP");
+    if (!(no && atoi(no) != 0) && e == hipSuccess) {
+      if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
+        ctx->side_stream = nullptr;  // no second stream: everything stays on the caller's
+    }
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_bnd, ((size_t)BS_BUCKETS + 16) * sizeof(u32));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_big, ((size_t)BS_BUCKETS + 16) * sizeof(u32));
   if (e != hipSuccess) {
@@ -723,6 +770,9 @@ int giql_hip_destroy(giql_hip_ctx* ctx) {
   if (ctx->part) (void)hipFree(ctx->part);
   if (ctx->d_meta) (void)hipFree(ctx->d_meta);
   if (ctx->d_scratch64) (void)hipFree(ctx->d_scratch64);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->bucket_bnd) (void)hipFree(ctx->bucket_bnd);
   if (ctx->bucket_big) (void)hipFree(ctx->bucket_big);
   if (ctx->xplan) (void)hipFree(ctx->xplan);
@@ -792,7 +842,7 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
   InnerState& S = ctx->inner;
   u32 *tile_hist = nullptr, *cnt2 = nullptr, *irr_cnt = nullptr;
   u32 *hist_a = nullptr, *hist_b = nullptr, *gbase_a = nullptr, *gbase_b = nullptr;
-  u32* os_status = nullptr;
+  u32 *os_status = nullptr, *os_status2 = nullptr;
   u64* bsums = nullptr;
   const bool onesweep = !ctx->classic_sort && na <= OS_MAX_ROWS && nb <= OS_MAX_ROWS;
   const size_t n_max = na > nb ? na : nb;
@@ -812,6 +862,7 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
       gbase_a = c.take<u32>(1024);
       gbase_b = c.take<u32>(1024);
       os_status = c.take<u32>(4 * os_pass_words(n_max));
+      os_status2 = c.take<u32>(4 * os_pass_words(na < nb ? na : nb));  // the smaller side's, when its chain runs beside
       lb.abase = c.take<u32>(MM_HIST_CHROMS);
       lb.top_partial = c.take<u32>((size_t)LIN_HIST_REPLICAS * MM_TOP_WORDS);
     } else {
@@ -899,7 +950,9 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     SortBufs& su = q_is_a ? sbb : sa;
     const size_t nqr = q_is_a ? na : nb, nu = q_is_a ? nb : na;
     su.end[0] = su.end[1] = nullptr;  // the uniform side carries (key, rid) only
-    GIQL_TRY(run_linearize(ctx, st, qs_, n_chrom, lb, sq.key[0], sq.end[0],
+    // the query side's chain (linearize + sort) beside the other side's when it is small
+    SideChain sc(ctx, st, nqr <= nu ? nqr : 0, nu);
+    GIQL_TRY(run_linearize(ctx, sc.stream(), qs_, n_chrom, lb, sq.key[0], sq.end[0],
                            q_is_a ? ctx->irr_a_list : ctx->irr_b_list, q_is_a ? 0 : 1, 0,
                            q_is_a ? hist_a : hist_b, q_is_a ? gbase_a : gbase_b));
     if (keygen) {
@@ -923,10 +976,11 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     // only on the context's guess that there are none, validated with the other guesses below.
     const int q_skip = (speculated && ctx->last_no_irr && !ctx->no_skip_digit && !sort_is_local(ctx, nqr)) ? 1 : 0;
     coarse_q = q_skip != 0;
-    GIQL_TRY(run_sort_onesweep(ctx, st, sq, (u32)nqr, q_is_a ? gbase_a : gbase_b, os_status, false, nullptr, nullptr,
-                               q_skip));
+    GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sq, (u32)nqr, q_is_a ? gbase_a : gbase_b,
+                               sc.active ? os_status2 : os_status, false, nullptr, nullptr, q_skip));
     GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, os_status, false,
                                keygen ? &us_ : nullptr, lb.abase));
+    GIQL_TRY(sc.join());
     constexpr u32 TQ = RC_NT * RC_ITEMS_C2;
     S.nt2 = cdiv(nqr, TQ);
     {
@@ -979,13 +1033,18 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     // the early fill stands only if every guess held and the pairs fitted
     ctx->fuse_done = fused && ctx->h_meta->irr_a + ctx->h_meta->irr_b == 0 && ctx->n_reg <= ctx->fuse_cap;
   } else {
-  GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], ctx->irr_a_list, 0, 0,
+  // the smaller side's chain (linearize + sort) beside the larger side's when it is small
+  SideChain sc(ctx, st, onesweep ? (na < nb ? na : nb) : 0, na < nb ? nb : na);
+  const bool a_small = na < nb;
+  hipStream_t st_a = a_small ? sc.stream() : st, st_b = a_small ? st : sc.stream();
+  GIQL_TRY(run_linearize(ctx, st_a, *a, n_chrom, lb, sa.key[0], sa.end[0], ctx->irr_a_list, 0, 0,
                          hist_a, gbase_a));
-  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], ctx->irr_b_list, 1, 0,
+  GIQL_TRY(run_linearize(ctx, st_b, *b, n_chrom, lb, sbb.key[0], sbb.end[0], ctx->irr_b_list, 1, 0,
                          hist_b, gbase_b));
   if (onesweep) {
-    GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, gbase_a, os_status));
-    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, gbase_b, os_status));
+    GIQL_TRY(run_sort_onesweep(ctx, st_a, sa, (u32)na, gbase_a, (sc.active && a_small) ? os_status2 : os_status));
+    GIQL_TRY(run_sort_onesweep(ctx, st_b, sbb, (u32)nb, gbase_b, (sc.active && !a_small) ? os_status2 : os_status));
+    GIQL_TRY(sc.join());
   } else {
     GIQL_TRY(run_sort(ctx, st, sa, (u32)na, tile_hist, bsums));
     GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
@@ -1219,7 +1278,7 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
 
   LinBufs lb;
   SortBufs sa, sbb;
-  OsScratch os;
+  OsScratch os, os_a;
   u32 *flag = nullptr, *pmax = nullptr, *bmax = nullptr, *dummy_irr = nullptr;
   u64 *bsums = nullptr, *off = nullptr;
   auto carve = [&](char* base) {
@@ -1231,7 +1290,8 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
       sbb.end[k] = c.take<u32>(nb ? nb : 1);
       sbb.rid[k] = nullptr;
     }
-    os_scratch_sizes(c, na > nb ? na : nb, os);
+    os_scratch_sizes(c, nb ? nb : 1, os);
+    os_scratch_sizes(c, na, os_a);   // A's own histogram / status words: its chain may run beside B's
     bsums = c.take<u64>(cdiv(na, SCAN_TILE) + 2);
     flag = c.take<u32>(na);
     off = c.take<u64>(na + 1);
@@ -1247,6 +1307,12 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   i64 uni_len = 0;
   bool speculated = false;
   if (nb > 0) GIQL_TRY(row_form_guess(ctx, st, uni_len, speculated));
+  {
+    // the query side's chain (linearize + sort) beside B's when it is small
+    SideChain sc(ctx, st, nb > 0 ? na : 0, nb);
+    GIQL_TRY(run_linearize(ctx, sc.stream(), *a, nch, lb, sa.key[0], sa.end[0], dummy_irr + 8, 0, 1, os_a.hist, os_a.gbase));
+    GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sa, (u32)na, os_a.gbase, os_a.status, false, nullptr, nullptr,
+                               /*skip_digits=*/1));  // the query side's order only serves locality; every row keeps its real key here
   if (nb > 0 && uni_len > 0) {
     // fixed-length B: keys only (its `end` column is not read again), no prefix max
     sbb.end[0] = sbb.end[1] = nullptr;
@@ -1265,9 +1331,8 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
     GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status));
     GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
   }
-  GIQL_TRY(run_linearize(ctx, st, *a, nch, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist, os.gbase));
-  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, false, nullptr, nullptr,
-                             /*skip_digits=*/1));  // the query side's order only serves locality; every row keeps its real key here
+    GIQL_TRY(sc.join());
+  }
   {
     Phase ph(ctx, st, GIQL_PH_COUNT);
     if (nb > 0 && uni_len > 0)
@@ -1324,7 +1389,7 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
   }
   LinBufs lb;
   SortBufs sa, sstart, send;
-  OsScratch os;
+  OsScratch os, os_a;
   u32 *irr_a_list = nullptr, *irr_b_list = nullptr;
   auto carve = [&](char* base) {
     Carver c{base};
@@ -1336,7 +1401,8 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
       send.key[k] = c.take<u32>(nb);
       send.end[k] = send.rid[k] = nullptr;
     }
-    os_scratch_sizes(c, na > nb ? na : nb, os);
+    os_scratch_sizes(c, nb, os);
+    os_scratch_sizes(c, na, os_a);   // A's chain may run beside B's (SideChain)
     irr_a_list = c.take<u32>(na);
     irr_b_list = c.take<u32>(nb);
     return c.off;
@@ -1348,6 +1414,11 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
   i64 uni_len = 0;
   bool speculated = false;
   GIQL_TRY(row_form_guess(ctx, st, uni_len, speculated));
+  {
+  SideChain sc(ctx, st, na, nb);
+  GIQL_TRY(run_linearize(ctx, sc.stream(), *a, n_chrom, lb, sa.key[0], sa.end[0], irr_a_list, 0, 0, os_a.hist,
+                         os_a.gbase));
+  GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sa, (u32)na, os_a.gbase, os_a.status));
   if (uni_len > 0) {
     // fixed-length B: one sorted array (its sorted ends are its sorted starts + L)
     GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sstart.key[0], nullptr, irr_b_list, 1, 0, os.hist,
@@ -1359,9 +1430,8 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
     GIQL_TRY(run_sort_onesweep(ctx, st, sstart, (u32)nb, os.gbase, os.status));
     GIQL_TRY(run_sort_onesweep(ctx, st, send, (u32)nb, os.gbase_e, os.status));
   }
-  GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], irr_a_list, 0, 0, os.hist,
-                         os.gbase));
-  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status));
+  GIQL_TRY(sc.join());
+  }
   {
     Phase ph(ctx, st, GIQL_PH_COUNT);
     hipLaunchKernelGGL(k_count_rows, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0],
@@ -1418,7 +1488,7 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
   }
   LinBufs lb;
   SortBufs sa, sbb;
-  OsScratch os;
+  OsScratch os, os_a;
   u32 *pmax = nullptr, *bmax = nullptr, *dummy_irr = nullptr, *chrom_lo = nullptr;
   NearestRec* recs = nullptr;
   auto carve = [&](char* base) {
@@ -1426,7 +1496,8 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
     common_sizes(c, n_chrom, lb);
     sort_sizes(c, na, sa, true);
     sort_sizes(c, nb, sbb, true);
-    os_scratch_sizes(c, na > nb ? na : nb, os);
+    os_scratch_sizes(c, nb, os);
+    os_scratch_sizes(c, na, os_a);   // A's chain may run beside B's (SideChain)
     recs = c.take<NearestRec>(na);
     pmax = c.take<u32>(nb);
     bmax = c.take<u32>(cdiv(nb, PM_TILE) + 1);
@@ -1439,6 +1510,11 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
   const bool two_sorts = ctx->nearest_two_sorts;
+  SideChain sc(ctx, st, na, nb);
+  GIQL_TRY(run_linearize(ctx, sc.stream(), *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr + 8, 0, 1, os_a.hist,
+                         os_a.gbase));
+  GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sa, (u32)na, os_a.gbase, os_a.status, false, nullptr, nullptr,
+                             /*skip_digits=*/1));  // the query side's order only serves locality; every row keeps its real key here
   GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist,
                          os.gbase, two_sorts ? os.hist_e : nullptr, two_sorts ? os.gbase_e : nullptr));
   {
@@ -1463,10 +1539,7 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
                        sbb.rid[0], (u32)nb, ctx->d_meta);
   }
   GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
-  GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist,
-                         os.gbase));
-  GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, false, nullptr, nullptr,
-                             /*skip_digits=*/1));  // the query side's order only serves locality; every row keeps its real key here
+  GIQL_TRY(sc.join());
   {
     Phase ph(ctx, st, GIQL_PH_COUNT, 3);
     hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st,
