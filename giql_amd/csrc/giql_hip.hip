@@ -83,6 +83,7 @@ struct SortBufs {
 struct InnerState {
   SortBufs sa, sb;   // sorted (key, end, rid) of A / B in buffer 0
   u32 nt1 = 0, nt2 = 0;
+  int c1_items = C1_ITEMS_MAX;  // class-1 rows per thread of this plan (k_c1_count / k_c1_emit)
   u32* wlo1 = nullptr;   // class-1 S-window starts per block
   u64* c1_base = nullptr;  // class-1 output base per block
   u32* wlo2 = nullptr;
@@ -106,6 +107,8 @@ struct giql_hip_ctx {
 
   bool classic_sort = false;  // GIQL_HIP_SORT=classic: three-launch radix passes
   int os_variant = 0;         // GIQL_HIP_OS_VARIANT: onesweep block shape (tuning)
+  int c1_items = 0;           // GIQL_HIP_C1_ITEMS: class-1 rows per thread, 2 or 8 (0 = by size)
+  size_t c1_small_rows = (size_t)4 << 20;  // class-1 sides up to this many rows take 2 rows per thread
   bool no_uniform = false;    // GIQL_HIP_NO_UNIFORM=1: always run the general two-class join
   int n_cu = 256;             // compute units of the device
   int os_order = 2;           // onesweep tile order (GIQL_HIP_OS_ORDER, see k_onesweep)
@@ -116,6 +119,8 @@ struct giql_hip_ctx {
   int32_t* fuse_b = nullptr;
   u64 fuse_cap = 0;
   bool fuse_done = false;
+  bool swapped = false;  // the last INNER plan ran with the sides exchanged (giql_hip_inner_plan_dev_impl)
+  bool no_swap = false;  // GIQL_HIP_NO_SWAP=1: plan the sides as given
   bool last_no_irr = false;   // the previous plan met no irregular row
   bool nearest_two_sorts = false;  // NEAREST: a B table with long equal-start runs was seen
   bool spec_valid = false;    // INNER: the previous plan's form decision, speculated on next time
@@ -138,6 +143,7 @@ struct giql_hip_ctx {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   u64 overlap_max_rows = 4u << 20;
+  int overlap_mask = 3;  // GIQL_HIP_OVERLAP_MASK: 1 = the sides' sort chains, 2 = the two count classes
   bool no_skip_digit = false;  // GIQL_HIP_NO_SKIP_DIGIT=1: query sides are sorted on every digit
   bool local_sort = true;
   u64 local_min_rows = 1u << 25;
@@ -607,8 +613,8 @@ struct SideChain {
   // n_small / n_large: rows of the side given to the second stream / of the side that stays.  BOTH must
   // be small: beside a sort of many tiles the look-back chains of the two kernels delay each other
   // (measured: SEMI 1M x 10M 0.38 -> 0.50 ms with the 1M side beside the 10M one; 1M x 1M 0.38 -> 0.34).
-  SideChain(giql_hip_ctx* c, hipStream_t m, size_t n_small, size_t n_large) : ctx(c), main(m) {
-    if (!c->side_stream || n_small == 0 || n_small > c->overlap_max_rows || n_large > c->overlap_max_rows) return;
+  SideChain(giql_hip_ctx* c, hipStream_t m, size_t n_small, size_t n_large, int which = 1) : ctx(c), main(m) {
+    if (!c->side_stream || !(c->overlap_mask & which) || n_small == 0 || n_small > c->overlap_max_rows || n_large > c->overlap_max_rows) return;
     if (sort_is_local(c, n_small)) return;  // the bucket sort's boundary / queue buffers are one per context
     if (hipEventRecord(c->ev_fork, m) != hipSuccess) return;
     if (hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) return;
@@ -716,6 +722,10 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->classic_sort = e && strcmp(e, "classic") == 0;
     const char* v = getenv("GIQL_HIP_OS_VARIANT");
     ctx->os_variant = v ? atoi(v) : 0;
+    const char* nsw = getenv("GIQL_HIP_NO_SWAP");
+    ctx->no_swap = nsw && atoi(nsw) != 0;
+    const char* c1i = getenv("GIQL_HIP_C1_ITEMS");
+    if (c1i && (atoi(c1i) == 2 || atoi(c1i) == C1_ITEMS_MAX)) ctx->c1_items = atoi(c1i);
     const char* o = getenv("GIQL_HIP_OS_ORDER");
     if (o) ctx->os_order = atoi(o);
     const char* ha = getenv("GIQL_HIP_OS_HELP_AFTER");
@@ -743,6 +753,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_meta, sizeof(DevMeta), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_scratch64, 64);
   {
+    const char* om = getenv("GIQL_HIP_OVERLAP_MASK");
+    if (om) ctx->overlap_mask = atoi(om);
     const char* no = getenv("GIQL_HIP_NO_OVERLAP");
     if (!(no && atoi(no) != 0) && e == hipSuccess) {
       if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -805,18 +817,14 @@ int giql_hip_get_stats(giql_hip_ctx* ctx, giql_hip_stats* out) {
   // byte 0: join form (+ bit 5: a side was sorted in three stages, bit 6: this context fell back to
   // the four-pass sort for good); byte 1: sort tile order in force; bytes 2-3: order fallbacks so far
   out->reserved = (ctx->stats.reserved & 0x1F) | (ctx->last_sort_local ? 0x20 : 0) |
-                  (ctx->local_resorts ? 0x40 : 0) | ((ctx->os_order & 0xFF) << 8) |
+                  (ctx->local_resorts ? 0x40 : 0) | (ctx->swapped ? 0x80 : 0) | ((ctx->os_order & 0xFF) << 8) |
                   ((ctx->order_fallbacks & 0x3FFF) << 16) | (ctx->fuse_done ? (1 << 30) : 0);
   return GIQL_OK;
 }
 
 // ------------------------------------------------------------------ INNER
-static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
-                            int32_t n_chrom, void* stream, int64_t* n_pairs) {
-  if (!ctx || !n_pairs) return set_err(GIQL_ERR_INVALID, "ctx/n_pairs is NULL");
-  GIQL_TRY(check_side(a, "a"));
-  GIQL_TRY(check_side(b, "b"));
-  if (n_chrom < 0) return set_err(GIQL_ERR_INVALID, "n_chrom < 0");
+static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
+                           int32_t n_chrom, void* stream, int64_t* n_pairs) {
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   ctx->planned = false;
@@ -849,7 +857,9 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
   const size_t n_tiles_max = cdiv(n_max, RS_TILE);
   const size_t scan_max = (nq > n_tiles_max * RS_BINS ? nq : n_tiles_max * RS_BINS);
   constexpr u32 TQ2 = RC_NT * RC_ITEMS_C2;
-  S.nt1 = cdiv(nb, C1_TQ);
+  S.c1_items = ctx->c1_items ? ctx->c1_items : (nb <= ctx->c1_small_rows ? 2 : C1_ITEMS_MAX);
+  const u32 c1_tq = (u32)(C1_NT * S.c1_items);  // class-1 rows per block
+  S.nt1 = cdiv(nb, c1_tq);
   S.nt2 = cdiv(na, TQ2);
   auto carve = [&](char* base) {
     Carver c{base};
@@ -1049,15 +1059,25 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
     GIQL_TRY(run_sort(ctx, st, sa, (u32)na, tile_hist, bsums));
     GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
   }
+  // class 1 (count + the scan of its block totals) runs beside class 2 when both sides are small
+  SideChain sc1(ctx, st, onesweep ? (na < nb ? na : nb) : 0, na < nb ? nb : na, 2);
+  hipStream_t st1 = sc1.stream();
   {
     Phase ph(ctx, st, GIQL_PH_COUNT, 4);
     // class 1: queries = sorted B, points = sorted A starts, range [b.start, b.end);
     // only one total per block is kept (see k_c1_count)
-    hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt1 + 1, 256)), dim3(256), 0, st,
-                       sbb.key[0], (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, (i64)0, (u32)C1_TQ, S.nt1,
+    hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt1 + 1, 256)), dim3(256), 0, st1,
+                       sbb.key[0], (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, (i64)0, c1_tq, S.nt1,
                        S.wlo1);
-    hipLaunchKernelGGL(k_c1_count, dim3(S.nt1), dim3(C1_NT), 0, st, sbb.key[0], sbb.end[0], (u32)nb,
-                       irr_b, sa.key[0], (u32)na, irr_a, S.wlo1, S.c1_base);
+    if (S.c1_items == 2)
+      hipLaunchKernelGGL(k_c1_count<2>, dim3(S.nt1), dim3(C1_NT), 0, st1, sbb.key[0], sbb.end[0], (u32)nb,
+                         irr_b, sa.key[0], (u32)na, irr_a, S.wlo1, S.c1_base);
+    else
+      hipLaunchKernelGGL(k_c1_count<C1_ITEMS_MAX>, dim3(S.nt1), dim3(C1_NT), 0, st1, sbb.key[0], sbb.end[0], (u32)nb,
+                         irr_b, sa.key[0], (u32)na, irr_a, S.wlo1, S.c1_base);
+    // class-1 block totals -> block bases (one block, in place); total -> n_out_c1
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st1, S.c1_base, S.nt1,
+                       &ctx->d_meta->n_out_c1);
     // class 2: queries = sorted A, points = sorted B starts, range (a.start, a.end)
     hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt2 + 1, 256)), dim3(256), 0, st,
                        sa.key[0], (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, (i64)1, TQ2, S.nt2, S.wlo2);
@@ -1066,14 +1086,9 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
                        S.lo2, cnt2);
     GIQL_TRY(post_launch("range count"));
   }
-  {
-    Phase ph(ctx, st, GIQL_PH_SCAN);
-    // class-1 block totals -> block bases (one block, in place); total -> n_out_c1
-    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, S.c1_base, S.nt1,
-                       &ctx->d_meta->n_out_c1);
-  }
   GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt2, na, S.off2, bsums, S.off2 + na));
   HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out, S.off2 + na, sizeof(u64), hipMemcpyDeviceToDevice, st));
+  GIQL_TRY(sc1.join());
   GIQL_TRY(read_meta(ctx, st));
   ctx->n_c1 = ctx->h_meta->n_out_c1;
   ctx->n_reg = ctx->h_meta->n_out + ctx->n_c1;
@@ -1088,7 +1103,7 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
       ctx->spec_valid = false;  // wrong guess: plan again from the numbers just read
       ctx->spec_misses++;
       ctx->fuse_done = false;
-      return giql_hip_inner_plan_dev_impl(ctx, a, b, n_chrom, stream, n_pairs);
+      return inner_plan_core(ctx, a, b, n_chrom, stream, n_pairs);
     }
     ctx->spec_valid = true;
     ctx->spec_form = form;
@@ -1126,6 +1141,38 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
   return GIQL_OK;
 }
 
+// The plan works with "B = the larger side": the general form keeps per-row arrays (bounds, counts, 64-bit
+// offsets) for its class-2 queries, the A rows, and only block totals for class 1, the B rows, so the
+// sides' roles are not symmetric in cost (10M x 100M reads: 4.4 ms; the same tables as (100M, 10M):
+// 12.9 ms before this swap).  INTERSECTS is symmetric, so a call with the larger table first is planned
+// with the sides exchanged and everything that leaves the context (pairs, stats, the exported plan) is
+// labelled back; only the order of the pairs -- never part of the contract -- differs.
+static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
+                                        int32_t n_chrom, void* stream, int64_t* n_pairs) {
+  if (!ctx || !n_pairs) return set_err(GIQL_ERR_INVALID, "ctx/n_pairs is NULL");
+  GIQL_TRY(check_side(a, "a"));
+  GIQL_TRY(check_side(b, "b"));
+  if (n_chrom < 0) return set_err(GIQL_ERR_INVALID, "n_chrom < 0");
+  const bool swap = !ctx->no_swap && a->n > b->n;
+  ctx->swapped = swap;
+  if (!swap) return inner_plan_core(ctx, a, b, n_chrom, stream, n_pairs);
+  int32_t* t = ctx->fuse_a;
+  ctx->fuse_a = ctx->fuse_b;
+  ctx->fuse_b = t;
+  const int rc = inner_plan_core(ctx, b, a, n_chrom, stream, n_pairs);
+  // stats in the caller's labels
+  giql_hip_stats& stt = ctx->stats;
+  const int64_t tn = stt.n_a;
+  stt.n_a = stt.n_b;
+  stt.n_b = tn;
+  const int64_t ti = stt.n_irregular_a;
+  stt.n_irregular_a = stt.n_irregular_b;
+  stt.n_irregular_b = ti;
+  const int form = stt.reserved & 0xF;
+  if (form == 1 || form == 2) stt.reserved = (stt.reserved & ~0xF) | (3 - form);
+  return rc;
+}
+
 int giql_hip_inner_plan_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
                             void* stream, int64_t* n_pairs) {
   return with_order_fallback(ctx, [&] { return giql_hip_inner_plan_dev_impl(ctx, a, b, n_chrom, stream, n_pairs); });
@@ -1143,6 +1190,11 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
                    (unsigned long long)total);
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
+  if (ctx->swapped) {  // planned with the sides exchanged: the plan's "A" rows are the caller's B rows
+    int32_t* t = row_a;
+    row_a = row_b;
+    row_b = t;
+  }
   const u32 nq = ctx->n_a + ctx->n_b;
   InnerState& S = ctx->inner;
   const u32* irr_a = &ctx->d_meta->irr_a;
@@ -1175,8 +1227,12 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
   {
     Phase ph(ctx, st, GIQL_PH_FILL, 2);
     // class 1 -> outputs [0, p1): query = B row, matches = A rows
-    if (p1 > 0)
-      hipLaunchKernelGGL(k_c1_emit, dim3(S.nt1), dim3(C1_NT), 0, st, S.sb.key[0], S.sb.end[0],
+    if (p1 > 0 && S.c1_items == 2)
+      hipLaunchKernelGGL(k_c1_emit<2>, dim3(S.nt1), dim3(C1_NT), 0, st, S.sb.key[0], S.sb.end[0],
+                         S.sb.rid[0], ctx->n_b, irr_b, S.sa.key[0], S.sa.rid[0], ctx->n_a, irr_a,
+                         S.wlo1, S.c1_base, (u64)0, row_b, row_a);
+    else if (p1 > 0)
+      hipLaunchKernelGGL(k_c1_emit<C1_ITEMS_MAX>, dim3(S.nt1), dim3(C1_NT), 0, st, S.sb.key[0], S.sb.end[0],
                          S.sb.rid[0], ctx->n_b, irr_b, S.sa.key[0], S.sa.rid[0], ctx->n_a, irr_a,
                          S.wlo1, S.c1_base, (u64)0, row_b, row_a);
     // range fill -> outputs [p1, p1 + p2)
@@ -2046,8 +2102,13 @@ int giql_hip_inner_plan_export_dev(giql_hip_ctx* ctx, int32_t* q_rid_out, uint32
   if (!empty && (S.uniform == 0 || ctx->n_irr != 0 || ctx->n_c1 != 0))
     return set_err(GIQL_ERR_STATE, "the last plan is not in the compact single-range form "
                                    "(general two-class join or irregular rows): exchange the pairs instead");
-  const bool q_is_a = S.uniform != 2;
-  *query_is_a = q_is_a ? 1 : 0;
+  const bool q_is_a = S.uniform != 2;  // in the plan's labels
+  *query_is_a = (q_is_a != ctx->swapped) ? 1 : 0;
+  if (ctx->swapped) {
+    const int32_t t = rid_add_a;
+    rid_add_a = rid_add_b;
+    rid_add_b = t;
+  }
   *n_q = empty ? 0 : (q_is_a ? ctx->n_a : ctx->n_b);
   *n_s = empty ? 0 : (q_is_a ? ctx->n_b : ctx->n_a);
   if (empty) return GIQL_OK;

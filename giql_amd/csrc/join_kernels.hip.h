@@ -701,8 +701,10 @@ __global__ __launch_bounds__(RC_NT) void k_range_count(
 // pairs straight away.  Each thread owns C1_ITEMS CONSECUTIVE sorted rows (16-byte
 // loads), so after one binary search the next bound is found by galloping forward
 // from the previous one: ~2 LDS probes per bound instead of ~11.
-constexpr int C1_ITEMS = 8;
-constexpr int C1_TQ = C1_NT * C1_ITEMS;  // 2048 B rows per block
+// C1_ITEMS = 8 for sides of millions of rows (2048 B rows per block); 2 for small sides, where 8 rows
+// per thread leave two waves per SIMD and the chain search -> gather -> store of one thread is
+// what the kernel waits for.
+constexpr int C1_ITEMS_MAX = 8;
 constexpr int C1_CAP = 3072;             // staged A starts (12 KB)
 constexpr u32 C1_COOP = 16;              // matches per row above which a wave co-writes
 
@@ -728,13 +730,15 @@ __device__ __forceinline__ u32 gallop_lb(const u32* v, u32 len, u32 from, u32 x)
 
 // Bounds of C1_ITEMS consecutive sorted queries against the staged window.
 // prev = staged-relative lower bound of the previous query (0 for the first).
+template <int C1_ITEMS>
 struct C1Bounds {
   u32 lo[C1_ITEMS], cnt[C1_ITEMS];
 };
 
+template <int C1_ITEMS>
 __device__ __forceinline__ void c1_bounds(const SWindow& w, const u32 (&xs)[C1_ITEMS],
                                           const u32 (&xe)[C1_ITEMS], u32 q_first, u32 nq,
-                                          C1Bounds& out) {
+                                          C1Bounds<C1_ITEMS>& out) {
   u32 prev = 0;
 #pragma unroll
   for (int i = 0; i < C1_ITEMS; i++) {
@@ -757,19 +761,28 @@ __device__ __forceinline__ void c1_bounds(const SWindow& w, const u32 (&xs)[C1_I
   }
 }
 
+template <int C1_ITEMS>
 __device__ __forceinline__ void c1_load8(const u32* __restrict__ p, u32 q, u32 n_ok, u32 fill,
                                          u32 (&x)[C1_ITEMS]) {
+  static_assert(C1_ITEMS == 2 || C1_ITEMS % 4 == 0, "vector loads of 2 or 4 words");
   if (q + C1_ITEMS <= n_ok) {
-    const uint4 t0 = *reinterpret_cast<const uint4*>(p + q);
-    const uint4 t1 = *reinterpret_cast<const uint4*>(p + q + 4);
-    x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w;
-    x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
+    if constexpr (C1_ITEMS == 2) {
+      const uint2 t = *reinterpret_cast<const uint2*>(p + q);
+      x[0] = t.x; x[1] = t.y;
+    } else {
+#pragma unroll
+      for (int k = 0; k < C1_ITEMS / 4; k++) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p + q + 4 * k);
+        x[4 * k] = t.x; x[4 * k + 1] = t.y; x[4 * k + 2] = t.z; x[4 * k + 3] = t.w;
+      }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < C1_ITEMS; i++) x[i] = (q + i < n_ok) ? p[q + i] : fill;
   }
 }
 
+template <int C1_ITEMS>
 __global__ __launch_bounds__(C1_NT) void k_c1_count(
     const u32* __restrict__ qs, const u32* __restrict__ qe, u32 nq_total,
     const u32* __restrict__ irr_q, const u32* __restrict__ ss, u32 ns_total,
@@ -779,12 +792,12 @@ __global__ __launch_bounds__(C1_NT) void k_c1_count(
   const u32 nq = nq_total - *irr_q;
   const u32 ns = ns_total - *irr_s;
   const u32 tid = threadIdx.x;
-  const u32 q = blockIdx.x * C1_TQ + tid * C1_ITEMS;
+  const u32 q = blockIdx.x * (C1_NT * C1_ITEMS) + tid * C1_ITEMS;
   u32 xs[C1_ITEMS], xe[C1_ITEMS];
   c1_load8(qs, q, nq, U32_MAX, xs);
   c1_load8(qe, q, nq, U32_MAX, xe);
   const SWindow w = stage_window<C1_CAP, C1_NT>(ss, ns, w_lo_arr[blockIdx.x], w_lo_arr[blockIdx.x + 1], s_tile);
-  C1Bounds b;
+  C1Bounds<C1_ITEMS> b;
   c1_bounds(w, xs, xe, q, nq, b);
   u64 total = 0;
 #pragma unroll
@@ -803,6 +816,7 @@ __global__ __launch_bounds__(C1_NT) void k_c1_count(
 // block_base[] = exclusive scan of block_sum.  Output slots of a block are given
 // out thread by thread (row order), so every slot is written exactly once; rows
 // with many matches are written cooperatively by their wave (coalesced).
+template <int C1_ITEMS>
 __global__ __launch_bounds__(C1_NT) void k_c1_emit(
     const u32* __restrict__ qs, const u32* __restrict__ qe, const u32* __restrict__ q_rid,
     u32 nq_total, const u32* __restrict__ irr_q, const u32* __restrict__ ss,
@@ -814,13 +828,13 @@ __global__ __launch_bounds__(C1_NT) void k_c1_emit(
   const u32 nq = nq_total - *irr_q;
   const u32 ns = ns_total - *irr_s;
   const u32 tid = threadIdx.x;
-  const u32 q = blockIdx.x * C1_TQ + tid * C1_ITEMS;
+  const u32 q = blockIdx.x * (C1_NT * C1_ITEMS) + tid * C1_ITEMS;
   u32 xs[C1_ITEMS], xe[C1_ITEMS], rid[C1_ITEMS];
   c1_load8(qs, q, nq, U32_MAX, xs);
   c1_load8(qe, q, nq, U32_MAX, xe);
   c1_load8(q_rid, q, nq, 0u, rid);
   const SWindow w = stage_window<C1_CAP, C1_NT>(ss, ns, w_lo_arr[blockIdx.x], w_lo_arr[blockIdx.x + 1], s_tile);
-  C1Bounds b;
+  C1Bounds<C1_ITEMS> b;
   c1_bounds(w, xs, xe, q, nq, b);
   u64 mine = 0;
 #pragma unroll

@@ -119,7 +119,10 @@ typedef struct giql_hip_stats {
                                its raw columns (digit histogram in the span pass); bit 5: a side
                                was sorted in three stages (two global passes + the in-LDS
                                bucket sort); bit 6: the context fell back to the four-pass
-                               sort (a bucket too large for LDS); byte 1: sort tile order in force (2 =
+                               sort (a bucket too large for LDS); bit 7: the INNER plan ran with
+                               the sides exchanged (the larger table planned as B; pairs, stats and
+                               the exported plan are in the caller's labels all the same);
+                               byte 1: sort tile order in force (2 =
                                blockIdx order, 0 = ticket order); bits 16-29: calls
                                repeated in ticket order after a look-back timeout;
                                bit 30: the last plan launched its own fill

@@ -1072,3 +1072,46 @@ def test_fused_fill_never_writes_past_a_short_buffer():
         assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), want)
     finally:
         e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["general", "uniform"])
+def test_inner_larger_side_first_is_planned_swapped(form):
+    """A call with the larger table as A is planned with the sides exchanged (B = the larger side):
+    same pair set in the caller's labels, stats labelled back, both the plan+fill and the one-call path."""
+    import torch
+
+    from giql_amd.engine import DeviceSide, HipEngine
+
+    r = np.random.default_rng(77)
+
+    def side(n, fixed):
+        ch = r.integers(0, 5, n).astype(np.int32)
+        st = r.integers(0, 3_000_000, n).astype(np.int32)
+        ln = np.full(n, 120, np.int32) if fixed else r.integers(1, 700, n).astype(np.int32)
+        return ora.Side(ch, st, st + ln)
+
+    big = side(90_000, form == "uniform")
+    small = side(7_000, False)
+    small.end[:5] = small.start[:5]  # a few irregular rows on the small side (general form only keeps them apart)
+    if form == "uniform":
+        small = side(7_000, False)
+    want = ora.sort_pairs(*ora.c_inner(big, small, "sweep"))
+    eng = HipEngine(0)
+    da = DeviceSide.from_numpy(big.chrom, big.start, big.end)
+    db = DeviceSide.from_numpy(small.chrom, small.start, small.end)
+    for _ in range(3):  # the third call runs on the context's guesses
+        ra, rb = eng.inner_join(da, db, 5)
+        st = eng.stats()
+        assert st["swapped"] and st["n_a"] == 90_000 and st["n_b"] == 7_000
+        assert st["join_form"] == ("uniform_a" if form == "uniform" else "general")
+        assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), want)
+    out_a = torch.empty(want.shape[0] + 100, dtype=torch.int32, device="cuda")
+    out_b = torch.empty_like(out_a)
+    n = eng.inner_join_into(da, db, 5, out_a, out_b)
+    assert n == want.shape[0]
+    assert np.array_equal(ora.sort_pairs(out_a[:n].cpu().numpy(), out_b[:n].cpu().numpy()), want)
+    if form == "uniform":  # the exported plan names the caller's sides
+        q_is_a, n_q, n_s = eng.plan_sizes()
+        assert (q_is_a, n_q, n_s) == (False, 7_000, 90_000)
+    eng.close()
