@@ -119,6 +119,7 @@ struct giql_hip_ctx {
   int32_t* fuse_b = nullptr;
   u64 fuse_cap = 0;
   bool fuse_done = false;
+  bool no_keygen_general = false;  // GIQL_HIP_NO_KEYGEN_GENERAL=1: the general form always linearises both sides
   bool swapped = false;  // the last INNER plan ran with the sides exchanged (giql_hip_inner_plan_dev_impl)
   bool no_swap = false;  // GIQL_HIP_NO_SWAP=1: plan the sides as given
   bool last_no_irr = false;   // the previous plan met no irregular row
@@ -464,16 +465,24 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
         // algorithmic bytes of this pass: every array it reads + every array it writes, 4 B per row
         // (KEYGEN reads chrom + start instead of the key; a first pass synthesises the row ids)
         const int w_out = 1 + (sb.rid[0] ? 1 : 0) + (sb.end[0] ? 1 : 0);
-        const int w_in = (pass == 0 && keygen) ? 2 : 1 + ((sb.rid[0] && !first) ? 1 : 0) + (sb.end[0] ? 1 : 0);
+        const int w_in = (pass == 0 && keygen) ? 2 + (sb.end[0] ? 1 : 0)
+                                               : 1 + ((sb.rid[0] && !first) ? 1 : 0) + (sb.end[0] ? 1 : 0);
         ctx->stats.phase_bytes[GIQL_PH_SORT_SCATTER] += (int64_t)4 * (w_in + w_out) * n;
       }
       if (pass == 0 && keygen) {
         const u32 grid = cdiv(n, 1024 * 8);
         u32* claim = stat + (size_t)cdiv(n, OS_MIN_TILE) * OS_BINS;
-        hipLaunchKernelGGL((k_onesweep<1, 1024, 8, true>), dim3(grid), dim3(1024), 0, st,
-                           reinterpret_cast<const u32*>(keygen->start), reinterpret_cast<const u32*>(keygen->chrom),
-                           (const u32*)nullptr, sb.key[dst], (u32*)nullptr, sb.rid[dst], n, digit * 8, gb, stat, claim,
-                           ctx->d_meta, ctx->os_order, ctx->os_help_after, abase, (u32)keygen->start_off);
+        if (sb.end[0])  // (key, end, rid): the end keys are built from the raw end column as well
+          hipLaunchKernelGGL((k_onesweep<3, 1024, 8, true>), dim3(grid), dim3(1024), 0, st,
+                             reinterpret_cast<const u32*>(keygen->start), reinterpret_cast<const u32*>(keygen->end),
+                             reinterpret_cast<const u32*>(keygen->chrom), sb.key[dst], sb.end[dst], sb.rid[dst], n,
+                             digit * 8, gb, stat, claim, ctx->d_meta, ctx->os_order, ctx->os_help_after, abase,
+                             (u32)keygen->start_off, (u32)keygen->end_off);
+        else
+          hipLaunchKernelGGL((k_onesweep<1, 1024, 8, true>), dim3(grid), dim3(1024), 0, st,
+                             reinterpret_cast<const u32*>(keygen->start), reinterpret_cast<const u32*>(keygen->chrom),
+                             (const u32*)nullptr, sb.key[dst], (u32*)nullptr, sb.rid[dst], n, digit * 8, gb, stat, claim,
+                             ctx->d_meta, ctx->os_order, ctx->os_help_after, abase, (u32)keygen->start_off);
         continue;
       }
       switch (ctx->os_variant) {  // block-shape sweep (tools/os_variants.py); default 1024 x 8
@@ -722,6 +731,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->classic_sort = e && strcmp(e, "classic") == 0;
     const char* v = getenv("GIQL_HIP_OS_VARIANT");
     ctx->os_variant = v ? atoi(v) : 0;
+    const char* nkg = getenv("GIQL_HIP_NO_KEYGEN_GENERAL");
+    ctx->no_keygen_general = nkg && atoi(nkg) != 0;
     const char* nsw = getenv("GIQL_HIP_NO_SWAP");
     ctx->no_swap = nsw && atoi(nsw) != 0;
     const char* c1i = getenv("GIQL_HIP_C1_ITEMS");
@@ -904,10 +915,11 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   // hold, it is sorted straight from its raw columns with no linearize pass.  A context that
   // has planned before asks for it only when its last plan ended that way.
   const int big_side = nb >= na ? 1 : 0;
-  bool want_hist = onesweep && !ctx->no_uniform && !ctx->no_span_hist && ctx->os_variant == 0 &&
+  bool want_hist = onesweep && !ctx->no_span_hist && ctx->os_variant == 0 &&
                    n_chrom <= MM_HIST_CHROMS;
-  if (want_hist && ctx->spec_valid)
-    want_hist = ctx->spec_aligned && ctx->spec_form == (big_side ? 1 : 2);
+  if (want_hist && ctx->spec_valid)  // ... or in the general form without irregular rows (its larger side)
+    want_hist = ctx->spec_aligned && (ctx->spec_form == (big_side ? 1 : 2) ||
+                                      (ctx->spec_form == 0 && ctx->last_no_irr && !ctx->no_keygen_general));
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb, want_hist ? big_side : -1, big_side ? hist_b : hist_a));
   bool aligned = false;
   // Uniform-length side?  (fixed-length reads: min == max canonical length > 0 over ALL its
@@ -925,6 +937,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     const bool ua = m.len_min_a == m.len_max_a && m.len_max_a > 0;
     form = 0;
     len = 0;
+    if (ctx->no_uniform) return;  // GIQL_HIP_NO_UNIFORM: the general form whatever the lengths
     // sort the uniform side without its end; prefer the larger side when both are
     if (ub && (!ua || nb >= na)) {
       form = 1;
@@ -936,7 +949,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   };
   bool speculated = false;
   bool coarse_q = false;  // the query side was sorted without its lowest digit (a guess: no irregular rows)
-  if (onesweep && !ctx->no_uniform) {
+  if (onesweep) {
     if (ctx->spec_valid) {
       S.uniform = ctx->spec_form;
       uni_len = ctx->spec_len;
@@ -949,6 +962,12 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     }
   }
   const bool keygen = aligned && S.uniform == (big_side ? 1 : 2);
+  // General form: the larger side's (key, end, rid) sort can start from the raw columns too, as long as
+  // that side holds no irregular row (those carry the sentinel key, which depends on `end`; the span pass
+  // counted digits of start alone).  Known from the read-back on a first plan, a guess afterwards.
+  const bool keygen_g = aligned && S.uniform == 0 && !ctx->no_keygen_general &&
+                        (speculated ? ctx->last_no_irr
+                                    : (big_side ? ctx->h_meta->len_min_b : ctx->h_meta->len_min_a) > 0);
   const u32* irr_a = &ctx->d_meta->irr_a;
   const u32* irr_b = &ctx->d_meta->irr_b;
   if (S.uniform) {
@@ -1047,13 +1066,31 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   SideChain sc(ctx, st, onesweep ? (na < nb ? na : nb) : 0, na < nb ? nb : na);
   const bool a_small = na < nb;
   hipStream_t st_a = a_small ? sc.stream() : st, st_b = a_small ? st : sc.stream();
-  GIQL_TRY(run_linearize(ctx, st_a, *a, n_chrom, lb, sa.key[0], sa.end[0], ctx->irr_a_list, 0, 0,
-                         hist_a, gbase_a));
-  GIQL_TRY(run_linearize(ctx, st_b, *b, n_chrom, lb, sbb.key[0], sbb.end[0], ctx->irr_b_list, 1, 0,
-                         hist_b, gbase_b));
+  const bool kg_a = keygen_g && !big_side, kg_b = keygen_g && big_side;
+  for (int k = 0; k < 2; k++) {
+    const bool is_b = k == 1;
+    hipStream_t stk = is_b ? st_b : st_a;
+    if (is_b ? kg_b : kg_a) {
+      // the span pass counted this side's digits: fold the top ones onto the bases and scan (no linearize pass)
+      Phase ph(ctx, stk, GIQL_PH_LINEARIZE, 2);
+      u32* hist_k = is_b ? hist_b : hist_a;
+      hipLaunchKernelGGL(k_fold_top, dim3(MM_HIST_CHROMS), dim3(256), 0, stk, lb.top_partial, lb.abase, hist_k);
+      hipLaunchKernelGGL(k_digit_offsets, dim3(4), dim3(256), 0, stk, hist_k, (u32)LIN_HIST_REPLICAS,
+                         is_b ? gbase_b : gbase_a);
+      GIQL_TRY(post_launch("digit offsets (span histogram, general form)"));
+    } else if (is_b) {
+      GIQL_TRY(run_linearize(ctx, st_b, *b, n_chrom, lb, sbb.key[0], sbb.end[0], ctx->irr_b_list, 1, 0,
+                             hist_b, gbase_b));
+    } else {
+      GIQL_TRY(run_linearize(ctx, st_a, *a, n_chrom, lb, sa.key[0], sa.end[0], ctx->irr_a_list, 0, 0,
+                             hist_a, gbase_a));
+    }
+  }
   if (onesweep) {
-    GIQL_TRY(run_sort_onesweep(ctx, st_a, sa, (u32)na, gbase_a, (sc.active && a_small) ? os_status2 : os_status));
-    GIQL_TRY(run_sort_onesweep(ctx, st_b, sbb, (u32)nb, gbase_b, (sc.active && !a_small) ? os_status2 : os_status));
+    GIQL_TRY(run_sort_onesweep(ctx, st_a, sa, (u32)na, gbase_a, (sc.active && a_small) ? os_status2 : os_status,
+                               false, kg_a ? a : nullptr, lb.abase));
+    GIQL_TRY(run_sort_onesweep(ctx, st_b, sbb, (u32)nb, gbase_b, (sc.active && !a_small) ? os_status2 : os_status,
+                               false, kg_b ? b : nullptr, lb.abase));
     GIQL_TRY(sc.join());
   } else {
     GIQL_TRY(run_sort(ctx, st, sa, (u32)na, tile_hist, bsums));
@@ -1093,13 +1130,17 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   ctx->n_c1 = ctx->h_meta->n_out_c1;
   ctx->n_reg = ctx->h_meta->n_out + ctx->n_c1;
   }
-  if (onesweep && !ctx->no_uniform) {
+  if (onesweep) {
     int form;
     i64 len;
     decide(*ctx->h_meta, form, len);
     const bool aligned_now = ctx->h_meta->aligned_ok != 0;
     const bool coarse_wrong = coarse_q && ctx->h_meta->irr_a + ctx->h_meta->irr_b > 0;
-    if (speculated && (form != S.uniform || len != uni_len || (want_hist && !aligned_now) || coarse_wrong)) {
+    // a side sorted from its raw columns in the general form must hold no irregular row (its length
+    // range starts above 0); such a row was keyed as if regular, and never listed
+    const bool keygen_wrong = keygen_g && (big_side ? ctx->h_meta->len_min_b : ctx->h_meta->len_min_a) <= 0;
+    if (keygen_wrong) ctx->last_no_irr = false;
+    if (speculated && (form != S.uniform || len != uni_len || (want_hist && !aligned_now) || coarse_wrong || keygen_wrong)) {
       ctx->spec_valid = false;  // wrong guess: plan again from the numbers just read
       ctx->spec_misses++;
       ctx->fuse_done = false;
@@ -1134,7 +1175,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   collect_spans(ctx);
   // which form ran: 0 general, 1 B uniform, 2 A uniform; bit 4: the fixed-length side was sorted
   // from its raw columns (histogram in the span pass, no linearize pass)
-  ctx->stats.reserved = S.uniform | (keygen ? 0x10 : 0);
+  ctx->stats.reserved = S.uniform | ((keygen || keygen_g) ? 0x10 : 0);
   ctx->stats.n_out = (int64_t)(ctx->n_reg + ctx->n_irr);
   *n_pairs = (int64_t)(ctx->n_reg + ctx->n_irr);
   ctx->planned = true;

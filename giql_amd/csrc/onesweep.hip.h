@@ -106,17 +106,21 @@ __device__ __forceinline__ void os_store(u32* p, u32 v) { *p = v; }
 // 2 = (key, end), 3 = (key, end, rid).
 // FULL = every row of the tile is valid (all tiles but the last): no per-item
 // bounds predicates.
-// KEYGEN (first pass of the fixed-length side in the aligned form, PAYLOAD 1 only): the keys
-// are not read but built from the raw columns -- keys_in = the start column, ends_in = the
-// chrom column, key = abase[chrom] + start + start_off (u32, wrapping: exactly what the span
-// pass's histogram counted, k_chrom_minmax<true>) -- so that side has no linearize pass.
+// KEYGEN (first pass of a side in the aligned form, PAYLOAD 1 or 3): the keys are not read but
+// built from the raw columns -- keys_in = the start column, and the chrom column in ends_in
+// (PAYLOAD 1) or rids_in (PAYLOAD 3, where ends_in is the raw end column and the end keys are built
+// the same way); key = abase[chrom] + start + start_off (u32, wrapping: exactly what the span
+// pass's histogram counted, k_chrom_minmax<HIST>) -- so that side has no linearize pass.  The keys
+// do not depend on the row being regular (end > start): the caller takes this pass only on the guess
+// that every row is, and checks the guess afterwards.
 template <int PAYLOAD, int OS_NT, int OS_ITEMS, bool FULL, bool KEYGEN = false>
 __device__ __forceinline__ u32 onesweep_tile(
     const u32* __restrict__ keys_in, const u32* __restrict__ ends_in, const u32* __restrict__ rids_in,
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n_valid,
     u32 tile, u32 tile_base, int shift, const u32* __restrict__ gbase, u32* __restrict__ status,
     DevMeta* __restrict__ meta, u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff,
-    u32* s_scan, u32* s_help, u32 help_after, u32 n_total, const u32* s_abase = nullptr, u32 start_off = 0) {
+    u32* s_scan, u32* s_help, u32 help_after, u32 n_total, const u32* s_abase = nullptr, u32 start_off = 0,
+    u32 end_off = 0) {
   constexpr int OS_NW = OS_NT / WAVE;
   const u32 tid = threadIdx.x;
   const u32 lane = lane_id();
@@ -129,9 +133,11 @@ __device__ __forceinline__ u32 onesweep_tile(
   const u32 wbase = w * (OS_ITEMS * WAVE);
   const u32* kin = keys_in + tile_base;  // block-uniform bases: 32-bit lane offsets
   const u32* ein = (PAYLOAD & 2) ? ends_in + tile_base : nullptr;
-  const u32* rin = ((PAYLOAD & 1) && rids_in) ? rids_in + tile_base : nullptr;
+  // KEYGEN: the row ids are synthesised (a first pass); with the end payload the chrom column comes in
+  // through rids_in, without it through ends_in
+  const u32* rin = ((PAYLOAD & 1) && rids_in && !KEYGEN) ? rids_in + tile_base : nullptr;
+  const int* cin = KEYGEN ? reinterpret_cast<const int*>((PAYLOAD & 2) ? rids_in : ends_in) + tile_base : nullptr;
   if (KEYGEN) {
-    const int* cin = reinterpret_cast<const int*>(ends_in) + tile_base;
     u32 cc[OS_ITEMS];
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
@@ -242,7 +248,10 @@ __device__ __forceinline__ u32 onesweep_tile(
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
       const u32 r = wbase + i * WAVE + lane;
-      pay[i] = (FULL || r < n_valid) ? ein[r] : 0u;
+      if (KEYGEN)  // the end key from the raw columns (the chrom words were read a moment ago: L2)
+        pay[i] = (FULL || r < n_valid) ? s_abase[(u32)cin[r] & 31u] + ein[r] + end_off : 0u;
+      else
+        pay[i] = (FULL || r < n_valid) ? ein[r] : 0u;
     }
   } else if (PAYLOAD & 1) {
 #pragma unroll
@@ -467,7 +476,7 @@ __device__ __forceinline__ u32 os_run_tile(
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n, u32 tile,
     int shift, const u32* __restrict__ gbase, u32* __restrict__ status, DevMeta* __restrict__ meta,
     u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff, u32* s_scan, u32* s_help,
-    u32 help_after, const u32* s_abase = nullptr, u32 start_off = 0) {
+    u32 help_after, const u32* s_abase = nullptr, u32 start_off = 0, u32 end_off = 0) {
   constexpr int OS_TILE = OS_NT * OS_ITEMS;
   const u32 tile_base = tile * OS_TILE;
   const u32 n_valid = (n - tile_base) < (u32)OS_TILE ? (n - tile_base) : (u32)OS_TILE;
@@ -475,11 +484,11 @@ __device__ __forceinline__ u32 os_run_tile(
     return onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, true, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
                                                                  rids_out, n_valid, tile, tile_base, shift, gbase,
                                                                  status, meta, s_buf, s_wcnt, s_dstart, s_goff,
-                                                                 s_scan, s_help, help_after, n, s_abase, start_off);
+                                                                 s_scan, s_help, help_after, n, s_abase, start_off, end_off);
   return onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, false, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
                                                                 rids_out, n_valid, tile, tile_base, shift, gbase,
                                                                 status, meta, s_buf, s_wcnt, s_dstart, s_goff,
-                                                                s_scan, s_help, help_after, n, s_abase, start_off);
+                                                                s_scan, s_help, help_after, n, s_abase, start_off, end_off);
 }
 
 // The cold path: compute the silent predecessor `need` (recursively the earliest silent
@@ -491,7 +500,7 @@ __device__ __noinline__ void os_help_loop(
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n, u32 own,
     u32 need, int shift, const u32* __restrict__ gbase, u32* __restrict__ status,
     DevMeta* __restrict__ meta, u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff,
-    u32* s_scan, u32* s_help, u32 help_after, const u32* s_abase = nullptr, u32 start_off = 0) {
+    u32* s_scan, u32* s_help, u32 help_after, const u32* s_abase = nullptr, u32 start_off = 0, u32 end_off = 0) {
   constexpr int OS_NW = OS_NT / WAVE;
   const u32 tid = threadIdx.x;
   u32 cur = need;
@@ -504,7 +513,7 @@ __device__ __noinline__ void os_help_loop(
     const u32 r = os_run_tile<PAYLOAD, OS_NT, OS_ITEMS, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
                                                                rids_out, n, cur, shift, gbase, status, meta, s_buf,
                                                                s_wcnt, s_dstart, s_goff, s_scan, s_help, help_after,
-                                                               s_abase, start_off);
+                                                               s_abase, start_off, end_off);
     if (r == OS_NO_TILE) {
       if (cur == own) return;
       cur = own;  // the helped tile is done: start over on this block's own tile
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
     int shift, const u32* __restrict__ gbase, u32* __restrict__ status, u32* __restrict__ ticket,
     DevMeta* __restrict__ meta, int order, u32 help_after, const u32* __restrict__ abase = nullptr,
-    u32 start_off = 0) {
+    u32 start_off = 0, u32 end_off = 0) {
   constexpr int OS_TILE = OS_NT * OS_ITEMS;
   constexpr int OS_NW = OS_NT / WAVE;
   __shared__ u32 s_buf[OS_TILE];          // staging, reused for key / end / rid
@@ -565,11 +574,11 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
   const u32 need = os_run_tile<PAYLOAD, OS_NT, OS_ITEMS, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
                                                                 rids_out, n, own, shift, gbase, status, meta, s_buf,
                                                                 s_wcnt, s_dstart, s_goff, s_scan, &s_help, help_after,
-                                                                s_abase, start_off);
+                                                                s_abase, start_off, end_off);
   if (need != OS_NO_TILE)
     os_help_loop<PAYLOAD, OS_NT, OS_ITEMS, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out, rids_out, n, own,
                                                    need, shift, gbase, status, meta, s_buf, s_wcnt, s_dstart,
-                                                   s_goff, s_scan, &s_help, help_after, s_abase, start_off);
+                                                   s_goff, s_scan, &s_help, help_after, s_abase, start_off, end_off);
 }
 
 }  // namespace giql

@@ -1115,3 +1115,51 @@ def test_inner_larger_side_first_is_planned_swapped(form):
         q_is_a, n_q, n_s = eng.plan_sizes()
         assert (q_is_a, n_q, n_s) == (False, 7_000, 90_000)
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("local_sort", [False, True])
+def test_general_form_sorts_larger_side_from_raw_columns(local_sort, monkeypatch):
+    """General form (variable lengths): the larger side's (key, end, rid) sort starts from the raw columns
+    (digit histogram in the span pass, no linearize pass) while that side holds no irregular row; an
+    irregular row appearing under the same context makes the plan repeat itself the ordinary way."""
+    from giql_amd.engine import DeviceSide, HipEngine
+
+    if local_sort:
+        monkeypatch.setenv("GIQL_HIP_LOCAL_MIN_ROWS", "1")
+    r = np.random.default_rng(91)
+
+    def side(n):
+        ch = r.integers(0, 7, n).astype(np.int32)
+        st = r.integers(0, 40_000_000, n).astype(np.int32)
+        ln = r.integers(1, 5_000, n).astype(np.int32)
+        return ora.Side(ch, st, st + ln)
+
+    a, b = side(20_000), side(150_000)
+    eng = HipEngine(0)
+    da = DeviceSide.from_numpy(a.chrom, a.start, a.end)
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    for it in range(3):
+        ra, rb = eng.inner_join(da, DeviceSide.from_numpy(b.chrom, b.start, b.end), 7)
+        st = eng.stats()
+        assert st["join_form"] == "general" and st["span_hist"], (it, st)
+        assert st["sort_local"] == local_sort
+        assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), want)
+    # offsets on both columns (1-based closed input): keys and end keys built with them
+    db1 = DeviceSide.from_numpy(b.chrom, b.start + 1, b.end, encoding=("1based", "closed"))
+    ra, rb = eng.inner_join(da, db1, 7)
+    assert eng.stats()["span_hist"]
+    assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), want)
+    # irregular rows on the larger side: the guess fails, the plan is repeated with the linearize pass
+    b2 = ora.Side(b.chrom.copy(), b.start.copy(), b.end.copy())
+    b2.end[::1000] = b2.start[::1000] - 3
+    want2 = ora.sort_pairs(*ora.c_inner(a, b2, "sweep"))
+    for it in range(2):
+        ra, rb = eng.inner_join(da, DeviceSide.from_numpy(b2.chrom, b2.start, b2.end), 7)
+        st = eng.stats()
+        assert not st["span_hist"] and st["n_irregular_b"] == 150
+        assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), want2)
+    # ... and back
+    ra, rb = eng.inner_join(da, DeviceSide.from_numpy(b.chrom, b.start, b.end), 7)
+    assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), want)
+    eng.close()
