@@ -86,6 +86,11 @@ struct InnerState {
   int c1_items = C1_ITEMS_MAX;  // class-1 rows per thread of this plan (k_c1_count / k_c1_emit)
   u32* wlo1 = nullptr;   // class-1 S-window starts per block
   u64* c1_base = nullptr;  // class-1 output base per block
+  // small B sides: class 1 takes the same count -> scan -> merge-path fill as class 2 (per-row arrays are
+  // cheap there, and the fill stays coalesced when rows have many matches; k_c1_emit does not)
+  bool c1_fill = false;
+  u32 *lo1 = nullptr, *cnt1 = nullptr;
+  u64* off1 = nullptr;
   u32* wlo2 = nullptr;
   u32* lo2 = nullptr;    // class-2 first matching B index per A row
   u32* cnt2 = nullptr;   // ... and the number of matches (kept for giql_hip_inner_plan_export_dev)
@@ -119,6 +124,7 @@ struct giql_hip_ctx {
   int32_t* fuse_b = nullptr;
   u64 fuse_cap = 0;
   bool fuse_done = false;
+  bool no_c1_fill = false;  // GIQL_HIP_NO_C1_FILL=1: class 1 always through k_c1_count / k_c1_emit
   bool no_keygen_general = false;  // GIQL_HIP_NO_KEYGEN_GENERAL=1: the general form always linearises both sides
   bool swapped = false;  // the last INNER plan ran with the sides exchanged (giql_hip_inner_plan_dev_impl)
   bool no_swap = false;  // GIQL_HIP_NO_SWAP=1: plan the sides as given
@@ -731,6 +737,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->classic_sort = e && strcmp(e, "classic") == 0;
     const char* v = getenv("GIQL_HIP_OS_VARIANT");
     ctx->os_variant = v ? atoi(v) : 0;
+    const char* nc1 = getenv("GIQL_HIP_NO_C1_FILL");
+    ctx->no_c1_fill = nc1 && atoi(nc1) != 0;
     const char* nkg = getenv("GIQL_HIP_NO_KEYGEN_GENERAL");
     ctx->no_keygen_general = nkg && atoi(nkg) != 0;
     const char* nsw = getenv("GIQL_HIP_NO_SWAP");
@@ -862,7 +870,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   u32 *tile_hist = nullptr, *cnt2 = nullptr, *irr_cnt = nullptr;
   u32 *hist_a = nullptr, *hist_b = nullptr, *gbase_a = nullptr, *gbase_b = nullptr;
   u32 *os_status = nullptr, *os_status2 = nullptr;
-  u64* bsums = nullptr;
+  u64 *bsums = nullptr, *bsums1 = nullptr;
   const bool onesweep = !ctx->classic_sort && na <= OS_MAX_ROWS && nb <= OS_MAX_ROWS;
   const size_t n_max = na > nb ? na : nb;
   const size_t n_tiles_max = cdiv(n_max, RS_TILE);
@@ -871,6 +879,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   S.c1_items = ctx->c1_items ? ctx->c1_items : (nb <= ctx->c1_small_rows ? 2 : C1_ITEMS_MAX);
   const u32 c1_tq = (u32)(C1_NT * S.c1_items);  // class-1 rows per block
   S.nt1 = cdiv(nb, c1_tq);
+  S.c1_fill = !ctx->no_c1_fill && nb <= ctx->c1_small_rows;
   S.nt2 = cdiv(na, TQ2);
   auto carve = [&](char* base) {
     Carver c{base};
@@ -890,8 +899,13 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
       tile_hist = c.take<u32>(n_tiles_max * RS_BINS);
     }
     bsums = c.take<u64>(cdiv(scan_max, SCAN_TILE) + 2);
-    S.wlo1 = c.take<u32>((size_t)S.nt1 + 2);
+    S.wlo1 = c.take<u32>((size_t)S.nt1 + 2 + (S.c1_fill ? cdiv(nb, TQ2) : 0));
     S.c1_base = c.take<u64>((size_t)S.nt1 + 2);
+    const size_t n1 = S.c1_fill ? nb : 0;
+    S.lo1 = c.take<u32>(n1);
+    S.cnt1 = c.take<u32>(n1);
+    S.off1 = c.take<u64>(n1 + 1);
+    bsums1 = c.take<u64>(cdiv(n1 ? n1 : 1, SCAN_TILE) + 2);
     const size_t nq2 = ctx->no_uniform ? na : n_max;  // the uniform form may query the other side
     S.wlo2 = c.take<u32>((size_t)cdiv(nq2, TQ2) + 2);
     cnt2 = c.take<u32>(nq2);
@@ -1103,6 +1117,14 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     Phase ph(ctx, st, GIQL_PH_COUNT, 4);
     // class 1: queries = sorted B, points = sorted A starts, range [b.start, b.end);
     // only one total per block is kept (see k_c1_count)
+    if (S.c1_fill) {
+      const u32 nt1r = cdiv(nb, TQ2);
+      hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)nt1r + 1, 256)), dim3(256), 0, st1,
+                         sbb.key[0], (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, (i64)0, TQ2, nt1r, S.wlo1);
+      hipLaunchKernelGGL((k_range_count<RC_ITEMS_C2, RC_LDS_CAP>), dim3(nt1r), dim3(RC_NT), 0, st1,
+                         sbb.key[0], sbb.end[0], (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, (i64)0, S.wlo1,
+                         S.lo1, S.cnt1);
+    } else {
     hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt1 + 1, 256)), dim3(256), 0, st1,
                        sbb.key[0], (u32)nb, irr_b, sa.key[0], (u32)na, irr_a, (i64)0, c1_tq, S.nt1,
                        S.wlo1);
@@ -1115,6 +1137,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     // class-1 block totals -> block bases (one block, in place); total -> n_out_c1
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st1, S.c1_base, S.nt1,
                        &ctx->d_meta->n_out_c1);
+    }
     // class 2: queries = sorted A, points = sorted B starts, range (a.start, a.end)
     hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt2 + 1, 256)), dim3(256), 0, st,
                        sa.key[0], (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, (i64)1, TQ2, S.nt2, S.wlo2);
@@ -1122,6 +1145,10 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
                        sa.key[0], sa.end[0], (u32)na, irr_a, sbb.key[0], (u32)nb, irr_b, (i64)1, S.wlo2,
                        S.lo2, cnt2);
     GIQL_TRY(post_launch("range count"));
+  }
+  if (S.c1_fill) {
+    GIQL_TRY(run_scan<u64>(ctx, st1, GIQL_PH_SCAN, S.cnt1, nb, S.off1, bsums1, S.off1 + nb));
+    HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out_c1, S.off1 + nb, sizeof(u64), hipMemcpyDeviceToDevice, st1));
   }
   GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt2, na, S.off2, bsums, S.off2 + na));
   HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out, S.off2 + na, sizeof(u64), hipMemcpyDeviceToDevice, st));
@@ -1245,13 +1272,15 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
   // or B rows (A uniform)
   const bool q_is_a = S.uniform != 2;
   const u32 nq2 = q_is_a ? ctx->n_a : ctx->n_b;
-  u32 nt2 = 0;
-  if (p2 > 0) {
+  u32 nt2 = 0, nt1f = 0;
+  const bool c1_fill = S.uniform == 0 && S.c1_fill && p1 > 0;
+  if (p2 > 0 || c1_fill) {
     constexpr u32 T2 = FILL_NT * FILL_ITEMS_C2;
-    const u64 nt2_64 = (p2 + T2 - 1) / T2;
-    if (nt2_64 > 0x7FFFFFF0ull) return set_err(GIQL_ERR_INVALID, "output too large");
+    const u64 nt2_64 = (p2 + T2 - 1) / T2, nt1_64 = c1_fill ? (p1 + T2 - 1) / T2 : 0;
+    if (nt2_64 + nt1_64 > 0x7FFFFFF0ull) return set_err(GIQL_ERR_INVALID, "output too large");
     nt2 = (u32)nt2_64;
-    const size_t part_need = (size_t)nt2 + 2;
+    nt1f = (u32)nt1_64;
+    const size_t part_need = (size_t)nt2 + 2 + (c1_fill ? (size_t)nt1f + 2 : 0);
     if (part_need > ctx->part_cap) {
       HIP_TRY(hipStreamSynchronize(st));
       if (ctx->part) HIP_TRY(hipFree(ctx->part));
@@ -1262,13 +1291,20 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
       ctx->part_cap = want;
     }
     Phase ph(ctx, st, GIQL_PH_PARTITION);
-    hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt2 + 1, 256)), dim3(256), 0, st, S.off2, nq2,
-                       (u64)0, T2, nt2, ctx->part);
+    if (p2 > 0)
+      hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt2 + 1, 256)), dim3(256), 0, st, S.off2, nq2,
+                         (u64)0, T2, nt2, ctx->part);
+    if (c1_fill)  // class 1's tiles behind class 2's in the partition array
+      hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt1f + 1, 256)), dim3(256), 0, st, S.off1, ctx->n_b,
+                         (u64)0, T2, nt1f, ctx->part + nt2 + 2);
   }
   {
     Phase ph(ctx, st, GIQL_PH_FILL, 2);
     // class 1 -> outputs [0, p1): query = B row, matches = A rows
-    if (p1 > 0 && S.c1_items == 2)
+    if (c1_fill)
+      hipLaunchKernelGGL((k_fill<FILL_ITEMS_C2>), dim3(nt1f), dim3(FILL_NT), 0, st, S.off1, S.lo1, S.sb.rid[0],
+                         ctx->n_b, S.sa.rid[0], ctx->part + nt2 + 2, (u64)0, p1, row_b, row_a);
+    else if (p1 > 0 && S.c1_items == 2)
       hipLaunchKernelGGL(k_c1_emit<2>, dim3(S.nt1), dim3(C1_NT), 0, st, S.sb.key[0], S.sb.end[0],
                          S.sb.rid[0], ctx->n_b, irr_b, S.sa.key[0], S.sa.rid[0], ctx->n_a, irr_a,
                          S.wlo1, S.c1_base, (u64)0, row_b, row_a);
