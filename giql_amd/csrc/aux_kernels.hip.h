@@ -339,93 +339,240 @@ __device__ __forceinline__ u32 gallop_back_upper_u32(const u32* __restrict__ v, 
   return lo;
 }
 
+// ---- searches through an accessor (an array served partly from LDS) -----------------
+template <typename F>
+__device__ __forceinline__ u32 lower_bound_f(F f, u32 lo, u32 hi, u32 x) {  // first idx with f(idx) >= x
+  while (lo < hi) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (f(mid) < x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+template <typename F>
+__device__ __forceinline__ u32 upper_bound_f(F f, u32 lo, u32 hi, u32 x) {  // first idx with f(idx) > x
+  while (lo < hi) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (f(mid) <= x)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+// gallop_back_lower_u32 / gallop_back_upper_u32 over an accessor
+template <typename F>
+__device__ __forceinline__ u32 gallop_back_lower_f(F f, u32 lo, u32 hi, u32 x) {
+  u32 step = 1, right = hi;  // invariant: f(right..hi) >= x
+  while (right > lo) {
+    const u32 probe = right - lo > step ? right - step : lo;
+    if (f(probe) >= x) {
+      right = probe;
+      step <<= 1;
+    } else {
+      return lower_bound_f(f, probe + 1, right, x);
+    }
+  }
+  return lo;
+}
+template <typename F>
+__device__ __forceinline__ u32 gallop_back_upper_f(F f, u32 lo, u32 hi, u32 x) {
+  u32 step = 1, right = hi;  // invariant: f(right..hi) > x
+  while (right > lo) {
+    const u32 probe = right - lo > step ? right - step : lo;
+    if (f(probe) > x) {
+      right = probe;
+      step <<= 1;
+    } else {
+      return upper_bound_f(f, probe + 1, right, x);
+    }
+  }
+  return lo;
+}
+
 // B sorted by (linearised start, end); b_pmax = inclusive prefix max of ends.
 // A rows come sorted by start; results are scattered back by row id.
 // Distance CASE of _distance.py:67-87; order ABS(d), start, end (nearest.py:392).
 //
-// The A rows of a wave are neighbours on the linear axis, so the wave first brackets
-// all of its lower_bound(b_keys, a.end) results with two cooperative 64-ary searches
-// (min and max a.end of the wave; the keys are globally sorted, chromosome after
-// chromosome) and each lane then searches inside that bracket only; the prefix-max
-// lookups gallop backwards from the result.
-__global__ __launch_bounds__(256) void k_nearest(
+// The 1024 A rows of a block are neighbours on the linear axis, so the block first brackets
+// all of its lower_bound(b_keys, a.end) results with two cooperative 64-ary searches (min and
+// max a.end of the block; the keys are globally sorted, chromosome after chromosome) and stages
+// that bracket of b_keys / b_pmax -- plus NR_BACK rows below it, where the upstream lookups
+// gallop to -- in LDS.  Every row then searches inside the bracket, in LDS: a row's ~25 dependent
+// loads are LDS loads (~0.1 us each) instead of L2 hits (~0.5 us), which is what bounded the kernel
+// (10M x 10M: 0.36 ms of searching with one wave-level bracket and global loads).  An index outside
+// the staged window (a bracket wider than the stage, a gallop past its lower edge) is read from
+// global memory by the same accessor.
+constexpr int NR_NT = 256;
+#ifndef GIQL_NR_ITEMS
+#define GIQL_NR_ITEMS 4
+#endif
+constexpr int NR_ITEMS = GIQL_NR_ITEMS;
+constexpr int NR_CHROMS = 511;           // chromosome tables staged in LDS up to this many chromosomes
+constexpr int NR_TQ = NR_NT * NR_ITEMS;  // A rows per block
+constexpr int NR_CAP = 4096;             // staged B rows (keys + prefix max: 32 KB)
+constexpr u32 NR_BACK = 128;             // rows staged below the bracket
+
+__global__ __launch_bounds__(NR_NT) void k_nearest(
     const u32* __restrict__ a_keys, const u32* __restrict__ a_ends, const u32* __restrict__ a_rids,
     u32 n_a, int n_chrom, const u32* __restrict__ chrom_first, const u32* __restrict__ chrom_lo,
     const u32* __restrict__ b_keys, const u32* __restrict__ b_pmax, const u32* __restrict__ b_rids,
     u32 n_b, int is_signed, i64 max_distance, NearestRec* __restrict__ rec_out,
     DevMeta* __restrict__ meta) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n_a;
+  __shared__ u32 s_keys[NR_CAP], s_pmax[NR_CAP];
+  __shared__ u32 s_min[NR_NT / WAVE], s_max[NR_NT / WAVE];
+  __shared__ u32 s_w[2];
+  __shared__ u32 s_cfirst[NR_CHROMS + 1], s_clo[NR_CHROMS + 1];
+  const u32 tid = threadIdx.x;
+  const u32 base = blockIdx.x * NR_TQ;
   const u32 sentinel = meta->sentinel;
-  const u32 qs = live ? a_keys[i] : 0u, qe = live ? a_ends[i] : 0u, r = live ? a_rids[i] : 0u;
-  const bool searchable = live && n_b > 0 && qs < sentinel;
-  // wave bracket of lower_bound(b_keys, qe) over the searchable lanes
-  u32 w_lo = 0, w_hi = n_b;
-  if (__ballot(searchable) != 0ull && n_b > 0) {
-    u32 emin = searchable ? qe : U32_MAX, emax = searchable ? qe : 0u;
+  const bool lds_chroms = n_chrom <= NR_CHROMS;
+  if (lds_chroms)
+    for (u32 k = tid; k <= (u32)n_chrom; k += NR_NT) {
+      s_cfirst[k] = chrom_first[k];
+      s_clo[k] = chrom_lo[k];
+    }
+  u32 qs[NR_ITEMS], qe[NR_ITEMS], rr[NR_ITEMS];
+  bool srch[NR_ITEMS];
+  u32 emin = U32_MAX, emax = 0u;
 #pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) {
-      const u32 tmin = (u32)__shfl_xor((int)emin, d, WAVE), tmax = (u32)__shfl_xor((int)emax, d, WAVE);
-      emin = tmin < emin ? tmin : emin;
-      emax = tmax > emax ? tmax : emax;
-    }
-    w_lo = wave_lower_bound_u32(b_keys, 0, n_b, emin);
-    w_hi = wave_lower_bound_u32(b_keys, w_lo, n_b, emax);
-  }
-  if (!live) return;
-  int32_t best = -1;
-  i64 best_d = 0;
-  if (searchable) {
-    // inverted row: NEAREST needs start <= end (never masks an earlier error, e.g. a
-    // span overflow that made these keys meaningless)
-    if (qe < qs && meta->status == 0) meta->status = -1;
-    // chromosome of the row = last c with chrom_first[c] <= key
-    const u32 c = upper_bound_u32(chrom_first, 0, (u32)n_chrom + 1, qs) - 1;
-    const u32 blo = chrom_lo[c];
-    const u32 bhi = chrom_lo[c + 1];
-    if (bhi > blo) {
-      // global lower bound inside the wave's bracket, clamped to the chromosome
-      u32 hi = lower_bound_u32(b_keys, w_lo, w_hi, qe);
-      hi = hi < blo ? blo : (hi > bhi ? bhi : hi);
-      u32 j = U32_MAX;
-      if (hi > blo && b_pmax[hi - 1] > qs) {
-        // overlap: first row in (start,end) order whose end exceeds a.start
-        j = gallop_back_upper_u32(b_pmax, blo, hi, qs);
-        best_d = 0;
-      } else {
-        i64 up_d = 0, dn_d = 0;
-        u32 up = U32_MAX, dn = U32_MAX;
-        if (hi > blo) {
-          const u32 m = b_pmax[hi - 1];  // nearest upstream end (<= a.start)
-          up = gallop_back_lower_u32(b_pmax, blo, hi, m);
-          up_d = (i64)qs - (i64)m + 1;
-        }
-        if (hi < bhi) {
-          dn = hi;
-          dn_d = (i64)b_keys[hi] - (i64)qe + 1;
-        }
-        if (up != U32_MAX && (dn == U32_MAX || up_d <= dn_d)) {
-          j = up;
-          best_d = is_signed ? -up_d : up_d;
-        } else if (dn != U32_MAX) {
-          j = dn;
-          best_d = dn_d;
-        }
-      }
-      if (j != U32_MAX) {
-        const i64 ad = best_d < 0 ? -best_d : best_d;
-        if (max_distance < 0 || ad <= max_distance) best = (int32_t)b_rids[j];
-      }
+  for (int u = 0; u < NR_ITEMS; u++) {
+    const u32 i = base + u * NR_NT + tid;
+    const bool live = i < n_a;
+    qs[u] = live ? a_keys[i] : 0u;
+    qe[u] = live ? a_ends[i] : 0u;
+    rr[u] = live ? a_rids[i] : 0u;
+    srch[u] = live && n_b > 0 && qs[u] < sentinel;
+    if (srch[u]) {
+      emin = qe[u] < emin ? qe[u] : emin;
+      emax = qe[u] > emax ? qe[u] : emax;
     }
   }
-  // ONE 16-byte scattered store per row (a partial-line write costs about the same
-  // whatever its width); k_nearest_unpack then streams the records into the two
-  // output arrays.  Two scattered stores (4 B + 8 B) took 0.39 of the kernel's 0.77 ms.
-  NearestRec rec;
-  rec.dist = best < 0 ? 0 : best_d;
-  rec.idx = best;
-  rec.pad = 0;
-  rec_out[r] = rec;
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) {
+    const u32 tmin = (u32)__shfl_xor((int)emin, d, WAVE), tmax = (u32)__shfl_xor((int)emax, d, WAVE);
+    emin = tmin < emin ? tmin : emin;
+    emax = tmax > emax ? tmax : emax;
+  }
+  if (lane_id() == 0) {
+    s_min[wave_id()] = emin;
+    s_max[wave_id()] = emax;
+  }
+  __syncthreads();
+  if (wave_id() == 0) {  // the block's bracket of lower_bound(b_keys, a.end)
+    u32 bmin = U32_MAX, bmax = 0u;
+#pragma unroll
+    for (int k = 0; k < NR_NT / WAVE; k++) {
+      bmin = s_min[k] < bmin ? s_min[k] : bmin;
+      bmax = s_max[k] > bmax ? s_max[k] : bmax;
+    }
+    u32 lo = 0, hi = n_b;
+    if (bmin <= bmax && n_b > 0) {  // some row of the block searches
+      lo = wave_lower_bound_u32(b_keys, 0, n_b, bmin);
+      hi = wave_lower_bound_u32(b_keys, lo, n_b, bmax);
+    }
+    if (lane_id() == 0) {
+      s_w[0] = lo;
+      s_w[1] = hi;
+    }
+  }
+  __syncthreads();
+  const u32 w_lo = s_w[0], w_hi = s_w[1];
+  const u32 w0 = w_lo > NR_BACK ? w_lo - NR_BACK : 0u;
+  u32 w1 = w_hi < n_b ? w_hi + 1u : n_b;  // one row above: the nearest downstream row of the last lookups
+  if (w1 - w0 > (u32)NR_CAP) w1 = w0;     // a bracket wider than the stage: everything from global memory
+  for (u32 k = tid; k < w1 - w0; k += NR_NT) {
+    s_keys[k] = b_keys[w0 + k];
+    s_pmax[k] = b_pmax[w0 + k];
+  }
+  __syncthreads();
+  const u32 wn = w1 - w0;
+  auto key_at = [&](u32 j) -> u32 { return (j - w0 < wn) ? s_keys[j - w0] : b_keys[j]; };
+  auto pmax_at = [&](u32 j) -> u32 { return (j - w0 < wn) ? s_pmax[j - w0] : b_pmax[j]; };
+  u32 jv[NR_ITEMS];   // matched sorted-B index per row (U32_MAX: none)
+  i64 dv[NR_ITEMS];
+#pragma unroll
+  for (int u = 0; u < NR_ITEMS; u++) {
+    jv[u] = U32_MAX;
+    dv[u] = 0;
+    i64 best_d = 0;
+#if defined(GIQL_NEAREST_ABLATE) && GIQL_NEAREST_ABLATE == 2  // timing-only build: no search
+    if (srch[u] && qs[u] == 0x12345u) {
+#else
+    if (srch[u]) {
+#endif
+      const u32 s = qs[u], e = qe[u];
+      // inverted row: NEAREST needs start <= end (never masks an earlier error, e.g. a
+      // span overflow that made these keys meaningless)
+      if (e < s && meta->status == 0) meta->status = -1;
+      // chromosome of the row = last c with chrom_first[c] <= key
+      const u32 c = upper_bound_u32(lds_chroms ? s_cfirst : chrom_first, 0, (u32)n_chrom + 1, s) - 1;
+      const u32 blo = lds_chroms ? s_clo[c] : chrom_lo[c];
+      const u32 bhi = lds_chroms ? s_clo[c + 1] : chrom_lo[c + 1];
+      if (bhi > blo) {
+        // global lower bound inside the block's bracket, clamped to the chromosome
+        u32 hi = lower_bound_f(key_at, w_lo, w_hi, e);
+        hi = hi < blo ? blo : (hi > bhi ? bhi : hi);
+        u32 j = U32_MAX;
+        const u32 m = hi > blo ? pmax_at(hi - 1) : 0u;  // largest end among the rows starting below a.end
+        if (hi > blo && m > s) {
+          // overlap: first row in (start,end) order whose end exceeds a.start
+          j = gallop_back_upper_f(pmax_at, blo, hi, s);
+          best_d = 0;
+        } else {
+          i64 up_d = 0, dn_d = 0;
+          u32 up = U32_MAX, dn = U32_MAX;
+          if (hi > blo) {  // m = the nearest upstream end (<= a.start)
+            up = gallop_back_lower_f(pmax_at, blo, hi, m);
+            up_d = (i64)s - (i64)m + 1;
+          }
+          if (hi < bhi) {
+            dn = hi;
+            dn_d = (i64)key_at(hi) - (i64)e + 1;
+          }
+          if (up != U32_MAX && (dn == U32_MAX || up_d <= dn_d)) {
+            j = up;
+            best_d = is_signed ? -up_d : up_d;
+          } else if (dn != U32_MAX) {
+            j = dn;
+            best_d = dn_d;
+          }
+        }
+        if (j != U32_MAX) {
+          const i64 ad = best_d < 0 ? -best_d : best_d;
+          if (max_distance < 0 || ad <= max_distance) {
+            jv[u] = j;
+            dv[u] = best_d;
+          }
+        }
+      }
+    }
+  }
+  // the row ids of the matches: NR_ITEMS independent gathers in flight, not one at the end of every search
+  int32_t bv[NR_ITEMS];
+#pragma unroll
+  for (int u = 0; u < NR_ITEMS; u++) bv[u] = jv[u] != U32_MAX ? (int32_t)b_rids[jv[u]] : -1;
+#pragma unroll
+  for (int u = 0; u < NR_ITEMS; u++) {
+    const u32 i = base + u * NR_NT + tid;
+    if (i >= n_a) continue;
+    const int32_t best = bv[u];
+    const i64 best_d = dv[u];
+    // ONE 16-byte scattered store per row (a partial-line write costs about the same
+    // whatever its width); k_nearest_unpack then streams the records into the two
+    // output arrays.  Two scattered stores (4 B + 8 B) took 0.39 of the kernel's 0.77 ms.
+    NearestRec rec;
+    rec.dist = best < 0 ? 0 : best_d;
+    rec.idx = best;
+    rec.pad = 0;
+#if defined(GIQL_NEAREST_ABLATE) && GIQL_NEAREST_ABLATE == 1  // timing-only build: records in sorted order, no scatter
+    rec_out[i] = rec;
+#else
+    rec_out[rr[u]] = rec;
+#endif
+  }
 }
 
 __global__ __launch_bounds__(256) void k_nearest_unpack(const NearestRec* __restrict__ rec, u32 n,

@@ -1677,7 +1677,7 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
     Phase ph(ctx, st, GIQL_PH_COUNT, 3);
     hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st,
                        lb.chrom_first, n_chrom, sbb.key[0], (u32)nb, chrom_lo);
-    hipLaunchKernelGGL(k_nearest, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0], sa.rid[0],
+    hipLaunchKernelGGL(k_nearest, dim3(cdiv(na, NR_TQ)), dim3(NR_NT), 0, st, sa.key[0], sa.end[0], sa.rid[0],
                        (u32)na, n_chrom, lb.chrom_first, chrom_lo, sbb.key[0], pmax, sbb.rid[0], (u32)nb,
                        is_signed, (i64)max_distance, recs, ctx->d_meta);
     hipLaunchKernelGGL(k_nearest_unpack, dim3(cdiv(na, 256)), dim3(256), 0, st, recs, (u32)na, idx_b_out,
