@@ -150,6 +150,7 @@ struct giql_hip_ctx {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   u64 overlap_max_rows = 4u << 20;
+  bool overlap_large = true;  // GIQL_HIP_OVERLAP_LARGE=0: the small side's chain runs beside the other side's only when that is small too
   int overlap_mask = 3;  // GIQL_HIP_OVERLAP_MASK: 1 = the sides' sort chains, 2 = the two count classes
   bool no_skip_digit = false;  // GIQL_HIP_NO_SKIP_DIGIT=1: query sides are sorted on every digit
   bool local_sort = true;
@@ -625,11 +626,13 @@ struct SideChain {
   giql_hip_ctx* ctx;
   hipStream_t main;
   bool active = false, joined = false;
-  // n_small / n_large: rows of the side given to the second stream / of the side that stays.  BOTH must
-  // be small: beside a sort of many tiles the look-back chains of the two kernels delay each other
-  // (measured: SEMI 1M x 10M 0.38 -> 0.50 ms with the 1M side beside the 10M one; 1M x 1M 0.38 -> 0.34).
+  // n_small / n_large: rows of the side given to the second stream / of the side that stays.  The small
+  // side must be small (<= overlap_max_rows): its chain is then latency-bound and costs the other side's
+  // kernels little (SEMI 1M x 10M: 0.378 -> 0.349 ms; 1M x 1M: 0.387 -> 0.351 ms).
   SideChain(giql_hip_ctx* c, hipStream_t m, size_t n_small, size_t n_large, int which = 1) : ctx(c), main(m) {
-    if (!c->side_stream || !(c->overlap_mask & which) || n_small == 0 || n_small > c->overlap_max_rows || n_large > c->overlap_max_rows) return;
+    if (!c->side_stream || !(c->overlap_mask & which) || n_small == 0 || n_small > c->overlap_max_rows ||
+        (n_large > c->overlap_max_rows && !c->overlap_large))
+      return;
     if (sort_is_local(c, n_small)) return;  // the bucket sort's boundary / queue buffers are one per context
     if (hipEventRecord(c->ev_fork, m) != hipSuccess) return;
     if (hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) return;
@@ -776,6 +779,10 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     if (om) ctx->overlap_mask = atoi(om);
     const char* no = getenv("GIQL_HIP_NO_OVERLAP");
     if (!(no && atoi(no) != 0) && e == hipSuccess) {
+      const char* omr = getenv("GIQL_HIP_OVERLAP_MAX_ROWS");
+      if (omr && atoll(omr) > 0) ctx->overlap_max_rows = (u64)atoll(omr);
+      const char* ol = getenv("GIQL_HIP_OVERLAP_LARGE");
+      if (ol) ctx->overlap_large = atoi(ol) != 0;
       if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
           hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess)
