@@ -13,7 +13,10 @@ from oracle import pyoracle as ora
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
-eng = HipEngine(0)
+eng_default = HipEngine(0)
+os.environ["GIQL_HIP_LOCAL_MIN_ROWS"] = "1"   # a second context that takes the three-stage sort at every size
+eng_local = HipEngine(0)
+del os.environ["GIQL_HIP_LOCAL_MIN_ROWS"]
 ENC = list(ora.ENCODING_OFFSETS.values())
 
 
@@ -49,6 +52,7 @@ while time.time() - t0 < budget:
     a = side(na, nch, span, fixed_a, rng.random() < 0.25)
     b = side(nb, nch, span, fixed_b, rng.random() < 0.15)
     da, db = dev(a), dev(b)
+    eng = eng_local if rng.random() < 0.3 else eng_default
     try:
         ra, rb = eng.inner_join(da, db, nch)
     except Exception as exc:
@@ -60,6 +64,22 @@ while time.time() - t0 < budget:
     small = na * nb <= 4_000_000_000
     want = ora.sort_pairs(*ora.c_inner(a, b, "brute" if small and (na * nb < 3e8) else "sweep"))
     assert np.array_equal(got, want), ("inner", it, nch, na, nb, span, fixed_a, fixed_b)
+    forms[("swapped", st["swapped"])] = forms.get(("swapped", st["swapped"]), 0) + 1
+    # the one-call form into caller-owned buffers (the fill launched inside the plan when the guesses hold)
+    cap = want.shape[0] + int(rng.integers(0, 3)) * 1000
+    oa = torch.empty(cap, dtype=torch.int32, device="cuda:0")
+    ob = torch.empty(cap, dtype=torch.int32, device="cuda:0")
+    n = eng.inner_join_into(da, db, nch, oa, ob)
+    assert n == want.shape[0] and np.array_equal(ora.sort_pairs(oa[:n].cpu().numpy(), ob[:n].cpu().numpy()), want), ("into", it)
+    # NEAREST k = 1 (rows with start <= end only: the operator rejects inverted rows)
+    if not (np.any(a.end + a.end_off < a.start + a.start_off) or np.any(b.end + b.end_off < b.start + b.start_off)):
+        signed = bool(rng.random() < 0.5)
+        gi, gd = eng.nearest(da, db, nch, signed=signed)
+        wi, wd = ora.c_nearest_k1(a, b, signed=signed)
+        gi, gd = gi.cpu().numpy(), gd.cpu().numpy()
+        assert np.array_equal(gd, wd) and np.array_equal(gi >= 0, wi >= 0), ("nearest", it, nch, na, nb, span)
+        hit = gi >= 0
+        assert np.array_equal(b.start[gi[hit]], b.start[wi[hit]]) and np.array_equal(b.end[gi[hit]], b.end[wi[hit]]), ("nearest rows", it)
     assert np.array_equal(eng.semi_join(da, db, nch).cpu().numpy(), ora.c_semi_anti(a, b, False)), ("semi", it)
     assert np.array_equal(eng.anti_join(da, db, nch).cpu().numpy(), ora.c_semi_anti(a, b, True)), ("anti", it)
     assert np.array_equal(eng.count_overlaps(da, db, nch).cpu().numpy(),
@@ -67,5 +87,10 @@ while time.time() - t0 < budget:
     it += 1
     if it % 10 == 0:
         print(json.dumps({"iterations": it, "elapsed_s": round(time.time() - t0, 1)}), flush=True)
-print(json.dumps({"ok": True, "iterations": it, "seed": seed, "forms": {f"{k[0]}/{'span_hist' if k[1] else 'linearize'}": v
-                                                                      for k, v in forms.items()}}))
+def label(k):
+    if k[0] == "swapped":
+        return "sides exchanged" if k[1] else "sides as given"
+    return f"{k[0]}/{'span_hist' if k[1] else 'linearize'}"
+
+
+print(json.dumps({"ok": True, "iterations": it, "seed": seed, "forms": {label(k): v for k, v in forms.items()}}))
