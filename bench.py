@@ -763,22 +763,86 @@ def inner_extras(eng, dev_index, a, b, ha, hb, n_chrom, n_pairs, alloc_out, join
 def run_rowop(args):
     import numpy as np
     import torch
+    import torch.distributed as dist
 
+    from giql_amd import shard, synth
     from giql_amd.engine import DeviceSide, HipEngine
 
     wl = args.workload
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1:
-        raise SystemExit("the SEMI / ANTI / COUNT / NEAREST workloads run on one GPU in bench.py")
+    op, (n_a, kind_a, seed_a), (n_b, kind_b, seed_b), genome = WORKLOADS[wl]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and genome != HG38:
+        raise SystemExit("the single-chromosome workloads run on one GPU")
+    distributed = world > 1
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the exchange happens
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    # ---- shard: the A rows' chromosomes -> ranks (LPT on rows of both sides); every A row needs exactly the
+    # B rows of its chromosome, so a rank holds both sides of its chromosomes and there is no data-path collective
+    rank_chroms = None
+    my_chroms = None
+    if distributed:
+        rows = synth.rows_per_chrom(n_a, seed_a) + synth.rows_per_chrom(n_b, seed_b)
+        assign = shard.lpt_assign(rows.tolist(), world)
+        rank_chroms = [[c for c in range(len(synth.HG38_LENGTHS)) if assign[c] == r] for r in range(world)]
+        my_chroms = rank_chroms[rank]
     t0 = time.time()
-    op, ha, hb, n_chrom = make_inputs(wl)
+    op, ha, hb, n_chrom = make_inputs(wl, my_chroms)
     gen_s = time.time() - t0
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
     a = DeviceSide.from_numpy(*ha, device=dev)
     b = DeviceSide.from_numpy(*hb, device=dev)
-    eng = HipEngine(0)
-    fn = {"semi": lambda: eng.semi_join(a, b, n_chrom), "anti": lambda: eng.anti_join(a, b, n_chrom),
-          "count": lambda: eng.count_overlaps(a, b, n_chrom), "nearest": lambda: eng.nearest(a, b, n_chrom)}[op]
+    eng = HipEngine(dev_index)
+    # shard-local row -> global row: the global table is "rows of lower ranks first" (as in run_inner)
+    base_a = base_b = 0
+    if distributed:
+        from giql_amd import distributed as D
+
+        sizes_t = torch.tensor([a.n, b.n], dtype=torch.int64, device=xdev)
+        all_sizes = torch.empty((world, 2), dtype=torch.int64, device=xdev)
+        dist.all_gather_into_tensor(all_sizes.view(-1), sizes_t)
+        base_a, base_b = (int(x) for x in all_sizes[:rank].sum(0).tolist()) if rank else (0, 0)
+    local = {"semi": lambda: eng.semi_join(a, b, n_chrom), "anti": lambda: eng.anti_join(a, b, n_chrom),
+             "count": lambda: eng.count_overlaps(a, b, n_chrom), "nearest": lambda: eng.nearest(a, b, n_chrom)}[op]
+
+    last_local = [0]
+
+    def fn():
+        """One pass of the operator over this rank's rows; N > 1: + the path's one exchange, the all-gather
+        of the per-row results (global row ids; blocks in rank order = global A row order)."""
+        r = local()
+        last_local[0] = int((r[0] if isinstance(r, tuple) else r).shape[0])
+        if not distributed:
+            return r
+        if op in ("semi", "anti"):
+            block = (r.to(torch.int64) + base_a).to(xdev).view(1, -1)
+        elif op == "count":
+            block = r.to(xdev).view(1, -1)
+        else:
+            idx = r[0].to(torch.int64)
+            block = torch.stack([torch.where(idx >= 0, idx + base_b, idx), r[1]]).to(xdev)
+        blocks = D.gather_blocks(block)
+        if op in ("semi", "anti"):
+            return torch.cat([blk[0] for blk in blocks]).to(torch.int32)
+        if op == "count":
+            return torch.cat([blk[0] for blk in blocks])
+        return torch.cat([blk[0] for blk in blocks]).to(torch.int32), torch.cat([blk[1] for blk in blocks])
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
     eng.set_profiling(True)
     res = None
     for _ in range(max(args.warmup, 1)):
@@ -787,15 +851,34 @@ def run_rowop(args):
     st = eng.stats()
     phases = {k: v for k, v in st["phase_ms"].items() if v > 0}
     eng.set_profiling(False)
-    torch.cuda.synchronize(dev)
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = fn()
-    torch.cuda.synchronize(dev)
+    sync_all()
     elapsed = time.perf_counter() - t0
+    loc_na, loc_nb = a.n, b.n
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
+        tot = torch.tensor([loc_na, loc_nb], dtype=torch.int64, device=xdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = float(t.item())
+        tot_na, tot_nb = (int(x) for x in tot.tolist())
+        if rank != 0:
+            dist.barrier()   # rank 0 runs the CPU leg below; leave together
+            dist.destroy_process_group()
+            eng.close()
+            return None
+        if not args.no_cpu_baseline:
+            # the global tables the gathered result refers to: the ranks' shards, rank after rank
+            parts = [make_inputs(wl, cs) for cs in rank_chroms]
+            ha = tuple(np.concatenate([p[1][k] for p in parts]) for k in range(3))
+            hb = tuple(np.concatenate([p[2][k] for p in parts]) for k in range(3))
+    g_na, g_nb = (tot_na, tot_nb) if distributed else (loc_na, loc_nb)   # the whole job's rows
     n_out = int((res[0] if isinstance(res, tuple) else res).shape[0])
     device_ms = sum(phases.values())
-    alg = op_bytes(op, a.n, b.n, n_out)
+    alg = op_bytes(op, loc_na, loc_nb, last_local[0])   # this rank's shard: what its kernels (device_ms) moved
     dom = max(phases, key=lambda k: phases[k]) if phases else None
     dom_bytes = (st.get("phase_bytes") or {}).get(dom, 0) if dom else 0
     roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
@@ -839,24 +922,31 @@ def run_rowop(args):
             ok = j >= 0
             equal = bool(np.array_equal(res[1].cpu().numpy(), wd) and np.array_equal(ok, wi >= 0)
                          and np.array_equal(hb[1][j[ok]], hb[1][wi[ok]]) and np.array_equal(hb[2][j[ok]], hb[2][wi[ok]]))
-        cpu_baseline = {"value": round((a.n + b.n) / dt, 1), "unit": "rows/s", "cores": threads, "kind": "port",
-                        "sample": f"the whole workload: {a.n} x {b.n} rows in {dt:.2f} s (oracle OpenMP sweep, not DuckDB)",
+        cpu_baseline = {"value": round((g_na + g_nb) / dt, 1), "unit": "rows/s", "cores": threads, "kind": "port",
+                        "sample": f"the whole workload: {g_na} x {g_nb} rows in {dt:.2f} s (oracle OpenMP sweep, not DuckDB)",
                         "host_cpu_count": os.cpu_count(),
                         "parity": {"equal": equal, "checked": "every output row of the last timed call (NEAREST: distances, "
                                                                 "presence and the matched (start, end); ids are tie-ambiguous)"}}
     metric, unit = METRIC[op]
     line = {
-        "metric": metric.format(a=short(a.n), b=short(b.n)),
-        "value": round((a.n + b.n) * args.steps / elapsed, 1),
-        "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "metric": metric.format(a=short(g_na), b=short(g_nb)),
+        "value": round((g_na + g_nb) * args.steps / elapsed, 1),
+        "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": wl, "n_a": a.n, "n_b": b.n, "n_chrom": n_chrom, "rows_out": n_out,
-                   "inputs": "resident in HBM before the timed region", "form": st.get("join_form")},
-        "hbm_algorithmic_GBps": round(alg * args.steps / elapsed / 1e9, 1),
+        "config": {"workload": wl, "n_a": g_na, "n_b": g_nb, "n_chrom": n_chrom, "rows_out": n_out,
+                   "inputs": "resident in HBM before the timed region", "form": st.get("join_form"),
+                   "parallelism": (f"{world} ranks, the A rows' chromosomes LPT-sharded, one all-gather of the per-row results "
+                                   f"({args.backend})") if distributed else "1 GPU"},
+        "hbm_algorithmic_GBps": round(op_bytes(op, g_na, g_nb, n_out) * args.steps / elapsed / 1e9, 1),
+        "per_rank": [{"rank": 0, "rows_a": loc_na, "rows_b": loc_nb, "rows_out": last_local[0],
+                      "device_ms": round(device_ms, 3)}],
         "roofline": roofline, "cpu_baseline": cpu_baseline, "gen_seconds": round(gen_s, 1),
     }
     eng.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
     return line
 
 

@@ -34,7 +34,7 @@ def plan_shards(chrom_a: np.ndarray, chrom_b: np.ndarray, n_chrom: int, world: i
 
 
 def unit_rows(chrom_a: np.ndarray, chrom_b: np.ndarray, n_chrom: int, world: int, rank: int,
-              split_over: float = 1.0):
+              split_over: float = 1.0, split_side: str | None = None):
     """This rank's (rows_a, rows_b) under the unit plan of :func:`giql_amd.shard.plan_units`.
 
     Whole-chromosome units contribute all of the chromosome's rows on both sides.
@@ -48,7 +48,7 @@ def unit_rows(chrom_a: np.ndarray, chrom_b: np.ndarray, n_chrom: int, world: int
     chrom_b = np.asarray(chrom_b)
     na = np.bincount(chrom_a, minlength=n_chrom)
     nb = np.bincount(chrom_b, minlength=n_chrom)
-    units = plan_units(na.tolist(), nb.tolist(), world, split_over)
+    units = plan_units(na.tolist(), nb.tolist(), world, split_over, split_side)
     owner = assign_units(units, world)
     keep_a = np.zeros(chrom_a.shape[0], dtype=bool)
     keep_b = np.zeros(chrom_b.shape[0], dtype=bool)
@@ -345,3 +345,113 @@ def sharded_inner_join_compact(a, b, n_chrom: int, local_plan: Callable, expand:
         out_b.append(row_s if qa_r else row_q)
     z = torch.empty(0, dtype=torch.int32, device=dev)
     return (torch.cat(out_a) if out_a else z), (torch.cat(out_b) if out_b else z.clone())
+
+
+# ------------------------------------------------------------------ the per-row operators
+ROW_OPS = ("semi", "anti", "count", "nearest")
+
+
+def gather_blocks(block, group=None):
+    """All-gather one ``[k, n]`` block per rank (``n`` differs from rank to rank; same ``k`` and
+    dtype everywhere): the per-rank sizes first, then the blocks padded to the largest.
+    Returns ``[block_0, block_1, ...]`` (views into one receive buffer, rank order)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    k, n = int(block.shape[0]), int(block.shape[1])
+    dev = block.device
+    count = torch.tensor([n], dtype=torch.int64, device=dev)
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, count, group=group)
+    counts_h = [int(x) for x in counts.tolist()]
+    m = max(counts_h) if counts_h else 0
+    if m == 0:
+        return [block[:, :0] for _ in range(world)]
+    send = block if n == m else torch.cat([block, block.new_zeros((k, m - n))], dim=1)
+    recv = torch.empty((world, k, m), dtype=block.dtype, device=dev)
+    dist.all_gather_into_tensor(recv.view(-1), send.contiguous().view(-1), group=group)
+    return [recv[r, :, : counts_h[r]] for r in range(world)]
+
+
+def sharded_row_op(op: str, a, b, n_chrom: int, local_op: Callable, *, device=None, group=None,
+                   gather: bool = True, **kw):
+    """SEMI / ANTI / COUNT / NEAREST k=1 of host tables ``a`` / ``b`` across the ranks of ``group``.
+
+    The operators answer per A row from the B rows of the SAME chromosome
+    (``intersects_duckdb.py:1254-1282``; ``nearest.py:313-333``), so the units are the A rows'
+    chromosomes: LPT-packed like the join's, a chromosome heavier than one rank's share cut by
+    row ranges of A with all of its B rows on every part (``unit_rows(..., split_side="a")``).
+    No data-path collective; ONE exchange of the per-row results at the end.
+
+    ``local_op(op, chrom_a, start_a, end_a, offs_a, chrom_b, ..., offs_b, n_chrom, **kw)`` runs
+    this rank's shard: SEMI / ANTI -> local A row ids (int32); COUNT -> int64 per local A row;
+    NEAREST -> ``(idx_b int32 local or -1, distance int64)`` per local A row.
+    Returns, on every rank (``gather=False``: this rank's rows only, as
+    ``(global A row ids, ...)``): SEMI / ANTI the ascending global A row ids; COUNT one int64
+    per A row; NEAREST ``(idx_b, distance)`` per A row with GLOBAL B row ids.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if op not in ROW_OPS:
+        raise ValueError(f"op must be one of {ROW_OPS}")
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    ca, sa, ea = (np.asarray(x) for x in a[:3])
+    cb, sb, eb = (np.asarray(x) for x in b[:3])
+    offs_a = tuple(a[3:5]) if len(a) >= 5 else (0, 0)
+    offs_b = tuple(b[3:5]) if len(b) >= 5 else (0, 0)
+    n_a = int(ca.shape[0])
+    ia, ib = unit_rows(ca, cb, n_chrom, world, rank, split_side="a")
+    res = local_op(op, ca[ia], sa[ia], ea[ia], offs_a, cb[ib], sb[ib], eb[ib], offs_b, n_chrom, **kw)
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    ga = torch.from_numpy(ia.astype(np.int64)).to(dev)   # local A row -> global A row
+    gb = torch.from_numpy(ib.astype(np.int64)).to(dev)
+    if op in ("semi", "anti"):
+        block = ga[res.to(dev).long()].view(1, -1)
+    elif op == "count":
+        block = torch.stack([ga, res.to(dev).to(torch.int64)])
+    else:
+        idx, dist_ = res
+        idx = idx.to(dev).long()
+        hit = idx >= 0
+        gidx = torch.full_like(idx, -1)
+        gidx[hit] = gb[idx[hit]]
+        block = torch.stack([ga, gidx, dist_.to(dev).to(torch.int64)])
+    if not gather:
+        return tuple(block[k] for k in range(block.shape[0]))
+    blocks = gather_blocks(block, group=group)
+    if op in ("semi", "anti"):
+        return torch.sort(torch.cat([blk[0] for blk in blocks]))[0].to(torch.int32)
+    if op == "count":
+        out = torch.zeros(n_a, dtype=torch.int64, device=dev)
+        for blk in blocks:
+            out[blk[0]] = blk[1]
+        return out
+    out_i = torch.full((n_a,), -1, dtype=torch.int32, device=dev)
+    out_d = torch.zeros(n_a, dtype=torch.int64, device=dev)
+    for blk in blocks:
+        out_i[blk[0]] = blk[1].to(torch.int32)
+        out_d[blk[0]] = blk[2]
+    return out_i, out_d
+
+
+def hip_local_row_op(engine):
+    """``local_op`` of :func:`sharded_row_op` backed by a :class:`giql_amd.engine.HipEngine`."""
+    from .engine import DeviceSide
+
+    def run(op, ca, sa, ea, offs_a, cb, sb, eb, offs_b, n_chrom, **kw):
+        a = DeviceSide.from_numpy(ca, sa, ea, device=engine.device)
+        a.start_off, a.end_off = offs_a
+        b = DeviceSide.from_numpy(cb, sb, eb, device=engine.device)
+        b.start_off, b.end_off = offs_b
+        if op == "semi":
+            return engine.semi_join(a, b, n_chrom)
+        if op == "anti":
+            return engine.anti_join(a, b, n_chrom)
+        if op == "count":
+            return engine.count_overlaps(a, b, n_chrom)
+        return engine.nearest(a, b, n_chrom, **kw)
+
+    return run

@@ -30,7 +30,8 @@ def lpt_assign(weights: Sequence[float], n_bins: int) -> list[int]:
     return assign
 
 
-def plan_units(n_a: Sequence[int], n_b: Sequence[int], n_bins: int, split_over: float = 1.0):
+def plan_units(n_a: Sequence[int], n_b: Sequence[int], n_bins: int, split_over: float = 1.0,
+               split_side: str | None = None):
     """Work units for ``n_bins`` ranks: ``[(chrom, part, n_parts, split_side, weight)]``.
 
     A chromosome is normally one unit.  One whose rows (A + B) exceed
@@ -38,8 +39,12 @@ def plan_units(n_a: Sequence[int], n_b: Sequence[int], n_bins: int, split_over: 
     RANGES of its larger side (``split_side`` "a" or "b"); every such unit carries
     the whole of the chromosome's other side, so each (a, b) pair is still found
     exactly once ("if one chromosome dominates, split by row
-    ranges and replicate the other side").  Deterministic.
+    ranges and replicate the other side").  ``split_side="a"``: only ever cut along A
+    (the per-row operators SEMI / ANTI / COUNT / NEAREST: every A row needs ALL the B
+    rows of its chromosome, so B is never the side that is cut).  Deterministic.
     """
+    if split_side not in (None, "a", "b"):
+        raise ValueError("split_side must be None, 'a' or 'b'")
     if n_bins < 1:
         raise ValueError("n_bins must be >= 1")
     total = float(sum(n_a) + sum(n_b))
@@ -50,7 +55,8 @@ def plan_units(n_a: Sequence[int], n_b: Sequence[int], n_bins: int, split_over: 
         w = na + nb
         if w == 0:
             continue
-        big, small = max(na, nb), min(na, nb)
+        side = split_side or ("a" if na >= nb else "b")
+        big, small = (na, nb) if side == "a" else (nb, na)
         k = 1
         if n_bins > 1 and w > split_over * share and big > 1:
             # smallest k whose units (big/k + replicated small) fit the share, capped at n_bins
@@ -60,7 +66,8 @@ def plan_units(n_a: Sequence[int], n_b: Sequence[int], n_bins: int, split_over: 
                     k = cand
                     break
             k = min(k, big)
-        side = "a" if na >= nb else "b"
+            if split_side and small >= big and big / k + small > share:
+                k = 1  # cutting the smaller side only replicates the larger one: keep the chromosome whole
         for j in range(k):
             units.append((c, j, k, side, big / k + small))
     return units

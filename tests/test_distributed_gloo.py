@@ -255,3 +255,78 @@ def test_lpt_assign_and_shard_rows():
     assert shard.span_groups([2**31, 2**31, 5]) == [[0, 2], [1]] or shard.span_groups([2**31, 2**31, 5]) == [[0], [1, 2]]
     with pytest.raises(ValueError):
         shard.lpt_assign([1.0], 0)
+
+
+# ------------------------------------------------------------------ the per-row operators, sharded
+def _oracle_row_op(op, ca, sa, ea, offs_a, cb, sb, eb, offs_b, n_chrom, **kw):
+    from oracle import pyoracle as ora
+
+    a, b = ora.Side(ca, sa, ea, *offs_a), ora.Side(cb, sb, eb, *offs_b)
+    if op in ("semi", "anti"):
+        return torch.from_numpy(ora.c_semi_anti(a, b, op == "anti", threads=1))
+    if op == "count":
+        return torch.from_numpy(ora.c_count(a, b, "sweep", threads=1))
+    idx, d = ora.c_nearest_k1(a, b, signed=kw.get("signed", False), threads=1)
+    return torch.from_numpy(idx), torch.from_numpy(d)
+
+
+def _row_worker(rank, world, port, out_dir, skew=False):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from giql_amd import distributed as D
+
+        b, a = _tables(seed=21, skew=skew)   # A = the 6000-row table: with skew, chromosome 2 is A-dominant
+        if skew:  # chromosome 2 holds 80 % of A: its A rows must really be spread, each part with all of its B rows
+            ia, ib = D.unit_rows(a[0], b[0], 7, world, rank, split_side="a")
+            assert int((a[0][ia] == 2).sum()) < int((a[0] == 2).sum())
+            assert int((b[0][ib] == 2).sum()) in (0, int((b[0] == 2).sum()))
+        out = {}
+        for op in ("semi", "anti", "count"):
+            out[op] = D.sharded_row_op(op, a, b, 7, _oracle_row_op).numpy()
+        idx, d = D.sharded_row_op("nearest", a, b, 7, _oracle_row_op, signed=True)
+        out["nearest_idx"], out["nearest_d"] = idx.numpy(), d.numpy()
+        np.savez(os.path.join(out_dir, f"rows_{rank}.npz"), **out)
+        # ragged blocks, an empty rank
+        blk = torch.full((2, 0 if rank == 1 else rank + 2), rank, dtype=torch.int64)
+        got = D.gather_blocks(blk)
+        assert [tuple(g.shape) for g in got] == [(2, 0 if r == 1 else r + 2) for r in range(world)]
+        assert all(bool((g == r).all()) for r, g in enumerate(got))
+        assert [tuple(g.shape) for g in D.gather_blocks(torch.zeros((3, 0), dtype=torch.int64))] == [(3, 0)] * world
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,skew", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_row_ops_match_single_process(tmp_path, world, skew):
+    """SEMI / ANTI / COUNT / NEAREST sharded by the A rows' chromosomes (a dominant one cut by row ranges
+    of A), results gathered on every rank = the single-process oracle's, global row ids included."""
+    from oracle import pyoracle as ora
+
+    port = _free_port()
+    mp.spawn(_row_worker, args=(world, port, str(tmp_path), skew), nprocs=world, join=True)
+    b, a = _tables(seed=21, skew=skew)
+    sa, sb = ora.Side(*a), ora.Side(*b)
+    wi, wd = ora.c_nearest_k1(sa, sb, signed=True)
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rows_{rank}.npz"))
+        assert np.array_equal(got["semi"], np.sort(ora.c_semi_anti(sa, sb, False)))
+        assert np.array_equal(got["anti"], np.sort(ora.c_semi_anti(sa, sb, True)))
+        assert np.array_equal(got["count"], ora.c_count(sa, sb))
+        assert np.array_equal(got["nearest_d"], wd) and np.array_equal(got["nearest_idx"] >= 0, wi >= 0)
+        hit = wi >= 0   # ids are tie-ambiguous: compare the matched rows' coordinates
+        gi = got["nearest_idx"]
+        assert np.array_equal(b[1][gi[hit]], b[1][wi[hit]]) and np.array_equal(b[2][gi[hit]], b[2][wi[hit]])
+        assert np.array_equal(b[0][gi[hit]], a[0][hit])
+
+
+def test_plan_units_forced_side_never_cuts_b():
+    from giql_amd import shard
+
+    # A-dominant chromosome: cut along A; B-dominant one: kept whole (cutting A would only replicate B)
+    units = shard.plan_units([1000, 10, 5], [100, 1000, 5], 2, 1.0, split_side="a")
+    assert [(c, k, side) for c, _j, k, side, _w in units] == [(0, 2, "a"), (0, 2, "a"), (1, 1, "a"), (2, 1, "a")]
+    with pytest.raises(ValueError):
+        shard.plan_units([1], [1], 2, 1.0, split_side="x")
