@@ -152,6 +152,8 @@ struct giql_hip_ctx {
   u64 overlap_max_rows = 4u << 20;
   bool overlap_large = true;  // GIQL_HIP_OVERLAP_LARGE=0: the small side's chain runs beside the other side's only when that is small too
   int overlap_mask = 3;  // GIQL_HIP_OVERLAP_MASK: 1 = the sides' sort chains, 2 = the two count classes
+  int row_skip_digits = -1;    // GIQL_HIP_ROW_SKIP_DIGITS: low digits the per-row operators leave unsorted on their query side (-1: by density, row_skip())
+  u64 row_last_span = 0;       // linearised span of the last per-row call (the density guess of row_skip())
   bool no_skip_digit = false;  // GIQL_HIP_NO_SKIP_DIGIT=1: query sides are sorted on every digit
   bool local_sort = true;
   u64 local_min_rows = 1u << 25;
@@ -617,6 +619,17 @@ static void sort_sizes(Carver& c, size_t n, SortBufs& sb, bool payload) {
   }
 }
 
+// Low digits the per-row operators leave unsorted on their QUERY side (its order only serves locality: the
+// rows of a block should search neighbouring ranges of B).  One digit always; two (rows ordered by key >> 16
+// only: two passes instead of three) when B is sparse enough that a 65536-key range of it -- what a block's
+// bracket then covers at least -- still fits the LDS stage of k_nearest (cfg 5: 1.115 -> 1.063 ms).  The
+// density comes from the span of the context's previous per-row call: a guess that only ever costs speed.
+static inline int row_skip(const giql_hip_ctx* ctx, size_t nb) {
+  if (ctx->row_skip_digits >= 0) return ctx->row_skip_digits;
+  if (ctx->row_last_span == 0) return 1;
+  return (double)nb * 65536.0 / (double)ctx->row_last_span <= 1024.0 ? 2 : 1;
+}
+
 // Fork / join of the context's second stream.  A side of a few million rows is a chain of ~10 launches
 // of 10-40 us each that do not fill the GPU (look-back latency, not bandwidth, bounds them): run beside
 // the other side's chain it costs almost nothing.  Work given to stream() is ordered after everything
@@ -760,6 +773,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->no_span_hist = nh && atoi(nh) != 0;
     const char* nsd = getenv("GIQL_HIP_NO_SKIP_DIGIT");
     ctx->no_skip_digit = nsd && atoi(nsd) != 0;
+    const char* rsd = getenv("GIQL_HIP_ROW_SKIP_DIGITS");
+    if (rsd && atoi(rsd) >= 0 && atoi(rsd) <= 3) ctx->row_skip_digits = atoi(rsd);
     const char* nl = getenv("GIQL_HIP_NO_LOCAL_SORT");
     if (nl && atoi(nl) != 0) ctx->local_sort = false;
     const char* lm = getenv("GIQL_HIP_LOCAL_MIN_ROWS");
@@ -1452,7 +1467,7 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
     SideChain sc(ctx, st, nb > 0 ? na : 0, nb);
     GIQL_TRY(run_linearize(ctx, sc.stream(), *a, nch, lb, sa.key[0], sa.end[0], dummy_irr + 8, 0, 1, os_a.hist, os_a.gbase));
     GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sa, (u32)na, os_a.gbase, os_a.status, false, nullptr, nullptr,
-                               /*skip_digits=*/1));  // the query side's order only serves locality; every row keeps its real key here
+                               /*skip_digits=*/row_skip(ctx, nb)));  // the query side's order only serves locality; every row keeps its real key here
   if (nb > 0 && uni_len > 0) {
     // fixed-length B: keys only (its `end` column is not read again), no prefix max
     sbb.end[0] = sbb.end[1] = nullptr;
@@ -1498,6 +1513,7 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   *n_out = (int64_t)ctx->h_meta->n_out;
   ctx->stats.n_out = *n_out;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+  ctx->row_last_span = ctx->h_meta->total_span;
   return GIQL_OK;
 }
 
@@ -1595,6 +1611,7 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
   collect_spans(ctx);
   ctx->stats.n_out = a->n;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+  ctx->row_last_span = ctx->h_meta->total_span;
   return GIQL_OK;
 }
 
@@ -1654,7 +1671,7 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
   GIQL_TRY(run_linearize(ctx, sc.stream(), *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr + 8, 0, 1, os_a.hist,
                          os_a.gbase));
   GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sa, (u32)na, os_a.gbase, os_a.status, false, nullptr, nullptr,
-                             /*skip_digits=*/1));  // the query side's order only serves locality; every row keeps its real key here
+                             /*skip_digits=*/row_skip(ctx, nb)));  // the query side's order only serves locality; every row keeps its real key here
   GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist,
                          os.gbase, two_sorts ? os.hist_e : nullptr, two_sorts ? os.gbase_e : nullptr));
   {
@@ -1700,6 +1717,7 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
   collect_spans(ctx);
   ctx->stats.n_out = a->n;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+  ctx->row_last_span = ctx->h_meta->total_span;
   return GIQL_OK;
 }
 
@@ -1784,7 +1802,7 @@ static int giql_hip_nearest_k_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   GIQL_TRY(run_sort_onesweep(ctx, st, se, (u32)nb, os.gbase_e, os.status, /*keep_rids=*/true));
   GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist, os.gbase));
   GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, false, nullptr, nullptr,
-                             /*skip_digits=*/1));  // the query side's order only serves locality; every row keeps its real key here
+                             /*skip_digits=*/row_skip(ctx, nb)));  // the query side's order only serves locality; every row keeps its real key here
   {
     Phase ph(ctx, st, GIQL_PH_COUNT, 4);
     hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st, lb.chrom_first, n_chrom,
@@ -1803,6 +1821,7 @@ static int giql_hip_nearest_k_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   collect_spans(ctx);
   ctx->stats.n_out = a->n * (int64_t)k;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+  ctx->row_last_span = ctx->h_meta->total_span;
   return GIQL_OK;
 }
 
