@@ -202,17 +202,19 @@ __global__ __launch_bounds__(256) void k_compact(const u32* __restrict__ flag,
 // ------------------------------------------------------------------- COUNT
 // Regular rows: count(a) = #{b.start < a.end} - #{b.end <= a.start} over the
 // regular B rows (two sorted arrays, no candidate is touched); irregular rows on
-// either side are settled by the literal predicate.  A rows come sorted by start
-// (regular prefix only; the irregular tail is settled by k_count_irregular).
+// either side are settled by the literal predicate.  A rows come ordered by start -- coarsely: the
+// order only serves locality -- and the irregular ones (sentinel key, wherever the coarse order
+// left them) are settled by k_count_irregular.
 __global__ __launch_bounds__(256) void k_count_rows(
     const u32* __restrict__ a_keys, const u32* __restrict__ a_ends, const u32* __restrict__ a_rids,
     u32 n_a_total, SideView a, SideView b, const u32* __restrict__ b_keys_sorted,
     const u32* __restrict__ b_ends_sorted, u32 n_b_total, const u32* __restrict__ irr_b_list,
     const DevMeta* __restrict__ meta, i64* __restrict__ counts_out, i64 uni_len) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_a_total - meta->irr_a) return;
+  if (i >= n_a_total) return;
   const u32 n_reg = n_b_total - meta->irr_b;
   const u32 qs = a_keys[i], qe = a_ends[i], r = a_rids[i];
+  if (qs >= meta->sentinel) return;  // an irregular A row (real keys lie below the sentinel)
   const u32 below = lower_bound_u32(b_keys_sorted, 0, n_reg, qe);  // b.start < a.end
   u32 done;                                                        // b.end <= a.start
   if (uni_len > 0) {

@@ -1574,7 +1574,8 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
   SideChain sc(ctx, st, na, nb);
   GIQL_TRY(run_linearize(ctx, sc.stream(), *a, n_chrom, lb, sa.key[0], sa.end[0], irr_a_list, 0, 0, os_a.hist,
                          os_a.gbase));
-  GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sa, (u32)na, os_a.gbase, os_a.status));
+  GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sa, (u32)na, os_a.gbase, os_a.status, false, nullptr, nullptr,
+                             /*skip_digits=*/row_skip(ctx, nb)));  // locality only: k_count_rows tells irregular rows by their key
   if (uni_len > 0) {
     // fixed-length B: one sorted array (its sorted ends are its sorted starts + L)
     GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sstart.key[0], nullptr, irr_b_list, 1, 0, os.hist,
