@@ -674,13 +674,39 @@ def _finish_outer(out, plan: JoinPlan):
         order = list(plan.output) if plan.output else list(cols)
         keep = [n for n in order if n in cols] + [n for n in cols if n not in order]
         out = pa.Table.from_arrays([cols[n] for n in keep], names=keep)
+    elif plan.group_by:   # GROUP BY without an aggregate: one row per key
+        out = out.group_by(list(plan.group_by), use_threads=False).aggregate([])
+        if plan.output:
+            out = out.select([n for n in plan.output if n in out.column_names] +
+                             [n for n in out.column_names if n not in plan.output])
+    if plan.having:
+        import pyarrow.compute as pc
+
+        cmp = {"=": pc.equal, "!=": pc.not_equal, "<": pc.less, "<=": pc.less_equal, ">": pc.greater,
+               ">=": pc.greater_equal}
+        mask = None
+        for h in plan.having:
+            lhs, rhs = (out.column(o.value) if o.kind == "name" else pa.scalar(o.value) for o in (h.lhs, h.rhs))
+            m = cmp[h.op](lhs, rhs)
+            mask = m if mask is None else pc.and_kleene(mask, m)
+        out = out.filter(mask)   # NULL comparisons drop the group, as SQL's HAVING does
     visible = [n for n in out.column_names if not n.startswith("__giql_")]
     if plan.distinct:
-        if plan.order_by and any(n not in visible for n, _ in plan.order_by):
+        if plan.order_by and any(o[0] not in visible for o in plan.order_by):
             raise ValueError("ORDER BY a column that DISTINCT does not keep")
         out = out.select(visible).group_by(visible, use_threads=False).aggregate([])
     if plan.order_by:
-        out = out.sort_by([(n, "descending" if desc else "ascending") for n, desc in plan.order_by])
+        import pyarrow.compute as pc
+
+        # per-key NULL placement: a validity flag sorted ahead of each key (pyarrow's own null_placement
+        # is one setting for all the keys)
+        keys, tmp = [], out
+        for i, (n, desc, nulls_first) in enumerate(plan.order_by):
+            flag = f"__giql_n{i}"
+            tmp = tmp.append_column(flag, pc.is_null(tmp.column(n)))
+            keys.append((flag, "descending" if nulls_first else "ascending"))   # True (NULL) first / last
+            keys.append((n, "descending" if desc else "ascending"))
+        out = out.take(pc.sort_indices(tmp, sort_keys=keys))
     if plan.offset is not None or plan.limit is not None:
         start = plan.offset or 0
         out = out.slice(start, plan.limit) if plan.limit is not None else out.slice(start)

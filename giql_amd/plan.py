@@ -77,6 +77,17 @@ class Aggregate:
 
 
 @dataclass(frozen=True)
+class Having:
+    """One conjunct of the HAVING clause over the grouped result: ``lhs op rhs`` where an operand is an
+    output column of the grouping (``kind`` "name": a key, an aggregate of the SELECT list, or a hidden
+    ``__giql_h<n>`` aggregate computed for this clause only) or a literal ("int", "float", "str")."""
+
+    lhs: Operand
+    op: str        # = != < <= > >=
+    rhs: Operand
+
+
+@dataclass(frozen=True)
 class JoinPlan:
     kind: str
     left: PlanSide
@@ -96,7 +107,11 @@ class JoinPlan:
     # finished on the projected table: projection columns named "__giql_*" are carried for them only
     aggregates: tuple[Aggregate, ...] = field(default_factory=tuple)
     group_by: tuple[str, ...] = field(default_factory=tuple)       # output names of the key columns
-    order_by: tuple[tuple[str, bool], ...] = field(default_factory=tuple)   # (output name, descending)
+    having: tuple[Having, ...] = field(default_factory=tuple)      # conjuncts over the grouped result
+    # (output name, descending, NULLs first): the placement is explicit per key -- where the query does not
+    # write NULLS FIRST / LAST it is giql's dialect default, "NULLs are small" (first when ascending, last
+    # when descending), which the reference's emitted DuckDB SQL spells out the same way
+    order_by: tuple[tuple[str, bool, bool], ...] = field(default_factory=tuple)
     limit: int | None = None
     offset: int | None = None
     output: tuple[str, ...] = field(default_factory=tuple)         # final column names in SELECT order (grouped plans)
@@ -110,6 +125,7 @@ class JoinPlan:
         d["projection"] = [asdict(p) for p in self.projection]
         d["residuals"] = [asdict(r) for r in self.residuals]
         d["aggregates"] = [asdict(a) for a in self.aggregates]
+        d["having"] = [asdict(h) for h in self.having]
         d["order_by"] = [list(o) for o in self.order_by]
         return PLAN_PREFIX + json.dumps(d, sort_keys=True, separators=(",", ":"))
 
@@ -128,7 +144,9 @@ class JoinPlan:
                             for r in d.get("residuals", ())),
             distance=d.get("distance", 0), stranded=d.get("stranded", False), strand_col=d.get("strand_col"),
             aggregates=tuple(Aggregate(**a) for a in d.get("aggregates", ())),
-            group_by=tuple(d.get("group_by", ())), order_by=tuple((o[0], bool(o[1])) for o in d.get("order_by", ())),
+            having=tuple(Having(Operand(**h["lhs"]), h["op"], Operand(**h["rhs"])) for h in d.get("having", ())),
+            group_by=tuple(d.get("group_by", ())),
+            order_by=tuple((o[0], bool(o[1]), bool(o[2]) if len(o) > 2 else not bool(o[1])) for o in d.get("order_by", ())),
             limit=d.get("limit"), offset=d.get("offset"), output=tuple(d.get("output", ())))
 
 

@@ -319,15 +319,37 @@ def shape_from_ast(root, node, ctx) -> JoinShape:
             if _key(g) != "column":
                 raise decline("GROUP BY expression")
             shape.group_by.append(_colref(g))
-    if _arg(root, "having") is not None:
-        raise decline("HAVING clause")
+    having = _arg(root, "having")
+    if having is not None:
+        # the reference hands the clause to the engine verbatim (intersects_duckdb.py:1374-1380); here: a
+        # conjunction of comparisons between plain aggregates / key columns and literals
+        def having_operand(n):
+            if _key(n).upper() in AGG_FUNCS:
+                it = _select_item(n)
+                if it.ref is not None:
+                    it.ref.count = False
+                return ("agg", it)
+            if _key(n) in ("subquery", "select", "paren"):
+                raise decline("parenthesised / sub-query HAVING condition")
+            return _operand(n)
+
+        for c in _conjuncts(_arg(having, "this")):
+            if _key(c) not in _CMP:
+                raise decline(f"HAVING condition of kind {_key(c)!r}")
+            shape.having.append(("cmp", having_operand(_arg(c, "this")), _CMP[_key(c)],
+                                 having_operand(_arg(c, "expression"))))
     order = _arg(root, "order")
     if order is not None:
         for o in _arg(order, "expressions") or []:
             target = _arg(o, "this") if _key(o) == "ordered" else o
             if _key(target) != "column":
                 raise decline("ORDER BY expression")    # incl. sub-queries (intersects_duckdb.py:690-701)
-            shape.order_by.append(OrderKey(_colref(target), bool(_arg(o, "desc")) if _key(o) == "ordered" else False))
+            ordered = _key(o) == "ordered"
+            # sqlglot's parser fills nulls_first by the dialect's NULL ordering when the query does not say
+            # (giql's dialect: NULLs are small), so what the node holds IS the placement; absent: the same default
+            nf = _arg(o, "nulls_first") if ordered else None
+            shape.order_by.append(OrderKey(_colref(target), bool(_arg(o, "desc")) if ordered else False,
+                                           None if nf is None else bool(nf)))
     for clause in ("limit", "offset"):
         c = _arg(root, clause)
         if c is not None:

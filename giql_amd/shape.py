@@ -17,7 +17,8 @@ so both accept, decline and reject exactly the same queries.  It restates the wh
   windows, FILTER, sub-queries decline (#202, #204, #205);
 * DISTINCT / GROUP BY / ORDER BY / LIMIT / OFFSET over the result, which the reference lets "ride on
   the outer SELECT wrapper" (``:1336-1400``) and this target finishes on the projected Arrow table
-  (:func:`giql_amd.execute.execute`); HAVING and DISTINCT ON decline.
+  (:func:`giql_amd.execute.execute`); HAVING as a conjunction of comparisons between aggregates / keys
+  and literals; DISTINCT ON, sub-queries and expressions decline.
 
 Errors follow the reference's convention: user mistakes (unqualified / unknown-qualifier columns,
 right-side columns under SEMI / ANTI) are ``ValueError``; valid GIQL this target does not run is
@@ -28,7 +29,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass, field
 
-from .plan import Aggregate, JoinPlan, Operand, PlanSide, Projection, Residual
+from .plan import Aggregate, Having, JoinPlan, Operand, PlanSide, Projection, Residual
 from .table import Table, Tables
 
 
@@ -82,6 +83,7 @@ class SelItem:
 class OrderKey:
     ref: ColRef                  # qualified column, or an output name (table None)
     desc: bool = False
+    nulls_first: bool | None = None   # NULLS FIRST / NULLS LAST; None = not written (giql's dialect default: NULLs are small)
 
 
 @dataclass
@@ -98,6 +100,8 @@ class JoinShape:
     using: list[str] = field(default_factory=list)
     distinct: bool = False
     group_by: list[ColRef] = field(default_factory=list)
+    # HAVING conjuncts ("cmp", lhs, op, rhs); an operand is ("lit", value), ("col", ColRef) or ("agg", SelItem)
+    having: list = field(default_factory=list)
     order_by: list[OrderKey] = field(default_factory=list)
     limit: int | None = None
     offset: int | None = None
@@ -297,20 +301,81 @@ def _resolve_grouped(shape: JoinShape, left: PlanSide, right: PlanSide, left_onl
     return tuple(proj), tuple(aggs), tuple(groups), tuple(names)
 
 
+def _resolve_having(shape: JoinShape, proj, aggs, left: PlanSide, right: PlanSide, left_only: bool):
+    """HAVING conjuncts -> comparisons over the grouped result's columns.  An aggregate that the SELECT
+    list does not hold is added as a hidden ``__giql_h<n>`` aggregate (dropped from the output); a column
+    must be a grouping key (by its qualified name or its output name).  Returns (aggregates, having)."""
+    aggs = list(aggs)
+    by_col = {(p.side, p.column): p.name for p in proj}
+    out_names = {p.name for p in proj if not p.name.startswith("__giql_")} | {a.name for a in aggs}
+    having: list[Having] = []
+
+    def bind(o) -> Operand:
+        if o[0] == "lit":
+            v = o[1]
+            return Operand("str" if isinstance(v, str) else ("float" if isinstance(v, float) else "int"), v)
+        if o[0] == "col":
+            ref: ColRef = o[1]
+            if ref.star:
+                raise decline("star in HAVING")
+            if ref.table is None:
+                if ref.column in out_names:
+                    return Operand("name", ref.column)
+                raise ValueError(f"HAVING {ref.column!r}: not an output column; qualify it with a table alias")
+            side = _side_of(ref, left, right, "HAVING")
+            name = by_col.get((side, ref.column))
+            if name is None:
+                raise ValueError(f"HAVING {ref.table}.{ref.column}: the column must appear in GROUP BY "
+                                 "or inside an aggregate")
+            return Operand("name", name)
+        it: SelItem = o[1]
+        if it.func not in AGG_FUNCS:
+            raise decline(f"aggregate {it.func}")
+        if it.distinct and it.func != "COUNT":
+            raise decline(f"{it.func}(DISTINCT ...)")
+        if it.ref is None:
+            if it.func != "COUNT":
+                raise decline(f"{it.func}(*)")
+            side, column = "*", "*"
+        else:
+            if it.ref.star:
+                raise decline("star inside an aggregate")
+            side = _side_of(it.ref, left, right, "an aggregate argument")
+            if side == "r" and left_only:
+                raise ValueError(f"Column {it.ref.table}.{it.ref.column} references the right side of a SEMI/ANTI join "
+                                 "(left-side columns only)")
+            column = it.ref.column
+        for a in aggs:
+            if (a.func, a.side, a.column, a.distinct) == (it.func, side, column, it.distinct):
+                return Operand("name", a.name)
+        hidden = Aggregate(it.func, side, column, f"__giql_h{sum(a.name.startswith('__giql_h') for a in aggs)}",
+                           it.distinct)
+        aggs.append(hidden)
+        return Operand("name", hidden.name)
+
+    for _tag, lhs, op, rhs in shape.having:
+        a, b = bind(lhs), bind(rhs)
+        if a.kind != "name" and b.kind != "name":
+            raise decline("constant HAVING predicate")
+        having.append(Having(a, op, b))
+    return tuple(aggs), tuple(having)
+
+
 def _resolve_order(shape: JoinShape, proj, aggs, left: PlanSide, right: PlanSide, left_only: bool, grouped: bool):
     """ORDER BY keys -> output column names; a qualified column that is not projected rides along as
     a hidden column (dropped after the sort).  Returns (extra hidden projections, order spec)."""
     out_names = [p.name for p in proj] + [a.name for a in aggs]
     by_col = {(p.side, p.column): p.name for p in proj}
     hidden: list[Projection] = []
-    order: list[tuple[str, bool]] = []
+    order: list[tuple[str, bool, bool]] = []
     for k in shape.order_by:
+        nulls_first = (not k.desc) if k.nulls_first is None else bool(k.nulls_first)
         ref = k.ref
         if ref.star:
             raise decline("ORDER BY *")
         if ref.table is None:
             if ref.column in out_names:        # an output name (alias)
-                order.append((ref.column, k.desc))
+                order.append((ref.column, k.desc, nulls_first))
                 continue
             raise ValueError(f"ORDER BY {ref.column!r}: not an output column; qualify it with a table alias")
         side = _side_of(ref, left, right, "ORDER BY")
@@ -323,7 +388,7 @@ def _resolve_order(shape: JoinShape, proj, aggs, left: PlanSide, right: PlanSide
             name = f"__giql_o{len(hidden)}"
             hidden.append(Projection(side, ref.column, name))
             by_col[(side, ref.column)] = name
-        order.append((name, k.desc))
+        order.append((name, k.desc, nulls_first))
     return tuple(hidden), tuple(order)
 
 
@@ -393,19 +458,27 @@ def lower_join_shape(shape: JoinShape, tables: Tables) -> JoinPlan:
     if kind == "COUNT":
         if shape.distinct:
             raise decline("DISTINCT with count_overlaps")
-        if shape.order_by or shape.limit is not None or shape.offset is not None:
-            raise decline("ORDER BY / LIMIT over count_overlaps")
+        if shape.order_by or shape.limit is not None or shape.offset is not None or shape.having:
+            raise decline("HAVING / ORDER BY / LIMIT over count_overlaps")
         return JoinPlan("COUNT", left, right, resolve_count_projection(items, shape.group_by, left, right))
 
     left_only = kind in ("SEMI", "ANTI")
-    grouped = bool(shape.group_by) or any(it.func is not None for it in items)
+    grouped = bool(shape.group_by) or any(it.func is not None for it in items) or bool(shape.having)
     output: tuple[str, ...] = ()
+    having: tuple[Having, ...] = ()
     if grouped:
         proj, aggs, groups, output = _resolve_grouped(shape, left, right, left_only)
+        visible_aggs = aggs
+        aggs, having = _resolve_having(shape, proj, aggs, left, right, left_only)
+        if not visible_aggs and not groups and aggs:
+            # HAVING over the whole result as ONE group, nothing aggregated in the SELECT list: the plain
+            # columns it projects are neither grouped nor aggregated
+            raise ValueError("a projected column must appear in GROUP BY or inside an aggregate")
     else:
         proj, aggs, groups = resolve_projection(items, left, right, left_only), (), ()
-    hidden, order = _resolve_order(shape, proj, aggs, left, right, left_only, grouped)
+        visible_aggs = ()
+    hidden, order = _resolve_order(shape, proj, visible_aggs, left, right, left_only, grouped)
     residuals = tuple(resolve_residual(clause, t, left, right, kind) for clause, t in cmp_terms)
     return JoinPlan(kind, left, right, tuple(proj) + hidden, shape.distinct, residuals=residuals,
-                    aggregates=aggs, group_by=groups, order_by=order, limit=shape.limit, offset=shape.offset,
-                    output=output)
+                    aggregates=aggs, group_by=groups, having=having, order_by=order,
+                    limit=shape.limit, offset=shape.offset, output=output)

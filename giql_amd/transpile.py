@@ -264,6 +264,78 @@ def _parse_conjunction(p: _Parser, allow_literal: bool = False):
 _UNSUPPORTED_TAIL = ("GROUP", "ORDER", "HAVING", "LIMIT", "OFFSET", "UNION")
 
 
+def _parse_aggregate_call(p: _Parser, where: str):
+    """``FUNC([DISTINCT] <col> | *)`` at the cursor -> (func, distinct, ColRef | None)."""
+    func = p.peek().text.upper()
+    if func not in AGG_FUNCS:
+        raise _decline(f"function call in {where}")
+    p.next()
+    p.next()
+    distinct = False
+    if p.at_kw("DISTINCT"):
+        p.next()
+        distinct = True
+    if p.at_punct("*"):
+        p.next()
+        ref = None
+        if func != "COUNT" or distinct:
+            raise _decline(f"{func}(*)")
+    else:
+        if p.peek().kind != "id":
+            raise _decline("aggregate over an expression")
+        ref = p.colref()
+        if ref.star:
+            raise _decline("star inside an aggregate")   # COUNT(a.*), #204
+        if p.peek().kind == "punct" and p.peek().text in "+-/*=<>(":
+            raise _decline("aggregate over an expression")
+    p.expect_punct(")")
+    if p.peek().kind == "id" and not p.peek().quoted and p.peek().text.upper() in ("OVER", "FILTER"):
+        raise _decline("window aggregate / FILTER clause")
+    return func, distinct, ref
+
+
+def _parse_having(p: _Parser):
+    """``term (AND term)*`` with ``<operand> op <operand>``, an operand being a plain aggregate, a
+    column (qualified key or output name) or a literal (the reference hands HAVING to the engine
+    verbatim, intersects_duckdb.py:1336-1400; sub-queries, OR / NOT, arithmetic decline here)."""
+
+    def operand():
+        t = p.peek()
+        if p.at_punct("(") or p.at_kw("NOT", "EXISTS", "SELECT"):
+            raise _decline("parenthesised / sub-query HAVING condition")
+        if t.kind == "id" and not t.quoted and p.peek(1).kind == "punct" and p.peek(1).text == "(":
+            func, distinct, ref = _parse_aggregate_call(p, "HAVING")
+            return ("agg", SelItem(ref, None, func, distinct))
+        return _parse_operand(p)
+
+    terms = []
+    while True:
+        lhs = operand()
+        t = p.peek()
+        op = None
+        if t.kind == "punct" and t.text in "=<>!":
+            p.next()
+            op = t.text
+            n = p.peek()
+            if n.kind == "punct" and ((op == "<" and n.text in "=>") or (op == ">" and n.text == "=")
+                                      or (op == "!" and n.text == "=")):
+                p.next()
+                op += n.text
+        if op is None or op == "!":
+            raise _decline("HAVING condition other than simple comparisons")
+        op = {"<>": "!=", "==": "="}.get(op, op)
+        rhs = operand()
+        if p.peek().kind == "punct" and p.peek().text in "+-*/":
+            raise _decline("arithmetic in HAVING")
+        terms.append(("cmp", lhs, op, rhs))
+        if p.at_kw("AND"):
+            p.next()
+            continue
+        if p.at_kw("OR"):
+            raise _decline("OR in HAVING")
+        return terms
+
+
 def _parse_projection(p: _Parser) -> list[SelItem]:
     """SELECT list: qualified columns and plain aggregates ``FUNC([DISTINCT] <col>)`` / ``COUNT(*)``
     (the projections ``_resolve_projections`` can rebuild, intersects_duckdb.py:1402-1644); every
@@ -279,30 +351,7 @@ def _parse_projection(p: _Parser) -> list[SelItem]:
         func = None
         distinct = False
         if is_call:
-            func = t.text.upper()
-            if func not in AGG_FUNCS:
-                raise _decline("function call in the SELECT list")
-            p.next()
-            p.next()
-            if p.at_kw("DISTINCT"):
-                p.next()
-                distinct = True
-            if p.at_punct("*"):
-                p.next()
-                ref = None
-                if func != "COUNT" or distinct:
-                    raise _decline(f"{func}(*)")
-            else:
-                if p.peek().kind != "id":
-                    raise _decline("aggregate over an expression")
-                ref = p.colref()
-                if ref.star:
-                    raise _decline("star inside an aggregate")   # COUNT(a.*), #204
-                if p.peek().kind == "punct" and p.peek().text in "+-/*=<>(":
-                    raise _decline("aggregate over an expression")
-            p.expect_punct(")")
-            if p.peek().kind == "id" and not p.peek().quoted and p.peek().text.upper() in ("OVER", "FILTER"):
-                raise _decline("window aggregate / FILTER clause")
+            func, distinct, ref = _parse_aggregate_call(p, "the SELECT list")
             if ref is not None and func == "COUNT" and not distinct:
                 ref.count = True
         else:
@@ -851,7 +900,8 @@ def _lower(giql: str, tables, want_sql: bool):
                 continue
             break
     if p.at_kw("HAVING"):
-        raise _decline("HAVING clause")
+        p.next()
+        shape.having = _parse_having(p)
     if p.at_kw("ORDER"):
         p.next()
         p.expect_kw("BY")
@@ -864,9 +914,14 @@ def _lower(giql: str, tables, want_sql: bool):
             desc = False
             if p.peek().kind == "id" and not p.peek().quoted and p.peek().text.upper() in ("ASC", "DESC"):
                 desc = p.next().text.upper() == "DESC"
+            nulls_first = None
             if p.peek().kind == "id" and not p.peek().quoted and p.peek().text.upper() == "NULLS":
-                raise _decline("ORDER BY ... NULLS FIRST/LAST")
-            shape.order_by.append(OrderKey(ref, desc))
+                p.next()
+                t = p.next()
+                if t.kind not in ("id", "kw") or t.text.upper() not in ("FIRST", "LAST"):
+                    raise ValueError("ORDER BY ... NULLS must be followed by FIRST or LAST")
+                nulls_first = t.text.upper() == "FIRST"
+            shape.order_by.append(OrderKey(ref, desc, nulls_first))
             if p.at_punct(","):
                 p.next()
                 continue

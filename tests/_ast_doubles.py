@@ -77,8 +77,11 @@ def select(items, frm, joins, where=None, group=None, having=None, order=None, l
            distinct=False, with_=None):
     return N("select", expressions=list(items), from_=N("from", this=frm), joins=list(joins),
              where=N("where", this=where) if where is not None else None,
-             group=N("group", expressions=list(group)) if group else None, having=having,
-             order=N("order", expressions=[N("ordered", this=k, desc=d) for k, d in order]) if order else None,
+             group=N("group", expressions=list(group)) if group else None,
+             having=N("having", this=having) if having is not None else None,
+             # (key, desc) or (key, desc, nulls_first): sqlglot's parser always fills nulls_first (dialect default)
+             order=N("order", expressions=[N("ordered", this=o[0], desc=o[1], nulls_first=o[2] if len(o) > 2 else None)
+                                           for o in order]) if order else None,
              limit=N("limit", expression=lit(limit)) if limit is not None else None,
              offset=N("offset", expression=lit(offset)) if offset is not None else None,
              distinct=N("distinct") if distinct is True else distinct or None, with_=with_)

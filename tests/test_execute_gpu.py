@@ -547,3 +547,68 @@ def test_nearest_k2_and_stranded_reference_known_answers():
     with pytest.raises(ValueError, match="strands other than"):
         t["genes"] = make_table([("chr1", 100, 150, "g", 0, ".")])
         execute(transpile(q, ["peaks", "genes"], dialect="hip"), t)
+
+
+def test_having_group_without_aggregate_and_null_placement():
+    """HAVING over aggregates (in the SELECT list or hidden), GROUP BY without an aggregate, and the
+    per-key NULL placement of ORDER BY -- expected rows restated in Python from the brute-force pair list."""
+    n = 300
+
+    def tbl(seed, with_nulls):
+        r = np.random.default_rng(seed)
+        st = r.integers(0, 15_000, n)
+        rows = [(f"chr{int(c)}", int(s), int(s + l), f"n{i}", int(sc), "+-"[int(k)])
+                for i, (c, s, l, sc, k) in enumerate(zip(r.integers(1, 5, n), st, r.integers(1, 300, n),
+                                                         r.integers(0, 30, n), r.integers(0, 2, n)))]
+        t = make_table(rows)
+        if with_nulls:   # NULL scores on every seventh row
+            sc = [None if i % 7 == 0 else row[4] for i, row in enumerate(rows)]
+            t = t.set_column(t.schema.get_field_index("score"), "score", pa.array(sc, pa.int32()))
+        return t
+
+    tables = {"peaks": tbl(11, False), "genes": tbl(12, True)}
+    P, Gn = tables["peaks"].to_pylist(), tables["genes"].to_pylist()
+    pairs = [(p, g) for p in P for g in Gn if p["chrom"] == g["chrom"] and p["start"] < g["end"] and p["end"] > g["start"]]
+    assert len(pairs) > 300
+    J = "FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval"
+
+    def run(q):
+        return execute(transpile(q, ["peaks", "genes"], dialect="hip"), tables).to_pylist()
+
+    groups = {}
+    for p, g in pairs:
+        w = groups.setdefault(p["name"], [0, 0, 0])
+        w[0] += 1
+        if g["score"] is not None:
+            w[1] += g["score"]
+            w[2] += 1
+    # HAVING on a SELECT-list aggregate and on a hidden one (SUM ignores NULLs; an all-NULL group's SUM is NULL
+    # and the comparison drops it)
+    got = run(f"SELECT a.name, COUNT(*) AS n {J} GROUP BY a.name HAVING COUNT(*) >= 3 AND SUM(b.score) > 20")
+    want = sorted((k, w[0]) for k, w in groups.items() if w[0] >= 3 and w[2] > 0 and w[1] > 20)
+    assert sorted((d["name"], d["n"]) for d in got) == want and want
+    # literal on the left, a key column in HAVING
+    got = run(f"SELECT a.chrom AS c, COUNT(*) AS n {J} GROUP BY a.chrom HAVING 'chr2' <= a.chrom AND n > 1")
+    bych = {}
+    for p, _ in pairs:
+        bych[p["chrom"]] = bych.get(p["chrom"], 0) + 1
+    assert sorted((d["c"], d["n"]) for d in got) == sorted((c, k) for c, k in bych.items() if c >= "chr2" and k > 1)
+    # HAVING without GROUP BY: the whole result is one group
+    assert run(f"SELECT COUNT(*) AS n {J} HAVING COUNT(*) > 0") == [{"n": len(pairs)}]
+    assert run(f"SELECT COUNT(*) AS n {J} HAVING COUNT(*) < 0") == []
+    # GROUP BY without any aggregate = one row per key
+    got = run(f"SELECT a.chrom, b.strand {J} GROUP BY a.chrom, b.strand")
+    assert sorted((d["chrom"], d["strand"]) for d in got) == sorted({(p["chrom"], g["strand"]) for p, g in pairs})
+    # NULL placement: unwritten = NULLs are small (first ascending, last descending); written = as written, per key
+    vals = sorted({(g["score"], g["name"]) for _, g in pairs}, key=lambda t: (t[0] is not None, t[0] if t[0] is not None else 0, t[1]))
+    got = run(f"SELECT DISTINCT b.score, b.name {J} ORDER BY b.score, b.name")
+    assert [(d["score"], d["name"]) for d in got] == vals
+    got = run(f"SELECT DISTINCT b.score, b.name {J} ORDER BY b.score DESC, b.name")
+    want = sorted(vals, key=lambda t: (t[0] is None, -(t[0] or 0), t[1]))
+    assert [(d["score"], d["name"]) for d in got] == want
+    got = run(f"SELECT DISTINCT b.score, b.name {J} ORDER BY b.score NULLS LAST, b.name DESC")
+    want = sorted(sorted(vals, key=lambda t: t[1], reverse=True), key=lambda t: (t[0] is None, t[0] or 0))
+    assert [(d["score"], d["name"]) for d in got] == want
+    got = run(f"SELECT DISTINCT b.score, b.name {J} ORDER BY b.score DESC NULLS FIRST, b.name LIMIT 12")
+    want = sorted(vals, key=lambda t: (t[0] is not None, -(t[0] or 0), t[1]))[:12]
+    assert [(d["score"], d["name"]) for d in got] == want

@@ -57,7 +57,7 @@ def test_inner_join_lowers_to_the_same_plan_as_the_mirror():
     want = build_plan("SELECT a.name, b.name AS g FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score > 5 "
                       "WHERE b.strand = '+' ORDER BY a.start DESC LIMIT 3", ["peaks", "genes"])
     assert JoinPlan.from_string(payload) == want
-    assert want.order_by == (("__giql_o0", True),) and want.limit == 3 and len(want.residuals) == 2
+    assert want.order_by == (("__giql_o0", True, False),) and want.limit == 3 and len(want.residuals) == 2
 
 
 @pytest.mark.parametrize("enc", [("1based", "closed"), ("1based", "half_open"), ("0based", "closed"), ("0based", "half_open")])
@@ -132,7 +132,6 @@ def test_declined_shapes_defer_to_the_naive_predicate():
     _declined(*basic([A.col("a", "start")], on_extra=[A.N("or", this=A.cmp("gt", A.col("a", "score"), A.lit(1)),
                                                             expression=A.cmp("lt", A.col("a", "score"), A.lit(0)))]))
     _declined(*basic([A.col("a", "start")], on_extra=[A.N("paren", this=A.cmp("gt", A.col("a", "score"), A.lit(1)))]))
-    _declined(*basic([A.col("a", "start")], having=A.cmp("gt", A.agg("count"), A.lit(1)), group=[A.col("a", "start")]))
     _declined(*basic([A.col("a", "start")], distinct=A.N("distinct", on=A.N("tuple", expressions=[A.col("a", "chrom")]))))
     _declined(*basic([A.col("a", "start")], with_=A.N("with", expressions=[])))
     _declined(*basic([A.col("a", "start")], order=[(A.N("subquery", this=A.N("select", expressions=[])), False)]))
@@ -182,3 +181,29 @@ def test_fragment_parser():
     assert plugin._parse_fragment('A.chrom') == ("a", "chrom", 0)
     with pytest.raises(ValueError):
         plugin._parse_fragment('COALESCE(a."start", 0)')
+
+
+def test_having_and_null_placement_lower_like_the_mirror():
+    # HAVING COUNT(*) > 1 AND SUM(b.score) >= 2.5 (the second aggregate is not in the SELECT list), ORDER BY with the
+    # NULL placement sqlglot's parser leaves on every Ordered node (giql's dialect: NULLs are small)
+    root, it = basic([A.alias(A.col("a", "chrom"), "c"), A.alias(A.agg("count"), "n")], group=[A.col("a", "chrom")],
+                     having=A.conj(A.cmp("gt", A.agg("count"), A.lit(1)), A.cmp("gte", A.agg("sum", A.col("b", "score")), A.lit(2.5))),
+                     order=[(A.col(None, "n"), True, True), (A.col("a", "chrom"), False, True)])
+    out, ctx, calls = run(root, it, ["peaks", "genes"])
+    assert out is it and not calls
+    _tag, payload = ctx.finalizers[0](root)
+    want = build_plan("SELECT a.chrom AS c, COUNT(*) AS n FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval "
+                      "GROUP BY a.chrom HAVING COUNT(*) > 1 AND SUM(b.score) >= 2.5 ORDER BY n DESC NULLS FIRST, a.chrom",
+                      ["peaks", "genes"])
+    got = JoinPlan.from_string(payload)
+    assert got == want
+    assert [(h.lhs.value, h.op, h.rhs.value) for h in got.having] == [("n", ">", 1), ("__giql_h0", ">=", 2.5)]
+    assert got.order_by == (("n", True, True), ("c", False, True))
+    assert [a.name for a in got.aggregates] == ["n", "__giql_h0"] and got.output == ("c", "n")
+
+
+def test_having_shapes_this_target_does_not_run_decline():
+    sub = A.N("subquery", this=A.N("select"))
+    _declined(*basic([A.col("a", "chrom")], group=[A.col("a", "chrom")], having=A.cmp("gt", A.agg("sum", A.col("a", "score")), sub)))
+    _declined(*basic([A.col("a", "chrom")], group=[A.col("a", "chrom")],
+                     having=A.N("or", this=A.cmp("gt", A.agg("count"), A.lit(1)), expression=A.cmp("lt", A.agg("count"), A.lit(9)))))

@@ -22,8 +22,11 @@ def test_gate_accepts_what_the_reference_engages(case):
     for key in ("limit", "offset", "distinct"):
         if key in case:
             assert getattr(plan, key) == case[key], key
-    if "order_by" in case:
-        assert [list(o) for o in plan.order_by] == case["order_by"]
+    if "order_by" in case:   # [name, descending] or [name, descending, NULLs first]
+        assert [list(o)[:len(w)] for o, w in zip(plan.order_by, case["order_by"])] == case["order_by"]
+        assert len(plan.order_by) == len(case["order_by"])
+    if "having" in case:
+        assert [[h.lhs.value, h.op, h.rhs.value] for h in plan.having] == case["having"]
     if "group_by" in case:
         assert list(plan.group_by) == case["group_by"]
     if "aggregates" in case:
@@ -47,7 +50,7 @@ def test_hidden_order_column_rides_along_and_is_marked():
     plan = build_plan("SELECT a.start AS s FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval ORDER BY b.score DESC",
                       ["peaks", "genes"])
     assert [(p.side, p.column, p.name) for p in plan.projection] == [("l", "start", "s"), ("r", "score", "__giql_o0")]
-    assert plan.order_by == (("__giql_o0", True),)
+    assert plan.order_by == (("__giql_o0", True, False),)   # DESC: NULLs last unless the query says otherwise
 
 
 def test_using_must_name_both_chromosome_columns():

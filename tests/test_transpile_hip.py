@@ -102,7 +102,10 @@ def test_case_insensitive_aliases():
     "SELECT a.start FROM peaks a JOIN genes b ON a.score > 5",
     "SELECT a.start + 1 FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
     "SELECT a.start FROM peaks a JOIN genes b USING (chrom)",                      # USING without any INTERSECTS
-    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval HAVING COUNT(*) > 1",
+    "SELECT a.chrom FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom "
+    "HAVING COUNT(*) > 1 OR COUNT(*) < 9",
+    "SELECT a.chrom FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom "
+    "HAVING SUM(a.score) > (SELECT AVG(score) FROM peaks)",
     "SELECT a.start FROM peaks a SEMI JOIN genes b ON TRUE WHERE a.interval INTERSECTS b.interval",
     "SELECT a.start FROM peaks a, genes b, exons c WHERE a.interval INTERSECTS b.interval",
     "WITH x AS (SELECT 1) SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
