@@ -144,3 +144,38 @@ def test_skewed_reads_hot_windows_take_the_big_bucket_path(monkeypatch):
         assert np.array_equal(e.count_overlaps(dev(a), dev(b), 24).cpu().numpy(), ora.c_count(a, b, "sweep"))
     finally:
         e.close()
+
+
+def test_config4_sized_join_with_variable_length_reads_both_argument_orders(monkeypatch):
+    """10M x 100M rows with VARIABLE read lengths (no fixed-length shortcut applies): the general two-class
+    form at the headline size -- the larger side's three-array sort from its raw columns through the
+    three-stage sort, class 1 over 100M rows, the plan exchanging the sides when the larger table comes
+    first.  Pair count and the order-independent 64-bit multiset checksum of all ~4.5e8 pairs against the
+    oracle's sort-merge, for both argument orders, twice each (the second call runs on the context's guesses)."""
+    r = np.random.default_rng(606)
+    ac, as_, ae = synth.make_table(10_000_000, 5, "peaks")
+    bc, bs, be = synth.make_table(100_000_000, 6, "reads")
+    be = (be + r.integers(0, 60, be.shape[0])).astype(np.int32)       # lengths 150..209
+    a, b = ora.Side(ac, as_, ae), ora.Side(bc, bs, be)
+    wa, wb = ora.c_inner(a, b, "sweep")
+    n_want = int(wa.shape[0])
+    want_sum = ora.c_pairs_checksum(wa, wb)
+    want_swapped = ora.c_pairs_checksum(wb, wa)
+    del wa, wb
+    assert 4.0e8 < n_want < 5.5e8
+    e = _engine(monkeypatch)
+    try:
+        da, db = dev(a), dev(b)
+        for it in range(2):
+            ra, rb = e.inner_join(da, db, 24)
+            st = e.stats()
+            assert st["join_form"] == "general" and st["sort_local"] and not st["swapped"] and st["span_hist"]
+            assert int(ra.shape[0]) == n_want and e.pairs_checksum(ra, rb) == want_sum, it
+            del ra, rb
+            rb2, ra2 = e.inner_join(db, da, 24)     # the larger table first
+            st = e.stats()
+            assert st["join_form"] == "general" and st["swapped"] and st["n_a"] == 100_000_000
+            assert int(ra2.shape[0]) == n_want and e.pairs_checksum(rb2, ra2) == want_swapped, it
+            del ra2, rb2
+    finally:
+        e.close()
