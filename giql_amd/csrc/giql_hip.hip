@@ -153,7 +153,8 @@ struct giql_hip_ctx {
   bool overlap_large = true;  // GIQL_HIP_OVERLAP_LARGE=0: the small side's chain runs beside the other side's only when that is small too
   int overlap_mask = 3;  // GIQL_HIP_OVERLAP_MASK: 1 = the sides' sort chains, 2 = the two count classes
   int row_skip_digits = -1;    // GIQL_HIP_ROW_SKIP_DIGITS: low digits the per-row operators leave unsorted on their query side (-1: by density, row_skip())
-  u64 row_last_span = 0;       // linearised span of the last per-row call (the density guess of row_skip())
+  u64 last_span = 0;           // linearised span of the context's last call: the density guess of row_skip() / sort_is_local()
+  double local_max_bucket_rows = 2800.0;  // three-stage sort only while a 16-bit bucket holds at most this many rows on average
   bool no_skip_digit = false;  // GIQL_HIP_NO_SKIP_DIGIT=1: query sides are sorted on every digit
   bool local_sort = true;
   u64 local_min_rows = 1u << 25;
@@ -441,7 +442,14 @@ static void launch_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, int
 // 16-23 and 24-31 only, then every 16-bit bucket sorted on its low bits inside LDS, in place
 // (bucket_sort.hip.h) -- three trips through HBM instead of four.
 static inline bool sort_is_local(const giql_hip_ctx* ctx, size_t n) {
-  return ctx->local_sort && ctx->bucket_bnd && ctx->os_variant == 0 && n >= ctx->local_min_rows;
+  if (!(ctx->local_sort && ctx->bucket_bnd && ctx->os_variant == 0 && n >= ctx->local_min_rows)) return false;
+  // The in-LDS stage holds 4096 rows per bucket; larger buckets go through a slow queue (one block each, two
+  // more passes: 30M x 300M reads, ~6000 rows per bucket, spent 10.4 of 21 ms there).  So the form is taken
+  // only while the AVERAGE bucket is comfortably below that -- by the span of the context's previous call
+  // (a human-genome-sized axis until one has run); denser tables take the four global passes.  The value is
+  // constant during a call (updated when it ends), so every decision of one call agrees.
+  const double span = ctx->last_span ? (double)ctx->last_span : 3.2e9;
+  return (double)n * 65536.0 / span <= ctx->local_max_bucket_rows;
 }
 
 // skip_digits = 1 (four-pass form only): the lowest digit is left unsorted -- rows come out ordered
@@ -626,8 +634,8 @@ static void sort_sizes(Carver& c, size_t n, SortBufs& sb, bool payload) {
 // density comes from the span of the context's previous per-row call: a guess that only ever costs speed.
 static inline int row_skip(const giql_hip_ctx* ctx, size_t nb) {
   if (ctx->row_skip_digits >= 0) return ctx->row_skip_digits;
-  if (ctx->row_last_span == 0) return 1;
-  return (double)nb * 65536.0 / (double)ctx->row_last_span <= 1024.0 ? 2 : 1;
+  if (ctx->last_span == 0) return 1;
+  return (double)nb * 65536.0 / (double)ctx->last_span <= 1024.0 ? 2 : 1;
 }
 
 // Fork / join of the context's second stream.  A side of a few million rows is a chain of ~10 launches
@@ -778,7 +786,12 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     const char* nl = getenv("GIQL_HIP_NO_LOCAL_SORT");
     if (nl && atoi(nl) != 0) ctx->local_sort = false;
     const char* lm = getenv("GIQL_HIP_LOCAL_MIN_ROWS");
-    if (lm) ctx->local_min_rows = strtoull(lm, nullptr, 10);
+    if (lm) {
+      ctx->local_min_rows = strtoull(lm, nullptr, 10);
+      ctx->local_max_bucket_rows = 1e30;  // a forced size threshold (tests, sweeps) is not second-guessed by density
+    }
+    const char* lmb = getenv("GIQL_HIP_LOCAL_MAX_BUCKET_ROWS");
+    if (lmb && atof(lmb) > 0) ctx->local_max_bucket_rows = atof(lmb);
   }
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   {
@@ -1205,6 +1218,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   ctx->stats.n_irregular_a = ctx->h_meta->irr_a;
   ctx->stats.n_irregular_b = ctx->h_meta->irr_b;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
+  ctx->last_span = ctx->h_meta->total_span;
   ctx->last_no_irr = ctx->h_meta->irr_a + ctx->h_meta->irr_b == 0;
 
   if (ctx->h_meta->irr_a + ctx->h_meta->irr_b > 0) {
@@ -1513,7 +1527,7 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   *n_out = (int64_t)ctx->h_meta->n_out;
   ctx->stats.n_out = *n_out;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
-  ctx->row_last_span = ctx->h_meta->total_span;
+  ctx->last_span = ctx->h_meta->total_span;
   return GIQL_OK;
 }
 
@@ -1612,7 +1626,7 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
   collect_spans(ctx);
   ctx->stats.n_out = a->n;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
-  ctx->row_last_span = ctx->h_meta->total_span;
+  ctx->last_span = ctx->h_meta->total_span;
   return GIQL_OK;
 }
 
@@ -1718,7 +1732,7 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
   collect_spans(ctx);
   ctx->stats.n_out = a->n;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
-  ctx->row_last_span = ctx->h_meta->total_span;
+  ctx->last_span = ctx->h_meta->total_span;
   return GIQL_OK;
 }
 
@@ -1822,7 +1836,7 @@ static int giql_hip_nearest_k_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   collect_spans(ctx);
   ctx->stats.n_out = a->n * (int64_t)k;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
-  ctx->row_last_span = ctx->h_meta->total_span;
+  ctx->last_span = ctx->h_meta->total_span;
   return GIQL_OK;
 }
 

@@ -179,3 +179,26 @@ def test_config4_sized_join_with_variable_length_reads_both_argument_orders(monk
             del ra2, rb2
     finally:
         e.close()
+
+
+def test_dense_table_leaves_the_three_stage_sort_once_its_span_is_known(monkeypatch):
+    """40M rows on a 2e8-position axis = ~13,000 rows per 16-bit bucket, three times what the in-LDS stage
+    holds: a fresh context (which assumes a genome-sized axis) sorts it in three stages through the
+    big-bucket queue, the next call -- the span now known -- takes the four global passes.  Same rows out."""
+    r = np.random.default_rng(99)
+    nb, na = 40_000_000, 200_000
+    sb = r.integers(0, 200_000_000, nb).astype(np.int32)
+    b = ora.Side(np.zeros(nb, np.int32), sb, (sb + 100).astype(np.int32))
+    sa = r.integers(0, 200_000_000, na).astype(np.int32)
+    a = ora.Side(np.zeros(na, np.int32), sa, (sa + r.integers(1, 500, na)).astype(np.int32))
+    want = ora.c_count(a, b, "sweep")
+    e = _engine(monkeypatch)
+    try:
+        da, db = dev(a), dev(b)
+        got1 = e.count_overlaps(da, db, 1).cpu().numpy()
+        first_local = e.stats()["sort_local"]
+        got2 = e.count_overlaps(da, db, 1).cpu().numpy()
+        assert first_local and not e.stats()["sort_local"] and not e.stats()["sort_resorted"]
+        assert np.array_equal(got1, want) and np.array_equal(got2, want)
+    finally:
+        e.close()
