@@ -1111,9 +1111,20 @@ def test_inner_larger_side_first_is_planned_swapped(form):
     n = eng.inner_join_into(da, db, 5, out_a, out_b)
     assert n == want.shape[0]
     assert np.array_equal(ora.sort_pairs(out_a[:n].cpu().numpy(), out_b[:n].cpu().numpy()), want)
-    if form == "uniform":  # the exported plan names the caller's sides
+    if form == "uniform":  # the exported plan names the caller's sides, row ids and offsets included
+        n = eng.inner_plan(da, db, 5)
         q_is_a, n_q, n_s = eng.plan_sizes()
         assert (q_is_a, n_q, n_s) == (False, 7_000, 90_000)
+        i32 = dict(dtype=torch.int32, device="cuda")
+        q_rid, lo, cnt, s_rid = (torch.empty(n_q, **i32), torch.empty(n_q, **i32), torch.empty(n_q, **i32),
+                                 torch.empty(n_s, **i32))
+        eng.plan_export(q_rid, lo, cnt, s_rid, rid_add_a=1000, rid_add_b=50)   # global ids = local + shard base
+        assert int(q_rid.min()) >= 50 and int(q_rid.max()) < 50 + 7_000           # the query side is the caller's B
+        assert int(s_rid.min()) >= 1000 and int(s_rid.max()) < 1000 + 90_000
+        rq, rs = torch.empty(n, **i32), torch.empty(n, **i32)
+        assert eng.fill_from_plan(q_rid, lo, cnt, s_rid, rq, rs, n_pairs_expected=n) == n
+        got = ora.sort_pairs((rs - 1000).cpu().numpy(), (rq - 50).cpu().numpy())   # (row_a, row_b) in the caller's labels
+        assert np.array_equal(got, want)
     eng.close()
 
 
