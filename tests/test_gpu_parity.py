@@ -1174,3 +1174,26 @@ def test_general_form_sorts_larger_side_from_raw_columns(local_sort, monkeypatch
     ra, rb = eng.inner_join(da, DeviceSide.from_numpy(b.chrom, b.start, b.end), 7)
     assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), want)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_host_buffer_entry_with_the_larger_table_first():
+    """giql_hip_inner (host columns in, pinned host pairs out) plans an (80K, 6K) call with the sides
+    exchanged like the device entry points; the pairs come back in the caller's labels."""
+    from giql_amd.engine import HipEngine
+
+    r = np.random.default_rng(31)
+
+    def side(n):
+        ch = r.integers(0, 4, n).astype(np.int32)
+        st = r.integers(0, 2_000_000, n).astype(np.int32)
+        return ora.Side(ch, st, st + r.integers(1, 900, n).astype(np.int32))
+
+    a, b = side(80_000), side(6_000)
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    eng = HipEngine(0)
+    for _ in range(2):
+        ra, rb = eng.inner_join_host((a.chrom, a.start, a.end), (b.chrom, b.start, b.end), 4)
+        assert eng.stats()["swapped"]
+        assert np.array_equal(ora.sort_pairs(ra, rb), want)
+    eng.close()
