@@ -715,6 +715,7 @@ static int row_form_guess(giql_hip_ctx* ctx, hipStream_t st, i64& uni_len, bool&
   }
   GIQL_TRY(read_meta(ctx, st));
   uni_len = uniform_len_b(*ctx->h_meta);
+  ctx->last_span = ctx->h_meta->total_span;  // known before anything is sorted: the sort form follows the real density
   return GIQL_OK;
 }
 
@@ -1008,6 +1009,14 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
       GIQL_TRY(read_meta(ctx, st));
       decide(*ctx->h_meta, S.uniform, uni_len);
       aligned = want_hist && ctx->h_meta->aligned_ok != 0;
+      // the span is known now, before anything is sorted: the sort form follows the table's real density
+      // already on this first plan.  The span pass counted its digits for the form it expected: if the
+      // larger side leaves the three-stage sort, its high-digits-only histogram is of no use and that side
+      // is linearized (which counts all four digits)
+      const size_t n_big = big_side ? nb : na;
+      const bool expected_local = sort_is_local(ctx, n_big);
+      ctx->last_span = ctx->h_meta->total_span;
+      if (expected_local && !sort_is_local(ctx, n_big)) aligned = false;
     }
   }
   const bool keygen = aligned && S.uniform == (big_side ? 1 : 2);

@@ -183,8 +183,9 @@ def test_config4_sized_join_with_variable_length_reads_both_argument_orders(monk
 
 def test_dense_table_leaves_the_three_stage_sort_once_its_span_is_known(monkeypatch):
     """40M rows on a 2e8-position axis = ~13,000 rows per 16-bit bucket, three times what the in-LDS stage
-    holds: a fresh context (which assumes a genome-sized axis) sorts it in three stages through the
-    big-bucket queue, the next call -- the span now known -- takes the four global passes.  Same rows out."""
+    holds: the span is read back before anything is sorted on a context's first call, so already that call
+    takes the four global passes (as does every later one, on the remembered span).  A context forced
+    into the three-stage sort goes through the big-bucket queue instead.  Same rows out of all of them."""
     r = np.random.default_rng(99)
     nb, na = 40_000_000, 200_000
     sb = r.integers(0, 200_000_000, nb).astype(np.int32)
@@ -198,7 +199,17 @@ def test_dense_table_leaves_the_three_stage_sort_once_its_span_is_known(monkeypa
         got1 = e.count_overlaps(da, db, 1).cpu().numpy()
         first_local = e.stats()["sort_local"]
         got2 = e.count_overlaps(da, db, 1).cpu().numpy()
-        assert first_local and not e.stats()["sort_local"] and not e.stats()["sort_resorted"]
+        assert not first_local and not e.stats()["sort_local"] and not e.stats()["sort_resorted"]
         assert np.array_equal(got1, want) and np.array_equal(got2, want)
+        # the INNER plan: first call (span read back mid-plan, the span pass's histogram dropped), then speculated
+        for it in range(2):
+            n = e.inner_plan(da, db, 1)
+            assert n == int(want.sum()) and not e.stats()["sort_local"], it
     finally:
         e.close()
+    f = _engine(monkeypatch, GIQL_HIP_LOCAL_MAX_BUCKET_ROWS="1e9")
+    try:
+        got3 = f.count_overlaps(dev(a), dev(b), 1).cpu().numpy()
+        assert f.stats()["sort_local"] and np.array_equal(got3, want)
+    finally:
+        f.close()
