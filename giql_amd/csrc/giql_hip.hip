@@ -5,6 +5,8 @@
 // is in the *.hip.h kernels.  gfx950 only; there is no CPU fallback: without a
 // HIP device every entry point fails with GIQL_ERR_HIP.
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -107,6 +109,8 @@ struct giql_hip_ctx {
   DevMeta* d_meta = nullptr;
   DevMeta* h_meta = nullptr;  // pinned
   u32* part = nullptr;        // fill partition (grown on demand)
+  void* stage_out = nullptr;  // device staging of the host-buffer entry points' outputs (grown on demand)
+  size_t stage_out_cap = 0;
   size_t part_cap = 0;
   u64* d_scratch64 = nullptr;  // small device scratch (checksum)
 
@@ -835,6 +839,7 @@ int giql_hip_destroy(giql_hip_ctx* ctx) {
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->part) (void)hipFree(ctx->part);
+  if (ctx->stage_out) (void)hipFree(ctx->stage_out);
   if (ctx->d_meta) (void)hipFree(ctx->d_meta);
   if (ctx->d_scratch64) (void)hipFree(ctx->d_scratch64);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -2596,12 +2601,74 @@ static int upload_side(const giql_side* h, DevSide& d) {
   return GIQL_OK;
 }
 
-// pinned host memory for library-owned outputs (released by giql_hip_free_host)
-static void* host_alloc(size_t bytes) {
-  void* p = nullptr;
-  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-  return p;
+// Pinned host memory for library-owned outputs (released by giql_hip_free_host).  Page-locking is the
+// expensive part of the PCIe-inclusive calls -- 3.2 GB of pairs: 203 ms to pin, 57 ms to copy
+// (GIQL_HIP_DEBUG_E2E=1) -- so released buffers are kept for the next call: a small process-wide pool,
+// best fit, at most GIQL_HIP_HOST_POOL_MB (default 8192; 0 = none) of idle memory.
+struct HostPool {
+  struct Buf {
+    void* p;
+    size_t bytes;
+    bool idle;
+  };
+  std::mutex mu;
+  std::vector<Buf> bufs;
+  size_t idle_limit;
+  HostPool() {
+    const char* e = getenv("GIQL_HIP_HOST_POOL_MB");
+    idle_limit = (size_t)(e ? strtoull(e, nullptr, 10) : 8192ull) << 20;
+  }
+  void* get(size_t bytes) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      Buf* best = nullptr;
+      for (auto& b : bufs)
+        if (b.idle && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+      if (best && best->bytes <= 2 * bytes + (1u << 20)) {  // not a 3 GB buffer for a 4-byte result
+        best->idle = false;
+        return best->p;
+      }
+    }
+    void* p = nullptr;
+    const size_t cap = bytes + bytes / 16;  // a little head-room: the next result of a similar call fits too
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    bufs.push_back({p, cap, false});
+    return p;
+  }
+  void put(void* p) {
+    std::vector<void*> drop;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      bool known = false;
+      for (auto& b : bufs)
+        if (b.p == p) {
+          b.idle = true;
+          known = true;
+        }
+      if (!known) drop.push_back(p);
+      // over the limit: release the smallest idle buffers first (the big ones are the ones worth keeping)
+      size_t idle = 0;
+      for (auto& b : bufs)
+        if (b.idle) idle += b.bytes;
+      while (idle > idle_limit) {
+        size_t k = bufs.size();
+        for (size_t i = 0; i < bufs.size(); i++)
+          if (bufs[i].idle && (k == bufs.size() || bufs[i].bytes < bufs[k].bytes)) k = i;
+        if (k == bufs.size()) break;
+        idle -= bufs[k].bytes;
+        drop.push_back(bufs[k].p);
+        bufs.erase(bufs.begin() + (long)k);
+      }
+    }
+    for (void* d : drop) (void)hipHostFree(d);
+  }
+};
+static HostPool& host_pool() {
+  static HostPool* pool = new HostPool();  // never destroyed: no HIP calls at process exit
+  return *pool;
 }
+static void* host_alloc(size_t bytes) { return host_pool().get(bytes ? bytes : 1); }
 
 struct DevBuf {
   void* p = nullptr;
@@ -2617,11 +2684,22 @@ int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, in
   GIQL_TRY(check_side(b, "b"));
   HIP_TRY(hipSetDevice(ctx->device));
   *row_a = *row_b = nullptr;
+  // GIQL_HIP_DEBUG_E2E=1: where the PCIe-inclusive call spends its wall time (stderr)
+  const bool dbg = getenv("GIQL_HIP_DEBUG_E2E") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(now() - t).count();
+  };
+  auto t0 = now();
   DevSide da, db;
   GIQL_TRY(upload_side(a, da));
   GIQL_TRY(upload_side(b, db));
+  const double ms_h2d = ms_since(t0);
+  t0 = now();
   int64_t n = 0;
   GIQL_TRY(giql_hip_inner_plan_dev(ctx, &da.s, &db.s, n_chrom, nullptr, &n));
+  const double ms_plan = ms_since(t0);
+  t0 = now();
   *n_pairs = n;
   // library-owned host outputs are PINNED (the D2H copy of the pairs runs at link speed, not
   // through a pageable bounce buffer); giql_hip_free_host releases them
@@ -2632,17 +2710,34 @@ int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, in
     giql_hip_free_host(hb);
     return set_err(GIQL_ERR_NOMEM, "out of host memory for %lld pairs", (long long)n);
   }
+  const double ms_pin = ms_since(t0);
+  t0 = now();
+  double ms_fill = 0, ms_d2h = 0;
   if (n > 0) {
-    DevBuf out;
     // row_b starts on a 2 MiB boundary of its own: a row that begins in the middle of a cache
     // line makes every 256-byte wave store of the fill touch three lines instead of two
     const size_t stride = align_up((size_t)n, (size_t)1 << 19);
-    hipError_t e = hipMalloc(&out.p, 2 * stride * sizeof(int32_t));
+    // the device staging of the pairs is kept by the context (a fresh 3.2 GB hipMalloc costs ~160 ms)
+    const size_t need = 2 * stride * sizeof(int32_t);
     int rc = GIQL_OK;
-    if (e != hipSuccess) rc = set_err(GIQL_ERR_NOMEM, "hipMalloc for %lld pairs failed", (long long)n);
-    int32_t* d_a = (int32_t*)out.p;
+    if (need > ctx->stage_out_cap) {
+      if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+      ctx->stage_out = nullptr;
+      ctx->stage_out_cap = 0;
+      const size_t want = need + need / 16;
+      if (hipMalloc(&ctx->stage_out, want) != hipSuccess)
+        rc = set_err(GIQL_ERR_NOMEM, "hipMalloc for %lld pairs failed", (long long)n);
+      else
+        ctx->stage_out_cap = want;
+    }
+    int32_t* d_a = (int32_t*)ctx->stage_out;
     int32_t* d_b = d_a + stride;
     if (rc == GIQL_OK) rc = giql_hip_inner_fill_dev(ctx, d_a, d_b, n, nullptr);
+    if (dbg) {
+      (void)hipDeviceSynchronize();
+      ms_fill = ms_since(t0);
+      t0 = now();
+    }
     if (rc == GIQL_OK && hipMemcpy(ha, d_a, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
       rc = set_err(GIQL_ERR_HIP, "D2H copy of row_a failed");
     if (rc == GIQL_OK && hipMemcpy(hb, d_b, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess)
@@ -2653,6 +2748,10 @@ int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, in
       return rc;
     }
   }
+  ms_d2h = ms_since(t0);
+  if (dbg)
+    fprintf(stderr, "[giql_hip_inner] H2D %.1f ms, plan %.1f, pinned alloc %.1f, output alloc + fill %.1f, D2H %.1f (%lld pairs)\n",
+            ms_h2d, ms_plan, ms_pin, ms_fill, ms_d2h, (long long)n);
   *row_a = ha;
   *row_b = hb;
   return GIQL_OK;
@@ -2724,7 +2823,7 @@ int giql_hip_nearest(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, 
 }
 
 void giql_hip_free_host(void* p) {
-  if (p) (void)hipHostFree(p);
+  if (p) host_pool().put(p);
 }
 
 #if defined(GIQL_OS_TIMELINE)

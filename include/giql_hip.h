@@ -37,7 +37,10 @@
  *     = the default stream); results stay on the device.  The host-buffer entry
  *     points stage H2D/D2H themselves and return PINNED host arrays
  *     (hipHostMalloc: the D2H copy runs at link speed) that the caller releases
- *     with giql_hip_free_host() -- not with free().
+ *     with giql_hip_free_host() -- not with free().  Page-locking costs more than the
+ *     copy (3.2 GB: ~200 ms against ~60 ms), so released arrays are kept in a small
+ *     process-wide pool for the next call (GIQL_HIP_HOST_POOL_MB of idle memory at most,
+ *     default 8192; 0 = release at once).
  *   - caller-owned DEVICE outputs (row_a / row_b of the fill) should start on a
  *     128-byte boundary each: the fill stores 256 bytes per wave instruction, and a
  *     row that begins inside a cache line makes every store touch three lines

@@ -1197,3 +1197,46 @@ def test_host_buffer_entry_with_the_larger_table_first():
         assert eng.stats()["swapped"]
         assert np.array_equal(ora.sort_pairs(ra, rb), want)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_host_outputs_come_from_a_pool_and_stay_valid_until_released(monkeypatch):
+    """Library-owned pinned outputs: a released array is handed out again by the next call of a similar
+    size (page-locking costs more than the copy), two results alive at once never share memory, and
+    GIQL_HIP_HOST_POOL_MB=0 turns the reuse off."""
+    import ctypes
+
+    from giql_amd import _lib
+    from giql_amd.engine import HipEngine
+
+    r = np.random.default_rng(8)
+    ch = r.integers(0, 3, 50_000).astype(np.int32)
+    st = r.integers(0, 1_000_000, 50_000).astype(np.int32)
+    en = (st + r.integers(1, 600, 50_000)).astype(np.int32)
+    eng = HipEngine(0)
+    L = eng._L
+
+    def call():
+        ca = _lib.CSide(ch.ctypes.data, st.ctypes.data, en.ctypes.data, 20_000, 0, 0)
+        cb = _lib.CSide(ch[20_000:].ctypes.data, st[20_000:].ctypes.data, en[20_000:].ctypes.data, 30_000, 0, 0)
+        n, pa_, pb_ = ctypes.c_int64(0), ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(L.giql_hip_inner(eng._h, ctypes.byref(ca), ctypes.byref(cb), 3, ctypes.byref(n), ctypes.byref(pa_), ctypes.byref(pb_)))
+        return n.value, pa_.value, pb_.value
+
+    def pairs(n, pa_, pb_):
+        view = lambda p: np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_int32)), shape=(n,)).copy()
+        return ora.sort_pairs(view(pa_), view(pb_))
+
+    want = ora.sort_pairs(*ora.c_inner(ora.Side(ch[:20_000], st[:20_000], en[:20_000]),
+                                       ora.Side(ch[20_000:], st[20_000:], en[20_000:]), "sweep"))
+    n1, a1, b1 = call()
+    n2, a2, b2 = call()                      # the first result is still alive: four distinct arrays
+    assert len({a1, b1, a2, b2}) == 4
+    assert np.array_equal(pairs(n1, a1, b1), want) and np.array_equal(pairs(n2, a2, b2), want)
+    for p in (a1, b1, a2, b2):
+        L.giql_hip_free_host(ctypes.c_void_p(p))
+    n3, a3, b3 = call()                      # released arrays are handed out again
+    assert {a3, b3} <= {a1, b1, a2, b2} and np.array_equal(pairs(n3, a3, b3), want)
+    L.giql_hip_free_host(ctypes.c_void_p(a3))
+    L.giql_hip_free_host(ctypes.c_void_p(b3))
+    eng.close()
