@@ -28,7 +28,9 @@
  * Conventions
  *   - C linkage, plain pointers and sizes, no C++ / torch types.
  *   - Every entry returns an int status: 0 = ok, < 0 = error; the message is
- *     available from giql_hip_last_error() (thread-local).
+ *     available from giql_hip_last_error() (thread-local).  A context belongs to one thread at
+ *     a time; different contexts may run on different threads and streams at once (the
+ *     pinned-output pool is the only shared state, and it is locked).
  *   - Column buffers are BORROWED Arrow int32 data buffers (validity must be
  *     all-valid, offset already applied); the library never writes or frees them.
  *   - chrom is a dictionary id in [0, n_chrom) from a dictionary SHARED by both

@@ -1240,3 +1240,56 @@ def test_host_outputs_come_from_a_pool_and_stay_valid_until_released(monkeypatch
     L.giql_hip_free_host(ctypes.c_void_p(a3))
     L.giql_hip_free_host(ctypes.c_void_p(b3))
     eng.close()
+
+
+@pytest.mark.gpu
+def test_two_contexts_on_two_threads():
+    """One context per thread (a context is not shared between threads; the error string is thread-local,
+    the pinned-output pool is locked): two threads joining different tables at the same time, device and
+    host-buffer entry points alike, each get their own oracle's answer."""
+    import threading
+
+    import torch
+
+    from giql_amd.engine import DeviceSide, HipEngine
+
+    def tables(seed, fixed):
+        r = np.random.default_rng(seed)
+
+        def side(n, f):
+            ch = r.integers(0, 5, n).astype(np.int32)
+            st = r.integers(0, 5_000_000, n).astype(np.int32)
+            ln = np.full(n, 90, np.int32) if f else r.integers(1, 1500, n).astype(np.int32)
+            return ora.Side(ch, st, st + ln)
+
+        return side(30_000, False), side(200_000, fixed)
+
+    errors = []
+
+    def worker(seed, fixed):
+        try:
+            a, b = tables(seed, fixed)
+            want = ora.sort_pairs(*ora.c_inner(a, b, "sweep", threads=1))
+            want_cnt = ora.c_count(a, b, "sweep", threads=1)
+            eng = HipEngine(0)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                da = DeviceSide.from_numpy(a.chrom, a.start, a.end)
+                db = DeviceSide.from_numpy(b.chrom, b.start, b.end)
+                for _ in range(6):
+                    ra, rb = eng.inner_join(da, db, 5)
+                    stream.synchronize()
+                    assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), want)
+                    assert np.array_equal(eng.count_overlaps(da, db, 5).cpu().numpy(), want_cnt)
+                    ha, hb = eng.inner_join_host((a.chrom, a.start, a.end), (b.chrom, b.start, b.end), 5)
+                    assert np.array_equal(ora.sort_pairs(ha, hb), want)
+            eng.close()
+        except BaseException as exc:  # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(exc))
+
+    ts = [threading.Thread(target=worker, args=(s, f)) for s, f in ((101, True), (202, False))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
