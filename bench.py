@@ -873,7 +873,7 @@ def run_rowop(args):
             dist.destroy_process_group()
             eng.close()
             return None
-        if not args.no_cpu_baseline:
+        if args.verify:
             # the global tables the gathered result refers to: the ranks' shards, rank after rank
             parts = [make_inputs(wl, cs) for cs in rank_chroms]
             ha = tuple(np.concatenate([p[1][k] for p in parts]) for k in range(3))
@@ -904,7 +904,8 @@ def run_rowop(args):
         roofline.update({"kernel": f"whole operator (dominant phase: {dom})", "achieved": w["achieved"], "frac": w["frac"]})
 
     cpu_baseline = None
-    if not args.no_cpu_baseline:
+    # the CPU leg: at N = 1 (the contract); at N > 1 only to verify the gathered result (--verify)
+    if (not args.no_cpu_baseline and not distributed) or (distributed and args.verify):
         from oracle import pyoracle as ora
 
         oa, ob = ora.Side(*ha), ora.Side(*hb)

@@ -7,7 +7,7 @@ RANKS="${*:-2 3}"
 mkdir -p gpurun_out
 for wl in cfg3_semi_1Mx10M_24chrom cfg3_anti_1Mx10M_24chrom cfg3_count_1Mx10M_24chrom cfg5_nearest_10Mx10M_24chrom; do
   for n in $RANKS; do
-    timeout -k 10 400 python3 bench.py --workload "$wl" --gpus "$n" --backend gloo --steps 3 --warmup 1 \
+    timeout -k 10 400 python3 bench.py --workload "$wl" --gpus "$n" --backend gloo --steps 3 --warmup 1 --verify \
       > "gpurun_out/${TAG}_${wl}_g${n}.json.log" 2> "gpurun_out/${TAG}_${wl}_g${n}.err"
     echo "$wl g$n rc=$?"
     python3 - "gpurun_out/${TAG}_${wl}_g${n}.json.log" <<'PY'
