@@ -55,6 +55,91 @@ __global__ __launch_bounds__(256) void k_bucket_bounds(const u32* __restrict__ k
   bnd[v] = lower_bound_u32(keys, lo < n ? lo : n, hi < n ? hi : n, v << 16);
 }
 
+// ---- the range count of the fixed-length INNER form, fused into the bucket sort (round 3) ----
+// In that form (giql_hip.hip, inner_plan_core) every query row q matches the rows of the sorted side U
+// whose key lies in [q.key + lo_off, q.end): two lower bounds per query over U's sorted keys.  The block
+// that sorts bucket v HAS the bucket's keys in LDS -- as the scanned bin table of bucket_sort_body, from
+// which the rank of any 16-bit value is ONE cell read -- so it answers every bound that falls into its
+// bucket and U's sorted keys never go back to HBM (only the row ids do): the count kernel, its read of
+// the 100M keys and their write disappear.  The queries whose lower bound (q.key + lo_off) or upper bound
+// (q.end <= q.key + len_max_q) can fall into bucket v = [K0, K1) have q.key in [K0 - len_max_q, K1 - lo_off):
+// a contiguous window of the start-sorted queries, found per bucket by k_bucket_bounds_fused.  Every
+// regular query gets its `lo` from exactly one block and its `hi` from exactly one block.
+constexpr u32 BS_FUSE_WCAP = 1u << 15;  // longest query the windows allow for (the host takes the fused form only below it)
+struct BsFuse {
+  const u32* qkey;   // the query side's sorted keys (ordered at least by key & key_mask) ...
+  const u32* qend;   // ... and end keys
+  u32* qwin;         // [2 * BS_BUCKETS] {first, past-last} sorted query row whose bounds may fall into bucket v
+  u32* lo_out;       // per sorted query row: first matching sorted U row ...
+  u32* hi_out;       // ... and one past the last
+  i64 lo_off;
+};
+
+__device__ __forceinline__ u32 bs_shift_key(u32 k, i64 off) {  // = shift_key of join_kernels.hip.h
+  const i64 x = (i64)k + off;
+  return x < 0 ? 0u : (x > (i64)U32_MAX ? U32_MAX : (u32)x);
+}
+
+// k_bucket_bounds + the query windows of the fused count, one thread per value: threads [0, 65536] the
+// bucket boundaries, the next 65536 the windows' first rows, the last 65536 their ends.  gbq3 = the query
+// sort's own top-digit offsets (they narrow each search to 1/256 of the rows); key_mask as in
+// k_count_partition (a query side sorted without its lowest digit is ordered by key & 0xFFFFFF00 only).
+__global__ __launch_bounds__(256) void k_bucket_bounds_fused(const u32* __restrict__ keys, u32 n,
+                                                              const u32* __restrict__ gb3,
+                                                              u32* __restrict__ bnd, u32* __restrict__ big_list,
+                                                              BsFuse fq, u32 nq_total,
+                                                              const u32* __restrict__ irr_q,
+                                                              const u32* __restrict__ gbq3, u32 key_mask,
+                                                              const int* __restrict__ len_max_q) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (t == 0) big_list[0] = 0;  // the queue of buckets too large for LDS starts empty
+  if (t <= BS_BUCKETS) {
+    if (t == BS_BUCKETS) {
+      bnd[t] = n;
+      return;
+    }
+    const u32 d3 = t >> 8;
+    const u32 lo = gb3[d3];
+    const u32 hi = d3 == 255u ? n : gb3[d3 + 1];
+    bnd[t] = lower_bound_u32(keys, lo < n ? lo : n, hi < n ? hi : n, t << 16);
+    return;
+  }
+  const u32 u = t - (BS_BUCKETS + 1);
+  if (u >= 2 * BS_BUCKETS) return;
+  const u32 v = u & (BS_BUCKETS - 1);
+  const bool upper = u >= BS_BUCKETS;
+  const u32 nq = nq_total - *irr_q;  // the regular rows: a sorted prefix
+  const u32 k0 = v << 16;
+  u32 target;  // lower: first row with masked key >= target; upper: first row with masked key > target
+  if (!upper) {
+    int lm = *len_max_q;
+    const u32 w = lm < 0 ? 0u : ((u32)lm > BS_FUSE_WCAP ? BS_FUSE_WCAP : (u32)lm);
+    target = k0 > w ? k0 - w : 0u;
+  } else {
+    const u64 tmax = (u64)k0 + 65535ull + (u64)(-fq.lo_off);  // lo_off <= 0: keys up to K1 - 1 - lo_off
+    if (tmax >= (u64)U32_MAX) {
+      fq.qwin[2 * v + 1] = nq;
+      return;
+    }
+    target = (u32)tmax;
+  }
+  const u32 tm = target & key_mask;
+  const u32 d3 = tm >> 24;
+  u32 lo = gbq3[d3];
+  u32 hi = d3 == 255u ? nq : gbq3[d3 + 1];
+  lo = lo < nq ? lo : nq;
+  hi = hi < nq ? hi : nq;
+  while (lo < hi) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    const u32 km = fq.qkey[mid] & key_mask;
+    if (upper ? km <= tm : km < tm)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  fq.qwin[2 * v + (upper ? 1 : 0)] = lo;
+}
+
 // One bucket per block, in place.  PAYLOAD bit 0: a rid array travels with the keys, bit 1: an
 // end array.
 //
@@ -104,10 +189,24 @@ constexpr u32 BS_NB = 1u << BS_LOG_BINS;
 
 // The body for a bucket of (R - 1) * BS_NT < cnt <= R * BS_NT rows: row i * BS_NT + tid is item i
 // of thread tid, so every item but the last is a full round (no bounds predicates).
-template <int PAYLOAD, int R>
+// rank of a 16-bit value inside the bucket = rows of the bucket with a smaller low key half.  Valid
+// between the barrier that ends the placing of the distinct-key rows (the bins with equal keys have
+// gathered their words in s_buf by then) and the barrier before s_buf / the cells are overwritten.
+__device__ __forceinline__ u32 bs_rank16(u32 x16, const u64* s_cell, const u32* s_buf) {
+  const u64 cell = s_cell[x16 >> BS_SUB_BITS];
+  const u32 lo = (u32)cell, start = lo & BS_CELL_START_MASK;
+  if (!(lo & BS_CELL_DUP)) return start + (u32)__popc((u32)(cell >> 32) & ((1u << (x16 & 31u)) - 1u));
+  const u32 m = (lo >> 13) & BS_CELL_START_MASK;
+  u32 c = 0;
+  for (u32 j = 0; j < m; j++) c += (u32)((s_buf[start + j] >> 12) < x16);
+  return start + c;
+}
+
+template <int PAYLOAD, int R, bool FUSE = false>
 __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __restrict__ pp,
                                                  u32* __restrict__ ep, u32 cnt, u32 v, u32* s_buf,
-                                                 u64* s_cell, u32* s_scan) {
+                                                 u64* s_cell, u32* s_scan, const BsFuse& fq,
+                                                 u32 b0, u32 qw0, u32 qw1) {
   constexpr int BIN_SHIFT = 12 + BS_SUB_BITS;
   constexpr int PER = BS_NB / BS_NT;  // cells scanned per thread
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -185,6 +284,14 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
   }
   __syncthreads();
   GIQL_BS_STOP(4);  // + places of the rows with distinct keys
+  if (FUSE) {
+    // the bounds of the query window that fall into this bucket: one cell read each
+    for (u32 q = qw0 + tid; q < qw1; q += BS_NT) {
+      const u32 xs = bs_shift_key(fq.qkey[q], fq.lo_off), xe = fq.qend[q];
+      if ((xs >> 16) == v) fq.lo_out[q] = b0 + bs_rank16(xs & 0xFFFFu, s_cell, s_buf);
+      if ((xe >> 16) == v) fq.hi_out[q] = b0 + bs_rank16(xe & 0xFFFFu, s_cell, s_buf);
+    }
+  }
   if (any_dup) {
     // four words from the bin's start at once (independent loads: one LDS round trip per row
     // instead of one per bin-mate), the rare longer bin in a loop
@@ -208,7 +315,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
   for (int i = 0; i < R; i++) {
     const u32 r = i * BS_NT + tid;
     if (GIQL_BS_OK(i, r)) {
-      s_key16[slot[i]] = (uint16_t)(pk[i] >> 12);
+      if (!FUSE) s_key16[slot[i]] = (uint16_t)(pk[i] >> 12);  // the fused form never stores the sorted keys
       if (PAYLOAD) s_buf[slot[i]] = pay[i];
     }
   }
@@ -220,7 +327,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
   for (int i = 0; i < R; i++) {
     const u32 r = i * BS_NT + tid;
     if (GIQL_BS_OK(i, r)) {
-      kp[r] = (v << 16) | (u32)s_key16[r];
+      if (!FUSE) kp[r] = (v << 16) | (u32)s_key16[r];
       if (PAYLOAD) pp[r] = s_buf[r];
     }
   }
@@ -337,12 +444,12 @@ __device__ __forceinline__ void bucket_sort_big(u32* __restrict__ k0, u32* __res
   }
 }
 
-template <int PAYLOAD>
+template <int PAYLOAD, bool FUSE = false>
 __global__ __launch_bounds__(BS_NT, GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* __restrict__ keys, u32* __restrict__ ends,
                                                            u32* __restrict__ rids,
                                                            const u32* __restrict__ bnd,
                                                            DevMeta* __restrict__ meta,
-                                                           u32* __restrict__ big_list) {
+                                                           u32* __restrict__ big_list, BsFuse fq = BsFuse()) {
   static_assert(BS_NB % BS_NT == 0, "bins must be a multiple of the block size");
   static_assert(BS_NB * sizeof(u64) >= BS_CAP * sizeof(uint16_t), "the cell table doubles as the 16-bit key stage");
   static_assert(BS_SUB_BITS == 5, "one 32-bit map of sub-values per bin");
@@ -352,7 +459,12 @@ __global__ __launch_bounds__(BS_NT, GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* _
   const u32 v = blockIdx.x;
   const u32 b0 = bnd[v];
   const u32 cnt = bnd[v + 1] - b0;
-  if (cnt < 2u) return;  // block-uniform
+  u32 qw0 = 0, qw1 = 0;
+  if (FUSE) {
+    qw0 = fq.qwin[2 * v];
+    qw1 = fq.qwin[2 * v + 1];
+  }
+  if (cnt < 2u && qw0 >= qw1) return;  // block-uniform: nothing to sort, no bound to answer
   if (cnt > BS_CAP) {
     // too large for LDS: queued for k_bucket_sort_big (a launch of its own keeps this kernel free of
     // the big path's registers and scratch frame); past BS_BIG_MAX the whole call is repeated
@@ -368,25 +480,27 @@ __global__ __launch_bounds__(BS_NT, GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* _
   // the payload that rides along in registers: rid when there is one, else end
   u32* pp = (PAYLOAD & 1) ? rids + b0 : ((PAYLOAD & 2) ? ends + b0 : nullptr);
   u32* ep = (PAYLOAD == 3) ? ends + b0 : nullptr;  // a second payload array takes a round of its own
+#define GIQL_BS_BODY(RR) bucket_sort_body<PAYLOAD, RR, FUSE>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan, fq, b0, qw0, qw1)
   switch ((cnt + BS_NT - 1) / BS_NT) {  // rows per thread: 1..BS_ITEMS, block-uniform
-    case 1: bucket_sort_body<PAYLOAD, 1>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
-    case 2: bucket_sort_body<PAYLOAD, 2>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
-    case 3: bucket_sort_body<PAYLOAD, 3>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
-    case 4: bucket_sort_body<PAYLOAD, 4>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
-    case 5: bucket_sort_body<PAYLOAD, 5>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
-    case 6: bucket_sort_body<PAYLOAD, 6>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
-    case 7: bucket_sort_body<PAYLOAD, 7>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
-    default: bucket_sort_body<PAYLOAD, 8>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan); break;
+    case 0: case 1: GIQL_BS_BODY(1); break;  // (0: an empty bucket with bounds to answer)
+    case 2: GIQL_BS_BODY(2); break;
+    case 3: GIQL_BS_BODY(3); break;
+    case 4: GIQL_BS_BODY(4); break;
+    case 5: GIQL_BS_BODY(5); break;
+    case 6: GIQL_BS_BODY(6); break;
+    case 7: GIQL_BS_BODY(7); break;
+    default: GIQL_BS_BODY(8); break;
   }
+#undef GIQL_BS_BODY
 }
 
 // The buckets k_bucket_sort queued (big_list[0] = how many): one block each, grid-stride.
-template <int PAYLOAD>
+template <int PAYLOAD, bool FUSE = false>
 __global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ keys, u32* __restrict__ ends,
                                                             u32* __restrict__ rids, u32* __restrict__ keys1,
                                                             u32* __restrict__ ends1, u32* __restrict__ rids1,
                                                             const u32* __restrict__ bnd,
-                                                            const u32* __restrict__ big_list) {
+                                                            const u32* __restrict__ big_list, BsFuse fq = BsFuse()) {
   __shared__ u32 s_wcnt[BS_NW * OS_BINS];
   __shared__ u32 s_base[OS_BINS];
   __shared__ u32 s_scan[BS_NW];
@@ -399,6 +513,16 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ key
                              keys1 + b0, (PAYLOAD & 2) ? ends1 + b0 : nullptr, (PAYLOAD & 1) ? rids1 + b0 : nullptr, cnt,
                              s_wcnt, s_base, s_scan);
     __syncthreads();
+    if (FUSE) {
+      // this bucket's keys are sorted in global memory now: the bounds of its query window by binary search
+      // (the block's own stores are visible to it after the barrier)
+      const u32* kb = keys + b0;
+      for (u32 q = fq.qwin[2 * v] + threadIdx.x; q < fq.qwin[2 * v + 1]; q += BS_NT) {
+        const u32 xs = bs_shift_key(fq.qkey[q], fq.lo_off), xe = fq.qend[q];
+        if ((xs >> 16) == v) fq.lo_out[q] = b0 + lower_bound_u32(kb, 0, cnt, xs);
+        if ((xe >> 16) == v) fq.hi_out[q] = b0 + lower_bound_u32(kb, 0, cnt, xe);
+      }
+    }
   }
 }
 

@@ -164,6 +164,12 @@ struct giql_hip_ctx {
   u64 local_min_rows = 1u << 25;
   int local_resorts = 0;      // calls repeated with the four-pass sort
   bool last_sort_local = false;  // the call in flight sorted at least one side in three stages
+  // fused range count (fixed-length INNER form whose sorted side takes the three-stage sort): the bucket
+  // sort answers the queries' bounds from LDS, the sorted keys never return to HBM (bucket_sort.hip.h)
+  bool no_fuse_count = false;   // GIQL_HIP_NO_FUSE_COUNT=1: the separate count kernel always
+  bool spec_fuse_len_ok = false;  // the previous plan's query rows were all short enough for the fused windows
+  bool count_fused = false;     // the call in flight answered its bounds in the bucket sort
+  u32* bucket_qwin = nullptr;   // [2 * BS_BUCKETS] query window per bucket
   u32* bucket_bnd = nullptr;  // [BS_BUCKETS + 1] bucket boundaries of the sort in flight
   u32* bucket_big = nullptr;  // [1 + BS_BUCKETS] buckets too large for LDS, queued for k_bucket_sort_big ([0] = count)
   char* xplan = nullptr;      // scratch of giql_hip_fill_from_plan_dev (offsets + scan partials), grown on demand
@@ -249,6 +255,7 @@ struct Phase {
 static void reset_stats(giql_hip_ctx* ctx) {
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   ctx->last_sort_local = false;
+  ctx->count_fused = false;
   ctx->spans.clear();
   ctx->ev_used = 0;
 }
@@ -300,19 +307,33 @@ static int post_launch(const char* what) {
 }
 
 // exclusive scan of u32 counts; TOut in {u32,u64}; in-place allowed for u32.
+// total_out2: a second place for the total (DevMeta::n_out ...), written by the spine kernel itself.
 template <typename TOut>
 static int run_scan(giql_hip_ctx* ctx, hipStream_t st, int phase, const u32* in, u64 n, TOut* out,
-                    u64* bsums, u64* total_out) {
+                    u64* bsums, u64* total_out, u64* total_out2 = nullptr) {
   if (n == 0) {
     if (total_out) HIP_TRY(hipMemsetAsync(total_out, 0, sizeof(u64), st));
+    if (total_out2) HIP_TRY(hipMemsetAsync(total_out2, 0, sizeof(u64), st));
     return GIQL_OK;
   }
   const u32 nb = cdiv(n, SCAN_TILE);
   Phase ph(ctx, st, phase, 3);
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_NT), 0, st, in, n, bsums);
-  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, bsums, nb, total_out);
+  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, bsums, nb, total_out, total_out2);
   hipLaunchKernelGGL((k_scan_down<TOut>), dim3(nb), dim3(SCAN_NT), 0, st, in, n, bsums, out);
   return post_launch("scan");
+}
+
+// The same over counts given as two bounds per row (cnt = hi - lo below the regular prefix, 0 past it):
+// what the fused range count leaves.  The down-sweep rewrites `hi` as the counts.
+static int run_scan_diff(giql_hip_ctx* ctx, hipStream_t st, int phase, u32* hi, u32* lo, u64 n, const u32* n_irr,
+                         u64* out, u64* bsums, u64* total_out, u64* total_out2) {
+  const u32 nb = cdiv(n, SCAN_TILE);
+  Phase ph(ctx, st, phase, 3);
+  hipLaunchKernelGGL(k_scan_reduce_diff, dim3(nb), dim3(SCAN_NT), 0, st, hi, lo, n, n_irr, bsums);
+  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, bsums, nb, total_out, total_out2);
+  hipLaunchKernelGGL(k_scan_down_diff, dim3(nb), dim3(SCAN_NT), 0, st, hi, lo, n, n_irr, bsums, out);
+  return post_launch("scan (bounds)");
 }
 
 // Spans + linearised keys for both sides.
@@ -460,10 +481,21 @@ static inline bool sort_is_local(const giql_hip_ctx* ctx, size_t n) {
 // by key >> 8 and the result is left in buffer 0 by swapping the ping-pong pointers.  For QUERY
 // sides whose order only serves locality (neighbouring rows search neighbouring ranges): three
 // passes instead of four.
+// fuse (three-stage (key, rid) sorts only): the bucket sort also answers the range bounds of the
+// fixed-length INNER form's query rows and does not store the sorted keys (bucket_sort.hip.h).
+struct FuseCount {
+  BsFuse dev;
+  u32 nq_total;
+  const u32* irr_q;
+  const u32* gbq3;      // the query sort's top-digit offsets
+  u32 key_mask;         // 0xFFFFFF00 when the query side was sorted without its lowest digit
+  const int* len_max_q; // DevMeta: longest regular query row
+};
+
 static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
                              const u32* gbase, u32* status, bool keep_rids = false,
                              const giql_side* keygen = nullptr, const u32* abase = nullptr,
-                             int skip_digits = 0) {
+                             int skip_digits = 0, const FuseCount* fuse = nullptr) {
   if (n == 0) return GIQL_OK;
   const bool local = sort_is_local(ctx, n);
   if (local) ctx->last_sort_local = true;
@@ -524,13 +556,28 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
   }
   if (local) {
     // the rows are back in buffer 0, ordered by key >> 16: bucket boundaries, then one block per bucket
+    const int mode = (sb.rid[0] ? 1 : 0) | (sb.end[0] ? 2 : 0);
+    if (fuse && mode == 1) {
+      // (key, rid) rows + the query side's bounds: keys and rids read, rids written, the query rows' keys
+      // and ends read and their two bounds written -- the sorted keys never leave the CU
+      Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 3);
+      ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += (int64_t)12 * n + (int64_t)16 * fuse->nq_total;
+      ctx->count_fused = true;
+      hipLaunchKernelGGL(k_bucket_bounds_fused, dim3(cdiv((u64)3 * BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
+                         gbase + 3 * OS_BINS, ctx->bucket_bnd, ctx->bucket_big, fuse->dev, fuse->nq_total, fuse->irr_q,
+                         fuse->gbq3, fuse->key_mask, fuse->len_max_q);
+      hipLaunchKernelGGL((k_bucket_sort<1, true>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
+                         sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse->dev);
+      hipLaunchKernelGGL((k_bucket_sort_big<1, true>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
+                         sb.rid[0], sb.key[1], (u32*)nullptr, sb.rid[1], ctx->bucket_bnd, ctx->bucket_big, fuse->dev);
+      return post_launch("onesweep sort (fused count)");
+    }
     HIP_TRY(hipMemsetAsync(ctx->bucket_big, 0, sizeof(u32), st));
     Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 3);
     ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] +=
         (int64_t)8 * (1 + (sb.rid[0] ? 1 : 0) + (sb.end[0] ? 1 : 0)) * n;  // every array read once, written once
     hipLaunchKernelGGL(k_bucket_bounds, dim3(cdiv((u64)BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
                        gbase + 3 * OS_BINS, ctx->bucket_bnd);
-    const int mode = (sb.rid[0] ? 1 : 0) | (sb.end[0] ? 2 : 0);
 #define GIQL_BS_LAUNCH(M)                                                                              \
   hipLaunchKernelGGL((k_bucket_sort<M>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0],              \
                      sb.end[0] ? sb.end[0] : (u32*)nullptr, sb.rid[0] ? sb.rid[0] : (u32*)nullptr,      \
@@ -596,10 +643,9 @@ static int read_meta(giql_hip_ctx* ctx, hipStream_t st) {
   HIP_TRY(hipMemcpyAsync(ctx->h_meta, ctx->d_meta, sizeof(DevMeta), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   int status = ctx->h_meta->status;
-  if (ctx->inject_timeout && ctx->os_order != 0 && status == 0) {  // test hook (GIQL_HIP_INJECT_TIMEOUT)
-    ctx->inject_timeout = 0;
+  // test hook (GIQL_HIP_INJECT_TIMEOUT=n): the n-th clean read-back of the context reports a timeout
+  if (ctx->inject_timeout > 0 && ctx->os_order != 0 && status == 0 && --ctx->inject_timeout == 0)
     status = ctx->h_meta->status = GIQL_ERR_HIP;
-  }
   if (status == GIQL_STATUS_RESORT)  // internal: with_order_fallback repeats the call with the four-pass sort
     return set_err(GIQL_STATUS_RESORT, "a 16-bit key bucket holds more than %u rows", BS_CAP);
   if (status == GIQL_ERR_HIP)
@@ -788,6 +834,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->no_skip_digit = nsd && atoi(nsd) != 0;
     const char* rsd = getenv("GIQL_HIP_ROW_SKIP_DIGITS");
     if (rsd && atoi(rsd) >= 0 && atoi(rsd) <= 3) ctx->row_skip_digits = atoi(rsd);
+    const char* nfc = getenv("GIQL_HIP_NO_FUSE_COUNT");
+    ctx->no_fuse_count = nfc && atoi(nfc) != 0;
     const char* nl = getenv("GIQL_HIP_NO_LOCAL_SORT");
     if (nl && atoi(nl) != 0) ctx->local_sort = false;
     const char* lm = getenv("GIQL_HIP_LOCAL_MIN_ROWS");
@@ -824,6 +872,7 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
   }
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_bnd, ((size_t)BS_BUCKETS + 16) * sizeof(u32));
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_big, ((size_t)BS_BUCKETS + 16) * sizeof(u32));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_qwin, ((size_t)2 * BS_BUCKETS + 16) * sizeof(u32));
   if (e != hipSuccess) {
     giql_hip_destroy(ctx);
     return set_err(GIQL_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e));
@@ -847,6 +896,7 @@ int giql_hip_destroy(giql_hip_ctx* ctx) {
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   if (ctx->bucket_bnd) (void)hipFree(ctx->bucket_bnd);
   if (ctx->bucket_big) (void)hipFree(ctx->bucket_big);
+  if (ctx->bucket_qwin) (void)hipFree(ctx->bucket_qwin);
   if (ctx->xplan) (void)hipFree(ctx->xplan);
   if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
   delete ctx;
@@ -877,7 +927,8 @@ int giql_hip_get_stats(giql_hip_ctx* ctx, giql_hip_stats* out) {
   // byte 0: join form (+ bit 5: a side was sorted in three stages, bit 6: this context fell back to
   // the four-pass sort for good); byte 1: sort tile order in force; bytes 2-3: order fallbacks so far
   out->reserved = (ctx->stats.reserved & 0x1F) | (ctx->last_sort_local ? 0x20 : 0) |
-                  (ctx->local_resorts ? 0x40 : 0) | (ctx->swapped ? 0x80 : 0) | ((ctx->os_order & 0xFF) << 8) |
+                  (ctx->local_resorts ? 0x40 : 0) | (ctx->swapped ? 0x80 : 0) | ((ctx->os_order & 0x7F) << 8) |
+                  (ctx->count_fused ? 0x8000 : 0) |
                   ((ctx->order_fallbacks & 0x3FFF) << 16) | (ctx->fuse_done ? (1 << 30) : 0);
   return GIQL_OK;
 }
@@ -1042,8 +1093,15 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     SortBufs& su = q_is_a ? sbb : sa;
     const size_t nqr = q_is_a ? na : nb, nu = q_is_a ? nb : na;
     su.end[0] = su.end[1] = nullptr;  // the uniform side carries (key, rid) only
-    // the query side's chain (linearize + sort) beside the other side's when it is small
-    SideChain sc(ctx, st, nqr <= nu ? nqr : 0, nu);
+    // Fused range count: when U takes the three-stage sort, its bucket sort answers the queries' bounds
+    // (bucket_sort.hip.h) -- as long as no query row is longer than the windows allow for: known from the
+    // read-back on a first plan, the previous plan's answer afterwards (validated below like the other guesses)
+    const int q_len_max = q_is_a ? ctx->h_meta->len_max_a : ctx->h_meta->len_max_b;
+    const bool fuse_cnt = !ctx->no_fuse_count && sort_is_local(ctx, nu) &&
+                          (speculated ? ctx->spec_fuse_len_ok : q_len_max <= (int)BS_FUSE_WCAP);
+    // the query side's chain (linearize + sort) beside the other side's when it is small (the fused count
+    // needs the sorted queries before U's last stage: one stream)
+    SideChain sc(ctx, st, (nqr <= nu && !fuse_cnt) ? nqr : 0, nu);
     GIQL_TRY(run_linearize(ctx, sc.stream(), qs_, n_chrom, lb, sq.key[0], sq.end[0],
                            q_is_a ? ctx->irr_a_list : ctx->irr_b_list, q_is_a ? 0 : 1, 0,
                            q_is_a ? hist_a : hist_b, q_is_a ? gbase_a : gbase_b));
@@ -1070,11 +1128,29 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     coarse_q = q_skip != 0;
     GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sq, (u32)nqr, q_is_a ? gbase_a : gbase_b,
                                sc.active ? os_status2 : os_status, false, nullptr, nullptr, q_skip));
+    FuseCount fc;
+    if (fuse_cnt) {
+      fc.dev.qkey = sq.key[0];
+      fc.dev.qend = sq.end[0];
+      fc.dev.qwin = ctx->bucket_qwin;
+      fc.dev.lo_out = S.lo2;
+      fc.dev.hi_out = cnt2;  // the scan below turns the upper bounds into counts in place
+      fc.dev.lo_off = 1 - uni_len;  // u.start in [q.start - L + 1, q.end)
+      fc.nq_total = (u32)nqr;
+      fc.irr_q = q_is_a ? irr_a : irr_b;
+      fc.gbq3 = (q_is_a ? gbase_a : gbase_b) + 3 * OS_BINS;
+      fc.key_mask = coarse_q ? 0xFFFFFF00u : 0xFFFFFFFFu;
+      fc.len_max_q = q_is_a ? &ctx->d_meta->len_max_a : &ctx->d_meta->len_max_b;
+    }
     GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, os_status, false,
-                               keygen ? &us_ : nullptr, lb.abase));
+                               keygen ? &us_ : nullptr, lb.abase, 0, fuse_cnt ? &fc : nullptr));
     GIQL_TRY(sc.join());
     constexpr u32 TQ = RC_NT * RC_ITEMS_C2;
     S.nt2 = cdiv(nqr, TQ);
+    if (ctx->count_fused) {
+      GIQL_TRY(run_scan_diff(ctx, st, GIQL_PH_SCAN, cnt2, S.lo2, nqr, q_is_a ? irr_a : irr_b, S.off2, bsums,
+                             S.off2 + nqr, &ctx->d_meta->n_out));
+    } else {
     {
       Phase ph(ctx, st, GIQL_PH_COUNT, 2);
       const u32* irr_q = q_is_a ? irr_a : irr_b;
@@ -1088,8 +1164,8 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
                          S.wlo2, S.lo2, cnt2);
       GIQL_TRY(post_launch("range count (uniform)"));
     }
-    GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt2, nqr, S.off2, bsums, S.off2 + nqr));
-    HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out, S.off2 + nqr, sizeof(u64), hipMemcpyDeviceToDevice, st));
+    GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt2, nqr, S.off2, bsums, S.off2 + nqr, &ctx->d_meta->n_out));
+    }
     bool fused = false;
     if (ctx->fuse_a && speculated && ctx->last_no_irr && ctx->fuse_cap > 0) {
       // Fused join: the caller's buffers are here and everything about this plan is a guess
@@ -1196,11 +1272,9 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     GIQL_TRY(post_launch("range count"));
   }
   if (S.c1_fill) {
-    GIQL_TRY(run_scan<u64>(ctx, st1, GIQL_PH_SCAN, S.cnt1, nb, S.off1, bsums1, S.off1 + nb));
-    HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out_c1, S.off1 + nb, sizeof(u64), hipMemcpyDeviceToDevice, st1));
+    GIQL_TRY(run_scan<u64>(ctx, st1, GIQL_PH_SCAN, S.cnt1, nb, S.off1, bsums1, S.off1 + nb, &ctx->d_meta->n_out_c1));
   }
-  GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt2, na, S.off2, bsums, S.off2 + na));
-  HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out, S.off2 + na, sizeof(u64), hipMemcpyDeviceToDevice, st));
+  GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt2, na, S.off2, bsums, S.off2 + na, &ctx->d_meta->n_out));
   GIQL_TRY(sc1.join());
   GIQL_TRY(read_meta(ctx, st));
   ctx->n_c1 = ctx->h_meta->n_out_c1;
@@ -1216,7 +1290,12 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     // range starts above 0); such a row was keyed as if regular, and never listed
     const bool keygen_wrong = keygen_g && (big_side ? ctx->h_meta->len_min_b : ctx->h_meta->len_min_a) <= 0;
     if (keygen_wrong) ctx->last_no_irr = false;
-    if (speculated && (form != S.uniform || len != uni_len || (want_hist && !aligned_now) || coarse_wrong || keygen_wrong)) {
+    // the fused count's windows allow for query rows up to BS_FUSE_WCAP long (the query side of the form just decided)
+    const int q_len_now = form == 1 ? ctx->h_meta->len_max_a : ctx->h_meta->len_max_b;
+    const bool fuse_len_ok_now = form != 0 && q_len_now <= (int)BS_FUSE_WCAP;
+    const bool fuse_wrong = ctx->count_fused && !fuse_len_ok_now;
+    ctx->spec_fuse_len_ok = fuse_len_ok_now;
+    if (speculated && (form != S.uniform || len != uni_len || (want_hist && !aligned_now) || coarse_wrong || keygen_wrong || fuse_wrong)) {
       ctx->spec_valid = false;  // wrong guess: plan again from the numbers just read
       ctx->spec_misses++;
       ctx->fuse_done = false;
@@ -1274,10 +1353,16 @@ static int giql_hip_inner_plan_dev_impl(giql_hip_ctx* ctx, const giql_side* a, c
   const bool swap = !ctx->no_swap && a->n > b->n;
   ctx->swapped = swap;
   if (!swap) return inner_plan_core(ctx, a, b, n_chrom, stream, n_pairs);
-  int32_t* t = ctx->fuse_a;
-  ctx->fuse_a = ctx->fuse_b;
-  ctx->fuse_b = t;
+  // The offered output buffers follow the sides for the duration of THIS attempt only: with_order_fallback
+  // may run this function again (a resort, a look-back timeout), and an exchange left in place would then
+  // be undone by the second one -- the retry's early fill writing B ids into row_a.
+  int32_t* const fa = ctx->fuse_a;
+  int32_t* const fb = ctx->fuse_b;
+  ctx->fuse_a = fb;
+  ctx->fuse_b = fa;
   const int rc = inner_plan_core(ctx, b, a, n_chrom, stream, n_pairs);
+  ctx->fuse_a = fa;
+  ctx->fuse_b = fb;
   // stats in the caller's labels
   giql_hip_stats& stt = ctx->stats;
   const int64_t tn = stt.n_a;

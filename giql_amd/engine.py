@@ -134,7 +134,8 @@ class HipEngine:
         out["sort_local"] = bool(int(st.reserved) & 0x20)   # a side was sorted in three stages (bucket_sort.hip.h)
         out["sort_resorted"] = bool(int(st.reserved) & 0x40)  # the context fell back to the four-pass sort
         out["swapped"] = bool(int(st.reserved) & 0x80)  # the INNER plan ran with the sides exchanged (larger side as B)
-        out["sort_tile_order"] = (int(st.reserved) >> 8) & 0xFF
+        out["sort_tile_order"] = (int(st.reserved) >> 8) & 0x7F
+        out["count_fused"] = bool(int(st.reserved) & 0x8000)  # the bucket sort answered the range bounds (no count kernel)
         out["sort_order_fallbacks"] = (int(st.reserved) >> 16) & 0x3FFF
         out["fused_fill"] = bool((int(st.reserved) >> 30) & 1)  # the last plan launched its own fill
         out["total_ms"] = float(st.total_ms)

@@ -127,8 +127,10 @@ typedef struct giql_hip_stats {
                                sort (a bucket too large for LDS); bit 7: the INNER plan ran with
                                the sides exchanged (the larger table planned as B; pairs, stats and
                                the exported plan are in the caller's labels all the same);
-                               byte 1: sort tile order in force (2 =
-                               blockIdx order, 0 = ticket order); bits 16-29: calls
+                               bits 8-14: sort tile order in force (2 =
+                               blockIdx order, 0 = ticket order); bit 15: the range count of the
+                               fixed-length form ran inside the bucket sort (no count kernel, the
+                               sorted keys never stored); bits 16-29: calls
                                repeated in ticket order after a look-back timeout;
                                bit 30: the last plan launched its own fill
                                (giql_hip_inner_join_dev) */

@@ -187,3 +187,146 @@ def test_three_stage_randomized_sweep(eng_local, seed):
     a = rand_side(7000 + seed, na, n_chrom, max_start, max_len + 1, min_len=min_len, enc=encs[int(r.integers(0, 4))])
     b = rand_side(8000 + seed, nb, n_chrom, max_start, max_len + 1, min_len=min_len, enc=encs[int(r.integers(0, 4))])
     _all_ops(eng_local, a, b, n_chrom, nearest=min_len >= 0)
+
+
+@pytest.mark.parametrize("inject", [False, True])
+def test_one_call_join_keeps_its_orientation_when_the_plan_is_repeated(monkeypatch, inject):
+    # giql_hip_inner_join_dev offers the caller's buffers to the plan, and a plan with
+    # the LARGER table first exchanges the sides.  When that plan is repeated (an oversized bucket ->
+    # the four-pass sort; a look-back timeout -> ticket order) AFTER its early fill was launched, the
+    # repeat must see the buffers in the same orientation: row_a holds A ids, row_b holds B ids.
+    from giql_amd.engine import HipEngine
+
+    monkeypatch.setenv("GIQL_HIP_LOCAL_MIN_ROWS", "1")
+    if inject:  # the third clean read-back reports a timeout: the end of the second (speculated) call below
+        monkeypatch.setenv("GIQL_HIP_INJECT_TIMEOUT", "3")
+    e = HipEngine(0)
+    monkeypatch.delenv("GIQL_HIP_LOCAL_MIN_ROWS")
+    if inject:
+        monkeypatch.delenv("GIQL_HIP_INJECT_TIMEOUT")
+    try:
+        def check(a, b, nch):
+            want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+            cap = want.shape[0] + 1024
+            ra = torch.full((cap,), -7, dtype=torch.int32, device="cuda:0")
+            rb = torch.full((cap,), -7, dtype=torch.int32, device="cuda:0")
+            n = e.inner_join_into(dev(a), dev(b), nch, ra, rb)
+            assert n == want.shape[0]
+            got = ora.sort_pairs(ra[:n].cpu().numpy(), rb[:n].cpu().numpy())
+            assert np.array_equal(got, want)  # pair ORIENTATION included: column 0 = row of a
+            assert int((ra[n:] != -7).sum()) == 0 and int((rb[n:] != -7).sum()) == 0
+
+        # a first plan (two read-backs) so that the context speculates: fixed-length larger side, no irregular rows
+        check(uniform_side(1401, 30_000, 1, 40_000_000, 150), rand_side(1402, 5_000, 1, 40_000_000, 900), 1)
+        small = rand_side(1404, 20_000, 1, 60_000, 300)
+        if inject:
+            # larger table FIRST; the early fill is launched, the read-back reports the (injected) timeout,
+            # the call is repeated once in ticket order
+            big = uniform_side(1403, 300_000, 1, 40_000_000, 150)
+            check(big, small, 1)
+            assert e.stats()["sort_order_fallbacks"] == 1
+        else:
+            # larger table FIRST, 300K rows inside one 65536-wide window: the early fill is launched, the bucket
+            # sort reports the oversized bucket at the read-back, the call is repeated once with four passes
+            big = uniform_side(1403, 300_000, 1, 60_000, 150)
+            check(big, small, 1)
+            assert e.stats()["sort_resorted"]
+        check(big, small, 1)   # and once more on the settled context
+        check(small, big, 1)
+    finally:
+        e.close()
+
+
+# ---- the range count fused into the bucket sort (fixed-length INNER form, round 3) ----------------
+def _fused_inner(e, a, b, nch, expect_fused=True):
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    got = _inner(e, a, b, nch)
+    st = e.stats()
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert st["count_fused"] == expect_fused, st
+    return st
+
+
+def test_fused_count_matches_the_count_kernel_in_every_query_order(eng_local, monkeypatch):
+    from giql_amd.engine import HipEngine
+
+    reads = uniform_side(1501, 400_000, 5, 30_000_000, 150)
+    peaks = rand_side(1502, 60_000, 5, 30_000_000, 2000, min_len=200)
+    # first plan: queries sorted on every digit; second: the context's guesses hold -> lowest digit unsorted
+    st = _fused_inner(eng_local, peaks, reads, 5)
+    assert st["join_form"] == "uniform_b" and st["sort_local"]
+    _fused_inner(eng_local, peaks, reads, 5)
+    _fused_inner(eng_local, reads, peaks, 5)       # larger table first: the plan exchanges the sides
+    # the one-call form on the speculating context (early fill behind the fused count)
+    want = ora.sort_pairs(*ora.c_inner(peaks, reads, "sweep"))
+    ra = torch.empty(want.shape[0] + 64, dtype=torch.int32, device="cuda:0")
+    rb = torch.empty_like(ra)
+    n = eng_local.inner_join_into(dev(peaks), dev(reads), 5, ra, rb)
+    assert n == want.shape[0] and np.array_equal(ora.sort_pairs(ra[:n].cpu().numpy(), rb[:n].cpu().numpy()), want)
+    assert eng_local.stats()["count_fused"] and eng_local.stats()["fused_fill"]
+    # and the separate count kernel gives the same pairs
+    monkeypatch.setenv("GIQL_HIP_LOCAL_MIN_ROWS", "1")
+    monkeypatch.setenv("GIQL_HIP_NO_FUSE_COUNT", "1")
+    e2 = HipEngine(0)
+    monkeypatch.delenv("GIQL_HIP_LOCAL_MIN_ROWS")
+    monkeypatch.delenv("GIQL_HIP_NO_FUSE_COUNT")
+    try:
+        st2 = _fused_inner(e2, peaks, reads, 5, expect_fused=False)
+        assert st2["sort_local"]
+    finally:
+        e2.close()
+
+
+def test_fused_count_edges_of_the_axis_empty_buckets_and_irregular_queries(eng_local):
+    r = np.random.default_rng(1510)
+    # reads at both ends of two chromosomes with a wide empty stretch between (empty buckets that still
+    # have bounds to answer), queries reaching below the first read (q.start - L + 1 < 0) and past the last
+    st = np.concatenate([r.integers(0, 3_000, 4_000), r.integers(9_000_000, 9_100_000, 4_000)]).astype(np.int32)
+    reads = ora.Side(r.integers(0, 2, st.size).astype(np.int32), st, st + np.int32(100))
+    qs = np.concatenate([r.integers(0, 200, 500), r.integers(2_000_000, 7_000_000, 500),
+                         r.integers(9_050_000, 9_300_000, 500)]).astype(np.int32)
+    ql = r.integers(1, 4_000, qs.size).astype(np.int32)
+    peaks = ora.Side(r.integers(0, 2, qs.size).astype(np.int32), qs, qs + ql)
+    _fused_inner(eng_local, peaks, reads, 2)
+    _fused_inner(eng_local, peaks, reads, 2)
+    # zero-length and inverted QUERY rows take the literal path beside the fused count
+    pe = peaks.end.copy()
+    pe[::7] = peaks.start[::7]
+    pe[3::11] = peaks.start[3::11] - 5
+    irr = ora.Side(peaks.chrom, peaks.start, pe)
+    st3 = _fused_inner(eng_local, irr, reads, 2)
+    assert st3["n_irregular_a"] > 0
+    _fused_inner(eng_local, irr, reads, 2)
+    # every encoding of the query side (offsets on both columns)
+    for enc in ora.ENCODING_OFFSETS:
+        so, eo = ora.ENCODING_OFFSETS[enc]
+        _fused_inner(eng_local, ora.Side(peaks.chrom, peaks.start, peaks.end, so, eo), reads, 2)
+
+
+def test_fused_count_declines_long_query_rows_and_recovers(eng_local):
+    reads = uniform_side(1521, 300_000, 3, 20_000_000, 150)
+    short = rand_side(1522, 30_000, 3, 20_000_000, 3000)
+    long_ = rand_side(1523, 30_000, 3, 20_000_000, 3000)
+    long_.end[17] = long_.start[17] + 2_000_000      # one row longer than the windows allow for
+    _fused_inner(eng_local, short, reads, 3)
+    _fused_inner(eng_local, short, reads, 3)
+    # the speculating context launches the fused form, the read-back tells the long row: planned again without
+    _fused_inner(eng_local, long_, reads, 3, expect_fused=False)
+    _fused_inner(eng_local, long_, reads, 3, expect_fused=False)
+    _fused_inner(eng_local, short, reads, 3, expect_fused=False)   # the guess follows the previous plan ...
+    _fused_inner(eng_local, short, reads, 3)                        # ... and is back
+
+
+def test_fused_count_with_buckets_larger_than_lds(eng_local):
+    # ~6,500 rows in every 65536-wide window: every bucket goes through the in-block global sort, which
+    # answers its window's bounds by binary search
+    reads = uniform_side(1531, 700_000, 1, 7_000_000, 150)
+    peaks = rand_side(1532, 40_000, 1, 7_000_000, 2500)
+    _fused_inner(eng_local, peaks, reads, 1)
+    _fused_inner(eng_local, peaks, reads, 1)
+    # equal keys galore: 500 distinct read starts (bins with equal sub-values: the gathered-bin rank)
+    r = np.random.default_rng(1533)
+    st = (r.integers(0, 500, 200_000) * 37).astype(np.int32)
+    piled = ora.Side(np.zeros(st.size, np.int32), st, st + np.int32(150))
+    q = rand_side(1534, 3_000, 1, 20_000, 400)
+    _fused_inner(eng_local, q, piled, 1, expect_fused=True)
