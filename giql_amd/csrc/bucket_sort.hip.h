@@ -90,9 +90,12 @@ __global__ __launch_bounds__(256) void k_bucket_bounds_fused(const u32* __restri
                                                               BsFuse fq, u32 nq_total,
                                                               const u32* __restrict__ irr_q,
                                                               const u32* __restrict__ gbq3, u32 key_mask,
-                                                              const int* __restrict__ len_max_q) {
+                                                              const int* __restrict__ len_max_q,
+                                                              u32* __restrict__ zero_ptr, u32 zero_words) {
   const u32 t = blockIdx.x * 256 + threadIdx.x;
   if (t == 0) big_list[0] = 0;  // the queue of buckets too large for LDS starts empty
+  // the status words + ticket of the chained scan that follows the bucket sort (scan.hip.h) start at zero
+  for (u32 i = t; i < zero_words; i += gridDim.x * 256) zero_ptr[i] = 0u;
   if (t <= BS_BUCKETS) {
     if (t == BS_BUCKETS) {
       bnd[t] = n;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void k_bucket_bounds_fused(const u32* __restri
   u32 hi = d3 == 255u ? nq : gbq3[d3 + 1];
   lo = lo < nq ? lo : nq;
   hi = hi < nq ? hi : nq;
-  while (lo < hi) {
+  while (lo < hi) {  // (an 8-ary search with 7 probes in flight per round was SLOWER: 40 vs 25 us -- the kernel is bound by its number of random loads, not by their latency)
     const u32 mid = lo + ((hi - lo) >> 1);
     const u32 km = fq.qkey[mid] & key_mask;
     if (upper ? km <= tm : km < tm)
@@ -220,6 +223,15 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
     pay[i] = (PAYLOAD && ok) ? pp[r] : 0u;  // used at the very end: the load flies under everything
     slot[i] = 0;
   }
+  // fused count: this thread's first query of the window, loaded in the same round trip as the rows (every
+  // __syncthreads drains the wave's outstanding loads: issued any later, the round trip stands exposed)
+  // Two threads per query row: the even one answers its lower bound (from the key), the odd one its upper
+  // bound (from the end key) -- one load, one cell read and one store each, spread over all eight waves.
+  const u32* q_src = (tid & 1u) ? fq.qend : fq.qkey;
+  u32* q_dst = (tid & 1u) ? fq.hi_out : fq.lo_out;
+  const u32 n_probe = FUSE ? 2u * (qw1 - qw0) : 0u;
+  u32 q_val = 0;
+  if (FUSE && tid < n_probe) q_val = q_src[qw0 + (tid >> 1)];
   // cells zeroed while the loads fly
 #pragma unroll
   for (int k = 0; k < PER; k++) s_cell[tid + k * BS_NT] = 0;
@@ -286,10 +298,11 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
   GIQL_BS_STOP(4);  // + places of the rows with distinct keys
   if (FUSE) {
     // the bounds of the query window that fall into this bucket: one cell read each
-    for (u32 q = qw0 + tid; q < qw1; q += BS_NT) {
-      const u32 xs = bs_shift_key(fq.qkey[q], fq.lo_off), xe = fq.qend[q];
-      if ((xs >> 16) == v) fq.lo_out[q] = b0 + bs_rank16(xs & 0xFFFFu, s_cell, s_buf);
-      if ((xe >> 16) == v) fq.hi_out[q] = b0 + bs_rank16(xe & 0xFFFFu, s_cell, s_buf);
+    for (u32 i = tid; i < n_probe; i += BS_NT) {
+      const u32 q = qw0 + (i >> 1);
+      const u32 x = (tid & 1u) ? q_val : bs_shift_key(q_val, fq.lo_off);
+      if ((x >> 16) == v) q_dst[q] = b0 + bs_rank16(x & 0xFFFFu, s_cell, s_buf);
+      if (i + BS_NT < n_probe) q_val = q_src[q + BS_NT / 2];  // windows wider than half the block: the next round's row
     }
   }
   if (any_dup) {

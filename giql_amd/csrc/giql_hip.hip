@@ -167,6 +167,7 @@ struct giql_hip_ctx {
   // fused range count (fixed-length INNER form whose sorted side takes the three-stage sort): the bucket
   // sort answers the queries' bounds from LDS, the sorted keys never return to HBM (bucket_sort.hip.h)
   bool no_fuse_count = false;   // GIQL_HIP_NO_FUSE_COUNT=1: the separate count kernel always
+  int fuse_q_skip = 2;          // GIQL_HIP_Q_SKIP_DIGITS: low digits the fused form leaves unsorted on the query side
   bool spec_fuse_len_ok = false;  // the previous plan's query rows were all short enough for the fused windows
   bool count_fused = false;     // the call in flight answered its bounds in the bucket sort
   u32* bucket_qwin = nullptr;   // [2 * BS_BUCKETS] query window per bucket
@@ -336,6 +337,18 @@ static int run_scan_diff(giql_hip_ctx* ctx, hipStream_t st, int phase, u32* hi, 
   return post_launch("scan (bounds)");
 }
 
+// One launch: chained scan of the same bounds (status + ticket zeroed by the caller's previous kernel); out[n] =
+// total, also to total_out2; part (optional): the fill's merge-path partition for tiles of 2^tile_log2 outputs.
+static int run_scan_chain(giql_hip_ctx* ctx, hipStream_t st, int phase, const u32* hi, const u32* lo, u64 n,
+                          const u32* n_irr, u64* out, u64* chain_status, u64* total_out2, u32* part, u32 tile_log2,
+                          u32 part_cap) {
+  const u32 nb = cdiv(n, SC_TILE);
+  Phase ph(ctx, st, phase, 1);
+  hipLaunchKernelGGL(k_scan_chain_diff, dim3(nb), dim3(SC_NT), 0, st, hi, lo, (u32)n, n_irr, chain_status,
+                     reinterpret_cast<u32*>(chain_status + nb + 1), out, total_out2, part, tile_log2, part_cap);
+  return post_launch("scan (chained)");
+}
+
 // Spans + linearised keys for both sides.
 struct LinBufs {
   int* gmin;
@@ -490,6 +503,8 @@ struct FuseCount {
   const u32* gbq3;      // the query sort's top-digit offsets
   u32 key_mask;         // 0xFFFFFF00 when the query side was sorted without its lowest digit
   const int* len_max_q; // DevMeta: longest regular query row
+  u32* zero_ptr;        // words the bounds kernel zeroes on the way (the chained scan's status + ticket)
+  u32 zero_words;
 };
 
 static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
@@ -565,7 +580,7 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
       ctx->count_fused = true;
       hipLaunchKernelGGL(k_bucket_bounds_fused, dim3(cdiv((u64)3 * BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
                          gbase + 3 * OS_BINS, ctx->bucket_bnd, ctx->bucket_big, fuse->dev, fuse->nq_total, fuse->irr_q,
-                         fuse->gbq3, fuse->key_mask, fuse->len_max_q);
+                         fuse->gbq3, fuse->key_mask, fuse->len_max_q, fuse->zero_ptr, fuse->zero_words);
       hipLaunchKernelGGL((k_bucket_sort<1, true>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
                          sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse->dev);
       hipLaunchKernelGGL((k_bucket_sort_big<1, true>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
@@ -836,6 +851,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     if (rsd && atoi(rsd) >= 0 && atoi(rsd) <= 3) ctx->row_skip_digits = atoi(rsd);
     const char* nfc = getenv("GIQL_HIP_NO_FUSE_COUNT");
     ctx->no_fuse_count = nfc && atoi(nfc) != 0;
+    const char* qsd = getenv("GIQL_HIP_Q_SKIP_DIGITS");
+    if (qsd && atoi(qsd) >= 1 && atoi(qsd) <= 2) ctx->fuse_q_skip = atoi(qsd);
     const char* nl = getenv("GIQL_HIP_NO_LOCAL_SORT");
     if (nl && atoi(nl) != 0) ctx->local_sort = false;
     const char* lm = getenv("GIQL_HIP_LOCAL_MIN_ROWS");
@@ -962,7 +979,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   u32 *tile_hist = nullptr, *cnt2 = nullptr, *irr_cnt = nullptr;
   u32 *hist_a = nullptr, *hist_b = nullptr, *gbase_a = nullptr, *gbase_b = nullptr;
   u32 *os_status = nullptr, *os_status2 = nullptr;
-  u64 *bsums = nullptr, *bsums1 = nullptr;
+  u64 *bsums = nullptr, *bsums1 = nullptr, *scan_chain = nullptr;
   const bool onesweep = !ctx->classic_sort && na <= OS_MAX_ROWS && nb <= OS_MAX_ROWS;
   const size_t n_max = na > nb ? na : nb;
   const size_t n_tiles_max = cdiv(n_max, RS_TILE);
@@ -1004,6 +1021,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     S.cnt2 = cnt2;
     S.lo2 = c.take<u32>(nq2);
     S.off2 = c.take<u64>(nq2 + 1);
+    scan_chain = c.take<u64>((size_t)cdiv(nq2, SCAN_TILE) + 4);  // chained scan: a status word per tile + the ticket
     ctx->irr_a_list = c.take<u32>(na);
     ctx->irr_b_list = c.take<u32>(nb);
     irr_cnt = c.take<u32>(nq);
@@ -1124,12 +1142,28 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     // out by the scan), so its lowest digit stays unsorted: three passes.  Irregular rows would break
     // that (their sentinel keys must end up LAST, after every row of the top 256-key block): taken
     // only on the context's guess that there are none, validated with the other guesses below.
-    const int q_skip = (speculated && ctx->last_no_irr && !ctx->no_skip_digit && !sort_is_local(ctx, nqr)) ? 1 : 0;
+    // With the fused count the queries only have to be grouped by the bucket their key falls into (the windows
+    // of k_bucket_bounds_fused are computed under the same mask and then cover whole query buckets): TWO digits
+    // unsorted, two passes (GIQL_HIP_Q_SKIP_DIGITS=1 keeps three).
+    int q_skip = (speculated && ctx->last_no_irr && !ctx->no_skip_digit && !sort_is_local(ctx, nqr)) ? 1 : 0;
+    if (q_skip && fuse_cnt && ctx->fuse_q_skip > 1) q_skip = ctx->fuse_q_skip;
     coarse_q = q_skip != 0;
+    const u32 q_mask = q_skip == 2 ? 0xFFFF0000u : (q_skip == 1 ? 0xFFFFFF00u : 0xFFFFFFFFu);
     GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sq, (u32)nqr, q_is_a ? gbase_a : gbase_b,
                                sc.active ? os_status2 : os_status, false, nullptr, nullptr, q_skip));
+    // One-call join (giql_hip_inner_join_dev): the caller's buffers are here and everything about this plan is a
+    // guess that has held so far (same form as last time, no irregular rows), so the fill is launched inside the
+    // plan, with a grid bounded by the capacity and the true count read on the device.
+    constexpr u32 T2 = FILL_NT * FILL_ITEMS_C2;
+    static_assert((T2 & (T2 - 1)) == 0, "fill tiles are a power of two (k_scan_chain_diff shifts)");
+    const u64 nt_cap64 = (ctx->fuse_cap + T2 - 1) / T2;
+    const bool early_fill = ctx->fuse_a && speculated && ctx->last_no_irr && ctx->fuse_cap > 0 &&
+                            nt_cap64 <= 0x7FFFFFF0ull && (size_t)nt_cap64 + 2 <= ctx->part_cap;
+    bool part_done = false;  // the scan wrote the fill's partition
     FuseCount fc;
     if (fuse_cnt) {
+      fc.zero_ptr = reinterpret_cast<u32*>(scan_chain);
+      fc.zero_words = (u32)(2 * (cdiv(nqr, SC_TILE) + 2));
       fc.dev.qkey = sq.key[0];
       fc.dev.qend = sq.end[0];
       fc.dev.qwin = ctx->bucket_qwin;
@@ -1139,7 +1173,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
       fc.nq_total = (u32)nqr;
       fc.irr_q = q_is_a ? irr_a : irr_b;
       fc.gbq3 = (q_is_a ? gbase_a : gbase_b) + 3 * OS_BINS;
-      fc.key_mask = coarse_q ? 0xFFFFFF00u : 0xFFFFFFFFu;
+      fc.key_mask = q_mask;
       fc.len_max_q = q_is_a ? &ctx->d_meta->len_max_a : &ctx->d_meta->len_max_b;
     }
     GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, os_status, false,
@@ -1148,8 +1182,11 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     constexpr u32 TQ = RC_NT * RC_ITEMS_C2;
     S.nt2 = cdiv(nqr, TQ);
     if (ctx->count_fused) {
-      GIQL_TRY(run_scan_diff(ctx, st, GIQL_PH_SCAN, cnt2, S.lo2, nqr, q_is_a ? irr_a : irr_b, S.off2, bsums,
-                             S.off2 + nqr, &ctx->d_meta->n_out));
+      u32 log2_t2 = 0;
+      while ((1u << log2_t2) < T2) log2_t2++;
+      GIQL_TRY(run_scan_chain(ctx, st, GIQL_PH_SCAN, cnt2, S.lo2, nqr, q_is_a ? irr_a : irr_b, S.off2, scan_chain,
+                              &ctx->d_meta->n_out, early_fill ? ctx->part : nullptr, log2_t2, (u32)nt_cap64 + 1));
+      part_done = early_fill;
     } else {
     {
       Phase ph(ctx, st, GIQL_PH_COUNT, 2);
@@ -1158,7 +1195,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
       const i64 lo_off = 1 - uni_len;  // u.start in [q.start - L + 1, q.end)
       hipLaunchKernelGGL(k_count_partition, dim3(cdiv((u64)S.nt2 + 1, 256)), dim3(256), 0, st,
                          sq.key[0], (u32)nqr, irr_q, su.key[0], (u32)nu, irr_u, lo_off, TQ, S.nt2,
-                         S.wlo2, coarse_q ? 0xFFFFFF00u : 0xFFFFFFFFu);
+                         S.wlo2, q_mask);
       hipLaunchKernelGGL((k_range_count<RC_ITEMS_C2, RC_LDS_CAP>), dim3(S.nt2), dim3(RC_NT), 0, st,
                          sq.key[0], sq.end[0], (u32)nqr, irr_q, su.key[0], (u32)nu, irr_u, lo_off,
                          S.wlo2, S.lo2, cnt2);
@@ -1167,21 +1204,16 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, cnt2, nqr, S.off2, bsums, S.off2 + nqr, &ctx->d_meta->n_out));
     }
     bool fused = false;
-    if (ctx->fuse_a && speculated && ctx->last_no_irr && ctx->fuse_cap > 0) {
-      // Fused join: the caller's buffers are here and everything about this plan is a guess
-      // that has held so far (same form as last time, no irregular rows), so the fill is
-      // launched NOW with a grid bounded by the capacity and the true count read on the device
-      // -- no stream sync between plan and fill.  Validated below; a wrong guess leaves the
+    {
+      // The early fill: no stream sync between plan and fill.  Validated below; a wrong guess leaves the
       // buffers to the ordinary fill.
-      constexpr u32 T2 = FILL_NT * FILL_ITEMS_C2;
-      const u64 nt_cap64 = (ctx->fuse_cap + T2 - 1) / T2;
-      if (nt_cap64 <= 0x7FFFFFF0ull && (size_t)nt_cap64 + 2 <= ctx->part_cap) {
+      if (early_fill) {
         const u32 nt_cap = (u32)nt_cap64;
         const u32* qrid = q_is_a ? sa.rid[0] : sbb.rid[0];
         const u32* srid = q_is_a ? sbb.rid[0] : sa.rid[0];
         int32_t* rq = q_is_a ? ctx->fuse_a : ctx->fuse_b;
         int32_t* rs = q_is_a ? ctx->fuse_b : ctx->fuse_a;
-        {
+        if (!part_done) {
           Phase ph(ctx, st, GIQL_PH_PARTITION);
           hipLaunchKernelGGL(k_partition, dim3(cdiv((u64)nt_cap + 1, 256)), dim3(256), 0, st, S.off2,
                              (u32)nqr, (u64)0, T2, nt_cap, ctx->part, (const u64*)(S.off2 + nqr), ctx->fuse_cap);
@@ -2290,8 +2322,9 @@ int giql_hip_pairs_checksum_dev(giql_hip_ctx* ctx, const int32_t* row_a, const i
 // that side's row ids in sorted order -- 12 B per query row + 4 B per row instead of 8 B per
 // pair (65 MB instead of 400 MB per rank at BASELINE config 4 on 8 GPUs).  Ranks exchange THAT
 // and every receiver expands it with the same partition + fill kernels the local join uses.
+// (the counts come from the offsets: the fused count leaves upper bounds, not counts, in the plan's cnt array)
 __global__ __launch_bounds__(256) void k_plan_export(const u32* __restrict__ q_rid, const u32* __restrict__ lo,
-                                                      const u32* __restrict__ cnt, u32 n_q,
+                                                      const u64* __restrict__ off, u32 n_q,
                                                       const u32* __restrict__ s_rid, u32 n_s, u32 q_add, u32 s_add,
                                                       int32_t* __restrict__ q_rid_out, u32* __restrict__ lo_out,
                                                       u32* __restrict__ cnt_out, int32_t* __restrict__ s_rid_out) {
@@ -2300,7 +2333,7 @@ __global__ __launch_bounds__(256) void k_plan_export(const u32* __restrict__ q_r
     if (i < n_q) {
       q_rid_out[i] = (int32_t)(q_rid[i] + q_add);
       lo_out[i] = lo[i];
-      cnt_out[i] = cnt[i];
+      cnt_out[i] = (u32)(off[i + 1] - off[i]);
     } else {
       const u64 j = i - n_q;
       s_rid_out[j] = (int32_t)(s_rid[j] + s_add);
@@ -2339,7 +2372,7 @@ int giql_hip_inner_plan_export_dev(giql_hip_ctx* ctx, int32_t* q_rid_out, uint32
   const u32* srid = q_is_a ? S.sb.rid[0] : S.sa.rid[0];
   u32 grid = cdiv((u64)(*n_q + *n_s), 256 * 8);
   if (grid > GIQL_STREAM_GRID) grid = GIQL_STREAM_GRID;
-  hipLaunchKernelGGL(k_plan_export, dim3(grid), dim3(256), 0, st, qrid, S.lo2, S.cnt2, (u32)*n_q, srid, (u32)*n_s,
+  hipLaunchKernelGGL(k_plan_export, dim3(grid), dim3(256), 0, st, qrid, S.lo2, S.off2, (u32)*n_q, srid, (u32)*n_s,
                      (u32)(q_is_a ? rid_add_a : rid_add_b), (u32)(q_is_a ? rid_add_b : rid_add_a), q_rid_out,
                      lo_out, cnt_out, s_rid_out);
   return post_launch("plan export");

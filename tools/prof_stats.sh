@@ -7,7 +7,7 @@ REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 OUT="${REPO}/gpurun_out/prof_${TAG}"
 mkdir -p "${OUT}"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "${OUT}/trace" -o trace -- python3 "${REPO}/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras "$@" > "${OUT}/trace_bench.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "${OUT}/trace" -o trace -- python3 "${REPO}/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras "$@" > "${OUT}/trace_bench.log" 2>&1
 echo "trace rc=$?"
 tail -n 1 "${OUT}/trace_bench.log" | cut -c1-600
 f=$(find "${OUT}/trace" -name "*kernel_stats.csv" | head -1)

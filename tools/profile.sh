@@ -10,10 +10,10 @@ REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 OUT="${REPO}/gpurun_out/prof_${TAG}"
 mkdir -p "${OUT}"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "${OUT}/trace" -o trace -- python3 "${REPO}/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras > "${OUT}/trace_bench.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "${OUT}/trace" -o trace -- python3 "${REPO}/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-extras > "${OUT}/trace_bench.log" 2>&1
 echo "trace rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc "${c}" --kernel-trace -d "${OUT}/pmc_${c}" -o pmc -- python3 "${REPO}/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-extras > "${OUT}/pmc_${c}.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc "${c}" --kernel-trace --output-format csv -d "${OUT}/pmc_${c}" -o pmc -- python3 "${REPO}/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-extras > "${OUT}/pmc_${c}.log" 2>&1
   echo "pmc ${c} rc=$?"
 done
 find "${OUT}" -name "*.csv" | head -20
