@@ -166,6 +166,9 @@ struct giql_hip_ctx {
   bool last_sort_local = false;  // the call in flight sorted at least one side in three stages
   // fused range count (fixed-length INNER form whose sorted side takes the three-stage sort): the bucket
   // sort answers the queries' bounds from LDS, the sorted keys never return to HBM (bucket_sort.hip.h)
+  bool no_keygen_q = false;     // GIQL_HIP_NO_KEYGEN_Q=1: the fixed-length form always linearizes its query side
+  u32* span_hist_dirty[2] = {nullptr, nullptr};  // histograms the span pass of the call in flight counted into (a side that is linearized after all must zero its own again)
+  bool prezeroed = false;       // the call in flight zeroed its histograms and status words in ONE memset up front
   bool no_fuse_count = false;   // GIQL_HIP_NO_FUSE_COUNT=1: the separate count kernel always
   int fuse_q_skip = 2;          // GIQL_HIP_Q_SKIP_DIGITS: low digits the fused form leaves unsorted on the query side
   bool spec_fuse_len_ok = false;  // the previous plan's query rows were all short enough for the fused windows
@@ -359,6 +362,9 @@ struct LinBufs {
   // histogram-in-the-span-pass form (INNER plan only; NULL elsewhere)
   u32* abase = nullptr;        // [MM_HIST_CHROMS] 2^24-aligned chromosome bases
   u32* top_partial = nullptr;  // [LIN_HIST_REPLICAS][MM_HIST_CHROMS][256]
+  // the OTHER side's (the query side of the fixed-length form, when it is sorted from its raw columns too)
+  u32* top_partial2 = nullptr;
+  u32* hist_partial2 = nullptr;
 };
 
 static inline bool sort_is_local(const giql_hip_ctx* ctx, size_t n);
@@ -370,7 +376,9 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
                      int n_chrom, const LinBufs& lb, int hist_side = -1, u32* hist_partial = nullptr) {
   const bool hist = hist_side >= 0 && hist_partial && lb.abase && lb.top_partial &&
                     n_chrom <= MM_HIST_CHROMS && (hist_side ? b.n : a.n) > 0;
-  if (hist) {
+  // both sides count their digits (lb.hist_partial2 / top_partial2 for the other one; prezeroed plans only)
+  const bool hist2 = hist && lb.hist_partial2 && lb.top_partial2 && ctx->prezeroed && (hist_side ? a.n : b.n) > 0;
+  if (hist && !ctx->prezeroed) {
     HIP_TRY(hipMemsetAsync(hist_partial, 0, (size_t)LIN_HIST_REPLICAS * 1024 * sizeof(u32), st));
     HIP_TRY(hipMemsetAsync(lb.top_partial, 0, (size_t)LIN_HIST_REPLICAS * MM_TOP_WORDS * sizeof(u32), st));
   }
@@ -383,18 +391,21 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
   for (int k = 0; k < 2; k++) {
     const giql_side& s = *sides[k];
     if (s.n == 0) continue;
-    const bool with_hist = hist && k == hist_side;
+    const bool with_hist = hist && (k == hist_side || hist2);
+    u32* const hp = k == hist_side ? hist_partial : lb.hist_partial2;
+    if (with_hist) ctx->span_hist_dirty[k] = hp;
+    u32* const tp = k == hist_side ? lb.top_partial : lb.top_partial2;
     u32 grid = cdiv((u64)s.n, (u64)(with_hist ? MM_NT_HIST : MM_NT) * MM_ITEMS);
     if (grid > (u32)MM_MAX_BLOCKS) grid = MM_MAX_BLOCKS;
     nblk[k] = (int)grid;
     if (with_hist && sort_is_local(ctx, (size_t)s.n))  // the low digits are sorted in LDS: not counted
       hipLaunchKernelGGL((k_chrom_minmax<2, MM_NT_HIST>), dim3(grid), dim3(MM_NT_HIST), lds, st, s.chrom, s.start, s.end,
                          (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
-                         lb.len_part, s.start_off, hist_partial, lb.top_partial);
+                         lb.len_part, s.start_off, hp, tp);
     else if (with_hist)
       hipLaunchKernelGGL((k_chrom_minmax<1, MM_NT_HIST>), dim3(grid), dim3(MM_NT_HIST), lds, st, s.chrom, s.start, s.end,
                          (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
-                         lb.len_part, s.start_off, hist_partial, lb.top_partial);
+                         lb.len_part, s.start_off, hp, tp);
     else
       hipLaunchKernelGGL((k_chrom_minmax<0, MM_NT>), dim3(grid), dim3(MM_NT), lds, st, s.chrom, s.start, s.end,
                          (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
@@ -419,9 +430,17 @@ static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, 
                          u32* hist_end = nullptr, u32* gbase_end = nullptr, bool skip_end = false) {
   if (s.n == 0) return GIQL_OK;
   const int* end_col = skip_end ? (const int*)nullptr : s.end;  // a side known to hold no irregular row
-  if (hist_partial)
+  // (a plan zeroes its histograms once, up front -- but this one may hold the span pass's counts of a side that
+  // turned out to need the linearize pass after all: layout or form guess not taken)
+  bool dirty = false;
+  for (int k = 0; k < 2; k++)
+    if (hist_partial && ctx->span_hist_dirty[k] == hist_partial) {
+      dirty = true;
+      ctx->span_hist_dirty[k] = nullptr;
+    }
+  if (hist_partial && (!ctx->prezeroed || dirty))
     HIP_TRY(hipMemsetAsync(hist_partial, 0, (size_t)LIN_HIST_REPLICAS * 1024 * sizeof(u32), st));
-  if (hist_end)
+  if (hist_end && !ctx->prezeroed)
     HIP_TRY(hipMemsetAsync(hist_end, 0, (size_t)LIN_HIST_REPLICAS * 1024 * sizeof(u32), st));
   Phase ph(ctx, st, GIQL_PH_LINEARIZE, hist_partial ? 2 : 1);
   u32 grid = cdiv((u64)s.n, LIN_NT);
@@ -449,12 +468,17 @@ static int run_linearize(giql_hip_ctx* ctx, hipStream_t st, const giql_side& s, 
 static inline size_t os_pass_words(size_t n) {
   return (size_t)cdiv(n ? n : 1, OS_MIN_TILE) * OS_BINS + 16;
 }
+// ... and what a pass of this context really uses (the default 1024 x 8 block shape has 8192-row tiles: half
+// of the worst case, half the bytes to zero); the ticket word is the stride's 16th-last
+static inline size_t os_pass_stride(const giql_hip_ctx* ctx, size_t n) {
+  return ctx->os_variant == 0 ? (size_t)cdiv(n ? n : 1, 8192) * OS_BINS + 16 : os_pass_words(n);
+}
 
 template <int NT, int ITEMS>
 static void launch_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, int src, int dst, bool first,
                             u32 n, int shift, const u32* gbase, u32* status, DevMeta* meta) {
   const u32 grid = cdiv(n, NT * ITEMS);  // one block per tile
-  u32* claim = status + (size_t)cdiv(n, OS_MIN_TILE) * OS_BINS;  // the pass's ticket word
+  u32* claim = status + os_pass_stride(ctx, n) - 16;  // the pass's ticket word
   const u32* rin = (first || !sb.rid[0]) ? (const u32*)nullptr : sb.rid[src];
   const int mode = (sb.rid[0] ? 1 : 0) | (sb.end[0] ? 2 : 0);
 #define GIQL_OS_LAUNCH(M)                                                                            \
@@ -517,8 +541,8 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
   if (local || ctx->no_skip_digit) skip_digits = 0;
   const int n_pass = local ? 2 : 4 - skip_digits;
   const int first_digit = local ? 2 : skip_digits;
-  const size_t per_pass = os_pass_words(n);
-  HIP_TRY(hipMemsetAsync(status, 0, n_pass * per_pass * sizeof(u32), st));
+  const size_t per_pass = os_pass_stride(ctx, n);
+  if (!ctx->prezeroed) HIP_TRY(hipMemsetAsync(status, 0, n_pass * per_pass * sizeof(u32), st));
   {
     // one event pair around the passes (an event record between two launches costs the
     // stream ~8 us of idle time; the per-launch time is phase time / launches)
@@ -539,7 +563,7 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
       }
       if (pass == 0 && keygen) {
         const u32 grid = cdiv(n, 1024 * 8);
-        u32* claim = stat + (size_t)cdiv(n, OS_MIN_TILE) * OS_BINS;
+        u32* claim = stat + per_pass - 16;
         if (sb.end[0])  // (key, end, rid): the end keys are built from the raw end column as well
           hipLaunchKernelGGL((k_onesweep<3, 1024, 8, true>), dim3(grid), dim3(1024), 0, st,
                              reinterpret_cast<const u32*>(keygen->start), reinterpret_cast<const u32*>(keygen->end),
@@ -851,6 +875,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     if (rsd && atoi(rsd) >= 0 && atoi(rsd) <= 3) ctx->row_skip_digits = atoi(rsd);
     const char* nfc = getenv("GIQL_HIP_NO_FUSE_COUNT");
     ctx->no_fuse_count = nfc && atoi(nfc) != 0;
+    const char* nkq = getenv("GIQL_HIP_NO_KEYGEN_Q");
+    ctx->no_keygen_q = nkq && atoi(nkq) != 0;
     const char* qsd = getenv("GIQL_HIP_Q_SKIP_DIGITS");
     if (qsd && atoi(qsd) >= 1 && atoi(qsd) <= 2) ctx->fuse_q_skip = atoi(qsd);
     const char* nl = getenv("GIQL_HIP_NO_LOCAL_SORT");
@@ -978,8 +1004,9 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   InnerState& S = ctx->inner;
   u32 *tile_hist = nullptr, *cnt2 = nullptr, *irr_cnt = nullptr;
   u32 *hist_a = nullptr, *hist_b = nullptr, *gbase_a = nullptr, *gbase_b = nullptr;
-  u32 *os_status = nullptr, *os_status2 = nullptr;
+  u32 *os_status = nullptr, *os_status2 = nullptr, *top_partial_q = nullptr;
   u64 *bsums = nullptr, *bsums1 = nullptr, *scan_chain = nullptr;
+  size_t zero_off = 0, zero_end = 0;  // arena offsets of the region zeroed up front ([zero_off, zero_end + the larger side's status words))
   const bool onesweep = !ctx->classic_sort && na <= OS_MAX_ROWS && nb <= OS_MAX_ROWS;
   const size_t n_max = na > nb ? na : nb;
   const size_t n_tiles_max = cdiv(n_max, RS_TILE);
@@ -996,14 +1023,21 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     sort_sizes(c, na, S.sa, true);
     sort_sizes(c, nb, S.sb, true);
     if (onesweep) {
+      // everything that has to start at zero lies back to back, the larger side's status words last: ONE memset
+      // up front instead of one per histogram and per sort (5 launches of ~5 us at the headline sizes)
+      c.off = align_up(c.off, 256);
+      zero_off = c.off;
       hist_a = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
       hist_b = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
+      lb.top_partial = c.take<u32>((size_t)LIN_HIST_REPLICAS * MM_TOP_WORDS);
+      top_partial_q = c.take<u32>((size_t)LIN_HIST_REPLICAS * MM_TOP_WORDS);
       gbase_a = c.take<u32>(1024);
       gbase_b = c.take<u32>(1024);
-      os_status = c.take<u32>(4 * os_pass_words(n_max));
-      os_status2 = c.take<u32>(4 * os_pass_words(na < nb ? na : nb));  // the smaller side's, when its chain runs beside
       lb.abase = c.take<u32>(MM_HIST_CHROMS);
-      lb.top_partial = c.take<u32>((size_t)LIN_HIST_REPLICAS * MM_TOP_WORDS);
+      os_status2 = c.take<u32>(4 * os_pass_words(na < nb ? na : nb));  // the smaller side's
+      c.off = align_up(c.off, 256);
+      zero_end = c.off;
+      os_status = c.take<u32>(4 * os_pass_words(n_max));               // the larger side's
     } else {
       tile_hist = c.take<u32>(n_tiles_max * RS_BINS);
     }
@@ -1033,6 +1067,20 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   carve(ctx->arena);
   SortBufs& sa = S.sa;
   SortBufs& sbb = S.sb;
+  struct Prezero {  // the helpers skip their own memsets while this plan runs
+    giql_hip_ctx* c;
+    ~Prezero() { c->prezeroed = false; }
+  } prezero_guard{ctx};
+  ctx->prezeroed = false;
+  ctx->span_hist_dirty[0] = ctx->span_hist_dirty[1] = nullptr;
+  int big_passes_zeroed = 0;
+  if (onesweep) {
+    // the larger side takes at most 4 passes (2 in the three-stage form)
+    big_passes_zeroed = sort_is_local(ctx, n_max) ? 2 : 4;
+    const size_t big_words = (size_t)big_passes_zeroed * os_pass_stride(ctx, n_max);
+    HIP_TRY(hipMemsetAsync(ctx->arena + zero_off, 0, (zero_end - zero_off) + big_words * sizeof(u32), st));
+    ctx->prezeroed = true;
+  }
 
   // The larger side is the one the uniform form prefers as its fixed-length side: its span pass
   // also counts the digits of its keys (aligned layout), so that, if the form and the layout
@@ -1044,6 +1092,16 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   if (want_hist && ctx->spec_valid)  // ... or in the general form without irregular rows (its larger side)
     want_hist = ctx->spec_aligned && (ctx->spec_form == (big_side ? 1 : 2) ||
                                       (ctx->spec_form == 0 && ctx->last_no_irr && !ctx->no_keygen_general));
+  // ... and the QUERY side of the fixed-length form too (round 3): its (key, end, rid) sort starts from the raw
+  // columns as well (k_onesweep<3, .., KEYGEN>), so neither side has a linearize pass -- on the guesses that the
+  // form and the layout hold AND that the query side has no irregular row (those carry the sentinel key and a
+  // list entry, which only the linearize pass produces): validated at the read-back like the others.
+  const bool want_hist_q = want_hist && ctx->spec_valid && ctx->spec_form == (big_side ? 1 : 2) && ctx->last_no_irr &&
+                           !ctx->no_keygen_q && (big_side ? na : nb) > 0;
+  if (want_hist_q) {
+    lb.hist_partial2 = big_side ? hist_a : hist_b;
+    lb.top_partial2 = top_partial_q;
+  }
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb, want_hist ? big_side : -1, big_side ? hist_b : hist_a));
   bool aligned = false;
   // Uniform-length side?  (fixed-length reads: min == max canonical length > 0 over ALL its
@@ -1073,6 +1131,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   };
   bool speculated = false;
   bool coarse_q = false;  // the query side was sorted without its lowest digit (a guess: no irregular rows)
+  bool keygen_q = false;  // ... and from its raw columns (the same guess)
   if (onesweep) {
     if (ctx->spec_valid) {
       S.uniform = ctx->spec_form;
@@ -1091,6 +1150,13 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
       const bool expected_local = sort_is_local(ctx, n_big);
       ctx->last_span = ctx->h_meta->total_span;
       if (expected_local && !sort_is_local(ctx, n_big)) aligned = false;
+      if (big_passes_zeroed < 4 && !sort_is_local(ctx, n_max)) {
+        // the larger side leaves the three-stage sort after all: its third and fourth pass need zeroed status words too
+        const size_t stride = os_pass_stride(ctx, n_max);
+        HIP_TRY(hipMemsetAsync(os_status + (size_t)big_passes_zeroed * stride, 0,
+                               (size_t)(4 - big_passes_zeroed) * stride * sizeof(u32), st));
+        big_passes_zeroed = 4;
+      }
     }
   }
   const bool keygen = aligned && S.uniform == (big_side ? 1 : 2);
@@ -1120,17 +1186,29 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     // the query side's chain (linearize + sort) beside the other side's when it is small (the fused count
     // needs the sorted queries before U's last stage: one stream)
     SideChain sc(ctx, st, (nqr <= nu && !fuse_cnt) ? nqr : 0, nu);
-    GIQL_TRY(run_linearize(ctx, sc.stream(), qs_, n_chrom, lb, sq.key[0], sq.end[0],
-                           q_is_a ? ctx->irr_a_list : ctx->irr_b_list, q_is_a ? 0 : 1, 0,
-                           q_is_a ? hist_a : hist_b, q_is_a ? gbase_a : gbase_b));
+    // the query side sorted from its raw columns too (its digits were counted in the span pass)
+    keygen_q = keygen && want_hist_q;
+    u32* const hist_q = q_is_a ? hist_a : hist_b;
+    if (!keygen_q) {
+      GIQL_TRY(run_linearize(ctx, sc.stream(), qs_, n_chrom, lb, sq.key[0], sq.end[0],
+                             q_is_a ? ctx->irr_a_list : ctx->irr_b_list, q_is_a ? 0 : 1, 0,
+                             hist_q, q_is_a ? gbase_a : gbase_b));
+    }
     if (keygen) {
       // the span pass counted U's digits already: fold the per-chromosome top digits onto the
       // bases, scan, and let the first sort pass build the keys from (chrom, start)
       Phase ph(ctx, st, GIQL_PH_LINEARIZE, 2);
       u32* hist_u = q_is_a ? hist_b : hist_a;
-      hipLaunchKernelGGL(k_fold_top, dim3(MM_HIST_CHROMS), dim3(256), 0, st, lb.top_partial, lb.abase, hist_u);
-      hipLaunchKernelGGL(k_digit_offsets, dim3(4), dim3(256), 0, st, hist_u, (u32)LIN_HIST_REPLICAS,
-                         q_is_a ? gbase_b : gbase_a);
+      if (keygen_q) {  // both sides, one launch each
+        hipLaunchKernelGGL(k_fold_top2, dim3(MM_HIST_CHROMS, 2), dim3(256), 0, st, lb.top_partial, lb.top_partial2,
+                           lb.abase, hist_u, hist_q);
+        hipLaunchKernelGGL(k_digit_offsets2, dim3(4, 2), dim3(256), 0, st, hist_u, hist_q, (u32)LIN_HIST_REPLICAS,
+                           q_is_a ? gbase_b : gbase_a, q_is_a ? gbase_a : gbase_b);
+      } else {
+        hipLaunchKernelGGL(k_fold_top, dim3(MM_HIST_CHROMS), dim3(256), 0, st, lb.top_partial, lb.abase, hist_u);
+        hipLaunchKernelGGL(k_digit_offsets, dim3(4), dim3(256), 0, st, hist_u, (u32)LIN_HIST_REPLICAS,
+                           q_is_a ? gbase_b : gbase_a);
+      }
       GIQL_TRY(post_launch("digit offsets (span histogram)"));
     } else {
       GIQL_TRY(run_linearize(ctx, st, us_, n_chrom, lb, su.key[0], nullptr,
@@ -1149,8 +1227,11 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     if (q_skip && fuse_cnt && ctx->fuse_q_skip > 1) q_skip = ctx->fuse_q_skip;
     coarse_q = q_skip != 0;
     const u32 q_mask = q_skip == 2 ? 0xFFFF0000u : (q_skip == 1 ? 0xFFFFFF00u : 0xFFFFFFFFu);
+    // (the smaller side's passes use the smaller status buffer: both were zeroed up front, neither is reused)
+    u32* const stat_q = nqr <= nu ? os_status2 : os_status;
+    u32* const stat_u = nqr <= nu ? os_status : os_status2;
     GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sq, (u32)nqr, q_is_a ? gbase_a : gbase_b,
-                               sc.active ? os_status2 : os_status, false, nullptr, nullptr, q_skip));
+                               stat_q, false, keygen_q ? &qs_ : nullptr, lb.abase, q_skip));
     // One-call join (giql_hip_inner_join_dev): the caller's buffers are here and everything about this plan is a
     // guess that has held so far (same form as last time, no irregular rows), so the fill is launched inside the
     // plan, with a grid bounded by the capacity and the true count read on the device.
@@ -1176,7 +1257,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
       fc.key_mask = q_mask;
       fc.len_max_q = q_is_a ? &ctx->d_meta->len_max_a : &ctx->d_meta->len_max_b;
     }
-    GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, os_status, false,
+    GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, stat_u, false,
                                keygen ? &us_ : nullptr, lb.abase, 0, fuse_cnt ? &fc : nullptr));
     GIQL_TRY(sc.join());
     constexpr u32 TQ = RC_NT * RC_ITEMS_C2;
@@ -1258,9 +1339,9 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     }
   }
   if (onesweep) {
-    GIQL_TRY(run_sort_onesweep(ctx, st_a, sa, (u32)na, gbase_a, (sc.active && a_small) ? os_status2 : os_status,
+    GIQL_TRY(run_sort_onesweep(ctx, st_a, sa, (u32)na, gbase_a, a_small ? os_status2 : os_status,
                                false, kg_a ? a : nullptr, lb.abase));
-    GIQL_TRY(run_sort_onesweep(ctx, st_b, sbb, (u32)nb, gbase_b, (sc.active && !a_small) ? os_status2 : os_status,
+    GIQL_TRY(run_sort_onesweep(ctx, st_b, sbb, (u32)nb, gbase_b, a_small ? os_status : os_status2,
                                false, kg_b ? b : nullptr, lb.abase));
     GIQL_TRY(sc.join());
   } else {
@@ -1320,7 +1401,8 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     const bool coarse_wrong = coarse_q && ctx->h_meta->irr_a + ctx->h_meta->irr_b > 0;
     // a side sorted from its raw columns in the general form must hold no irregular row (its length
     // range starts above 0); such a row was keyed as if regular, and never listed
-    const bool keygen_wrong = keygen_g && (big_side ? ctx->h_meta->len_min_b : ctx->h_meta->len_min_a) <= 0;
+    const bool keygen_wrong = (keygen_g && (big_side ? ctx->h_meta->len_min_b : ctx->h_meta->len_min_a) <= 0) ||
+                              (keygen_q && (big_side ? ctx->h_meta->len_min_a : ctx->h_meta->len_min_b) <= 0);
     if (keygen_wrong) ctx->last_no_irr = false;
     // the fused count's windows allow for query rows up to BS_FUSE_WCAP long (the query side of the form just decided)
     const int q_len_now = form == 1 ? ctx->h_meta->len_max_a : ctx->h_meta->len_max_b;

@@ -403,6 +403,20 @@ __global__ __launch_bounds__(256) void k_fold_top(const u32* __restrict__ top_pa
   if (sum) atomicAdd(&hist_partial[3 * 256 + ((j + (abase[c] >> 24)) & 0xFFu)], sum);
 }
 
+// Both sides in one launch each (the query side of the fixed-length form is sorted from its raw columns
+// too, round 3): blockIdx.y = side.
+__global__ __launch_bounds__(256) void k_fold_top2(const u32* __restrict__ top_a, const u32* __restrict__ top_b,
+                                                    const u32* __restrict__ abase, u32* __restrict__ hist_a,
+                                                    u32* __restrict__ hist_b) {
+  const u32* top_partial = blockIdx.y ? top_b : top_a;
+  u32* hist_partial = blockIdx.y ? hist_b : hist_a;
+  const u32 c = blockIdx.x, j = threadIdx.x;
+  u32 sum = 0;
+#pragma unroll 8
+  for (int r = 0; r < LIN_HIST_REPLICAS; r++) sum += top_partial[(size_t)r * MM_TOP_WORDS + c * 256 + j];
+  if (sum) atomicAdd(&hist_partial[3 * 256 + ((j + (abase[c] >> 24)) & 0xFFu)], sum);
+}
+
 // -------------------------------------------------------------- linearise
 #ifndef GIQL_LIN_NT
 #define GIQL_LIN_NT 256
@@ -552,6 +566,21 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
 __global__ __launch_bounds__(256) void k_digit_offsets(const u32* __restrict__ partial, u32 n_blocks,
                                                         u32* __restrict__ gbase) {
   __shared__ u32 lds[256 / WAVE + 1];
+  const int p = blockIdx.x;
+  u32 c = 0;
+#pragma unroll 8
+  for (u32 b = 0; b < n_blocks; b++) c += partial[(size_t)b * 1024 + p * 256 + threadIdx.x];
+  u32 total;
+  const u32 ex = block_excl_scan<u32, 256>(c, lds, total);
+  gbase[p * 256 + threadIdx.x] = ex;
+}
+
+__global__ __launch_bounds__(256) void k_digit_offsets2(const u32* __restrict__ partial_a,
+                                                         const u32* __restrict__ partial_b, u32 n_blocks,
+                                                         u32* __restrict__ gbase_a, u32* __restrict__ gbase_b) {
+  __shared__ u32 lds[256 / WAVE + 1];
+  const u32* partial = blockIdx.y ? partial_b : partial_a;
+  u32* gbase = blockIdx.y ? gbase_b : gbase_a;
   const int p = blockIdx.x;
   u32 c = 0;
 #pragma unroll 8
