@@ -205,6 +205,21 @@ __device__ __forceinline__ u32 bs_rank16(u32 x16, const u64* s_cell, const u32* 
   return start + c;
 }
 
+// Barrier of the bucket sort's body.  __syncthreads() also drains the wave's outstanding GLOBAL loads and stores
+// (s_waitcnt vmcnt(0)); the fused form has the query bounds' stores in flight in the middle of the kernel, and
+// every block would stand still for their acknowledgement: its barriers wait for the wave's LDS operations only.
+template <bool LDS_ONLY>
+__device__ __forceinline__ void bs_sync() {
+  if (LDS_ONLY)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else
+    __syncthreads();
+}
+#ifndef GIQL_BS_QPRE
+#define GIQL_BS_QPRE 2
+#endif
+constexpr int BS_QPRE = GIQL_BS_QPRE;  // probe rounds whose values are loaded with the rows
+
 template <int PAYLOAD, int R, bool FUSE = false>
 __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __restrict__ pp,
                                                  u32* __restrict__ ep, u32 cnt, u32 v, u32* s_buf,
@@ -230,12 +245,18 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
   const u32* q_src = (tid & 1u) ? fq.qend : fq.qkey;
   u32* q_dst = (tid & 1u) ? fq.hi_out : fq.lo_out;
   const u32 n_probe = FUSE ? 2u * (qw1 - qw0) : 0u;
-  u32 q_val = 0;
-  if (FUSE && tid < n_probe) q_val = q_src[qw0 + (tid >> 1)];
+  // (the first BS_QPRE rounds' values are loaded up front, with the rows: a window of one bucket's queries is
+  // one round, the three buckets a query side grouped by bucket only brings along are three)
+  u32 q_val[BS_QPRE];
+#pragma unroll
+  for (int k = 0; k < BS_QPRE; k++) {
+    q_val[k] = 0;
+    if (FUSE && tid + k * BS_NT < n_probe) q_val[k] = q_src[qw0 + ((tid + k * BS_NT) >> 1)];
+  }
   // cells zeroed while the loads fly
 #pragma unroll
   for (int k = 0; k < PER; k++) s_cell[tid + k * BS_NT] = 0;
-  __syncthreads();
+  bs_sync<FUSE>();
   GIQL_BS_STOP(1);  // loads + table zeroing
 #pragma unroll
   for (int i = 0; i < R; i++) {
@@ -247,7 +268,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
       slot[i] = (u32)atomicAdd((unsigned long long*)&s_cell[pk[i] >> BIN_SHIFT], (unsigned long long)add);
     }
   }
-  __syncthreads();
+  bs_sync<FUSE>();
   GIQL_BS_STOP(2);  // + binning atomics
   {
     // exclusive scan of the bin counts: PER consecutive cells per thread, DPP scan per wave, the
@@ -262,7 +283,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
     }
     const u32 incl = wave_incl_scan_add_u32(t);
     if (lane == WAVE - 1) s_scan[w] = incl;
-    __syncthreads();
+    bs_sync<FUSE>();
     u32 ex = incl - t;
 #pragma unroll
     for (int k = 0; k < BS_NW; k++)
@@ -274,7 +295,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
       ex += c[k];
     }
   }
-  __syncthreads();
+  bs_sync<FUSE>();
   GIQL_BS_STOP(3);  // + scan
   bool any_dup = false;
 #pragma unroll
@@ -294,15 +315,23 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
       }
     }
   }
-  __syncthreads();
+  bs_sync<FUSE>();
   GIQL_BS_STOP(4);  // + places of the rows with distinct keys
   if (FUSE) {
     // the bounds of the query window that fall into this bucket: one cell read each
-    for (u32 i = tid; i < n_probe; i += BS_NT) {
+#pragma unroll
+    for (int k = 0; k < BS_QPRE; k++) {
+      const u32 i = tid + k * BS_NT;
+      if (i < n_probe) {
+        const u32 x = (tid & 1u) ? q_val[k] : bs_shift_key(q_val[k], fq.lo_off);
+        if ((x >> 16) == v) q_dst[qw0 + (i >> 1)] = b0 + bs_rank16(x & 0xFFFFu, s_cell, s_buf);
+      }
+    }
+    for (u32 i = tid + BS_QPRE * BS_NT; i < n_probe; i += BS_NT) {  // wider windows (dense query tables)
       const u32 q = qw0 + (i >> 1);
-      const u32 x = (tid & 1u) ? q_val : bs_shift_key(q_val, fq.lo_off);
+      const u32 qv = q_src[q];
+      const u32 x = (tid & 1u) ? qv : bs_shift_key(qv, fq.lo_off);
       if ((x >> 16) == v) q_dst[q] = b0 + bs_rank16(x & 0xFFFFu, s_cell, s_buf);
-      if (i + BS_NT < n_probe) q_val = q_src[q + BS_NT / 2];  // windows wider than half the block: the next round's row
     }
   }
   if (any_dup) {
@@ -321,7 +350,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
       }
     }
   }
-  __syncthreads();  // every gathered bin has been read: s_buf and the cells are free
+  bs_sync<FUSE>();  // every gathered bin has been read: s_buf and the cells are free
   GIQL_BS_STOP(5);  // + places of the rows with equal keys
   uint16_t* s_key16 = reinterpret_cast<uint16_t*>(s_cell);
 #pragma unroll
@@ -332,7 +361,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
       if (PAYLOAD) s_buf[slot[i]] = pay[i];
     }
   }
-  __syncthreads();
+  bs_sync<FUSE>();
   GIQL_BS_STOP(6);  // + staging by final place (everything but the stores)
   // keys: the high half is the bucket's number.  Every load of the block's rows completed before
   // the barriers above, so the in-place stores cannot overtake a load.
@@ -350,13 +379,13 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
       const u32 r = i * BS_NT + tid;
       pay[i] = GIQL_BS_OK(i, r) ? ep[r] : 0u;
     }
-    __syncthreads();  // the rid round has left s_buf
+    bs_sync<FUSE>();  // the rid round has left s_buf
 #pragma unroll
     for (int i = 0; i < R; i++) {
       const u32 r = i * BS_NT + tid;
       if (GIQL_BS_OK(i, r)) s_buf[slot[i]] = pay[i];
     }
-    __syncthreads();  // every `end` of the bucket is in LDS: the in-place stores may start
+    bs_sync<FUSE>();  // every `end` of the bucket is in LDS: the in-place stores may start
 #pragma unroll
     for (int i = 0; i < R; i++) {
       const u32 r = i * BS_NT + tid;
