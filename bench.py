@@ -82,13 +82,22 @@ def parse_args():
                         "(ranks share GPUs, the exchange runs through host memory)")
     p.add_argument("--cpu-sample-chroms", default="18,19,20,21",
                    help="chromosome ids of the bounded cpu_baseline probe")
-    p.add_argument("--verify", action="store_true",
-                   help="N>1: rank 0 also runs the CPU leg on the WHOLE workload after the timed region and checks the "
-                        "gathered result against it (count + multiset checksum); the other ranks wait")
+    p.add_argument("--exchange-impl", default="allgather", choices=["allgather", "p2p"],
+                   help="N>1: how the blocks move -- one padded all-gather (RCCL picks the algorithm) or grouped direct "
+                        "send / recv to every peer (ncclGroupStart .. End: each block crosses one xGMI link)")
+    p.add_argument("--gather", default="all", choices=["all", "root"],
+                   help="N>1: who ends up with the result -- every rank (the all-gatherv of the north star) or rank 0 "
+                        "only (the other ranks send their block there and skip the expansion)")
+    p.add_argument("--verify", action="store_true", help="(the default at N>1; kept for old command lines)")
+    p.add_argument("--no-verify", action="store_true",
+                   help="N>1: skip the CPU leg.  By default rank 0 runs it on the WHOLE workload after the timed region "
+                        "(the other ranks wait), checks the gathered result against it (count + multiset checksum) and "
+                        "the run exits non-zero on a mismatch")
     p.add_argument("--master-port", type=int, default=29531)
     a = p.parse_args()
     if a.no_gather:
         a.exchange = "none"
+    a.verify = (a.gpus > 1 or a.verify or a.force_exchange) and not a.no_verify
     return a
 
 
@@ -250,7 +259,7 @@ def duckdb_baseline(op, a, b, n_chrom, names):
         return {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
 
-def cpu_baseline_inner(args, wl, n_chrom, rank_chroms=None):
+def cpu_baseline_inner(args, wl, n_chrom, rank_chroms=None, whole=False):
     """Bounded CPU leg of an INNER workload + the data for the parity line.  DuckDB (the reference's
     path) when importable, else the oracle's OpenMP sort-merge port; a probe on four small
     chromosomes sizes the sample (the whole workload when the host does it in ~20 s)."""
@@ -294,6 +303,8 @@ def cpu_baseline_inner(args, wl, n_chrom, rank_chroms=None):
                 break
             chroms.append(c)
             acc += int(rows_total[c])
+        if whole:   # the N > 1 verification: the gathered result can only be checked against the whole workload
+            chroms = list(range(len(rows_total)))
         whole = len(chroms) == len(rows_total)
         sel = None if whole else chroms
     else:
@@ -379,7 +390,8 @@ def run_inner(args):
         dist.all_gather_into_tensor(all_sizes.view(-1), sizes_t)
         base_a, base_b = (int(x) for x in all_sizes[:rank].sum(0).tolist()) if rank else (0, 0)
     exchange = args.exchange if distributed else "none"
-    xplan = D.PlanGather(xdev) if exchange == "plan" else None
+    root = 0 if (args.gather == "root" and distributed) else None
+    xplan = D.PlanGather(xdev, impl=args.exchange_impl, root=root) if exchange == "plan" else None
     xpairs = D.PairGather(xdev) if exchange in ("plan", "pairs") else None   # "plan" falls back to it
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if distributed else None
     split_ms = [0.0, 0.0, 0.0]  # [local join, exchange, expansion] summed over the timed steps
@@ -455,7 +467,8 @@ def run_inner(args):
             if ev:
                 ev[1].record()
             total = sum(s[0] for s in sizes)
-            if gout is None or gout[0].shape[0] < total:
+            keeps = xplan.receives()   # gather-to-root: only the root expands (and holds) the result
+            if keeps and (gout is None or gout[0].shape[0] < total):
                 gout = None
                 gout = alloc_out(total)
             offs = [sum(s[0] for s in sizes[:r]) for r in range(world)]
@@ -472,14 +485,15 @@ def run_inner(args):
             # the all-gather runs on RCCL's own stream; this rank's OWN block is expanded meanwhile, straight
             # from the send block (it needs nothing from the wire)
             work = xplan.all_gather_async(sizes)
-            expand(rank, views)
+            if keeps:
+                expand(rank, views)
             blocks = work()
             if ev:
                 ev[2].record()
             for r, blk in enumerate(blocks):
-                if r != rank:
+                if keeps and r != rank and blk is not None:
                     expand(r, blk)
-            last_pairs[0] = (gout[0][:total], gout[1][:total])
+            last_pairs[0] = (gout[0][:total], gout[1][:total]) if keeps else None
         elif exchange in ("plan", "pairs"):
             used["pairs"] += 1
             if exchange == "pairs":
@@ -635,18 +649,22 @@ def run_inner(args):
         }
 
         cpu_baseline = None
-        if (not args.no_cpu_baseline and world == 1) or (args.verify and exchange in ("plan", "pairs")):
-            # rank 0 at N = 1 (the contract); at N > 1 only on request (--verify), as the gathered result's check
+        if (not args.no_cpu_baseline and world == 1 and not distributed) or (distributed and args.verify):
+            # rank 0 at N = 1 (the contract); at N > 1 the same leg checks the GATHERED result (--no-verify skips it)
             layout = ([[c for c in range(n_chrom) if assign[c] == r] for r in range(world)]
                       if world > 1 and genome == HG38 else None)
-            cpu_baseline, ref = cpu_baseline_inner(args, wl, n_chrom, layout)
+            cpu_baseline, ref = cpu_baseline_inner(args, wl, n_chrom, layout, whole=distributed)
             if ref is not None and last_pairs[0] is not None:
                 pa_, pb_ = last_pairs[0] if not isinstance(last_pairs[0], list) else (
                     torch.cat([x[0] for x in last_pairs[0]]), torch.cat([x[1] for x in last_pairs[0]]))
                 # (the gloo rehearsal gathers the pairs in HOST memory: the checksum kernel wants them on the device)
                 gpu_sum = eng.pairs_checksum(pa_.to(dev).contiguous(), pb_.to(dev).contiguous())
-                cpu_baseline["parity"] = {"pairs_equal": ref[0] == n_pairs, "multiset_checksum_equal": gpu_sum == ref[1],
+                cpu_baseline["parity"] = {"pairs_equal": ref[0] == n_pairs and int(pa_.shape[0]) == n_pairs,
+                                          "multiset_checksum_equal": gpu_sum == ref[1],
                                           "checked": "all %d pairs of the last timed step against the CPU leg" % n_pairs}
+            elif ref is not None:   # --exchange none: the results stay sharded, only their total can be checked here
+                cpu_baseline["parity"] = {"pairs_equal": ref[0] == n_pairs, "multiset_checksum_equal": None,
+                                          "checked": "the pair count only (no gathered result: --exchange none)"}
 
         extras = {}
         if world == 1 and not distributed and not args.no_extras:
@@ -672,7 +690,8 @@ def run_inner(args):
                 "workload": wl,
                 "n_a": tot_na, "n_b": tot_nb, "n_chrom": n_chrom, "pairs_per_step": n_pairs,
                 "parallelism": f"chrom-shard x{world}" + ("" if not distributed else {
-                    "plan": f" + {args.backend} all-gather of the compact plan, expanded on every rank",
+                    "plan": (f" + {args.backend} {'grouped send/recv' if xplan is not None and xplan.impl == 'p2p' else 'all-gather'}"
+                             f" of the compact plan, expanded on {'rank 0 only' if root is not None else 'every rank'}"),
                     "pairs": f" + {args.backend} all-gather of the pairs", "none": ", no gather"}[exchange]),
                 "inputs": "resident in HBM before the timed region",
                 "join_form": form,
@@ -690,7 +709,9 @@ def run_inner(args):
         }
         line.update(extras)
         if distributed:
-            line["exchange"] = {"mode": exchange, "steps_compact": used["plan"], "steps_expanded": used["pairs"],
+            line["exchange"] = {"mode": exchange, "impl": (xplan.impl if xplan is not None else "allgather"),
+                                "gather": "root" if root is not None else "all",
+                                "steps_compact": used["plan"], "steps_expanded": used["pairs"],
                                 "bytes_per_rank": (xplan.bytes_per_rank() if used["plan"] else None)}
     if distributed:
         dist.barrier()
@@ -814,6 +835,7 @@ def run_rowop(args):
         all_sizes = torch.empty((world, 2), dtype=torch.int64, device=xdev)
         dist.all_gather_into_tensor(all_sizes.view(-1), sizes_t)
         base_a, base_b = (int(x) for x in all_sizes[:rank].sum(0).tolist()) if rank else (0, 0)
+    root = 0 if (args.gather == "root" and distributed) else None
     local = {"semi": lambda: eng.semi_join(a, b, n_chrom), "anti": lambda: eng.anti_join(a, b, n_chrom),
              "count": lambda: eng.count_overlaps(a, b, n_chrom), "nearest": lambda: eng.nearest(a, b, n_chrom)}[op]
 
@@ -826,19 +848,24 @@ def run_rowop(args):
         last_local[0] = int((r[0] if isinstance(r, tuple) else r).shape[0])
         if not distributed:
             return r
+        # int32 blocks: row ids and counts are int32 (fewer than 2^31 rows per table); only NEAREST's distance is
+        # 64-bit and travels as two int32 words
         if op in ("semi", "anti"):
-            block = (r.to(torch.int64) + base_a).to(xdev).view(1, -1)
+            block = (r + base_a).to(xdev).view(1, -1)
         elif op == "count":
-            block = r.to(xdev).view(1, -1)
+            block = r.to(torch.int32).to(xdev).view(1, -1)
         else:
-            idx = r[0].to(torch.int64)
-            block = torch.stack([torch.where(idx >= 0, idx + base_b, idx), r[1]]).to(xdev)
-        blocks = D.gather_blocks(block)
+            idx = r[0]
+            block = torch.cat([torch.where(idx >= 0, idx + base_b, idx).view(1, -1), D._i64_as_i32_rows(r[1])]).to(xdev)
+        blocks = D.gather_blocks(block, impl=args.exchange_impl, root=root)
+        if root is not None and rank != root:
+            return r
         if op in ("semi", "anti"):
-            return torch.cat([blk[0] for blk in blocks]).to(torch.int32)
-        if op == "count":
             return torch.cat([blk[0] for blk in blocks])
-        return torch.cat([blk[0] for blk in blocks]).to(torch.int32), torch.cat([blk[1] for blk in blocks])
+        if op == "count":
+            return torch.cat([blk[0] for blk in blocks]).to(torch.int64)
+        return (torch.cat([blk[0] for blk in blocks]),
+                torch.cat([D._i32_rows_as_i64(blk[1:3]) for blk in blocks]))
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -940,8 +967,10 @@ def run_rowop(args):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": wl, "n_a": g_na, "n_b": g_nb, "n_chrom": n_chrom, "rows_out": n_out,
                    "inputs": "resident in HBM before the timed region", "form": st.get("join_form"),
-                   "parallelism": (f"{world} ranks, the A rows' chromosomes LPT-sharded, one all-gather of the per-row results "
-                                   f"({args.backend})") if distributed else "1 GPU"},
+                   "parallelism": (f"{world} ranks, the A rows' chromosomes LPT-sharded, one "
+                                   f"{'gather to rank 0' if root is not None else 'all-gather'} of the per-row results as int32 blocks "
+                                   f"({args.backend}, {'grouped send/recv' if (root is not None or args.exchange_impl == 'p2p') else 'padded all-gather'})")
+                   if distributed else "1 GPU"},
         "hbm_algorithmic_GBps": round(op_bytes(op, g_na, g_nb, n_out) * args.steps / elapsed / 1e9, 1),
         "per_rank": [{"rank": 0, "rows_a": loc_na, "rows_b": loc_nb, "rows_out": last_local[0],
                       "device_ms": round(device_ms, 3)}],
@@ -961,6 +990,10 @@ def main() -> None:
     line = run_inner(args) if op == "inner" else run_rowop(args)
     if line is not None:
         print(json.dumps(line), flush=True)
+        parity = ((line.get("cpu_baseline") or {}).get("parity") or {})
+        if any(v is False for v in parity.values()):
+            sys.stderr.write("bench.py: the result does NOT match the CPU leg: %s\n" % json.dumps(parity))
+            sys.exit(3)
 
 
 if __name__ == "__main__":

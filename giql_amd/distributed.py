@@ -7,9 +7,18 @@ the path's single exchange step is the final gather of the (row_a, row_b) index
 pairs -- over RCCL (``backend="nccl"`` is RCCL on ROCm) when the tensors are on
 GPUs, over gloo in the CPU tests.
 
-xGMI is a point-to-point mesh, so the gather is issued as one all-gather of
-equal-sized (padded) shards: every shard crosses each link once, in parallel,
-instead of a ring's serial hops.
+Two implementations of that one exchange (``impl=``), both moving the same blocks:
+
+* ``"allgather"`` -- one ``all_gather_into_tensor`` of equal-sized (padded) blocks; RCCL picks the
+  algorithm (ring / tree over the xGMI links).
+* ``"p2p"`` -- grouped direct ``send`` / ``recv`` (``batch_isend_irecv`` = ``ncclGroupStart`` ... ``End``):
+  every rank sends its block, exactly sized, to every peer at once.  xGMI is a point-to-point mesh
+  (7 links per GPU), so each block crosses ONE link and the 7 transfers of a rank run side by side;
+  what SURVEY.md section 8(e) asked for.
+
+and two result placements (``root=``): every rank ends up with the whole result (``None``, the
+reference's ``UNION ALL`` seen from any rank), or only rank ``root`` does (the other ranks send their
+block there and skip the expansion -- what a caller that wants ONE table needs).
 """
 
 from __future__ import annotations
@@ -69,6 +78,42 @@ def unit_rows(chrom_a: np.ndarray, chrom_b: np.ndarray, n_chrom: int, world: int
     keep_a |= whole[chrom_a]
     keep_b |= whole[chrom_b]
     return np.nonzero(keep_a)[0], np.nonzero(keep_b)[0]
+
+
+IMPLS = ("allgather", "p2p")
+
+
+def exchange_blocks(send, sizes, recv, group=None, impl="p2p", root=None, async_op=False):
+    """Move one 1-D block per rank: rank ``r`` contributes ``send[:sizes[r]]`` and ``recv[r][:sizes[r]]``
+    receives it (``recv`` = one preallocated 1-D tensor per rank; this rank's own block is NOT copied --
+    the caller reads it from ``send``).  ``root=None``: every rank receives every block; else only rank
+    ``root`` does.  Grouped point-to-point operations, exactly sized (``impl="p2p"``; the padded
+    all-gather form lives with its callers, which own the padded buffers).  Returns a ``wait()``
+    function when ``async_op`` else ``None`` (already waited)."""
+    import torch.distributed as dist
+
+    assert impl == "p2p"
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    ops = []
+    for r in range(world):
+        if r == rank:
+            continue
+        gr = r if group is None else dist.get_global_rank(group, r)
+        if (root is None or root == r) and sizes[rank] > 0:
+            ops.append(dist.P2POp(dist.isend, send[: sizes[rank]], gr, group=group))
+        if (root is None or root == rank) and sizes[r] > 0:
+            ops.append(dist.P2POp(dist.irecv, recv[r][: sizes[r]], gr, group=group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+
+    def wait():
+        for w in works:
+            w.wait()
+
+    if async_op:
+        return wait
+    wait()
+    return None
 
 
 def gather_pairs(row_a, row_b, group=None):
@@ -226,18 +271,30 @@ class PlanGather:
     every rank and the callers exchange the expanded pairs (:class:`PairGather`) instead.
     """
 
-    def __init__(self, device, group=None):
+    def __init__(self, device, group=None, impl="allgather", root=None):
         import torch
         import torch.distributed as dist
 
+        if impl not in IMPLS:
+            raise ValueError(f"impl must be one of {IMPLS}")
         self.group = group
         self.device = torch.device(device)
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        # a gather to ONE rank is point-to-point by nature (the padded all-gather would deliver every
+        # block to every rank): root mode always takes the send / recv form
+        self.impl = "p2p" if root is not None else impl
+        self.root = root
         self._q = self._s = -1
         self._send = None
         self._recv = None
         self._mine = torch.zeros(4, dtype=torch.int64, device=self.device)
         self._all = torch.zeros((self.world, 4), dtype=torch.int64, device=self.device)
+
+    def receives(self, rank=None) -> bool:
+        """Does ``rank`` (default: this one) end up with the other ranks' blocks?"""
+        r = self.rank if rank is None else rank
+        return self.root is None or self.root == r
 
     def sizes(self, n_pairs: int, n_q: int, n_s: int, query_is_a: bool):
         import torch
@@ -262,10 +319,13 @@ class PlanGather:
             self._s = (int(s_ * 1.02) + 1024 + 63) // 64 * 64
             block = 3 * self._q + self._s
             self._send = torch.empty(block, dtype=torch.int32, device=self.device)
-            self._recv = torch.empty((self.world, block), dtype=torch.int32, device=self.device)
+            n_recv = self.world if self.receives() else 1   # a non-root rank of a gather-to-root receives nothing
+            self._recv = torch.empty((n_recv, block), dtype=torch.int32, device=self.device)
 
     def _views(self, block, n_q, n_s):
-        q = self._q
+        # all-gather form: the four arrays at fixed strides of the padded block; p2p form: back to back
+        # (the message is exactly 3 n_q + n_s words)
+        q = self._q if self.impl == "allgather" else n_q
         return block[:n_q], block[q:q + n_q], block[2 * q:2 * q + n_q], block[3 * q:3 * q + n_s]
 
     def send_views(self, sizes, rank=None):
@@ -276,23 +336,40 @@ class PlanGather:
         return self._views(self._send, sizes[r][1], sizes[r][2])
 
     def all_gather(self, sizes):
-        import torch.distributed as dist
-
-        self._ensure(sizes)
-        dist.all_gather_into_tensor(self._recv.view(-1), self._send, group=self.group)
-        return [self._views(self._recv[r], s[1], s[2]) for r, s in enumerate(sizes)]
+        """The exchange (blocking): per-rank views ``[(q_rid, lo, cnt, s_rid)]`` in rank order; ``None``
+        for the blocks this rank does not receive (gather-to-root on a non-root rank).  This rank's own
+        entry is the send block itself."""
+        return self.all_gather_async(sizes)()
 
     def all_gather_async(self, sizes):
-        """Start the all-gather without blocking the caller's stream; returns a function that waits for
+        """Start the exchange without blocking the caller's stream; returns a function that waits for
         it (the current stream then waits for the collective) and yields the per-rank views."""
         import torch.distributed as dist
 
         self._ensure(sizes)
-        work = dist.all_gather_into_tensor(self._recv.view(-1), self._send, group=self.group, async_op=True)
+        if self.impl == "allgather":
+            work = dist.all_gather_into_tensor(self._recv.view(-1), self._send, group=self.group, async_op=True)
+
+            def wait():
+                work.wait()
+                return [self._views(self._recv[r], s[1], s[2]) for r, s in enumerate(sizes)]
+
+            return wait
+        words = [3 * s[1] + s[2] if s[1] >= 0 else 0 for s in sizes]
+        recv = [self._recv[r if self.receives() else 0] for r in range(self.world)]
+        wait_p2p = exchange_blocks(self._send, words, recv, group=self.group, impl="p2p", root=self.root, async_op=True)
 
         def wait():
-            work.wait()
-            return [self._views(self._recv[r], s[1], s[2]) for r, s in enumerate(sizes)]
+            wait_p2p()
+            out = []
+            for r, s in enumerate(sizes):
+                if r == self.rank:
+                    out.append(self._views(self._send, s[1], s[2]))
+                elif self.receives():
+                    out.append(self._views(self._recv[r], s[1], s[2]))
+                else:
+                    out.append(None)
+            return out
 
         return wait
 
@@ -301,8 +378,9 @@ class PlanGather:
 
 
 def sharded_inner_join_compact(a, b, n_chrom: int, local_plan: Callable, expand: Callable, *, device=None,
-                               group=None):
-    """:func:`sharded_inner_join` with the compact exchange.
+                               group=None, impl="allgather", root=None):
+    """:func:`sharded_inner_join` with the compact exchange (``impl`` / ``root``: see the module docstring;
+    with ``root`` set, the other ranks return their own pairs only).
 
     ``local_plan(chrom_a, start_a, end_a, offs_a, chrom_b, ..., n_chrom)`` plans this rank's
     shard and returns ``None`` (no compact form) or ``(query_is_a, q_rid, lo, cnt, s_rid,
@@ -322,7 +400,7 @@ def sharded_inner_join_compact(a, b, n_chrom: int, local_plan: Callable, expand:
     ia, ib = unit_rows(ca, cb, n_chrom, world, rank)
     plan = local_plan(ca[ia], sa[ia], ea[ia], offs_a, cb[ib], sb[ib], eb[ib], offs_b, n_chrom)
     dev = torch.device("cpu") if device is None else torch.device(device)
-    xg = PlanGather(dev, group=group)
+    xg = PlanGather(dev, group=group, impl=impl, root=root)
     if plan is None:
         sizes = xg.sizes(0, -1, -1, True)
     else:
@@ -337,9 +415,10 @@ def sharded_inner_join_compact(a, b, n_chrom: int, local_plan: Callable, expand:
     lo_v.copy_(lo.to(dev).to(torch.int32))
     cnt_v.copy_(cnt.to(dev).to(torch.int32))
     out_a, out_b = [], []
-    for (q_r, lo_r, cnt_r, s_r), (n_r, _nq, _ns, qa_r) in zip(xg.all_gather(sizes), sizes):
-        if n_r == 0:
+    for blk, (n_r, _nq, _ns, qa_r) in zip(xg.all_gather(sizes), sizes):
+        if n_r == 0 or blk is None:   # (None: a block this rank does not receive -- gather to another root)
             continue
+        q_r, lo_r, cnt_r, s_r = blk
         row_q, row_s = expand(q_r, lo_r, cnt_r, s_r, n_r)
         out_a.append(row_q if qa_r else row_s)
         out_b.append(row_s if qa_r else row_q)
@@ -351,14 +430,19 @@ def sharded_inner_join_compact(a, b, n_chrom: int, local_plan: Callable, expand:
 ROW_OPS = ("semi", "anti", "count", "nearest")
 
 
-def gather_blocks(block, group=None):
-    """All-gather one ``[k, n]`` block per rank (``n`` differs from rank to rank; same ``k`` and
-    dtype everywhere): the per-rank sizes first, then the blocks padded to the largest.
-    Returns ``[block_0, block_1, ...]`` (views into one receive buffer, rank order)."""
+def gather_blocks(block, group=None, impl="allgather", root=None):
+    """Gather one ``[k, n]`` block per rank (``n`` differs from rank to rank; same ``k`` and dtype
+    everywhere): the per-rank sizes first, then the blocks -- padded to the largest in one all-gather
+    (``impl="allgather"``) or exactly sized by grouped send / recv (``"p2p"``; always when ``root`` is
+    given: only that rank receives).  Returns ``[block_0, block_1, ...]`` in rank order (``None`` for
+    blocks this rank did not receive)."""
     import torch
     import torch.distributed as dist
 
+    if impl not in IMPLS:
+        raise ValueError(f"impl must be one of {IMPLS}")
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     k, n = int(block.shape[0]), int(block.shape[1])
     dev = block.device
     count = torch.tensor([n], dtype=torch.int64, device=dev)
@@ -368,28 +452,51 @@ def gather_blocks(block, group=None):
     m = max(counts_h) if counts_h else 0
     if m == 0:
         return [block[:, :0] for _ in range(world)]
-    send = block if n == m else torch.cat([block, block.new_zeros((k, m - n))], dim=1)
-    recv = torch.empty((world, k, m), dtype=block.dtype, device=dev)
-    dist.all_gather_into_tensor(recv.view(-1), send.contiguous().view(-1), group=group)
-    return [recv[r, :, : counts_h[r]] for r in range(world)]
+    if impl == "allgather" and root is None:
+        send = block if n == m else torch.cat([block, block.new_zeros((k, m - n))], dim=1)
+        recv = torch.empty((world, k, m), dtype=block.dtype, device=dev)
+        dist.all_gather_into_tensor(recv.view(-1), send.contiguous().view(-1), group=group)
+        return [recv[r, :, : counts_h[r]] for r in range(world)]
+    receives = root is None or root == rank
+    recv = [torch.empty(k * c if (receives and r != rank) else 0, dtype=block.dtype, device=dev)
+            for r, c in enumerate(counts_h)]
+    exchange_blocks(block.contiguous().view(-1), [k * c for c in counts_h], recv, group=group, impl="p2p", root=root)
+    return [block if r == rank else (recv[r].view(k, counts_h[r]) if receives else None) for r in range(world)]
+
+
+def _i64_as_i32_rows(x):
+    """An int64 vector as two int32 rows (low, high words) and back: the per-row blocks travel as int32."""
+    import torch
+
+    return x.contiguous().view(torch.int32).view(-1, 2).t()
+
+
+def _i32_rows_as_i64(lo_hi):
+    import torch
+
+    return lo_hi.t().contiguous().view(-1).view(torch.int64)
 
 
 def sharded_row_op(op: str, a, b, n_chrom: int, local_op: Callable, *, device=None, group=None,
-                   gather: bool = True, **kw):
+                   gather: bool = True, impl="allgather", root=None, **kw):
     """SEMI / ANTI / COUNT / NEAREST k=1 of host tables ``a`` / ``b`` across the ranks of ``group``.
 
     The operators answer per A row from the B rows of the SAME chromosome
     (``intersects_duckdb.py:1254-1282``; ``nearest.py:313-333``), so the units are the A rows'
     chromosomes: LPT-packed like the join's, a chromosome heavier than one rank's share cut by
     row ranges of A with all of its B rows on every part (``unit_rows(..., split_side="a")``).
-    No data-path collective; ONE exchange of the per-row results at the end.
+    No data-path collective; ONE exchange of the per-row results at the end (``impl`` / ``root``: see
+    the module docstring) -- as int32 blocks: row ids and counts are int32 (a table has fewer than 2^31
+    rows), only NEAREST's distance is 64-bit and travels as two int32 words (4 / 8 / 16 B per A row
+    instead of 8 / 16 / 24).
 
     ``local_op(op, chrom_a, start_a, end_a, offs_a, chrom_b, ..., offs_b, n_chrom, **kw)`` runs
     this rank's shard: SEMI / ANTI -> local A row ids (int32); COUNT -> int64 per local A row;
     NEAREST -> ``(idx_b int32 local or -1, distance int64)`` per local A row.
     Returns, on every rank (``gather=False``: this rank's rows only, as
-    ``(global A row ids, ...)``): SEMI / ANTI the ascending global A row ids; COUNT one int64
-    per A row; NEAREST ``(idx_b, distance)`` per A row with GLOBAL B row ids.
+    ``(global A row ids, ...)``; ``root=r``: the other ranks return ``None``): SEMI / ANTI the ascending
+    global A row ids; COUNT one int64 per A row; NEAREST ``(idx_b, distance)`` per A row with GLOBAL B
+    row ids.
     """
     import torch
     import torch.distributed as dist
@@ -406,34 +513,38 @@ def sharded_row_op(op: str, a, b, n_chrom: int, local_op: Callable, *, device=No
     ia, ib = unit_rows(ca, cb, n_chrom, world, rank, split_side="a")
     res = local_op(op, ca[ia], sa[ia], ea[ia], offs_a, cb[ib], sb[ib], eb[ib], offs_b, n_chrom, **kw)
     dev = torch.device("cpu") if device is None else torch.device(device)
-    ga = torch.from_numpy(ia.astype(np.int64)).to(dev)   # local A row -> global A row
-    gb = torch.from_numpy(ib.astype(np.int64)).to(dev)
+    ga = torch.from_numpy(ia.astype(np.int32)).to(dev)   # local A row -> global A row
+    gb = torch.from_numpy(ib.astype(np.int32)).to(dev)
     if op in ("semi", "anti"):
         block = ga[res.to(dev).long()].view(1, -1)
     elif op == "count":
-        block = torch.stack([ga, res.to(dev).to(torch.int64)])
+        block = torch.stack([ga, res.to(dev).to(torch.int32)])   # a count is at most the rows of B
     else:
         idx, dist_ = res
         idx = idx.to(dev).long()
         hit = idx >= 0
-        gidx = torch.full_like(idx, -1)
+        gidx = torch.full(idx.shape, -1, dtype=torch.int32, device=dev)
         gidx[hit] = gb[idx[hit]]
-        block = torch.stack([ga, gidx, dist_.to(dev).to(torch.int64)])
+        block = torch.cat([torch.stack([ga, gidx]), _i64_as_i32_rows(dist_.to(dev).to(torch.int64))])
     if not gather:
+        if op == "nearest":
+            return block[0], block[1], _i32_rows_as_i64(block[2:4])
         return tuple(block[k] for k in range(block.shape[0]))
-    blocks = gather_blocks(block, group=group)
+    blocks = gather_blocks(block, group=group, impl=impl, root=root)
+    if root is not None and rank != root:
+        return None
     if op in ("semi", "anti"):
         return torch.sort(torch.cat([blk[0] for blk in blocks]))[0].to(torch.int32)
     if op == "count":
         out = torch.zeros(n_a, dtype=torch.int64, device=dev)
         for blk in blocks:
-            out[blk[0]] = blk[1]
+            out[blk[0].long()] = blk[1].to(torch.int64)
         return out
     out_i = torch.full((n_a,), -1, dtype=torch.int32, device=dev)
     out_d = torch.zeros(n_a, dtype=torch.int64, device=dev)
     for blk in blocks:
-        out_i[blk[0]] = blk[1].to(torch.int32)
-        out_d[blk[0]] = blk[2]
+        out_i[blk[0].long()] = blk[1]
+        out_d[blk[0].long()] = _i32_rows_as_i64(blk[2:4])
     return out_i, out_d
 
 

@@ -144,6 +144,11 @@ def _compact_worker(rank, world, port, out_dir, skew=False):
         res = D.sharded_inner_join_compact(a, b, 7, _np_plan, _np_expand)
         assert res is not None
         np.save(os.path.join(out_dir, f"cpairs_{rank}.npy"), np.stack([res[0].numpy(), res[1].numpy()]))
+        # the same exchange as grouped direct send / recv, and gathered to ONE rank
+        for tag, impl, root in (("p2p", "p2p", None), ("root0", "p2p", 0), ("rootlast", "allgather", world - 1)):
+            res = D.sharded_inner_join_compact(a, b, 7, _np_plan, _np_expand, impl=impl, root=root)
+            assert res is not None
+            np.save(os.path.join(out_dir, f"cpairs_{tag}_{rank}.npy"), np.stack([res[0].numpy(), res[1].numpy()]))
         # a shard without a compact form on ONE rank makes every rank fall back, collectively
         def plan_or_none(*args):
             return None if rank == world - 1 else _np_plan(*args)
@@ -161,6 +166,22 @@ def _compact_worker(rank, world, port, out_dir, skew=False):
             for r, (q_r, lo_r, cnt_r, s_r) in enumerate(xg.all_gather(sizes)):
                 assert q_r.tolist() == [r] * sizes[r][1] and lo_r.tolist() == [10 + r] * sizes[r][1]
                 assert cnt_r.tolist() == [2] * sizes[r][1] and s_r.tolist() == [100 + r] * sizes[r][2]
+        for impl, root in (("p2p", None), ("p2p", 1), ("allgather", 0)):
+            xp = D.PlanGather("cpu", impl=impl, root=root)
+            assert xp.impl == "p2p"   # a gather to one rank is point-to-point whatever was asked
+            for step_no in (1, 4):
+                nq, ns = (rank + 1) * step_no, (0 if rank == 1 else 5 * step_no + rank)
+                sizes = xp.sizes(nq * 2, nq, ns, rank % 2 == 0)
+                q, lo, cnt, srid = xp.send_views(sizes)
+                q.fill_(rank); lo.fill_(10 + rank); cnt.fill_(2); srid.fill_(100 + rank)
+                blocks = xp.all_gather(sizes)
+                for r, blk in enumerate(blocks):
+                    if root is not None and rank != root and r != rank:
+                        assert blk is None
+                        continue
+                    q_r, lo_r, cnt_r, s_r = blk
+                    assert q_r.tolist() == [r] * sizes[r][1] and lo_r.tolist() == [10 + r] * sizes[r][1]
+                    assert cnt_r.tolist() == [2] * sizes[r][1] and s_r.tolist() == [100 + r] * sizes[r][2]
     finally:
         dist.destroy_process_group()
 
@@ -179,6 +200,16 @@ def test_compact_plan_exchange_matches_single_process(tmp_path, world, skew):
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"cpairs_{r}.npy"))
         assert np.array_equal(ora.sort_pairs(got[0], got[1]), want), r
+        got = np.load(os.path.join(str(tmp_path), f"cpairs_p2p_{r}.npy"))
+        assert np.array_equal(ora.sort_pairs(got[0], got[1]), want), ("p2p", r)
+    # gathered to one rank: that rank holds everything, the others their own pairs -- which together are the result
+    for tag, root in (("root0", 0), ("rootlast", world - 1)):
+        parts = [np.load(os.path.join(str(tmp_path), f"cpairs_{tag}_{r}.npy")) for r in range(world)]
+        assert np.array_equal(ora.sort_pairs(parts[root][0], parts[root][1]), want), tag
+        own = [p for r, p in enumerate(parts) if r != root]
+        assert all(p.shape[1] < want.shape[0] for p in own)
+        mine_root = want.shape[0] - sum(p.shape[1] for p in own)
+        assert mine_root >= 0
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -288,6 +319,16 @@ def _row_worker(rank, world, port, out_dir, skew=False):
             out[op] = D.sharded_row_op(op, a, b, 7, _oracle_row_op).numpy()
         idx, d = D.sharded_row_op("nearest", a, b, 7, _oracle_row_op, signed=True)
         out["nearest_idx"], out["nearest_d"] = idx.numpy(), d.numpy()
+        # grouped send / recv instead of the padded all-gather; and gathered to rank 0 only
+        for op in ("semi", "count"):
+            out[op + "_p2p"] = D.sharded_row_op(op, a, b, 7, _oracle_row_op, impl="p2p").numpy()
+        r0 = D.sharded_row_op("anti", a, b, 7, _oracle_row_op, root=0)
+        assert (r0 is None) == (rank != 0)
+        rn = D.sharded_row_op("nearest", a, b, 7, _oracle_row_op, signed=True, root=0, impl="p2p")
+        assert (rn is None) == (rank != 0)
+        if rank == 0:
+            out["anti_root"], out["nearest_idx_root"], out["nearest_d_root"] = r0.numpy(), rn[0].numpy(), rn[1].numpy()
+        assert out["count"].dtype == np.int64 and out["nearest_d"].dtype == np.int64 and out["semi"].dtype == np.int32
         np.savez(os.path.join(out_dir, f"rows_{rank}.npz"), **out)
         # ragged blocks, an empty rank
         blk = torch.full((2, 0 if rank == 1 else rank + 2), rank, dtype=torch.int64)
@@ -320,6 +361,10 @@ def test_sharded_row_ops_match_single_process(tmp_path, world, skew):
         gi = got["nearest_idx"]
         assert np.array_equal(b[1][gi[hit]], b[1][wi[hit]]) and np.array_equal(b[2][gi[hit]], b[2][wi[hit]])
         assert np.array_equal(b[0][gi[hit]], a[0][hit])
+        assert np.array_equal(got["semi_p2p"], got["semi"]) and np.array_equal(got["count_p2p"], got["count"])
+        if rank == 0:
+            assert np.array_equal(got["anti_root"], got["anti"])
+            assert np.array_equal(got["nearest_d_root"], wd) and np.array_equal(got["nearest_idx_root"], got["nearest_idx"])
 
 
 def test_plan_units_forced_side_never_cuts_b():
