@@ -1185,15 +1185,9 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
                           (speculated ? ctx->spec_fuse_len_ok : q_len_max <= (int)BS_FUSE_WCAP);
     // the query side's chain (linearize + sort) beside the other side's when it is small (the fused count
     // needs the sorted queries before U's last stage: one stream)
-    SideChain sc(ctx, st, (nqr <= nu && !fuse_cnt) ? nqr : 0, nu);
     // the query side sorted from its raw columns too (its digits were counted in the span pass)
     keygen_q = keygen && want_hist_q;
     u32* const hist_q = q_is_a ? hist_a : hist_b;
-    if (!keygen_q) {
-      GIQL_TRY(run_linearize(ctx, sc.stream(), qs_, n_chrom, lb, sq.key[0], sq.end[0],
-                             q_is_a ? ctx->irr_a_list : ctx->irr_b_list, q_is_a ? 0 : 1, 0,
-                             hist_q, q_is_a ? gbase_a : gbase_b));
-    }
     if (keygen) {
       // the span pass counted U's digits already: fold the per-chromosome top digits onto the
       // bases, scan, and let the first sort pass build the keys from (chrom, start)
@@ -1210,7 +1204,15 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
                            q_is_a ? gbase_b : gbase_a);
       }
       GIQL_TRY(post_launch("digit offsets (span histogram)"));
-    } else {
+    }
+    // (the fork comes AFTER the digit offsets above: the query side's sort on the second stream reads them)
+    SideChain sc(ctx, st, (nqr <= nu && !fuse_cnt) ? nqr : 0, nu);
+    if (!keygen_q) {
+      GIQL_TRY(run_linearize(ctx, sc.stream(), qs_, n_chrom, lb, sq.key[0], sq.end[0],
+                             q_is_a ? ctx->irr_a_list : ctx->irr_b_list, q_is_a ? 0 : 1, 0,
+                             hist_q, q_is_a ? gbase_a : gbase_b));
+    }
+    if (!keygen) {
       GIQL_TRY(run_linearize(ctx, st, us_, n_chrom, lb, su.key[0], nullptr,
                              q_is_a ? ctx->irr_b_list : ctx->irr_a_list, q_is_a ? 1 : 0, 0,
                              q_is_a ? hist_b : hist_a, q_is_a ? gbase_b : gbase_a, nullptr, nullptr,

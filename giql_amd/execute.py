@@ -11,6 +11,8 @@ returned row indices.  The join itself runs in ``libgiql_hip.so``.
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .engine import ENCODING_OFFSETS, DeviceSide, HipEngine
@@ -403,12 +405,18 @@ def _execute_filter(plan: JoinPlan, tables, eng: HipEngine, return_indices: bool
     return pa.Table.from_arrays(arrays, names=names)
 
 
-def _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices):
+def _finish_count(plan, lt, rt, counts, n_chrom, eng, ia, return_indices):
     """count_overlaps: COUNT(b.col) per distinct left key, zero-filled
     (src/giql/expanders/intersects_duckdb.py:806-854; oracle semantics of
     tests/test_duckdb_iejoin.py:66-81: a key held by k duplicate left rows counts
-    k times its overlaps)."""
+    k times its overlaps).  ``counts`` = the per-left-row overlap counts (``_join_piece``: a device tensor
+    from one engine, a host array from the multi-device call); ``eng`` = the engine the GROUP BY may run
+    on (``None``: on the host)."""
     import pyarrow as pa
+
+    counts_dev = counts if hasattr(counts, "cpu") else None
+    if counts_dev is not None:
+        counts = None   # fetched below only if the host needs them
 
     cnt_proj = [p for p in plan.projection if p.side == "count"][0]
     ccol = _column(rt, cnt_proj.column)
@@ -416,14 +424,17 @@ def _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices):
         # COUNT(col) skips NULLs; the kernels count rows
         raise ValueError(f"COUNT({plan.right.alias}.{cnt_proj.column}) over a column with NULLs is not "
                          "supported by dialect='hip'")
-    counts_dev = eng.count_overlaps(a, b, n_chrom)
+    n_left = int((counts_dev if counts_dev is not None else counts).shape[0])
     if return_indices:
-        return counts_dev.cpu().numpy()
+        return counts_dev.cpu().numpy() if counts_dev is not None else counts
     keys = [p for p in plan.projection if p.side == "l"]
     interval_cols = {plan.left.chrom_col, plan.left.start_col, plan.left.end_col}
-    if {p.column for p in keys} == interval_cols and isinstance(lt, pa.Table) and a.n:
+    if eng is not None and {p.column for p in keys} == interval_cols and isinstance(lt, pa.Table) and n_left:
         # GROUP BY the left interval itself: grouped and summed on the GPU
         # (giql_hip_group_rows_dev / giql_hip_segment_sum_dev), keys gathered by the take kernel
+        import torch
+
+        a = _device_side(lt, plan.left, ia, eng)
         try:
             gid, rep = eng.group_rows(a, n_chrom)
         except Exception as exc:  # e.g. a genome wider than 32 bits: group on the host below
@@ -431,12 +442,15 @@ def _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices):
                 raise
             gid = None
         if gid is not None:
+            if counts_dev is None:
+                counts_dev = torch.from_numpy(counts).to(eng.device)
             sums = eng.segment_sum(counts_dev, gid, int(rep.shape[0]))
             taken = _device_take(lt, [p.column for p in keys], rep, eng)
             cols = {p.name: taken[p.column] for p in keys}
             cols[cnt_proj.name] = pa.array(sums.cpu().numpy(), type=pa.int64())
             return pa.table(cols).select([p.name for p in plan.projection])
-    counts = counts_dev.cpu().numpy()
+    if counts is None:
+        counts = counts_dev.cpu().numpy()
     cols = {p.name: _column(lt, p.column) for p in keys}
     cols[cnt_proj.name] = pa.array(counts, type=pa.int64())
     tbl = pa.table({k: (v if isinstance(v, (pa.Array, pa.ChunkedArray)) else pa.array(v)) for k, v in cols.items()})
@@ -514,62 +528,97 @@ def _device_take(table, names, idx_dev, eng: HipEngine):
     return out
 
 
-def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, return_indices=False,
-            device_projection: bool = True):
-    """Run *plan* (a :class:`JoinPlan`, its string form, or a GIQL query string)
-    against ``tables`` (``{name: pyarrow.Table | dict of arrays}``).
+def _rows_of(table, rows: np.ndarray):
+    """The rows ``rows`` of a table (pyarrow.Table / dict of arrays / DataFrame), same container type."""
+    try:
+        import pyarrow as pa
 
-    Returns a ``pyarrow.Table`` with the plan's projected columns (bag semantics,
-    unspecified row order, as upstream), or ``{column: array}`` when pyarrow is
-    absent.  ``return_indices=True`` returns the raw row indices instead:
-    ``(row_a, row_b)`` for INNER, ``rows_a`` for SEMI/ANTI,
-    ``(rows_a, idx_b, distance)`` for NEAREST and the per-left-row counts for
-    count_overlaps.  ``device_projection`` (default) gathers the projected columns
-    on the GPU from the device-resident row ids; ``False`` ships the ids to the
-    host and takes there.
-    """
-    if isinstance(plan, str):
-        plan = JoinPlan.from_string(plan) if is_plan_string(plan) else build_plan(plan, giql_tables)
-    if not isinstance(plan, JoinPlan):
-        raise ValueError("plan must be a JoinPlan, a plan string or a GIQL query")
-    if plan.kind in ("CLUSTER", "MERGE"):
-        return _execute_cluster_merge(plan, tables, engine or default_engine(), return_indices)
-    if plan.kind == "FILTER":
-        return _execute_filter(plan, tables, engine or default_engine(), return_indices)
-    for side in (plan.left, plan.right):
-        if side.table not in tables:
-            raise ValueError(f"table {side.table!r} was not provided")
-    eng = engine or default_engine()
-    lt, rt = tables[plan.left.table], tables[plan.right.table]
-    ia, ib, dictionary = encode_chroms(_column(lt, plan.left.chrom_col), _column(rt, plan.right.chrom_col))
-    n_chrom = len(dictionary)
-    strand_sign = None
+        if isinstance(table, pa.Table):
+            return table.take(pa.array(rows, type=pa.int64()))
+    except ImportError:  # pragma: no cover
+        pass
+    if isinstance(table, dict):
+        return {k: np.asarray(v)[rows] for k, v in table.items()}
+    return table.iloc[rows]
+
+
+def _strand_codes(col, null_code: int) -> np.ndarray:
+    """'+' -> 0, '-' -> 1, NULL -> ``null_code`` (a NULL strand never equals anything)."""
+    v = np.asarray(_to_numpy_obj(col), dtype=object)
+    out = np.full(v.shape[0], null_code, np.int32)
+    out[v == "+"] = 0
+    out[v == "-"] = 1
+    bad = ~np.isin(out, (0, 1)) & np.array([x is not None for x in v], dtype=bool)
+    if bad.any():
+        raise ValueError("stranded NEAREST: strands other than '+' / '-' (the reference yields a NULL "
+                         "distance for '.' / '?') are not supported by dialect='hip'")
+    return out
+
+
+def _nearest_rows(plan: JoinPlan, a: DeviceSide, b: DeviceSide, n_chrom: int, eng: HipEngine):
+    """NEAREST of two device sides -> ``(rows_a, rows_b, distance)`` (device int32, device int32, host
+    int64): one entry per result row, A rows ascending, a row's k matches in the reference's order
+    ``ABS(distance), start, end`` (nearest.py:387-396).  A rows whose chromosome has no target row
+    yield no row."""
+    import torch
+
+    if plan.k == 1:
+        ib_dev, dist = eng.nearest(a, b, n_chrom, signed=plan.signed, max_distance=plan.max_distance)
+        keep = torch.nonzero(ib_dev >= 0).flatten().to(torch.int32)
+        return keep, ib_dev[keep.long()].contiguous(), dist[keep.long()].cpu().numpy()
+    ib_k, dist_k = eng.nearest_k(a, b, n_chrom, plan.k, signed=plan.signed, max_distance=plan.max_distance)
+    hit = torch.nonzero(ib_k >= 0)
+    return (hit[:, 0].to(torch.int32).contiguous(), ib_k[hit[:, 0], hit[:, 1]].contiguous(),
+            dist_k[hit[:, 0], hit[:, 1]].cpu().numpy())
+
+
+def _join_piece(plan: JoinPlan, lt, rt, ia: np.ndarray, ib: np.ndarray, n_chrom: int, eng: HipEngine,
+                return_indices: bool, device_projection: bool):
+    """The join of ``lt`` x ``rt`` (chrom ids ``ia`` / ``ib`` from one shared dictionary) on ONE engine,
+    up to but not including the outer clauses: the raw indices (``return_indices``), the per-left-row
+    counts (COUNT), or the projected Arrow table before ``_finish_outer``.  ``execute`` runs it once;
+    ``execute(devices=[...])`` once per device on that device's chromosomes."""
+    import torch
+
     if plan.kind == "NEAREST" and plan.stranded:
-        # stranded := true: a target row matches only on the reference row's strand (nearest.py:313-333),
-        # so (chrom, strand) is the partition; the distance of a '-' reference row flips its sign
-        # (_distance.py:88-117).  A NULL strand never equals anything: those rows get partitions of their own.
+        # stranded := true: a target row matches only on the reference row's strand (nearest.py:313-333).
+        # Rows of different strands never pair and NULL strands match nothing, so the '+' and the '-' rows
+        # are two independent NEAREST problems on the same chromosomes (folding the strand into the
+        # chromosome id instead would double the linearised span: a whole genome with reads on both strands
+        # is ~6.2e9 > 2^32, ADVICE r02); the distance of a '-' reference row flips its sign
+        # (_distance.py:88-117).
         ls, rs = (plan.strand_col or "strand,strand").split(",")
+        ca, cb = _strand_codes(_column(lt, ls), 2), _strand_codes(_column(rt, rs), 3)
+        sa = _int32_column(_column(lt, plan.left.start_col), f"{plan.left.table}.{plan.left.start_col}")
+        ea = _int32_column(_column(lt, plan.left.end_col), f"{plan.left.table}.{plan.left.end_col}")
+        sb = _int32_column(_column(rt, plan.right.start_col), f"{plan.right.table}.{plan.right.start_col}")
+        eb = _int32_column(_column(rt, plan.right.end_col), f"{plan.right.table}.{plan.right.end_col}")
+        parts = []
+        for code, sign in ((0, 1), (1, -1)):
+            ra_, rb_ = np.nonzero(ca == code)[0], np.nonzero(cb == code)[0]
+            if not ra_.size or not rb_.size:
+                continue
+            a = DeviceSide.from_numpy(ia[ra_], sa[ra_], ea[ra_], plan.left.encoding, device=eng.device)
+            b = DeviceSide.from_numpy(ib[rb_], sb[rb_], eb[rb_], plan.right.encoding, device=eng.device)
+            keep, ib_keep, dn = _nearest_rows(plan, a, b, n_chrom, eng)
+            parts.append((ra_[keep.cpu().numpy()], rb_[ib_keep.cpu().numpy()], dn * sign))
+        if parts:
+            ka = np.concatenate([p[0] for p in parts])
+            order = np.argsort(ka, kind="stable")   # A rows ascending; a row's k matches keep their order
+            ka, kb, dn = ka[order], np.concatenate([p[1] for p in parts])[order], np.concatenate([p[2] for p in parts])[order]
+        else:
+            ka = kb = np.zeros(0, np.int64)
+            dn = np.zeros(0, np.int64)
+        if return_indices:
+            return ka.astype(np.int32), kb.astype(np.int32), dn
+        idx = {"l": torch.from_numpy(ka.astype(np.int32)).to(eng.device), "r": torch.from_numpy(kb.astype(np.int32)).to(eng.device)}
+        return _project(plan, lt, rt, idx, {"distance": dn}, eng, device_projection)
 
-        def codes(col, null_code):
-            v = np.asarray(_to_numpy_obj(col), dtype=object)
-            out = np.full(v.shape[0], null_code, np.int32)
-            out[v == "+"] = 0
-            out[v == "-"] = 1
-            bad = ~np.isin(out, (0, 1)) & np.array([x is not None for x in v], dtype=bool)
-            if bad.any():
-                raise ValueError("stranded NEAREST: strands other than '+' / '-' (the reference yields a NULL "
-                                 "distance for '.' / '?') are not supported by dialect='hip'")
-            return out
-        ca, cb = codes(_column(lt, ls), 2), codes(_column(rt, rs), 3)
-        ia = (ia.astype(np.int64) * 4 + ca).astype(np.int32)
-        ib = (ib.astype(np.int64) * 4 + cb).astype(np.int32)
-        n_chrom *= 4
-        strand_sign = np.where(ca == 1, -1, 1).astype(np.int64)
     a = _device_side(lt, plan.left, ia, eng)
     b = _device_side(rt, plan.right, ib, eng)
-
     if plan.kind == "COUNT":
-        return _execute_count(plan, lt, rt, a, b, n_chrom, eng, return_indices)
+        return eng.count_overlaps(a, b, n_chrom)   # device int64, one per left row
+    extra = {}
     if plan.kind == "INNER":
         if plan.residuals:
             ra, rb = _join_with_residuals(plan, lt, rt, a, b, n_chrom, eng)
@@ -578,7 +627,6 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
         if return_indices:
             return ra.cpu().numpy(), rb.cpu().numpy()
         idx = {"l": ra, "r": rb}
-        extra = {}
     elif plan.kind in ("SEMI", "ANTI"):
         if plan.residuals:
             rows = _join_with_residuals(plan, lt, rt, a, b, n_chrom, eng)
@@ -587,35 +635,24 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
         if return_indices:
             return rows.cpu().numpy()
         idx = {"l": rows}
-        extra = {}
-    else:  # NEAREST: A rows whose chromosome (and strand) has no target row yield no row
-        import torch
-
-        if plan.k == 1:
-            ib_dev, dist = eng.nearest(a, b, n_chrom, signed=plan.signed, max_distance=plan.max_distance)
-            keep = torch.nonzero(ib_dev >= 0).flatten().to(torch.int32)
-            ib_keep = ib_dev[keep.long()].contiguous()
-            dn = dist[keep.long()].cpu().numpy()
-        else:  # up to k rows per A row, in the reference's order ABS(distance), start, end (nearest.py:387-396)
-            ib_k, dist_k = eng.nearest_k(a, b, n_chrom, plan.k, signed=plan.signed, max_distance=plan.max_distance)
-            hit = torch.nonzero(ib_k >= 0)
-            keep = hit[:, 0].to(torch.int32).contiguous()
-            ib_keep = ib_k[hit[:, 0], hit[:, 1]].contiguous()
-            dn = dist_k[hit[:, 0], hit[:, 1]].cpu().numpy()
-        if strand_sign is not None:
-            dn = dn * strand_sign[keep.cpu().numpy()]
+    else:  # NEAREST
+        keep, ib_keep, dn = _nearest_rows(plan, a, b, n_chrom, eng)
         if return_indices:
             return keep.cpu().numpy(), ib_keep.cpu().numpy(), dn
         idx = {"l": keep, "r": ib_keep}
         extra = {"distance": dn}
+    return _project(plan, lt, rt, idx, extra, eng, device_projection)
 
+
+def _project(plan: JoinPlan, lt, rt, idx: dict, extra: dict, eng: HipEngine, device_projection: bool):
+    """The plan's projected columns (+ the hidden carriers of ORDER BY / GROUP BY keys and aggregate
+    arguments) gathered by the device-resident row ids -- the reference's outer SELECT
+    (intersects_duckdb.py:1402-1644) -- as an Arrow table, before the outer clauses."""
     try:
         import pyarrow as pa
     except ImportError:  # pragma: no cover
         pa = None
     taken: dict = {}
-    # columns to materialise: the projection (incl. the hidden "__giql_*" carriers of ORDER BY / GROUP BY
-    # keys) + one carrier per aggregate argument
     wanted = list(plan.projection) + [Projection(a.side, a.column, f"__giql_a{i}")
                                       for i, a in enumerate(plan.aggregates) if a.side in ("l", "r")]
     if pa is not None and device_projection and all(isinstance(t, pa.Table) for t in (lt, rt)):
@@ -640,8 +677,139 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
     if not arrays:   # e.g. SELECT COUNT(*): no column to carry, only the row count
         n_rows = int(next(iter(idx.values())).shape[0])
         names, arrays = ["__giql_rows"], [pa.nulls(n_rows, pa.int8())]
-    out = pa.Table.from_arrays(arrays, names=names)
-    return _finish_outer(out, plan)
+    return pa.Table.from_arrays(arrays, names=names)
+
+
+_SHARD_ENGINES: dict = {}
+
+
+def _shard_engine(device: int, slot: int) -> HipEngine:
+    """One context per (device, position in ``devices``): ``devices=[0, 0]`` is two contexts on one GPU."""
+    key = (int(device), int(slot))
+    if key not in _SHARD_ENGINES:
+        _SHARD_ENGINES[key] = HipEngine(int(device))
+    return _SHARD_ENGINES[key]
+
+
+def _execute_sharded(plan: JoinPlan, lt, rt, ia, ib, n_chrom, devices, return_indices, device_projection):
+    """``execute(..., devices=[d0, d1, ...])``: ONE process, one context and one host thread per entry of
+    ``devices``.  Chromosomes are independent units of the join -- the reference partitions per chromosome
+    and concatenates with UNION ALL (``_per_chrom.py:3-9, 46-74``) -- so they are LPT-packed onto the
+    devices (``shard.plan_units``; a chromosome heavier than one device's share is cut by row ranges of
+    its larger side, of A for the per-row operators), every device joins AND projects its own chromosomes,
+    and the Arrow pieces are concatenated on the host: no index exchange at all.  The outer clauses
+    (aggregates, DISTINCT, ORDER BY, LIMIT) then run once, on the whole result."""
+    import threading
+
+    from .distributed import unit_rows
+
+    n_dev = len(devices)
+    split_side = None if plan.kind == "INNER" else "a"
+    shards = [unit_rows(ia, ib, n_chrom, n_dev, r, split_side=split_side) for r in range(n_dev)]
+    pieces: list = [None] * n_dev
+    errors: list = [None] * n_dev
+
+    def work(r):
+        try:
+            rows_a, rows_b = shards[r]
+            if rows_a.size == 0:
+                return   # no left row, no result row (INNER / SEMI / ANTI / COUNT / NEAREST alike)
+            eng = _shard_engine(devices[r], r)
+            pieces[r] = _join_piece(plan, _rows_of(lt, rows_a), _rows_of(rt, rows_b), ia[rows_a], ib[rows_b], n_chrom,
+                                    eng, return_indices, device_projection)
+        except BaseException as exc:  # noqa: BLE001 -- re-raised on the caller's thread
+            errors[r] = exc
+
+    threads = [threading.Thread(target=work, args=(r,), name=f"giql-hip-dev{devices[r]}-{r}") for r in range(n_dev)]
+    if os.environ.get("GIQL_EXECUTE_SERIAL"):   # debugging aid: the shards one after the other
+        for r in range(n_dev):
+            work(r)
+        threads = []
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    have = [r for r in range(n_dev) if pieces[r] is not None]
+    if plan.kind == "COUNT":
+        counts = np.zeros(ia.shape[0], np.int64)
+        for r in have:
+            counts[shards[r][0]] = pieces[r].cpu().numpy()   # every A row lies in exactly one shard
+        return counts
+    if return_indices:
+        if plan.kind == "INNER":
+            ra = [shards[r][0][pieces[r][0]] for r in have]
+            rb = [shards[r][1][pieces[r][1]] for r in have]
+            cat = lambda xs: np.concatenate(xs).astype(np.int32) if xs else np.zeros(0, np.int32)  # noqa: E731
+            return cat(ra), cat(rb)
+        if plan.kind in ("SEMI", "ANTI"):
+            rows = [shards[r][0][pieces[r]] for r in have]
+            return np.sort(np.concatenate(rows)).astype(np.int32) if rows else np.zeros(0, np.int32)
+        ka = np.concatenate([shards[r][0][pieces[r][0]] for r in have]) if have else np.zeros(0, np.int64)
+        kb = np.concatenate([shards[r][1][pieces[r][1]] for r in have]) if have else np.zeros(0, np.int64)
+        dn = np.concatenate([pieces[r][2] for r in have]) if have else np.zeros(0, np.int64)
+        order = np.argsort(ka, kind="stable")
+        return ka[order].astype(np.int32), kb[order].astype(np.int32), dn[order]
+    import pyarrow as pa
+
+    if not have:   # no left rows at all: an empty piece with the right schema from the first device
+        return _join_piece(plan, _rows_of(lt, np.zeros(0, np.int64)), _rows_of(rt, np.zeros(0, np.int64)),
+                           ia[:0], ib[:0], n_chrom, _shard_engine(devices[0], 0), False, device_projection)
+    return pa.concat_tables([pieces[r] for r in have])
+
+
+def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, return_indices=False,
+            device_projection: bool = True, devices=None):
+    """Run *plan* (a :class:`JoinPlan`, its string form, or a GIQL query string)
+    against ``tables`` (``{name: pyarrow.Table | dict of arrays}``).
+
+    Returns a ``pyarrow.Table`` with the plan's projected columns (bag semantics,
+    unspecified row order, as upstream), or ``{column: array}`` when pyarrow is
+    absent.  ``return_indices=True`` returns the raw row indices instead:
+    ``(row_a, row_b)`` for INNER, ``rows_a`` for SEMI/ANTI,
+    ``(rows_a, idx_b, distance)`` for NEAREST and the per-left-row counts for
+    count_overlaps.  ``device_projection`` (default) gathers the projected columns
+    on the GPU from the device-resident row ids; ``False`` ships the ids to the
+    host and takes there.
+
+    ``devices=[0, 1, ...]`` fans one call out over several GPUs of the node (one context and one host
+    thread each; INNER / SEMI / ANTI / COUNT / NEAREST): the chromosomes are sharded over the devices,
+    every device joins and projects its own, the pieces are concatenated (``_execute_sharded``).  One
+    entry = that device; the single-table operators (CLUSTER / MERGE / literal-range FILTER) run on the
+    first one.
+    """
+    if isinstance(plan, str):
+        plan = JoinPlan.from_string(plan) if is_plan_string(plan) else build_plan(plan, giql_tables)
+    if not isinstance(plan, JoinPlan):
+        raise ValueError("plan must be a JoinPlan, a plan string or a GIQL query")
+    devices = [int(d) for d in devices] if devices is not None else None
+    if devices is not None and not devices:
+        raise ValueError("devices must name at least one device")
+    if engine is not None and devices is not None and len(devices) > 1:
+        raise ValueError("pass either an engine or several devices, not both")
+    eng = engine or default_engine(devices[0] if devices else 0)
+    if plan.kind in ("CLUSTER", "MERGE"):
+        return _execute_cluster_merge(plan, tables, eng, return_indices)
+    if plan.kind == "FILTER":
+        return _execute_filter(plan, tables, eng, return_indices)
+    for side in (plan.left, plan.right):
+        if side.table not in tables:
+            raise ValueError(f"table {side.table!r} was not provided")
+    lt, rt = tables[plan.left.table], tables[plan.right.table]
+    ia, ib, dictionary = encode_chroms(_column(lt, plan.left.chrom_col), _column(rt, plan.right.chrom_col))
+    n_chrom = len(dictionary)
+    if devices is not None and len(devices) > 1:
+        piece = _execute_sharded(plan, lt, rt, ia, ib, n_chrom, devices, return_indices, device_projection)
+    else:
+        piece = _join_piece(plan, lt, rt, ia, ib, n_chrom, eng, return_indices, device_projection)
+    if plan.kind == "COUNT":
+        return _finish_count(plan, lt, rt, piece, n_chrom, eng if not (devices and len(devices) > 1) else None,
+                             ia, return_indices)
+    if return_indices or isinstance(piece, dict):
+        return piece
+    return _finish_outer(piece, plan)
 
 
 _PA_AGG = {"COUNT": "count", "SUM": "sum", "MIN": "min", "MAX": "max", "AVG": "mean"}

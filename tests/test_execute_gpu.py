@@ -612,3 +612,132 @@ def test_having_group_without_aggregate_and_null_placement():
     got = run(f"SELECT DISTINCT b.score, b.name {J} ORDER BY b.score DESC NULLS FIRST, b.name LIMIT 12")
     want = sorted(vals, key=lambda t: (t[0] is not None, -(t[0] or 0), t[1]))[:12]
     assert [(d["score"], d["name"]) for d in got] == want
+
+
+# --------------------------------------------------- execute(devices=[...]): one call over several contexts
+def _rand_tables(seed, n_a, n_b, dominant=False, strands="+-"):
+    r = np.random.default_rng(seed)
+
+    def tbl(n, tag, uniform_len=None):
+        ch = r.integers(1, 6, n)
+        if dominant:   # one chromosome heavier than a device's share: cut by row ranges (shard.plan_units)
+            ch[r.random(n) < 0.8] = 3
+        st = r.integers(0, 60_000, n)
+        ln = np.full(n, uniform_len) if uniform_len else r.integers(1, 400, n)
+        return pa.table({"chrom": pa.array([f"chr{int(c)}" for c in ch]), "start": pa.array(st, pa.int32()),
+                         "end": pa.array(st + ln, pa.int32()), "name": pa.array([f"{tag}{i}" for i in range(n)]),
+                         "score": pa.array(r.integers(0, 50, n), pa.int32()),
+                         "strand": pa.array([strands[int(k)] for k in r.integers(0, len(strands), n)])})
+    return {"peaks": tbl(n_a, "p"), "genes": tbl(n_b, "g", uniform_len=120 if seed % 2 else None)}
+
+
+@pytest.mark.parametrize("dominant", [False, True])
+def test_execute_fans_out_over_devices(dominant):
+    """``execute(plan, tables, devices=[...])`` -- chromosomes sharded over the contexts
+    (``devices=[0, 0]``: two contexts on the one GPU of this box, a third for an odd count), each shard
+    joined and projected on its own, the pieces concatenated -- returns what the single-device call
+    returns, for every operator, with a dominant chromosome too."""
+    T = ["peaks", "genes"]
+    tables = _rand_tables(41 + int(dominant), 3000, 5000, dominant)
+    J = "FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval"
+    X = "CROSS JOIN LATERAL NEAREST(genes, reference := a.interval"
+    queries = [
+        f"SELECT a.name, b.name AS g, a.start, b.score {J}",
+        f"SELECT a.name, b.name AS g {J} AND a.strand = b.strand WHERE a.score > 10",
+        "SELECT a.name, a.score FROM peaks a SEMI JOIN genes b ON a.interval INTERSECTS b.interval",
+        "SELECT a.name FROM peaks a ANTI JOIN genes b ON a.interval INTERSECTS b.interval",
+        ('SELECT a.chrom, a.start, a."end", COUNT(b.chrom) AS n FROM peaks a LEFT JOIN genes b '
+         'ON a.interval INTERSECTS b.interval GROUP BY a.chrom, a.start, a."end"'),
+        f"SELECT a.name, b.start AS b_start, b.end AS b_end, b.distance AS d FROM peaks a {X}, k := 1, signed := true) b",
+        f"SELECT a.name, b.start AS b_start, b.end AS b_end, b.distance AS d FROM peaks a {X}, k := 3) b",
+        f"SELECT a.name, b.start AS b_start, b.end AS b_end, b.distance AS d FROM peaks a {X}, k := 2, stranded := true, signed := true) b",
+        f"SELECT a.chrom, COUNT(*) AS n, SUM(b.score) AS t {J} GROUP BY a.chrom ORDER BY a.chrom",
+        f"SELECT DISTINCT a.name {J} ORDER BY a.name LIMIT 17 OFFSET 5",
+    ]
+    for q in queries:
+        plan = transpile(q, T, dialect="hip")
+        want = execute(plan, tables)
+        for devices in ([0, 0], [0, 0, 0]):
+            got = execute(plan, tables, devices=devices)
+            assert got.column_names == want.column_names, q
+            if "ORDER BY" in q:
+                assert got.to_pylist() == want.to_pylist(), (q, devices)
+            else:
+                assert rows_of(got) == rows_of(want), (q, devices)
+        assert want.num_rows > 0, q
+    # raw indices come back as GLOBAL row ids
+    plan = transpile(f"SELECT a.name, b.name AS g {J}", T, dialect="hip")
+    ra, rb = execute(plan, tables, return_indices=True)
+    ga, gb = execute(plan, tables, devices=[0, 0], return_indices=True)
+    assert sorted(zip(ra.tolist(), rb.tolist())) == sorted(zip(ga.tolist(), gb.tolist()))
+    plan = transpile("SELECT a.name FROM peaks a ANTI JOIN genes b ON a.interval INTERSECTS b.interval", T, dialect="hip")
+    assert np.array_equal(np.sort(execute(plan, tables, return_indices=True)), execute(plan, tables, devices=[0, 0], return_indices=True))
+    plan = transpile(f"SELECT a.name, b.distance AS d FROM peaks a {X}, k := 2) b", T, dialect="hip")
+    w = execute(plan, tables, return_indices=True)
+    g = execute(plan, tables, devices=[0, 0, 0], return_indices=True)
+    assert np.array_equal(w[0], g[0]) and np.array_equal(w[2], g[2])
+    assert np.array_equal(tables["genes"]["start"].to_numpy()[w[1]], tables["genes"]["start"].to_numpy()[g[1]])
+    # one device named explicitly = the single-device call; an empty list is an error
+    assert rows_of(execute(plan, tables, devices=[0])) == rows_of(execute(plan, tables))
+    with pytest.raises(ValueError):
+        execute(plan, tables, devices=[])
+
+
+def test_execute_devices_with_empty_and_one_sided_shards():
+    T = ["peaks", "genes"]
+    q = "SELECT a.name, b.name AS g FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval"
+    plan = transpile(q, T, dialect="hip")
+    # fewer chromosomes than devices; a chromosome present on one side only; no left rows at all
+    t = {"peaks": make_table([("chr1", 100, 200, "p1", 0, "+"), ("chr9", 5, 50, "p2", 0, "+")]),
+         "genes": make_table([("chr1", 150, 250, "g1", 0, "+"), ("chr2", 1, 9, "g2", 0, "-")])}
+    assert rows_of(execute(plan, t, devices=[0, 0, 0])) == [("p1", "g1")]
+    anti = transpile("SELECT a.name FROM peaks a ANTI JOIN genes b ON a.interval INTERSECTS b.interval", T, dialect="hip")
+    assert rows_of(execute(anti, t, devices=[0, 0, 0])) == [("p2",)]
+    empty = {"peaks": make_table([]), "genes": t["genes"]}
+    out = execute(plan, empty, devices=[0, 0])
+    assert out.num_rows == 0 and out.column_names == ["name", "g"]
+
+
+def test_stranded_nearest_on_a_genome_wider_than_half_the_axis():
+    """folding the strand into the partition id doubled the linearised span, so a
+    whole genome with rows on both strands (~6.2e9 for hg38) failed with GIQL_ERR_SPAN although the same
+    tables ran unstranded.  The '+' and '-' rows are now two NEAREST problems on the same axis."""
+    r = np.random.default_rng(77)
+    lens = [248_956_422, 242_193_529, 198_295_559, 190_214_555, 181_538_259, 170_805_979, 159_345_973, 145_138_636,
+            138_394_717, 133_797_422, 135_086_622, 133_275_309, 114_364_328, 107_043_718, 101_991_189, 90_338_345,
+            83_257_441, 80_373_285, 58_617_616, 64_444_167, 46_709_983, 50_818_468, 156_040_895, 57_227_415]
+
+    def tbl(n, tag):
+        ch = r.integers(0, 24, n)
+        st = np.array([int(r.integers(0, lens[c] - 5000)) for c in ch])
+        st[:24] = [lens[c] - 5000 for c in range(24)]   # every chromosome spans its whole length
+        ch[:24] = np.arange(24)
+        return pa.table({"chrom": pa.array([f"chr{int(c) + 1}" for c in ch]), "start": pa.array(st, pa.int32()),
+                         "end": pa.array(st + r.integers(1, 4000, n), pa.int32()), "name": pa.array([f"{tag}{i}" for i in range(n)]),
+                         "score": pa.array(np.zeros(n), pa.int32()), "strand": pa.array(["+-"[int(k)] for k in r.integers(0, 2, n)])})
+    t = {"peaks": tbl(4000, "p"), "genes": tbl(6000, "g")}
+    q = ("SELECT a.name, b.name AS g, b.distance AS d FROM peaks a CROSS JOIN LATERAL "
+         "NEAREST(genes, reference := a.interval, k := 1, stranded := true, signed := true) b")
+    out = execute(transpile(q, ["peaks", "genes"], dialect="hip"), t)
+    assert out.num_rows == 4000
+    P, G = t["peaks"].to_pylist(), t["genes"].to_pylist()
+    got = {d["name"]: (d["g"], d["d"]) for d in out.to_pylist()}
+    gi = {g["name"]: g for g in G}
+    for p in P[:300]:   # brute force on a sample: the nearest same-strand gene's distance (sign flipped for '-')
+        best = None
+        for g in G:
+            if g["chrom"] != p["chrom"] or g["strand"] != p["strand"]:
+                continue
+            if g["start"] < p["end"] and g["end"] > p["start"]:
+                d = 0
+            elif g["end"] <= p["start"]:
+                d = -(p["start"] - g["end"] + 1)
+            else:
+                d = g["start"] - p["end"] + 1
+            key = (abs(d), g["start"], g["end"])
+            if best is None or key < best[0]:
+                best = (key, d)
+        d = best[1] * (-1 if p["strand"] == "-" else 1)
+        assert got[p["name"]][1] == d, p
+        g = gi[got[p["name"]][0]]
+        assert g["chrom"] == p["chrom"] and g["strand"] == p["strand"]
