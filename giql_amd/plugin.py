@@ -10,8 +10,8 @@ The expander mirrors ``expand_intersects_duckdb``
 (``src/giql/expanders/intersects_duckdb.py:1674-1715``): for a column-to-column INTERSECTS join
 whose whole-query shape the path supports it installs a statement finalizer that replaces the root
 with ``exp.Command(this=<plan string>)`` -- the verbatim-payload precedent of ``:1713`` -- so
-``transpile()`` still returns ``str``; every other shape defers to ``_expand_spatial_op``
-(``:1715``), never errors.
+``transpile()`` still returns ``str``; every other VALID shape defers to ``_expand_spatial_op``
+(``:1715``); user mistakes raise ``ValueError`` as they do upstream (see "Errors" below).
 
 It lowers FROM THE NODE AND THE CONTEXT, not from re-serialised SQL text:
 
@@ -25,7 +25,17 @@ It lowers FROM THE NODE AND THE CONTEXT, not from re-serialised SQL text:
 * the statement's clauses are read from the AST by node ``key`` and ``args`` only (no sqlglot class
   is needed to READ a tree), into the neutral :class:`giql_amd.shape.JoinShape`;
 * ONE gate, :func:`giql_amd.shape.lower_join_shape`, shared with the sqlglot-free mirror
-  (:mod:`giql_amd.transpile`), decides accept / decline / error.
+  (:mod:`giql_amd.transpile`), decides accept / decline / error;
+* every node it reads is checked against a WHITELIST of the args it understands (:func:`_only`): a clause
+  sqlglot stores under any other key declines instead of being dropped.
+
+Errors -- which is which.  Shapes that are merely unsupported HERE raise :class:`HipDeclined`, which the
+expander catches: the naive predicate then runs the query, exactly as the reference's ``_DeclineIEJoin``
+does (``intersects_duckdb.py:797-801``).  A plain ``ValueError`` is kept for what the reference rejects as
+well and surfaces from ``giql.transpile`` there too (``_UnqualifiedProjectionError`` -> ``ValueError``,
+``:803-804, 925-958``): an unqualified or unknown-qualifier column, a column carrying a catalog / schema
+qualifier, a right-side column under SEMI / ANTI, an unqualified HAVING / ORDER BY name that is no output
+column (``giql_amd.shape.lower_join_shape``).  So the expander does let ``ValueError`` through -- by design.
 
 Because nothing here needs sqlglot to run, the expander is exercised on CPU with plain stand-ins
 for ``node`` / ``ExpansionContext`` / ``OperatorResolution`` (``tests/test_plugin_doubles.py``).
@@ -57,6 +67,20 @@ def _arg(n, *names):
         if a.get(k) is not None:
             return a[k]
     return None
+
+
+def _only(n, handled, what: str) -> None:
+    """Whitelist guard: every NON-EMPTY arg of node ``n`` must be one this lowering reads.
+
+    The lowering reads the statement by ``args`` key, so a clause sqlglot stores under a key it does not
+    know (QUALIFY, GROUP BY ROLLUP / CUBE / GROUPING SETS / ALL, TABLESAMPLE, PIVOT, LATERAL VIEW, named
+    WINDOWs, ``LIMIT ... OFFSET`` inside Limit, join hints, ...) would otherwise be dropped silently and a
+    plan emitted that ignores it.  The reference carries such clauses verbatim in its outer
+    wrapper; this target declines them, so the naive predicate runs the query instead."""
+    for k, v in (getattr(n, "args", None) or {}).items():
+        if k in handled or v is None or v is False or v == [] or v == () or v == "":
+            continue
+        raise decline(f"{what}: {k} is not supported by dialect='hip'")
 
 
 def _ident(n) -> tuple[str, bool]:
@@ -97,6 +121,9 @@ def _colref(n) -> ColRef:
     if _key(n) == "star":
         return ColRef(None, False, "*", star=True)
     if _arg(n, "db") is not None or _arg(n, "catalog") is not None:
+        # a user mistake the reference rejects as well (``_UnqualifiedProjectionError`` -> ValueError at
+        # intersects_duckdb.py:803-804, 951-958): the qualifier would survive the alias rewrite and address
+        # another relation.  NOT a decline.
         raise ValueError("a column with a catalog / schema qualifier cannot be attributed to a join side; "
                          "it must be qualified with the table alias only")
     t, tq = _ident(_arg(n, "table"))
@@ -115,8 +142,11 @@ def _tableref(n) -> TableRef:
         raise decline("table function / unnamed relation as a join operand")   # e.g. DISJOIN(genes)
     if _arg(n, "db") is not None or _arg(n, "catalog") is not None:
         raise decline("catalog/schema-qualified tables")
+    _only(n, ("this", "alias", "db", "catalog"), "table operand")   # TABLESAMPLE, PIVOT, hints, time travel ...
     alias_node = _arg(n, "alias")
     if alias_node is not None:
+        if _key(alias_node) == "tablealias":
+            _only(alias_node, ("this",), "table alias")               # an alias with a column list
         a, aq = _ident(_arg(alias_node, "this") if _key(alias_node) == "tablealias" else alias_node)
         if a:
             return TableRef(name, a, aq)
@@ -276,20 +306,31 @@ def has_sibling_spatial_predicate(node, root) -> bool:
     return False
 
 
+_SELECT_ARGS = ("with", "with_", "kind", "expressions", "distinct", "from", "from_", "joins", "where", "group", "having",
+                "order", "limit", "offset")
+
+
 def shape_from_ast(root, node, ctx) -> JoinShape:
     if _arg(root, "with_", "with") is not None:
         raise decline("top-level WITH")
+    _only(root, _SELECT_ARGS, "SELECT")   # QUALIFY, WINDOW, LATERAL VIEW, PIVOT, TABLESAMPLE, INTO, hints, locks ...
+    if _arg(root, "kind"):
+        raise decline("SELECT AS STRUCT / VALUE")
     distinct_node = _arg(root, "distinct")
     if distinct_node is not None and _arg(distinct_node, "on") is not None:
         raise decline("DISTINCT ON")
+    if distinct_node is not None:
+        _only(distinct_node, ("on",), "DISTINCT")
     from_node = _arg(root, "from_", "from")
     if from_node is None:
         raise decline("no FROM clause")
+    _only(from_node, ("this",), "FROM")
     from_ref = _tableref(_arg(from_node, "this"))
     joins = _arg(root, "joins") or []
     if len(joins) != 1:
         raise decline("a third table" if len(joins) > 1 else "no join (a single-table predicate)")
     j = joins[0]
+    _only(j, ("this", "on", "side", "kind", "method", "using"), "JOIN")   # hints, ASOF match_condition, GLOBAL ...
     if _arg(j, "method"):
         raise decline("NATURAL join")
     side = str(_arg(j, "side") or "").upper()
@@ -313,14 +354,18 @@ def shape_from_ast(root, node, ctx) -> JoinShape:
                       distinct=distinct_node is not None)
     shape.on_terms = _terms(on)
     shape.where_terms = _terms(_arg(where, "this") if where is not None else None)
+    if where is not None:
+        _only(where, ("this",), "WHERE")
     group = _arg(root, "group")
     if group is not None:
+        _only(group, ("expressions",), "GROUP BY")   # ROLLUP / CUBE / GROUPING SETS / ALL / WITH TOTALS
         for g in _arg(group, "expressions") or []:
             if _key(g) != "column":
                 raise decline("GROUP BY expression")
             shape.group_by.append(_colref(g))
     having = _arg(root, "having")
     if having is not None:
+        _only(having, ("this",), "HAVING")
         # the reference hands the clause to the engine verbatim (intersects_duckdb.py:1374-1380); here: a
         # conjunction of comparisons between plain aggregates / key columns and literals
         def having_operand(n):
@@ -340,7 +385,10 @@ def shape_from_ast(root, node, ctx) -> JoinShape:
                                  having_operand(_arg(c, "expression"))))
     order = _arg(root, "order")
     if order is not None:
+        _only(order, ("expressions",), "ORDER BY")   # ORDER SIBLINGS BY
         for o in _arg(order, "expressions") or []:
+            if _key(o) == "ordered":
+                _only(o, ("this", "desc", "nulls_first"), "ORDER BY key")   # WITH FILL
             target = _arg(o, "this") if _key(o) == "ordered" else o
             if _key(target) != "column":
                 raise decline("ORDER BY expression")    # incl. sub-queries (intersects_duckdb.py:690-701)
@@ -353,6 +401,7 @@ def shape_from_ast(root, node, ctx) -> JoinShape:
     for clause in ("limit", "offset"):
         c = _arg(root, clause)
         if c is not None:
+            _only(c, ("expression",), clause.upper())   # LIMIT a, b / LIMIT ... BY / WITH TIES / PERCENT
             v = _literal(_arg(c, "expression"))
             if v is None or not isinstance(v[1], int):
                 raise decline(f"{clause.upper()} that is not an integer literal")

@@ -44,16 +44,21 @@ class Table:
         return (self.coordinate_system, self.interval_type)
 
 
+def encoding_of(table) -> tuple[str, str]:
+    """``(coordinate_system, interval_type)`` of a Table -- this module's or the reference's own
+    ``giql.table.Table`` (same two fields, ``src/giql/table.py:16-136``).  A helper instead of a property
+    patched onto the upstream class: importing this package changes nothing in ``giql``."""
+    return (table.coordinate_system, table.interval_type)
+
+
 try:  # where the reference package is importable its own Table IS the schema type (same fields and
     # validation: src/giql/table.py:16-136); the mirror above serves boxes without giql / sqlglot
     from giql.table import Table as _GiqlTable
 
     if all(hasattr(_GiqlTable("t"), f) for f in ("genomic_col", "chrom_col", "start_col", "end_col", "strand_col",
                                                   "coordinate_system", "interval_type")):
-        if not hasattr(_GiqlTable, "encoding"):
-            _GiqlTable.encoding = property(lambda self: (self.coordinate_system, self.interval_type))
         Table = _GiqlTable  # noqa: F811
-except Exception:  # ImportError, or giql failing to import without sqlglot
+except ImportError:  # no giql (or giql failing to import without sqlglot): the mirror above
     pass
 
 

@@ -41,7 +41,7 @@ from .shape import genomic_col as _genomic_col
 from .shape import lower_join_shape, resolve_projection
 from .shape import norm as _norm
 from .shape import table_side as _table_side
-from .table import Table, Tables, build_tables
+from .table import Table, Tables, build_tables, encoding_of
 
 
 # ------------------------------------------------------------------- tokens
@@ -448,7 +448,7 @@ def _literal_range_sql(p: _Parser, proj_text: str, from_ref: _TableRef, tables: 
     t = tables.get(from_ref.name) or Table(from_ref.name)
     if col.column != t.genomic_col:
         raise ValueError(f"{col.column!r} is not the genomic column of {from_ref.name}")
-    if t.encoding != ("0based", "half_open"):
+    if encoding_of(t) != ("0based", "half_open"):
         raise _decline("literal predicate over a non-canonical table")
     q = (col.table + ".") if col.table else ""
     chrom = m.group("chr").replace("'", "''")
@@ -538,7 +538,7 @@ def _lower_filter(p: _Parser, tbls: Tables) -> JoinPlan:
     lo, hi = int(m.group("start")), int(m.group("end"))
     if lo >= hi:
         raise ValueError(f"Start must be less than end: {lo} >= {hi}")
-    if table.encoding != ("0based", "half_open"):
+    if encoding_of(table) != ("0based", "half_open"):
         raise _decline("literal predicate over a non-canonical table")
     residuals = [Residual("where", Operand("l", side.chrom_col), "=", Operand("str", m.group("chr"))),
                  Residual("where", Operand("l", side.start_col), "<", Operand("int", hi)),

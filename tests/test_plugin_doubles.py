@@ -207,3 +207,85 @@ def test_having_shapes_this_target_does_not_run_decline():
     _declined(*basic([A.col("a", "chrom")], group=[A.col("a", "chrom")], having=A.cmp("gt", A.agg("sum", A.col("a", "score")), sub)))
     _declined(*basic([A.col("a", "chrom")], group=[A.col("a", "chrom")],
                      having=A.N("or", this=A.cmp("gt", A.agg("count"), A.lit(1)), expression=A.cmp("lt", A.agg("count"), A.lit(9)))))
+
+
+def test_clauses_the_lowering_does_not_read_decline_instead_of_being_dropped():
+    """the lowering reads the statement by ``args`` key; a clause sqlglot stores under a
+    key it does not know must DECLINE (the naive predicate then runs the query) -- never be dropped with a
+    plan still emitted.  One case per node kind the whitelist guards."""
+    cols = [A.col("a", "start")]
+
+    def with_arg(node, **extra):
+        node.args.update(extra)
+        return node
+
+    # Select: QUALIFY, named WINDOWs, LATERAL VIEW, PIVOT, TABLESAMPLE, SELECT ... INTO, FOR UPDATE, hints
+    for key, val in [("qualify", A.N("qualify", this=A.cmp("gt", A.col("a", "score"), A.lit(1)))),
+                     ("windows", [A.N("window", this=A.ident("w"))]), ("laterals", [A.N("lateral")]),
+                     ("pivots", [A.N("pivot")]), ("sample", A.N("tablesample", percent=A.lit(10))),
+                     ("into", A.N("into", this=A.tbl("t"))), ("locks", [A.N("lock", update=True)]),
+                     ("hint", A.N("hint", expressions=[A.ident("x")])), ("connect", A.N("connect")),
+                     ("distribute", A.N("distribute")), ("sort", A.N("sort")), ("cluster", A.N("cluster"))]:
+        root, it = basic(cols)
+        with_arg(root, **{key: val})
+        _declined(root, it)
+    # GROUP BY ROLLUP / CUBE / GROUPING SETS / ALL / WITH TOTALS
+    for key, val in [("rollup", [A.col("a", "chrom")]), ("cube", [A.col("a", "chrom")]),
+                     ("grouping_sets", [A.N("tuple", expressions=[A.col("a", "chrom")])]), ("all", True), ("totals", True)]:
+        root, it = basic([A.col("a", "chrom"), A.agg("count")], group=[A.col("a", "chrom")])
+        with_arg(root.args["group"], **{key: val})
+        _declined(root, it)
+    # Table operand: TABLESAMPLE / PIVOT / hints / time travel; an alias with a column list
+    for key, val in [("sample", A.N("tablesample", percent=A.lit(10))), ("pivots", [A.N("pivot")]),
+                     ("hints", [A.N("withtablehint")]), ("version", A.N("version")), ("when", A.N("historicaldata")),
+                     ("only", True), ("ordinality", True)]:
+        for which in ("from", "join"):
+            root, it = basic(cols)
+            tnode = root.args["from_"].args["this"] if which == "from" else root.args["joins"][0].args["this"]
+            with_arg(tnode, **{key: val})
+            _declined(root, it)
+    root, it = basic(cols)
+    with_arg(root.args["joins"][0].args["this"].args["alias"], columns=[A.ident("c1")])
+    _declined(root, it)
+    # Join: hints, ASOF match_condition, GLOBAL
+    for key, val in [("hint", "BROADCAST"), ("match_condition", A.cmp("gt", A.col("a", "start"), A.col("b", "start"))),
+                     ("global", True), ("global_", True)]:
+        root, it = basic(cols)
+        with_arg(root.args["joins"][0], **{key: val})
+        _declined(root, it)
+    # LIMIT a, b (offset inside Limit) / LIMIT ... BY / WITH TIES; OFFSET with extra expressions; ORDER ... WITH FILL
+    for key, val in [("offset", A.lit(2)), ("expressions", [A.col("a", "chrom")]), ("limit_options", A.N("limitoptions"))]:
+        root, it = basic(cols, limit=5)
+        with_arg(root.args["limit"], **{key: val})
+        _declined(root, it)
+    root, it = basic(cols, offset=5)
+    with_arg(root.args["offset"], expressions=[A.col("a", "chrom")])
+    _declined(root, it)
+    root, it = basic(cols, order=[(A.col("a", "start"), False)])
+    with_arg(root.args["order"].args["expressions"][0], with_fill=A.N("withfill"))
+    _declined(root, it)
+    root, it = basic(cols, order=[(A.col("a", "start"), False)])
+    with_arg(root.args["order"], siblings=True)
+    _declined(root, it)
+    # empty / falsy values of unknown args are what sqlglot's parser leaves everywhere: still accepted
+    root, it = basic(cols, limit=5)
+    with_arg(root, qualify=None, windows=[], laterals=None, sample=None, locks=[], hint=None, kind=None, match=None)
+    with_arg(root.args["joins"][0], hint=None, match_condition=None)
+    with_arg(root.args["limit"], offset=None, expressions=[], limit_options=None, this=None)
+    out, ctx, calls = run(root, it, ["peaks", "genes"])
+    assert out is it and not calls and len(ctx.finalizers) == 1
+
+
+def test_user_mistakes_raise_as_upstream_and_are_not_swallowed_as_declines():
+    """Which is which (plugin docstring, "Errors"): a catalog / schema-qualified column is a user mistake the
+    reference rejects too (intersects_duckdb.py:803-804, 951-958): ValueError, through the expander."""
+    q = A.col("a", "score")
+    q.args["db"] = A.ident("myschema")
+    root, it = basic([A.col("a", "start")], on_extra=[A.cmp("gt", q, A.lit(5))])
+    with pytest.raises(ValueError, match="catalog / schema"):
+        run(root, it, ["peaks", "genes"])
+    from giql_amd.shape import HipDeclined
+    try:
+        run(root, it, ["peaks", "genes"])
+    except ValueError as exc:
+        assert not isinstance(exc, HipDeclined)
