@@ -38,9 +38,16 @@ def test_phase_bytes_agree_with_the_committed_pmc_run():
 
 
 def test_pmc_traffic_is_withheld_when_the_kernel_sources_changed(monkeypatch):
-    assert bench.pmc_traffic("cfg4_10Mx100M_24chrom", "uniform_b", "sort_scatter", 6) in (None,) or True
+    import json as _json
+
+    stamped = _json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    # collected on exactly these sources: the figure is handed out, per launch; on any other sources: withheld
+    monkeypatch.setattr(bench, "csrc_hash", lambda: stamped["csrc_hash"])
+    per_launch = bench.pmc_traffic("cfg4_10Mx100M_24chrom", "uniform_b", "sort_scatter", 4)
+    assert per_launch == round(stamped["cfg4_10Mx100M_24chrom"]["uniform_b"]["sort_scatter"] / 4)
+    assert bench.pmc_traffic("cfg4_10Mx100M_24chrom", "no_such_form", "sort_scatter", 4) is None
     monkeypatch.setattr(bench, "csrc_hash", lambda: "0" * 16)
-    assert bench.pmc_traffic("cfg4_10Mx100M_24chrom", "uniform_b", "sort_scatter", 6) is None
+    assert bench.pmc_traffic("cfg4_10Mx100M_24chrom", "uniform_b", "sort_scatter", 4) is None
 
 
 def test_operator_bytes_follow_survey_8d():

@@ -213,3 +213,77 @@ def test_dense_table_leaves_the_three_stage_sort_once_its_span_is_known(monkeypa
         assert f.stats()["sort_local"] and np.array_equal(got3, want)
     finally:
         f.close()
+
+
+# ---- past 2^32 pairs (the 64-bit offset paths under -m gpu, not in a tool) ------------------
+def _check_big_join(eng, A, B, n_chrom, expect_fused):
+    """No oracle at this size: the pair count must equal the sum of the COUNT operator's per-row counts, the
+    per-row multiplicity of the pairs must equal those counts, ids must be in range, the predicate must hold
+    on a strided sample, and the SEMI count must equal the rows with a non-zero count."""
+    from giql_amd.engine import DeviceSide
+
+    a, b = DeviceSide.from_numpy(*A), DeviceSide.from_numpy(*B)
+    counts = eng.count_overlaps(a, b, n_chrom)
+    total = int(counts.sum().item())
+    assert total > 2**32
+    n = eng.inner_plan(a, b, n_chrom)
+    assert n == total
+    ra = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    rb = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    assert eng.inner_join_into(a, b, n_chrom, ra, rb) == n      # the one-call form (speculating context: early fill)
+    st = eng.stats()
+    assert st["count_fused"] == expect_fused, st
+    got = torch.zeros(a.n, dtype=torch.int64, device="cuda:0")
+    lo_a, hi_a, lo_b, hi_b, bad = 1 << 40, -1, 1 << 40, -1, 0
+    chunk = 1 << 29
+    for s in range(0, n, chunk):       # chunked: a 40 GB index_add would not fit beside the pairs
+        xa, xb = ra[s:s + chunk].long(), rb[s:s + chunk].long()
+        got.index_add_(0, xa, torch.ones(xa.shape[0], dtype=torch.int64, device="cuda:0"))
+        lo_a, hi_a = min(lo_a, int(xa.min())), max(hi_a, int(xa.max()))
+        lo_b, hi_b = min(lo_b, int(xb.min())), max(hi_b, int(xb.max()))
+        sa, sb = xa[::97], xb[::97]
+        ok = (a.chrom[sa] == b.chrom[sb]) & (a.start[sa] < b.end[sb]) & (a.end[sa] > b.start[sb])
+        bad += int((~ok).sum())
+        del xa, xb
+    assert lo_a >= 0 and hi_a < a.n and lo_b >= 0 and hi_b < b.n and bad == 0
+    assert bool((got == counts).all())
+    del ra, rb, got
+    semi = eng.semi_join(a, b, n_chrom)
+    assert int(semi.shape[0]) == int((counts > 0).sum().item())
+    return n, st
+
+
+def test_join_past_2_pow_32_pairs_dense_tables_four_pass_sort():
+    """35M peaks x 350M reads (3.5x the headline sizes): 4.95e9 pairs, 40 GB of output.  ~7,400 rows per
+    65536-wide bucket: the tables leave the three-stage sort, the count kernel and the 64-bit scan run."""
+    from giql_amd.engine import HipEngine
+
+    A = synth.make_table(35_000_000, 5, "peaks")
+    B = synth.make_table(350_000_000, 6, "reads")
+    eng = HipEngine(0)
+    try:
+        n, st = _check_big_join(eng, A, B, 24, expect_fused=False)
+        # (the 35M-row QUERY side is sparse enough for the three-stage sort; the 350M-row side is not, so the
+        # bounds come from the count kernel: expect_fused=False above)
+        assert n == 4_952_361_736 and st["join_form"] == "uniform_b"
+    finally:
+        eng.close()
+
+
+def test_join_past_2_pow_32_pairs_fused_count_and_chained_scan():
+    """6M long peaks (20-32 kb) x 100M reads: ~850 reads per peak, > 2^32 pairs with the fused count
+    (bucket sort answering the bounds), the chained 64-bit scan and the in-scan partition."""
+    from giql_amd.engine import HipEngine
+
+    r = np.random.default_rng(1606)
+    ch, st_, _en = synth.make_table(6_000_000, 15, "peaks")
+    ln = r.integers(20_000, 32_000, ch.shape[0]).astype(np.int32)
+    st_ = np.maximum(st_ - 32_000, 0).astype(np.int32)     # (keeps the ends inside the chromosomes)
+    A = (ch, st_, st_ + ln)
+    B = synth.make_table(100_000_000, 6, "reads")
+    eng = HipEngine(0)
+    try:
+        n, st = _check_big_join(eng, A, B, 24, expect_fused=True)
+        assert st["join_form"] == "uniform_b" and st["sort_local"] and st["fused_fill"]
+    finally:
+        eng.close()
