@@ -47,6 +47,10 @@ WORKLOADS = {
     # name: op, (n_a, kind_a, seed_a), (n_b, kind_b, seed_b), genome (HG38 or a single-chromosome length)
     "cfg4_10Mx100M_24chrom": ("inner", (10_000_000, "peaks", 5), (100_000_000, "reads", 6), HG38),
     "cfg4_small_1Mx10M_24chrom": ("inner", (1_000_000, "peaks", 5), (10_000_000, "reads", 6), HG38),
+    # the SAME rows as cfg4, arriving in (chrom, start) order -- what coordinate-sorted BED / BAM-derived tables look
+    # like (docs/transpilation/performance.rst:111-130 of the reference advises an index for them); an extra line,
+    # never the headline: BASELINE's generator shuffles
+    "cfg4_sorted_10Mx100M_24chrom": ("inner", (10_000_000, "peaks", 5), (100_000_000, "reads", 6), HG38),
     "cfg2_sparse_1Mx1M_1chrom": ("inner", (1_000_000, "peaks", 1), (1_000_000, "peaks", 2), 248_956_422),
     "cfg2_dense_1Mx1M_1chrom": ("inner", (1_000_000, "peaks", 1), (1_000_000, "peaks", 2), 10_000_000),
     "cfg3_semi_1Mx10M_24chrom": ("semi", (1_000_000, "peaks", 3), (10_000_000, "reads", 4), HG38),
@@ -198,13 +202,27 @@ def pmc_traffic(workload, form, phase, launches):
 
 
 # ---------------------------------------------------------------------------- inputs
+def workload_table(wl, n, seed, kind, chroms=None):
+    """One synthetic table of a workload; the ``_sorted_`` workloads order its rows by
+    (chrom, start)."""
+    import numpy as np
+
+    from giql_amd import synth
+
+    t = synth.make_table(n, seed, kind, chroms=chroms)
+    if "_sorted_" in wl:
+        order = np.lexsort((t[1], t[0]))
+        t = tuple(np.ascontiguousarray(x[order]) for x in t)
+    return t
+
+
 def make_inputs(wl, chroms=None):
     from giql_amd import synth
 
     op, (n_a, kind_a, seed_a), (n_b, kind_b, seed_b), genome = WORKLOADS[wl]
     if genome == HG38:
-        a = synth.make_table(n_a, seed_a, kind_a, chroms=chroms)
-        b = synth.make_table(n_b, seed_b, kind_b, chroms=chroms)
+        a = workload_table(wl, n_a, seed_a, kind_a, chroms)
+        b = workload_table(wl, n_b, seed_b, kind_b, chroms)
         n_chrom = len(synth.HG38_LENGTHS)
     else:
         a = synth.make_single_chrom(n_a, seed_a, kind_a, genome)
@@ -279,11 +297,11 @@ def cpu_baseline_inner(args, wl, n_chrom, rank_chroms=None, whole=False):
             # global row ids use -- so the reference is the concatenation of the ranks' shards
             import numpy as np
 
-            parts_a = [synth.make_table(n_a, seed_a, kind_a, chroms=c) for c in rank_chroms]
-            parts_b = [synth.make_table(n_b, seed_b, kind_b, chroms=c) for c in rank_chroms]
+            parts_a = [workload_table(wl, n_a, seed_a, kind_a, c) for c in rank_chroms]
+            parts_b = [workload_table(wl, n_b, seed_b, kind_b, c) for c in rank_chroms]
             return (tuple(np.concatenate([p[k] for p in parts_a]) for k in range(3)),
                     tuple(np.concatenate([p[k] for p in parts_b]) for k in range(3)))
-        return (synth.make_table(n_a, seed_a, kind_a, chroms=chroms), synth.make_table(n_b, seed_b, kind_b, chroms=chroms))
+        return (workload_table(wl, n_a, seed_a, kind_a, chroms), workload_table(wl, n_b, seed_b, kind_b, chroms))
 
     def port(chroms):
         a, b = tables(chroms)
@@ -695,6 +713,7 @@ def run_inner(args):
                     "pairs": f" + {args.backend} all-gather of the pairs", "none": ", no gather"}[exchange]),
                 "inputs": "resident in HBM before the timed region",
                 "join_form": form,
+                "presorted_side_skipped_its_sort": bool(st.get("presorted", False)),
                 "span_hist": span_hist,
                 "sort": ("two global passes + in-LDS bucket sort for sides >= 32M rows" if st.get("sort_local")
                          else "four global passes"),

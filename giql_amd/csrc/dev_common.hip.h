@@ -32,6 +32,9 @@ struct DevMeta {
   // 1 when k_chrom_offsets laid the chromosomes out on 2^24-aligned bases (the
   // histogram-in-the-span-pass form, see k_chrom_minmax<true>); 0 = tight packing
   u32 aligned_ok;
+  // 1 as soon as a row of the side is found out of (chrom id, start) order or irregular (k_chrom_minmax): a side
+  // that stays 0 arrives sorted on the linear axis and needs no sort (coordinate-sorted BED / BAM-derived tables)
+  u32 unsorted_a, unsorted_b;
 };
 
 // XCD-aware block -> tile map.  Workgroups are dealt round-robin to the 8 XCDs, each

@@ -166,6 +166,11 @@ struct giql_hip_ctx {
   bool last_sort_local = false;  // the call in flight sorted at least one side in three stages
   // fused range count (fixed-length INNER form whose sorted side takes the three-stage sort): the bucket
   // sort answers the queries' bounds from LDS, the sorted keys never return to HBM (bucket_sort.hip.h)
+  // sorted inputs: a side the span pass found in (chrom id, start) order is not sorted again.  The answer of the
+  // previous plan is the guess of the next (validated at the read-back); plan labels (after the exchange of sides)
+  bool spec_sorted[2] = {false, false};
+  bool used_sorted[2] = {false, false};  // the call in flight skipped that side's sort
+  bool no_sorted = false;       // GIQL_HIP_NO_SORTED_INPUT=1: every side is sorted whatever its order
   bool no_keygen_q = false;     // GIQL_HIP_NO_KEYGEN_Q=1: the fixed-length form always linearizes its query side
   u32* span_hist_dirty[2] = {nullptr, nullptr};  // histograms the span pass of the call in flight counted into (a side that is linearized after all must zero its own again)
   bool prezeroed = false;       // the call in flight zeroed its histograms and status words in ONE memset up front
@@ -260,6 +265,7 @@ static void reset_stats(giql_hip_ctx* ctx) {
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   ctx->last_sort_local = false;
   ctx->count_fused = false;
+  ctx->used_sorted[0] = ctx->used_sorted[1] = false;
   ctx->spans.clear();
   ctx->ev_used = 0;
 }
@@ -534,8 +540,45 @@ struct FuseCount {
 static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
                              const u32* gbase, u32* status, bool keep_rids = false,
                              const giql_side* keygen = nullptr, const u32* abase = nullptr,
-                             int skip_digits = 0, const FuseCount* fuse = nullptr) {
+                             int skip_digits = 0, const FuseCount* fuse = nullptr, bool presorted = false) {
   if (n == 0) return GIQL_OK;
+  if (presorted) {
+    // the side arrives sorted: no scatter pass, one streaming pass for what a sort would have left in buffer 0
+    const int mode = (sb.rid[0] ? 1 : 0) | (sb.end[0] ? 2 : 0);
+    const bool local_fused = fuse && mode == 1 && sort_is_local(ctx, n);
+    {
+      Phase ph(ctx, st, GIQL_PH_SORT_SCATTER, 1);
+      u32 grid = cdiv(n, 256 * 8);
+      if (grid > GIQL_STREAM_GRID) grid = GIQL_STREAM_GRID;
+      if (keygen) {
+        ctx->stats.phase_bytes[GIQL_PH_SORT_SCATTER] += (int64_t)4 * n * ((mode & 2 ? 3 : 2) + 1 + (mode & 1) + (mode & 2 ? 1 : 0));
+        const u32 so = (u32)keygen->start_off, eo = (u32)keygen->end_off;
+        switch (mode) {
+          case 0: hipLaunchKernelGGL(k_keygen_stream<0>, dim3(grid), dim3(256), 0, st, keygen->chrom, keygen->start, keygen->end, n, abase, so, eo, sb.key[0], (u32*)nullptr, (u32*)nullptr); break;
+          case 1: hipLaunchKernelGGL(k_keygen_stream<1>, dim3(grid), dim3(256), 0, st, keygen->chrom, keygen->start, keygen->end, n, abase, so, eo, sb.key[0], (u32*)nullptr, sb.rid[0]); break;
+          case 2: hipLaunchKernelGGL(k_keygen_stream<2>, dim3(grid), dim3(256), 0, st, keygen->chrom, keygen->start, keygen->end, n, abase, so, eo, sb.key[0], sb.end[0], (u32*)nullptr); break;
+          default: hipLaunchKernelGGL(k_keygen_stream<3>, dim3(grid), dim3(256), 0, st, keygen->chrom, keygen->start, keygen->end, n, abase, so, eo, sb.key[0], sb.end[0], sb.rid[0]); break;
+        }
+      } else if (sb.rid[0] && !keep_rids) {
+        ctx->stats.phase_bytes[GIQL_PH_SORT_SCATTER] += (int64_t)4 * n;
+        hipLaunchKernelGGL(k_iota, dim3(grid), dim3(256), 0, st, sb.rid[0], n);
+      }
+      GIQL_TRY(post_launch("sorted input (no sort)"));
+    }
+    if (!local_fused) return GIQL_OK;   // sorted already: the bucket stage only runs as the carrier of the fused count
+    ctx->last_sort_local = true;
+    Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 3);
+    ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += (int64_t)12 * n + (int64_t)16 * fuse->nq_total;
+    ctx->count_fused = true;
+    hipLaunchKernelGGL(k_bucket_bounds_fused, dim3(cdiv((u64)3 * BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
+                       gbase + 3 * OS_BINS, ctx->bucket_bnd, ctx->bucket_big, fuse->dev, fuse->nq_total, fuse->irr_q,
+                       fuse->gbq3, fuse->key_mask, fuse->len_max_q, fuse->zero_ptr, fuse->zero_words);
+    hipLaunchKernelGGL((k_bucket_sort<1, true>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
+                       sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse->dev);
+    hipLaunchKernelGGL((k_bucket_sort_big<1, true>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
+                       sb.rid[0], sb.key[1], (u32*)nullptr, sb.rid[1], ctx->bucket_bnd, ctx->bucket_big, fuse->dev);
+    return post_launch("bucket stage (sorted input, fused count)");
+  }
   const bool local = sort_is_local(ctx, n);
   if (local) ctx->last_sort_local = true;
   if (local || ctx->no_skip_digit) skip_digits = 0;
@@ -875,6 +918,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     if (rsd && atoi(rsd) >= 0 && atoi(rsd) <= 3) ctx->row_skip_digits = atoi(rsd);
     const char* nfc = getenv("GIQL_HIP_NO_FUSE_COUNT");
     ctx->no_fuse_count = nfc && atoi(nfc) != 0;
+    const char* nso = getenv("GIQL_HIP_NO_SORTED_INPUT");
+    ctx->no_sorted = nso && atoi(nso) != 0;
     const char* nkq = getenv("GIQL_HIP_NO_KEYGEN_Q");
     ctx->no_keygen_q = nkq && atoi(nkq) != 0;
     const char* qsd = getenv("GIQL_HIP_Q_SKIP_DIGITS");
@@ -971,7 +1016,7 @@ int giql_hip_get_stats(giql_hip_ctx* ctx, giql_hip_stats* out) {
   // the four-pass sort for good); byte 1: sort tile order in force; bytes 2-3: order fallbacks so far
   out->reserved = (ctx->stats.reserved & 0x1F) | (ctx->last_sort_local ? 0x20 : 0) |
                   (ctx->local_resorts ? 0x40 : 0) | (ctx->swapped ? 0x80 : 0) | ((ctx->os_order & 0x7F) << 8) |
-                  (ctx->count_fused ? 0x8000 : 0) |
+                  (ctx->count_fused ? 0x8000 : 0) | ((ctx->used_sorted[0] || ctx->used_sorted[1]) ? (int32_t)0x80000000u : 0) |
                   ((ctx->order_fallbacks & 0x3FFF) << 16) | (ctx->fuse_done ? (1 << 30) : 0);
   return GIQL_OK;
 }
@@ -1159,6 +1204,15 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
       }
     }
   }
+  // Sorted inputs: a side the span pass found in (chrom id, start) order (and free of irregular rows) skips its
+  // sort -- from the read-back on a first plan, the previous plan's answer afterwards (validated below)
+  bool pre_a = false, pre_b = false;
+  if (onesweep && !ctx->no_sorted) {
+    pre_a = speculated ? ctx->spec_sorted[0] : ctx->h_meta->unsorted_a == 0;
+    pre_b = speculated ? ctx->spec_sorted[1] : ctx->h_meta->unsorted_b == 0;
+  }
+  ctx->used_sorted[0] = pre_a;
+  ctx->used_sorted[1] = pre_b;
   const bool keygen = aligned && S.uniform == (big_side ? 1 : 2);
   // General form: the larger side's (key, end, rid) sort can start from the raw columns too, as long as
   // that side holds no irregular row (those carry the sentinel key, which depends on `end`; the span pass
@@ -1233,7 +1287,8 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     u32* const stat_q = nqr <= nu ? os_status2 : os_status;
     u32* const stat_u = nqr <= nu ? os_status : os_status2;
     GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sq, (u32)nqr, q_is_a ? gbase_a : gbase_b,
-                               stat_q, false, keygen_q ? &qs_ : nullptr, lb.abase, q_skip));
+                               stat_q, false, keygen_q ? &qs_ : nullptr, lb.abase, q_skip, nullptr,
+                               q_is_a ? pre_a : pre_b));
     // One-call join (giql_hip_inner_join_dev): the caller's buffers are here and everything about this plan is a
     // guess that has held so far (same form as last time, no irregular rows), so the fill is launched inside the
     // plan, with a grid bounded by the capacity and the true count read on the device.
@@ -1260,7 +1315,8 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
       fc.len_max_q = q_is_a ? &ctx->d_meta->len_max_a : &ctx->d_meta->len_max_b;
     }
     GIQL_TRY(run_sort_onesweep(ctx, st, su, (u32)nu, q_is_a ? gbase_b : gbase_a, stat_u, false,
-                               keygen ? &us_ : nullptr, lb.abase, 0, fuse_cnt ? &fc : nullptr));
+                               keygen ? &us_ : nullptr, lb.abase, 0, fuse_cnt ? &fc : nullptr,
+                               q_is_a ? pre_b : pre_a));
     GIQL_TRY(sc.join());
     constexpr u32 TQ = RC_NT * RC_ITEMS_C2;
     S.nt2 = cdiv(nqr, TQ);
@@ -1342,9 +1398,9 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   }
   if (onesweep) {
     GIQL_TRY(run_sort_onesweep(ctx, st_a, sa, (u32)na, gbase_a, a_small ? os_status2 : os_status,
-                               false, kg_a ? a : nullptr, lb.abase));
+                               false, kg_a ? a : nullptr, lb.abase, 0, nullptr, pre_a));
     GIQL_TRY(run_sort_onesweep(ctx, st_b, sbb, (u32)nb, gbase_b, a_small ? os_status : os_status2,
-                               false, kg_b ? b : nullptr, lb.abase));
+                               false, kg_b ? b : nullptr, lb.abase, 0, nullptr, pre_b));
     GIQL_TRY(sc.join());
   } else {
     GIQL_TRY(run_sort(ctx, st, sa, (u32)na, tile_hist, bsums));
@@ -1411,7 +1467,12 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     const bool fuse_len_ok_now = form != 0 && q_len_now <= (int)BS_FUSE_WCAP;
     const bool fuse_wrong = ctx->count_fused && !fuse_len_ok_now;
     ctx->spec_fuse_len_ok = fuse_len_ok_now;
-    if (speculated && (form != S.uniform || len != uni_len || (want_hist && !aligned_now) || coarse_wrong || keygen_wrong || fuse_wrong)) {
+    // a side taken as sorted must be: an out-of-order row was left where it was
+    const bool sorted_wrong = (ctx->used_sorted[0] && ctx->h_meta->unsorted_a != 0) ||
+                              (ctx->used_sorted[1] && ctx->h_meta->unsorted_b != 0);
+    ctx->spec_sorted[0] = ctx->h_meta->unsorted_a == 0;
+    ctx->spec_sorted[1] = ctx->h_meta->unsorted_b == 0;
+    if (speculated && (form != S.uniform || len != uni_len || (want_hist && !aligned_now) || coarse_wrong || keygen_wrong || fuse_wrong || sorted_wrong)) {
       ctx->spec_valid = false;  // wrong guess: plan again from the numbers just read
       ctx->spec_misses++;
       ctx->fuse_done = false;

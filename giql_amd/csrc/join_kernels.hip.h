@@ -46,6 +46,8 @@ __global__ void k_init_minmax(int* __restrict__ gmin, int* __restrict__ gmax, in
     meta->len_min_b = INT_MAX;
     meta->len_max_b = 0;
     meta->aligned_ok = 0;
+    meta->unsorted_a = 0;
+    meta->unsorted_b = 0;
   }
 }
 
@@ -114,6 +116,19 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
   int cur = -1, mn = INT_MAX, mx = INT_MIN;
   int lmn = INT_MAX, lmx = 0;  // canonical length range (0 as soon as a row is irregular)
   bool bad = false;
+  // Is the side already in (chrom id, start) order -- the order of the linear axis?  One compare per row with
+  // its predecessor, which is the previous LANE's row (consecutive lanes hold consecutive rows): a DPP shift,
+  // no LDS; lane 0 of a wave loads its predecessor itself.  An irregular row (sentinel key) counts as out of order.
+  bool inv = false;
+  auto order = [&](const int c, const int s, const u64 i, const bool ok) {
+    int pc = __builtin_amdgcn_update_dpp(0, c, 0x138, 0xF, 0xF, false);   // wave_shr:1
+    int ps = __builtin_amdgcn_update_dpp(0, s, 0x138, 0xF, 0xF, false);
+    if (lane_id() == 0) {
+      pc = (ok && i > 0) ? chrom[i - 1] : INT_MIN;
+      ps = (ok && i > 0) ? start[i - 1] : INT_MIN;
+    }
+    if (ok && (pc > c || (pc == c && ps > s))) inv = true;
+  };
   // One row: length range, per-chromosome min/max through the run cache, digit counts.
   auto row = [&](const int c, const int s, const int e, const bool ok) {
     if (ok) {
@@ -131,6 +146,7 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
         lmx = len > lmx ? len : lmx;
       } else {
         lmn = 0;  // an irregular row (canonical end <= start): this side is not uniform
+        inv = true;
       }
       if (c < 0 || c >= n_chrom) {
         bad = true;
@@ -207,7 +223,10 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
       ev[u] = ep[u * NT];
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) row(cv[u], sv[u], ev[u], true);
+    for (int u = 0; u < 4; u++) {
+      order(cv[u], sv[u], t * TILE + (u64)u * NT + threadIdx.x, true);
+      row(cv[u], sv[u], ev[u], true);
+    }
   }
   if (blockIdx.x == (u32)(n_full % gridDim.x)) {  // the ragged tail: one block
     const u64 base = n_full * TILE;
@@ -215,7 +234,9 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
     for (int u = 0; u < 4; u++) {
       const u64 i = base + (u64)u * NT + threadIdx.x;
       const bool ok = i < (u64)n;
-      row(ok ? chrom[i] : 0, ok ? start[i] : 0, ok ? end[i] : 0, ok);
+      const int c_ = ok ? chrom[i] : 0, s_ = ok ? start[i] : 0;
+      order(c_, s_, i, ok);
+      row(c_, s_, ok ? end[i] : 0, ok);
     }
   }
   if (HIST) {
@@ -242,6 +263,7 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
     }
   }
   if (bad) meta->status = -4;  // GIQL_ERR_CHROM
+  if (__ballot(inv) != 0ull && lane_id() == 0) *(which ? &meta->unsorted_b : &meta->unsorted_a) = 1u;
   {
     // block-reduce the length range into this block's slot (no global atomics:
     // thousands of waves hitting two addresses serialise for ~0.2 ms)

@@ -581,4 +581,32 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
                                                    s_goff, s_scan, &s_help, help_after, s_abase, start_off, end_off);
 }
 
+// A side that arrives SORTED on the linear axis (coordinate-sorted BED / BAM-derived tables; the span pass
+// tells: DevMeta::unsorted_a / _b) takes no scatter pass at all: one streaming pass writes what the sort would
+// have left in buffer 0 -- the keys (and end keys) in input order and the identity row ids.  KEYGEN layout
+// (2^24-aligned bases, k_onesweep<.., KEYGEN>): key = abase[chrom] + start + start_off.
+template <int PAYLOAD>
+__global__ __launch_bounds__(256) void k_keygen_stream(const int* __restrict__ chrom, const int* __restrict__ start,
+                                                        const int* __restrict__ end, u32 n,
+                                                        const u32* __restrict__ abase, u32 start_off, u32 end_off,
+                                                        u32* __restrict__ keys, u32* __restrict__ ends,
+                                                        u32* __restrict__ rids) {
+  __shared__ u32 s_abase[32];
+  if (threadIdx.x < 32) s_abase[threadIdx.x] = abase[threadIdx.x];
+  __syncthreads();
+  const u32 stride = gridDim.x * 256u;
+  for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
+    const u32 b = s_abase[(u32)chrom[i] & 31u];
+    keys[i] = b + (u32)start[i] + start_off;
+    if (PAYLOAD & 2) ends[i] = b + (u32)end[i] + end_off;
+    if (PAYLOAD & 1) rids[i] = i;
+  }
+}
+
+// ... and a side whose keys the linearize pass already wrote in input order only needs its row ids.
+__global__ __launch_bounds__(256) void k_iota(u32* __restrict__ out, u32 n) {
+  const u32 stride = gridDim.x * 256u;
+  for (u32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += stride) out[i] = i;
+}
+
 }  // namespace giql

@@ -138,6 +138,7 @@ class HipEngine:
         out["count_fused"] = bool(int(st.reserved) & 0x8000)  # the bucket sort answered the range bounds (no count kernel)
         out["sort_order_fallbacks"] = (int(st.reserved) >> 16) & 0x3FFF
         out["fused_fill"] = bool((int(st.reserved) >> 30) & 1)  # the last plan launched its own fill
+        out["presorted"] = bool(int(st.reserved) & 0x80000000)  # a side arrived sorted and skipped its sort
         out["total_ms"] = float(st.total_ms)
         out["phase_ms"] = {name: float(st.phase_ms[i]) for i, name in enumerate(_lib.PHASES)}
         out["phase_launches"] = {name: int(st.phase_launches[i]) for i, name in enumerate(_lib.PHASES)}

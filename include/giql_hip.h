@@ -133,7 +133,8 @@ typedef struct giql_hip_stats {
                                sorted keys never stored); bits 16-29: calls
                                repeated in ticket order after a look-back timeout;
                                bit 30: the last plan launched its own fill
-                               (giql_hip_inner_join_dev) */
+                               (giql_hip_inner_join_dev); bit 31: a side arrived in (chrom id, start)
+                               order and skipped its sort */
 } giql_hip_stats;
 
 /* ---- library / context ------------------------------------------------- */

@@ -1293,3 +1293,68 @@ def test_two_contexts_on_two_threads():
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+# ---- inputs that arrive sorted skip their sort -------------------------------------------
+def _sorted_side(side):
+    order = np.lexsort((side.start, side.chrom))
+    return ora.Side(side.chrom[order], side.start[order], side.end[order], side.start_off, side.end_off)
+
+
+@pytest.mark.parametrize("which", ["both", "a", "b"])
+@pytest.mark.parametrize("uniform", [False, True])
+def test_sorted_inputs_skip_their_sort_and_unsorted_ones_are_noticed(eng_fresh, which, uniform):
+    a = rand_side(2101, 60_000, 7, 5_000_000, 900)
+    b = uniform_side(2102, 250_000, 7, 5_000_000, 150) if uniform else rand_side(2102, 250_000, 7, 5_000_000, 700)
+    sa = _sorted_side(a) if which in ("both", "a") else a
+    sb = _sorted_side(b) if which in ("both", "b") else b
+    want = ora.sort_pairs(*ora.c_inner(sa, sb, "sweep"))
+    for _ in range(3):   # first plan: read back; then the context's guess
+        assert np.array_equal(gpu_inner(eng_fresh, sa, sb, 7), want)
+        assert eng_fresh.stats()["presorted"]
+    # the one-call form on the speculating context
+    cap = want.shape[0] + 100
+    ra = torch.empty(cap, dtype=torch.int32, device="cuda:0")
+    rb = torch.empty(cap, dtype=torch.int32, device="cuda:0")
+    n = eng_fresh.inner_join_into(dev(sa), dev(sb), 7, ra, rb)
+    assert n == want.shape[0] and np.array_equal(ora.sort_pairs(ra[:n].cpu().numpy(), rb[:n].cpu().numpy()), want)
+    # ... now the same context meets the SHUFFLED tables: its guess is wrong, the plan is repeated
+    want_u = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    assert np.array_equal(gpu_inner(eng_fresh, a, b, 7), want_u)
+    assert not eng_fresh.stats()["presorted"]
+    assert np.array_equal(gpu_inner(eng_fresh, a, b, 7), want_u)
+    # one row out of place / one irregular row in an otherwise sorted side: not sorted
+    x = _sorted_side(a)
+    x.start[1000], x.start[1001] = x.start[1001], x.start[1000]
+    x.end[1000], x.end[1001] = max(x.end[1000], x.start[1000] + 1), max(x.end[1001], x.start[1001] + 1)
+    if x.start[1000] != x.start[1001] and x.chrom[1000] == x.chrom[1001]:
+        want_x = ora.sort_pairs(*ora.c_inner(x, sb, "sweep"))
+        assert np.array_equal(gpu_inner(eng_fresh, x, sb, 7), want_x)   # (the guess still says "b is shuffled": only slower)
+        assert np.array_equal(gpu_inner(eng_fresh, x, sb, 7), want_x)   # the guess follows the previous plan
+        assert eng_fresh.stats()["presorted"] == (which in ("both", "b"))
+    y = _sorted_side(a)
+    y.end[500] = y.start[500]
+    assert np.array_equal(gpu_inner(eng_fresh, y, sb, 7), ora.sort_pairs(*ora.c_inner(y, sb, "sweep")))
+
+
+def test_sorted_inputs_with_the_three_stage_sort_and_the_fused_count(monkeypatch):
+    from giql_amd.engine import HipEngine
+
+    monkeypatch.setenv("GIQL_HIP_LOCAL_MIN_ROWS", "1")
+    e = HipEngine(0)
+    monkeypatch.delenv("GIQL_HIP_LOCAL_MIN_ROWS")
+    try:
+        a = _sorted_side(rand_side(2111, 50_000, 5, 30_000_000, 2000, min_len=100))
+        b = _sorted_side(uniform_side(2112, 400_000, 5, 30_000_000, 150))
+        want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+        for _ in range(3):
+            assert np.array_equal(gpu_inner(e, a, b, 5), want)
+            st = e.stats()
+            assert st["presorted"] and st["count_fused"] and st["join_form"] == "uniform_b"
+        assert np.array_equal(gpu_inner(e, b, a, 5), ora.sort_pairs(*ora.c_inner(b, a, "sweep")))
+        # encodings on both sides (offsets in the streamed keys)
+        a1 = ora.Side(a.chrom, a.start + 1, a.end, -1, 0)
+        b1 = ora.Side(b.chrom, b.start + 1, b.end + 1, -1, -1)
+        assert np.array_equal(gpu_inner(e, a1, b1, 5), want)
+    finally:
+        e.close()
