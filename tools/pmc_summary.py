@@ -28,9 +28,16 @@ def main() -> None:
     joins = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     prof = os.path.join(ROOT, "profiles")
-    c = sqlite3.connect(os.path.join(src, "trace", "trace_results.db"))
-    rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
-                     "from kernels group by name order by sum(duration) desc").fetchall()
+    stats_csv = os.path.join(src, "trace", "trace_kernel_stats.csv")
+    if os.path.exists(stats_csv):  # rocprofv3 --output-format csv (tools/profile.sh since round 3)
+        with open(stats_csv) as f:
+            rows = [(r["Name"], int(r["Calls"]), int(r["TotalDurationNs"]), float(r["AverageNs"]), int(r["MinNs"]),
+                     int(r["MaxNs"])) for r in csv.DictReader(f)]
+        rows.sort(key=lambda r: -r[2])
+    else:
+        c = sqlite3.connect(os.path.join(src, "trace", "trace_results.db"))
+        rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                         "from kernels group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows)
     with open(os.path.join(prof, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
@@ -45,10 +52,17 @@ def main() -> None:
         w = csv.writer(f)
         w.writerow(["counter", "kernel", "dispatches", "sum_GB_raw", "max_dispatch_GB_raw"])
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            db = sqlite3.connect(os.path.join(src, f"pmc_{counter}", "pmc_results.db"))
+            cc_csv = os.path.join(src, f"pmc_{counter}", "pmc_counter_collection.csv")
+            if os.path.exists(cc_csv):
+                with open(cc_csv) as fc:
+                    values = [(r["Kernel_Name"], float(r["Counter_Value"])) for r in csv.DictReader(fc)
+                              if r["Counter_Name"] == counter]
+            else:
+                db = sqlite3.connect(os.path.join(src, f"pmc_{counter}", "pmc_results.db"))
+                values = db.execute("select kernel_name, value from counters_collection where counter_name = ?",
+                                    (counter,)).fetchall()
             agg = {}
-            for name, value in db.execute("select kernel_name, value from counters_collection where counter_name = ?",
-                                          (counter,)):
+            for name, value in values:
                 k = short(name)
                 a = agg.setdefault(k, [0, 0.0, 0.0])
                 a[0] += 1
