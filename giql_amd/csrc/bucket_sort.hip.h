@@ -73,6 +73,12 @@ struct BsFuse {
   u32* lo_out;       // per sorted query row: first matching sorted U row ...
   u32* hi_out;       // ... and one past the last
   i64 lo_off;
+  // FUSE == 2 (the join itself in the bucket stage, see bucket_join_emit): the pairs leave from here
+  const u32* qrid;   // the sorted query rows' ids
+  int32_t* row_q;    // output: query-side row id of every pair ...
+  int32_t* row_s;    // ... and the sorted side's
+  u64 cap;           // pairs the outputs hold
+  unsigned long long* cursor;  // pairs handed out so far (DevMeta::n_out): a block takes its output range with ONE atomic add
 };
 
 __device__ __forceinline__ u32 bs_shift_key(u32 k, i64 off) {  // = shift_key of join_kernels.hip.h
@@ -208,7 +214,7 @@ __device__ __forceinline__ u32 bs_rank16(u32 x16, const u64* s_cell, const u32* 
 // Barrier of the bucket sort's body.  __syncthreads() also drains the wave's outstanding GLOBAL loads and stores
 // (s_waitcnt vmcnt(0)); the fused form has the query bounds' stores in flight in the middle of the kernel, and
 // every block would stand still for their acknowledgement: its barriers wait for the wave's LDS operations only.
-template <bool LDS_ONLY>
+template <int LDS_ONLY>
 __device__ __forceinline__ void bs_sync() {
   if (LDS_ONLY)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -220,11 +226,107 @@ __device__ __forceinline__ void bs_sync() {
 #endif
 constexpr int BS_QPRE = GIQL_BS_QPRE;  // probe rounds whose values are loaded with the rows
 
-template <int PAYLOAD, int R, bool FUSE = false>
+// ---- the join itself in the bucket stage (FUSE == 2, round 3) ----
+// With the bounds answered from LDS (FUSE == 1) the sorted row ids still made a round trip through HBM: written by
+// the bucket sort (4 B per row), gathered again by the fill, with the per-query bounds, their scan and the fill's
+// partition in between -- 1.2 GB of the 11.3 GB a headline join moved.  But the block that sorts bucket v holds
+// everything the pairs of that bucket are made of: the bucket's row ids in sorted order (staged in LDS by final
+// place) and the window of queries whose range reaches into the bucket.  So in the one-call form (the caller's
+// output buffers are known, giql_hip_inner_join_dev) it writes the pairs itself: every query of the window gets
+// its range CLAMPED to the bucket (a range that spans two buckets is emitted half by each), the block adds up its
+// pairs, takes its place in the output with one atomic add on a global cursor, and its waves write the runs --
+// one query per wave iteration, the query's numbers broadcast from the lane that ranked it (v_readlane).  Neither
+// the sorted ids nor any per-query array reaches HBM, and the count / scan / partition / fill launches are gone.
+// The order of the pairs depends on the order the blocks arrive at the cursor: unspecified, as the order of an
+// INNER join's rows always was (bag semantics, intersects_duckdb.py:1283-1330 emits no ORDER BY).
+// A window holds at most BJ_QR queries per thread (their ranks live in registers while the bin table is reused);
+// denser windows, like buckets too large for LDS, go to the queue of k_bucket_sort_big.
+#ifndef GIQL_BJ_MIN_WAVES
+#define GIQL_BJ_MIN_WAVES 6  // the join form keeps its queries' ranks in registers next to the rows: 80 VGPRs, three blocks per CU
+#endif
+constexpr int BJ_QR = 4;
+constexpr u32 BJ_WCAP = BJ_QR * BS_NT;
+
+// The tail of a FUSE == 2 block (see above).  On entry every row knows its final place (slot), the bin table and
+// the gathered equal-key bins are still valid, and no barrier has passed since the last of them was read.
+template <int R>
+__device__ __forceinline__ void bucket_join_tail(const u32 (&pay)[R], const u32 (&slot)[R], u32 cnt, u32 v,
+                                                 u32* s_buf, const u64* s_cell, u32* s_jtot, const BsFuse& fq,
+                                                 u32 qw0, u32 nw, const u32 (&jq_key)[BJ_QR],
+                                                 const u32 (&jq_end)[BJ_QR]) {
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const u32 k0 = v << 16;
+  // ranks of my queries' bounds inside this bucket, clamped to it
+  u32 q_lo[BJ_QR], q_cnt[BJ_QR], q_rid[BJ_QR], incl[BJ_QR];
+#pragma unroll
+  for (int i = 0; i < BJ_QR; i++) {
+    const u32 j = i * BS_NT + tid;
+    q_lo[i] = q_cnt[i] = q_rid[i] = 0;
+    if (j < nw) {
+      const u32 xlo = bs_shift_key(jq_key[i], fq.lo_off), xhi = jq_end[i];
+      const u32 lo_l = xlo < k0 ? 0u : ((xlo >> 16) != v ? cnt : bs_rank16(xlo & 0xFFFFu, s_cell, s_buf));
+      const u32 hi_l = xhi <= k0 ? 0u : ((xhi >> 16) != v ? cnt : bs_rank16(xhi & 0xFFFFu, s_cell, s_buf));
+      q_lo[i] = lo_l;
+      q_cnt[i] = hi_l > lo_l ? hi_l - lo_l : 0u;
+      if (q_cnt[i]) q_rid[i] = fq.qrid[qw0 + j];  // (flies under the scan and the staging below)
+    }
+    incl[i] = wave_incl_scan_add_u32(q_cnt[i]);
+    if (lane == WAVE - 1) s_jtot[i * BS_NW + w] = incl[i];
+  }
+  bs_sync<2>();  // every rank has been read: s_buf and the cells are free; the wave totals are in
+  // pairs of the block, and where each (slot, wave) group of queries starts among them
+  u32 total = 0, q_off[BJ_QR];
+#pragma unroll
+  for (int i = 0; i < BJ_QR; i++) {
+    u32 mine = 0;
+#pragma unroll
+    for (int k = 0; k < BS_NW; k++) {
+      if (k == (int)w) mine = total;
+      total += s_jtot[i * BS_NW + k];
+    }
+    q_off[i] = mine + incl[i] - q_cnt[i];
+  }
+  if (total == 0) return;  // block-uniform: no query of the window reaches a row of this bucket
+  // the block's place in the output: one atomic, in flight while the row ids are staged by final place
+  unsigned long long base = 0;
+  if (tid == 0) base = atomicAdd(fq.cursor, (unsigned long long)total);
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const u32 r = i * BS_NT + tid;
+    if (i < R - 1 || r < cnt) s_buf[slot[i]] = pay[i];
+  }
+  unsigned long long* s_jbase = reinterpret_cast<unsigned long long*>(s_jtot + BJ_QR * BS_NW);
+  if (tid == 0) *s_jbase = base;
+  bs_sync<2>();
+  base = *s_jbase;
+  if (base + total > fq.cap) return;  // the caller's buffers are too small: the count still adds up, nothing is written
+  int32_t* const rq = fq.row_q + base;
+  int32_t* const rs = fq.row_s + base;
+  // one query per wave iteration: its numbers come from the lane that ranked it
+#pragma unroll
+  for (int i = 0; i < BJ_QR; i++) {
+    u64 m = __ballot(q_cnt[i] != 0u);
+    while (m) {
+      const int l = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const u32 c = (u32)__builtin_amdgcn_readlane((int)q_cnt[i], l);
+      const u32 lo = (u32)__builtin_amdgcn_readlane((int)q_lo[i], l);
+      const u32 off = (u32)__builtin_amdgcn_readlane((int)q_off[i], l);
+      const int qr = __builtin_amdgcn_readlane((int)q_rid[i], l);
+      for (u32 k = lane; k < c; k += WAVE) {
+        rq[off + k] = qr;
+        rs[off + k] = (int32_t)s_buf[lo + k];
+      }
+    }
+  }
+}
+
+
+template <int PAYLOAD, int R, int FUSE = 0>
 __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __restrict__ pp,
                                                  u32* __restrict__ ep, u32 cnt, u32 v, u32* s_buf,
                                                  u64* s_cell, u32* s_scan, const BsFuse& fq,
-                                                 u32 b0, u32 qw0, u32 qw1) {
+                                                 u32 b0, u32 qw0, u32 qw1, u32* s_jtot = nullptr) {
   constexpr int BIN_SHIFT = 12 + BS_SUB_BITS;
   constexpr int PER = BS_NB / BS_NT;  // cells scanned per thread
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -244,14 +346,25 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
   // bound (from the end key) -- one load, one cell read and one store each, spread over all eight waves.
   const u32* q_src = (tid & 1u) ? fq.qend : fq.qkey;
   u32* q_dst = (tid & 1u) ? fq.hi_out : fq.lo_out;
-  const u32 n_probe = FUSE ? 2u * (qw1 - qw0) : 0u;
+  const u32 n_probe = FUSE == 1 ? 2u * (qw1 - qw0) : 0u;
   // (the first BS_QPRE rounds' values are loaded up front, with the rows: a window of one bucket's queries is
   // one round, the three buckets a query side grouped by bucket only brings along are three)
   u32 q_val[BS_QPRE];
 #pragma unroll
   for (int k = 0; k < BS_QPRE; k++) {
     q_val[k] = 0;
-    if (FUSE && tid + k * BS_NT < n_probe) q_val[k] = q_src[qw0 + ((tid + k * BS_NT) >> 1)];
+    if (FUSE == 1 && tid + k * BS_NT < n_probe) q_val[k] = q_src[qw0 + ((tid + k * BS_NT) >> 1)];
+  }
+  // the join form: one thread per query of the window, key and end key, up to BJ_QR rounds
+  u32 jq_key[FUSE == 2 ? BJ_QR : 1], jq_end[FUSE == 2 ? BJ_QR : 1];
+  if constexpr (FUSE == 2) {
+#pragma unroll
+    for (int k = 0; k < BJ_QR; k++) {
+      const u32 j = k * BS_NT + tid;
+      const bool in = j < qw1 - qw0;
+      jq_key[k] = in ? fq.qkey[qw0 + j] : 0u;
+      jq_end[k] = in ? fq.qend[qw0 + j] : 0u;
+    }
   }
   // cells zeroed while the loads fly
 #pragma unroll
@@ -317,7 +430,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
   }
   bs_sync<FUSE>();
   GIQL_BS_STOP(4);  // + places of the rows with distinct keys
-  if (FUSE) {
+  if (FUSE == 1) {
     // the bounds of the query window that fall into this bucket: one cell read each
 #pragma unroll
     for (int k = 0; k < BS_QPRE; k++) {
@@ -349,6 +462,10 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
         slot[i] = start + c;
       }
     }
+  }
+  if constexpr (FUSE == 2) {  // the pairs leave from here: no sorted array is stored
+    bucket_join_tail<R>(pay, slot, cnt, v, s_buf, s_cell, s_jtot, fq, qw0, qw1 - qw0, jq_key, jq_end);
+    return;
   }
   bs_sync<FUSE>();  // every gathered bin has been read: s_buf and the cells are free
   GIQL_BS_STOP(5);  // + places of the rows with equal keys
@@ -486,8 +603,8 @@ __device__ __forceinline__ void bucket_sort_big(u32* __restrict__ k0, u32* __res
   }
 }
 
-template <int PAYLOAD, bool FUSE = false>
-__global__ __launch_bounds__(BS_NT, GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* __restrict__ keys, u32* __restrict__ ends,
+template <int PAYLOAD, int FUSE = 0>
+__global__ __launch_bounds__(BS_NT, FUSE == 2 ? GIQL_BJ_MIN_WAVES : GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* __restrict__ keys, u32* __restrict__ ends,
                                                            u32* __restrict__ rids,
                                                            const u32* __restrict__ bnd,
                                                            DevMeta* __restrict__ meta,
@@ -498,6 +615,7 @@ __global__ __launch_bounds__(BS_NT, GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* _
   __shared__ u32 s_buf[BS_CAP + 4];  // + 4: the four-wide read of a gathered bin may run past the last row
   __shared__ u64 s_cell[BS_NB];  // {sub-value map : 32 | count : 32}, after the scan {map | dup, count, start}
   __shared__ u32 s_scan[BS_NW];
+  __shared__ u32 s_jtot[FUSE == 2 ? BJ_QR * BS_NW + 4 : 1];  // join form: wave totals of the pair counts + the block's output base
   const u32 v = blockIdx.x;
   const u32 b0 = bnd[v];
   const u32 cnt = bnd[v + 1] - b0;
@@ -506,8 +624,12 @@ __global__ __launch_bounds__(BS_NT, GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* _
     qw0 = fq.qwin[2 * v];
     qw1 = fq.qwin[2 * v + 1];
   }
-  if (cnt < 2u && qw0 >= qw1) return;  // block-uniform: nothing to sort, no bound to answer
-  if (cnt > BS_CAP) {
+  if (FUSE == 2) {
+    if (cnt == 0u || qw0 >= qw1) return;  // block-uniform: no row or no query, no pair (nothing else leaves this kernel)
+  } else if (cnt < 2u && qw0 >= qw1) {
+    return;  // block-uniform: nothing to sort, no bound to answer
+  }
+  if (cnt > BS_CAP || (FUSE == 2 && qw1 - qw0 > BJ_WCAP)) {
     // too large for LDS: queued for k_bucket_sort_big (a launch of its own keeps this kernel free of
     // the big path's registers and scratch frame); past BS_BIG_MAX the whole call is repeated
     if (threadIdx.x == 0) {
@@ -522,7 +644,7 @@ __global__ __launch_bounds__(BS_NT, GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* _
   // the payload that rides along in registers: rid when there is one, else end
   u32* pp = (PAYLOAD & 1) ? rids + b0 : ((PAYLOAD & 2) ? ends + b0 : nullptr);
   u32* ep = (PAYLOAD == 3) ? ends + b0 : nullptr;  // a second payload array takes a round of its own
-#define GIQL_BS_BODY(RR) bucket_sort_body<PAYLOAD, RR, FUSE>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan, fq, b0, qw0, qw1)
+#define GIQL_BS_BODY(RR) bucket_sort_body<PAYLOAD, RR, FUSE>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan, fq, b0, qw0, qw1, s_jtot)
   switch ((cnt + BS_NT - 1) / BS_NT) {  // rows per thread: 1..BS_ITEMS, block-uniform
     case 0: case 1: GIQL_BS_BODY(1); break;  // (0: an empty bucket with bounds to answer)
     case 2: GIQL_BS_BODY(2); break;
@@ -537,7 +659,7 @@ __global__ __launch_bounds__(BS_NT, GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* _
 }
 
 // The buckets k_bucket_sort queued (big_list[0] = how many): one block each, grid-stride.
-template <int PAYLOAD, bool FUSE = false>
+template <int PAYLOAD, int FUSE = 0>
 __global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ keys, u32* __restrict__ ends,
                                                             u32* __restrict__ rids, u32* __restrict__ keys1,
                                                             u32* __restrict__ ends1, u32* __restrict__ rids1,
@@ -555,7 +677,59 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ key
                              keys1 + b0, (PAYLOAD & 2) ? ends1 + b0 : nullptr, (PAYLOAD & 1) ? rids1 + b0 : nullptr, cnt,
                              s_wcnt, s_base, s_scan);
     __syncthreads();
-    if (FUSE) {
+    if (FUSE == 2) {
+      // the join form of a queued bucket (too many rows for LDS, or too many queries in its window): the bucket is
+      // sorted in global memory now; the window in chunks of one query per thread, each chunk's pairs placed by
+      // one atomic and written as in bucket_join_tail
+      __shared__ unsigned long long s_jbase;
+      const u32* kb = keys + b0;
+      const u32* rb = rids + b0;
+      const u32 k0 = v << 16, qw0 = fq.qwin[2 * v], qw1 = fq.qwin[2 * v + 1];
+      const u32 lane = lane_id(), w = wave_id();
+      for (u32 c0 = qw0; c0 < qw1; c0 += BS_NT) {  // block-uniform
+        const u32 q = c0 + threadIdx.x;
+        u32 q_lo = 0, q_cnt = 0, q_rid = 0;
+        if (q < qw1) {
+          const u32 xlo = bs_shift_key(fq.qkey[q], fq.lo_off), xhi = fq.qend[q];
+          const u32 lo_l = xlo < k0 ? 0u : ((xlo >> 16) != v ? cnt : lower_bound_u32(kb, 0, cnt, xlo));
+          const u32 hi_l = xhi <= k0 ? 0u : ((xhi >> 16) != v ? cnt : lower_bound_u32(kb, 0, cnt, xhi));
+          q_lo = lo_l;
+          q_cnt = hi_l > lo_l ? hi_l - lo_l : 0u;
+          if (q_cnt) q_rid = fq.qrid[q];
+        }
+        const u32 incl = wave_incl_scan_add_u32(q_cnt);
+        if (lane == WAVE - 1) s_scan[w] = incl;
+        __syncthreads();
+        u32 total = 0, mine = 0;
+#pragma unroll
+        for (int k = 0; k < BS_NW; k++) {
+          if (k == (int)w) mine = total;
+          total += s_scan[k];
+        }
+        if (threadIdx.x == 0) s_jbase = total ? atomicAdd(fq.cursor, (unsigned long long)total) : 0ull;
+        __syncthreads();
+        const unsigned long long base = s_jbase;
+        if (total != 0u && base + total <= fq.cap) {
+          const u32 q_off = mine + incl - q_cnt;
+          int32_t* const rq = fq.row_q + base;
+          int32_t* const rs = fq.row_s + base;
+          u64 m = __ballot(q_cnt != 0u);
+          while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const u32 c = (u32)__builtin_amdgcn_readlane((int)q_cnt, l);
+            const u32 lo = (u32)__builtin_amdgcn_readlane((int)q_lo, l);
+            const u32 off = (u32)__builtin_amdgcn_readlane((int)q_off, l);
+            const int qr = __builtin_amdgcn_readlane((int)q_rid, l);
+            for (u32 k = lane; k < c; k += WAVE) {
+              rq[off + k] = qr;
+              rs[off + k] = (int32_t)rb[lo + k];
+            }
+          }
+        }
+        __syncthreads();  // s_scan and s_jbase are reused by the next chunk
+      }
+    } else if (FUSE) {
       // this bucket's keys are sorted in global memory now: the bounds of its query window by binary search
       // (the block's own stores are visible to it after the barrier)
       const u32* kb = keys + b0;

@@ -178,6 +178,11 @@ struct giql_hip_ctx {
   int fuse_q_skip = 2;          // GIQL_HIP_Q_SKIP_DIGITS: low digits the fused form leaves unsorted on the query side
   bool spec_fuse_len_ok = false;  // the previous plan's query rows were all short enough for the fused windows
   bool count_fused = false;     // the call in flight answered its bounds in the bucket sort
+  // the join itself in the bucket stage (bucket_sort.hip.h, FUSE == 2): one-call form only, on the same guesses as the
+  // early fill; the pairs leave from the bucket blocks, no sorted id / bound / offset array is written
+  bool no_bucket_join = false;  // GIQL_HIP_NO_BUCKET_JOIN=1: bounds from the bucket sort, then scan + fill as before
+  bool bucket_join = false;     // the call in flight emitted its pairs from the bucket stage
+  bool plan_is_join = false;    // ... and so left no plan arrays behind (fill / export need a plan of their own)
   u32* bucket_qwin = nullptr;   // [2 * BS_BUCKETS] query window per bucket
   u32* bucket_bnd = nullptr;  // [BS_BUCKETS + 1] bucket boundaries of the sort in flight
   u32* bucket_big = nullptr;  // [1 + BS_BUCKETS] buckets too large for LDS, queued for k_bucket_sort_big ([0] = count)
@@ -265,6 +270,7 @@ static void reset_stats(giql_hip_ctx* ctx) {
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   ctx->last_sort_local = false;
   ctx->count_fused = false;
+  ctx->bucket_join = false;
   ctx->used_sorted[0] = ctx->used_sorted[1] = false;
   ctx->spans.clear();
   ctx->ev_used = 0;
@@ -535,7 +541,29 @@ struct FuseCount {
   const int* len_max_q; // DevMeta: longest regular query row
   u32* zero_ptr;        // words the bounds kernel zeroes on the way (the chained scan's status + ticket)
   u32 zero_words;
+  bool join = false;    // FUSE == 2: the bucket blocks write the pairs themselves (dev.row_q / row_s / cap / cursor)
 };
+
+// The bucket stage of a fused (key, rid) sort: bounds only (FUSE 1) or the whole join (FUSE 2).
+static void launch_bucket_stage_fused(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, const FuseCount& fuse) {
+  if (fuse.join) {
+    hipLaunchKernelGGL((k_bucket_sort<1, 2>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
+                       sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse.dev);
+    hipLaunchKernelGGL((k_bucket_sort_big<1, 2>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
+                       sb.rid[0], sb.key[1], (u32*)nullptr, sb.rid[1], ctx->bucket_bnd, ctx->bucket_big, fuse.dev);
+  } else {
+    hipLaunchKernelGGL((k_bucket_sort<1, 1>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
+                       sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse.dev);
+    hipLaunchKernelGGL((k_bucket_sort_big<1, 1>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
+                       sb.rid[0], sb.key[1], (u32*)nullptr, sb.rid[1], ctx->bucket_bnd, ctx->bucket_big, fuse.dev);
+  }
+}
+// its algorithmic bytes up to the pairs (8 B each, added once the count is known): the rows' keys and ids read;
+// bounds form: the ids written, the queries' keys and end keys read, two bounds each written; join form: the
+// queries' keys, end keys and ids read
+static int64_t bucket_stage_fused_bytes(u32 n, const FuseCount& fuse) {
+  return fuse.join ? (int64_t)8 * n + (int64_t)12 * fuse.nq_total : (int64_t)12 * n + (int64_t)16 * fuse.nq_total;
+}
 
 static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n,
                              const u32* gbase, u32* status, bool keep_rids = false,
@@ -568,15 +596,13 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
     if (!local_fused) return GIQL_OK;   // sorted already: the bucket stage only runs as the carrier of the fused count
     ctx->last_sort_local = true;
     Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 3);
-    ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += (int64_t)12 * n + (int64_t)16 * fuse->nq_total;
+    ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += bucket_stage_fused_bytes(n, *fuse);
     ctx->count_fused = true;
+    ctx->bucket_join = fuse->join;
     hipLaunchKernelGGL(k_bucket_bounds_fused, dim3(cdiv((u64)3 * BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
                        gbase + 3 * OS_BINS, ctx->bucket_bnd, ctx->bucket_big, fuse->dev, fuse->nq_total, fuse->irr_q,
                        fuse->gbq3, fuse->key_mask, fuse->len_max_q, fuse->zero_ptr, fuse->zero_words);
-    hipLaunchKernelGGL((k_bucket_sort<1, true>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
-                       sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse->dev);
-    hipLaunchKernelGGL((k_bucket_sort_big<1, true>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
-                       sb.rid[0], sb.key[1], (u32*)nullptr, sb.rid[1], ctx->bucket_bnd, ctx->bucket_big, fuse->dev);
+    launch_bucket_stage_fused(ctx, st, sb, *fuse);
     return post_launch("bucket stage (sorted input, fused count)");
   }
   const bool local = sort_is_local(ctx, n);
@@ -643,15 +669,13 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
       // (key, rid) rows + the query side's bounds: keys and rids read, rids written, the query rows' keys
       // and ends read and their two bounds written -- the sorted keys never leave the CU
       Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 3);
-      ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += (int64_t)12 * n + (int64_t)16 * fuse->nq_total;
+      ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += bucket_stage_fused_bytes(n, *fuse);
       ctx->count_fused = true;
+      ctx->bucket_join = fuse->join;
       hipLaunchKernelGGL(k_bucket_bounds_fused, dim3(cdiv((u64)3 * BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
                          gbase + 3 * OS_BINS, ctx->bucket_bnd, ctx->bucket_big, fuse->dev, fuse->nq_total, fuse->irr_q,
                          fuse->gbq3, fuse->key_mask, fuse->len_max_q, fuse->zero_ptr, fuse->zero_words);
-      hipLaunchKernelGGL((k_bucket_sort<1, true>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
-                         sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse->dev);
-      hipLaunchKernelGGL((k_bucket_sort_big<1, true>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
-                         sb.rid[0], sb.key[1], (u32*)nullptr, sb.rid[1], ctx->bucket_bnd, ctx->bucket_big, fuse->dev);
+      launch_bucket_stage_fused(ctx, st, sb, *fuse);
       return post_launch("onesweep sort (fused count)");
     }
     HIP_TRY(hipMemsetAsync(ctx->bucket_big, 0, sizeof(u32), st));
@@ -918,6 +942,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     if (rsd && atoi(rsd) >= 0 && atoi(rsd) <= 3) ctx->row_skip_digits = atoi(rsd);
     const char* nfc = getenv("GIQL_HIP_NO_FUSE_COUNT");
     ctx->no_fuse_count = nfc && atoi(nfc) != 0;
+    const char* nbj = getenv("GIQL_HIP_NO_BUCKET_JOIN");
+    ctx->no_bucket_join = nbj && atoi(nbj) != 0;
     const char* nso = getenv("GIQL_HIP_NO_SORTED_INPUT");
     ctx->no_sorted = nso && atoi(nso) != 0;
     const char* nkq = getenv("GIQL_HIP_NO_KEYGEN_Q");
@@ -1017,7 +1043,8 @@ int giql_hip_get_stats(giql_hip_ctx* ctx, giql_hip_stats* out) {
   out->reserved = (ctx->stats.reserved & 0x1F) | (ctx->last_sort_local ? 0x20 : 0) |
                   (ctx->local_resorts ? 0x40 : 0) | (ctx->swapped ? 0x80 : 0) | ((ctx->os_order & 0x7F) << 8) |
                   (ctx->count_fused ? 0x8000 : 0) | ((ctx->used_sorted[0] || ctx->used_sorted[1]) ? (int32_t)0x80000000u : 0) |
-                  ((ctx->order_fallbacks & 0x3FFF) << 16) | (ctx->fuse_done ? (1 << 30) : 0);
+                  ((ctx->order_fallbacks & 0x1FFF) << 16) | (ctx->bucket_join ? (1 << 29) : 0) |
+                  (ctx->fuse_done ? (1 << 30) : 0);
   return GIQL_OK;
 }
 
@@ -1040,6 +1067,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   *n_pairs = 0;
   if (a->n == 0 || b->n == 0 || n_chrom == 0) {  // empty result (tests :4173-4229)
     ctx->planned = true;
+    ctx->plan_is_join = false;
     return GIQL_OK;
   }
   const size_t na = (size_t)a->n, nb = (size_t)b->n, nq = na + nb;
@@ -1298,8 +1326,22 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     const bool early_fill = ctx->fuse_a && speculated && ctx->last_no_irr && ctx->fuse_cap > 0 &&
                             nt_cap64 <= 0x7FFFFFF0ull && (size_t)nt_cap64 + 2 <= ctx->part_cap;
     bool part_done = false;  // the scan wrote the fill's partition
+    // ... and, when the other side's bucket stage answers the bounds anyway, the pairs are written right there
+    // (bucket_sort.hip.h, FUSE == 2) -- as long as the query windows stay well inside what a block holds in
+    // registers: a window covers three 65536-key buckets of the coarsely grouped query side
+    const bool join_in_buckets = fuse_cnt && !ctx->no_bucket_join && ctx->fuse_a && speculated && ctx->last_no_irr &&
+                                 ctx->fuse_cap > 0 && ctx->last_span > 0 &&
+                                 3.0 * (double)nqr * 65536.0 / (double)ctx->last_span <= 0.5 * (double)BJ_WCAP;
     FuseCount fc;
     if (fuse_cnt) {
+      if (join_in_buckets) {
+        fc.join = true;
+        fc.dev.qrid = sq.rid[0];
+        fc.dev.row_q = q_is_a ? ctx->fuse_a : ctx->fuse_b;
+        fc.dev.row_s = q_is_a ? ctx->fuse_b : ctx->fuse_a;
+        fc.dev.cap = ctx->fuse_cap;
+        fc.dev.cursor = reinterpret_cast<unsigned long long*>(&ctx->d_meta->n_out);  // zeroed by the span pass
+      }
       fc.zero_ptr = reinterpret_cast<u32*>(scan_chain);
       fc.zero_words = (u32)(2 * (cdiv(nqr, SC_TILE) + 2));
       fc.dev.qkey = sq.key[0];
@@ -1320,7 +1362,9 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     GIQL_TRY(sc.join());
     constexpr u32 TQ = RC_NT * RC_ITEMS_C2;
     S.nt2 = cdiv(nqr, TQ);
-    if (ctx->count_fused) {
+    if (ctx->bucket_join) {
+      // the pairs are out already, counted in DevMeta::n_out
+    } else if (ctx->count_fused) {
       u32 log2_t2 = 0;
       while ((1u << log2_t2) < T2) log2_t2++;
       GIQL_TRY(run_scan_chain(ctx, st, GIQL_PH_SCAN, cnt2, S.lo2, nqr, q_is_a ? irr_a : irr_b, S.off2, scan_chain,
@@ -1346,7 +1390,9 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     {
       // The early fill: no stream sync between plan and fill.  Validated below; a wrong guess leaves the
       // buffers to the ordinary fill.
-      if (early_fill) {
+      if (ctx->bucket_join) {
+        fused = true;
+      } else if (early_fill) {
         const u32 nt_cap = (u32)nt_cap64;
         const u32* qrid = q_is_a ? sa.rid[0] : sbb.rid[0];
         const u32* srid = q_is_a ? sbb.rid[0] : sa.rid[0];
@@ -1371,6 +1417,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     ctx->n_reg = ctx->h_meta->n_out;
     // the early fill stands only if every guess held and the pairs fitted
     ctx->fuse_done = fused && ctx->h_meta->irr_a + ctx->h_meta->irr_b == 0 && ctx->n_reg <= ctx->fuse_cap;
+    if (ctx->bucket_join) ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += (int64_t)8 * (int64_t)ctx->n_reg;  // the pairs
   } else {
   // the smaller side's chain (linearize + sort) beside the larger side's when it is small
   SideChain sc(ctx, st, onesweep ? (na < nb ? na : nb) : 0, na < nb ? nb : na);
@@ -1472,7 +1519,13 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
                               (ctx->used_sorted[1] && ctx->h_meta->unsorted_b != 0);
     ctx->spec_sorted[0] = ctx->h_meta->unsorted_a == 0;
     ctx->spec_sorted[1] = ctx->h_meta->unsorted_b == 0;
-    if (speculated && (form != S.uniform || len != uni_len || (want_hist && !aligned_now) || coarse_wrong || keygen_wrong || fuse_wrong || sorted_wrong)) {
+    // a join in the bucket stage that did not stand (the pairs did not fit the caller's buffers, or a guess failed)
+    // left no plan arrays for the ordinary fill: plan again, unspeculated -- which never takes that form
+    const bool join_wrong = ctx->bucket_join && !ctx->fuse_done;
+    if (join_wrong && getenv("GIQL_HIP_DEBUG_JOIN"))
+      fprintf(stderr, "[giql_hip] join in the bucket stage did not stand: %llu pairs, capacity %llu, irregular %u + %u\n",
+              (unsigned long long)ctx->n_reg, (unsigned long long)ctx->fuse_cap, ctx->h_meta->irr_a, ctx->h_meta->irr_b);
+    if (speculated && (form != S.uniform || len != uni_len || (want_hist && !aligned_now) || coarse_wrong || keygen_wrong || fuse_wrong || sorted_wrong || join_wrong)) {
       ctx->spec_valid = false;  // wrong guess: plan again from the numbers just read
       ctx->spec_misses++;
       ctx->fuse_done = false;
@@ -1512,6 +1565,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   ctx->stats.n_out = (int64_t)(ctx->n_reg + ctx->n_irr);
   *n_pairs = (int64_t)(ctx->n_reg + ctx->n_irr);
   ctx->planned = true;
+  ctx->plan_is_join = ctx->bucket_join;
   return GIQL_OK;
 }
 
@@ -1564,6 +1618,9 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b, i
   if (!ctx->planned) return set_err(GIQL_ERR_STATE, "inner_fill without a successful inner_plan");
   const u64 total = ctx->n_reg + ctx->n_irr;
   if (total == 0) return GIQL_OK;
+  if (ctx->plan_is_join)
+    return set_err(GIQL_ERR_STATE, "the last giql_hip_inner_join_dev wrote its pairs itself and kept no plan: "
+                                   "call giql_hip_inner_plan_dev first");
   if (!row_a || !row_b) return set_err(GIQL_ERR_INVALID, "row_a/row_b is NULL");
   if (capacity < 0 || (u64)capacity < total)
     return set_err(GIQL_ERR_CAPACITY, "capacity %lld < %llu pairs", (long long)capacity,
@@ -2492,6 +2549,9 @@ int giql_hip_inner_plan_export_dev(giql_hip_ctx* ctx, int32_t* q_rid_out, uint32
                                    int64_t* n_s, void* stream) {
   if (!ctx || !query_is_a || !n_q || !n_s) return set_err(GIQL_ERR_INVALID, "NULL argument");
   if (!ctx->planned) return set_err(GIQL_ERR_STATE, "plan export without a successful inner_plan");
+  if (ctx->plan_is_join && ctx->n_reg + ctx->n_irr != 0)
+    return set_err(GIQL_ERR_STATE, "the last giql_hip_inner_join_dev wrote its pairs itself and kept no plan: "
+                                   "call giql_hip_inner_plan_dev first");
   InnerState& S = ctx->inner;
   const bool empty = ctx->n_reg + ctx->n_irr == 0;
   if (!empty && (S.uniform == 0 || ctx->n_irr != 0 || ctx->n_c1 != 0))

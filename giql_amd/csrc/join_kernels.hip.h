@@ -120,12 +120,14 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
   // its predecessor, which is the previous LANE's row (consecutive lanes hold consecutive rows): a DPP shift,
   // no LDS; lane 0 of a wave loads its predecessor itself.  An irregular row (sentinel key) counts as out of order.
   bool inv = false;
-  auto order = [&](const int c, const int s, const u64 i, const bool ok) {
+  // (pc0, ps0: the predecessor of lane 0's row, loaded by the caller in the same batch as the rows themselves --
+  // loaded here, after the rows had arrived, it was one more exposed round trip per item: 240 -> 267 us at 100M rows)
+  auto order = [&](const int c, const int s, const int pc0, const int ps0, const bool ok) {
     int pc = __builtin_amdgcn_update_dpp(0, c, 0x138, 0xF, 0xF, false);   // wave_shr:1
     int ps = __builtin_amdgcn_update_dpp(0, s, 0x138, 0xF, 0xF, false);
     if (lane_id() == 0) {
-      pc = (ok && i > 0) ? chrom[i - 1] : INT_MIN;
-      ps = (ok && i > 0) ? start[i - 1] : INT_MIN;
+      pc = pc0;
+      ps = ps0;
     }
     if (ok && (pc > c || (pc == c && ps > s))) inv = true;
   };
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
     const int* cp = chrom + t * TILE + threadIdx.x;
     const int* sp = start + t * TILE + threadIdx.x;
     const int* ep = end + t * TILE + threadIdx.x;
-    int cv[4], sv[4], ev[4];
+    int cv[4], sv[4], ev[4], pc0[4], ps0[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       cv[u] = cp[u * NT];
@@ -224,7 +226,15 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      order(cv[u], sv[u], t * TILE + (u64)u * NT + threadIdx.x, true);
+      pc0[u] = ps0[u] = INT_MIN;
+      if (lane_id() == 0 && (t | (u64)u | (u64)threadIdx.x) != 0) {  // row 0 of the table has no predecessor
+        pc0[u] = cp[u * NT - 1];
+        ps0[u] = sp[u * NT - 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      order(cv[u], sv[u], pc0[u], ps0[u], true);
       row(cv[u], sv[u], ev[u], true);
     }
   }
@@ -235,7 +245,8 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
       const u64 i = base + (u64)u * NT + threadIdx.x;
       const bool ok = i < (u64)n;
       const int c_ = ok ? chrom[i] : 0, s_ = ok ? start[i] : 0;
-      order(c_, s_, i, ok);
+      const bool pred = ok && i > 0 && lane_id() == 0;
+      order(c_, s_, pred ? chrom[i - 1] : INT_MIN, pred ? start[i - 1] : INT_MIN, ok);
       row(c_, s_, ok ? end[i] : 0, ok);
     }
   }

@@ -136,7 +136,8 @@ class HipEngine:
         out["swapped"] = bool(int(st.reserved) & 0x80)  # the INNER plan ran with the sides exchanged (larger side as B)
         out["sort_tile_order"] = (int(st.reserved) >> 8) & 0x7F
         out["count_fused"] = bool(int(st.reserved) & 0x8000)  # the bucket sort answered the range bounds (no count kernel)
-        out["sort_order_fallbacks"] = (int(st.reserved) >> 16) & 0x3FFF
+        out["sort_order_fallbacks"] = (int(st.reserved) >> 16) & 0x1FFF
+        out["bucket_join"] = bool((int(st.reserved) >> 29) & 1)  # the bucket stage wrote the pairs itself (one-call form)
         out["fused_fill"] = bool((int(st.reserved) >> 30) & 1)  # the last plan launched its own fill
         out["presorted"] = bool(int(st.reserved) & 0x80000000)  # a side arrived sorted and skipped its sort
         out["total_ms"] = float(st.total_ms)

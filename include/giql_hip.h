@@ -130,8 +130,10 @@ typedef struct giql_hip_stats {
                                bits 8-14: sort tile order in force (2 =
                                blockIdx order, 0 = ticket order); bit 15: the range count of the
                                fixed-length form ran inside the bucket sort (no count kernel, the
-                               sorted keys never stored); bits 16-29: calls
-                               repeated in ticket order after a look-back timeout;
+                               sorted keys never stored); bits 16-28: calls
+                               repeated in ticket order after a look-back timeout; bit 29: the
+                               bucket stage wrote the pairs itself (one-call form: no sorted id,
+                               bound or offset array was stored, no scan and no fill kernel ran);
                                bit 30: the last plan launched its own fill
                                (giql_hip_inner_join_dev); bit 31: a side arrived in (chrom id, start)
                                order and skipped its sort */
@@ -164,7 +166,13 @@ int giql_hip_inner_fill_dev(giql_hip_ctx* ctx, int32_t* row_a, int32_t* row_b,
  * context's guesses hold -- same join form as its previous plan, no irregular
  * rows, the pairs fit -- the fill is launched inside the plan with no stream sync
  * in between.  GIQL_ERR_CAPACITY leaves the plan valid: *n_pairs is the size to
- * offer to giql_hip_inner_fill_dev. */
+ * offer to giql_hip_inner_fill_dev.
+ * In the fixed-length form with a table of 32M rows and more the pairs may be written
+ * by the sort's last stage itself (stats.reserved bit 29): nothing but the pairs leaves
+ * that call, so giql_hip_inner_fill_dev / giql_hip_inner_plan_export_dev after it
+ * return GIQL_ERR_STATE -- they follow a giql_hip_inner_plan_dev.  The ORDER of the
+ * pairs is unspecified in every form (and not reproducible from call to call in this
+ * one); the multiset of pairs is exact. */
 int giql_hip_inner_join_dev(giql_hip_ctx* ctx, const giql_side* a,
                             const giql_side* b, int32_t n_chrom, int32_t* row_a,
                             int32_t* row_b, int64_t capacity, void* stream,

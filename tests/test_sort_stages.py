@@ -330,3 +330,119 @@ def test_fused_count_with_buckets_larger_than_lds(eng_local):
     piled = ora.Side(np.zeros(st.size, np.int32), st, st + np.int32(150))
     q = rand_side(1534, 3_000, 1, 20_000, 400)
     _fused_inner(eng_local, q, piled, 1, expect_fused=True)
+
+
+# ---- the join itself in the bucket stage (one-call form, round 3) ---------------------------------
+def _join_into(e, a, b, nch, expect_join=True, slack=64):
+    """inner_join_into on a context whose guesses hold: pairs (orientation included) against the oracle,
+    nothing written past the count."""
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    cap = want.shape[0] + slack
+    ra = torch.full((cap,), -7, dtype=torch.int32, device="cuda:0")
+    rb = torch.full((cap,), -7, dtype=torch.int32, device="cuda:0")
+    n = e.inner_join_into(dev(a), dev(b), nch, ra, rb)
+    st = e.stats()
+    assert n == want.shape[0]
+    assert np.array_equal(ora.sort_pairs(ra[:n].cpu().numpy(), rb[:n].cpu().numpy()), want)
+    assert int((ra[n:] != -7).sum()) == 0 and int((rb[n:] != -7).sum()) == 0
+    if expect_join is not None:
+        assert st["bucket_join"] == expect_join, st
+    return st
+
+
+def test_bucket_join_matches_the_oracle_in_both_argument_orders(eng_local):
+    from giql_amd import _lib
+
+    reads = uniform_side(1601, 400_000, 5, 30_000_000, 150)
+    peaks = rand_side(1602, 60_000, 5, 30_000_000, 2000, min_len=200)
+    _fused_inner(eng_local, peaks, reads, 5)            # a first plan: the context learns form, span, lengths
+    st = _join_into(eng_local, peaks, reads, 5)
+    assert st["count_fused"] and st["fused_fill"] and st["join_form"] == "uniform_b"
+    _join_into(eng_local, peaks, reads, 5)
+    _fused_inner(eng_local, reads, peaks, 5)
+    st = _join_into(eng_local, reads, peaks, 5)         # larger table first: planned with the sides exchanged
+    assert st["swapped"]
+    # nothing but the pairs left that call: fill and export need a plan of their own
+    ra = torch.empty(16, dtype=torch.int32, device="cuda:0")
+    with pytest.raises(_lib.GiqlHipError) as exc:
+        eng_local.inner_fill(ra, ra.clone())
+    assert exc.value.code == _lib.GIQL_ERR_STATE
+    n = eng_local.inner_plan(dev(peaks), dev(reads), 5)  # ... and after one they work again
+    ra = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    rb = torch.empty_like(ra)
+    eng_local.inner_fill(ra, rb)
+    assert np.array_equal(ora.sort_pairs(ra.cpu().numpy(), rb.cpu().numpy()), ora.sort_pairs(*ora.c_inner(peaks, reads, "sweep")))
+
+
+def test_bucket_join_edges_long_queries_and_every_encoding(eng_local):
+    r = np.random.default_rng(1610)
+    st = np.concatenate([r.integers(0, 3_000, 4_000), r.integers(9_000_000, 9_100_000, 4_000)]).astype(np.int32)
+    reads = ora.Side(r.integers(0, 2, st.size).astype(np.int32), st, st + np.int32(100))
+    qs = np.concatenate([r.integers(0, 200, 500), r.integers(2_000_000, 7_000_000, 500),
+                         r.integers(9_000_000, 9_300_000, 1500)]).astype(np.int32)
+    ql = r.integers(1, 30_000, qs.size).astype(np.int32)   # ranges that span two (and touch three) buckets
+    peaks = ora.Side(r.integers(0, 2, qs.size).astype(np.int32), qs, qs + ql)
+    _fused_inner(eng_local, peaks, reads, 2)
+    _join_into(eng_local, peaks, reads, 2)
+    joined = 0
+    for enc in ora.ENCODING_OFFSETS:
+        # (a 1-based encoding puts the query at start 0 on canonical -1: the aligned layout declines, the call is
+        # planned again the ordinary way and the context's next call joins in the bucket stage again)
+        so, eo = ora.ENCODING_OFFSETS[enc]
+        side = ora.Side(peaks.chrom, peaks.start, peaks.end, so, eo)
+        _join_into(eng_local, side, reads, 2, expect_join=None)
+        joined += int(_join_into(eng_local, side, reads, 2, expect_join=None)["bucket_join"])
+    assert joined >= 2
+    _join_into(eng_local, peaks, reads, 2, expect_join=None)
+    _join_into(eng_local, peaks, reads, 2)
+    # irregular query rows: the guess fails at the read-back, the call is planned again the ordinary way
+    pe = peaks.end.copy()
+    pe[::7] = peaks.start[::7]
+    irr = ora.Side(peaks.chrom, peaks.start, pe)
+    _join_into(eng_local, irr, reads, 2, expect_join=False)
+    _join_into(eng_local, irr, reads, 2, expect_join=False)
+    _join_into(eng_local, peaks, reads, 2, expect_join=False)   # the guess follows the previous plan ...
+    _join_into(eng_local, peaks, reads, 2)                      # ... and is back
+
+
+def test_bucket_join_queued_buckets_equal_keys_and_crowded_windows(eng_local):
+    # ~6,500 rows in every 65536-wide window: every bucket goes through the queue (sorted in global memory,
+    # its window answered by binary search, its pairs written from there)
+    reads = uniform_side(1631, 700_000, 1, 7_000_000, 150)
+    peaks = rand_side(1632, 40_000, 1, 7_000_000, 2500)
+    _fused_inner(eng_local, peaks, reads, 1)
+    _join_into(eng_local, peaks, reads, 1)
+    # equal keys galore (bins with equal sub-values: the gathered-bin rank)
+    r = np.random.default_rng(1633)
+    st = (r.integers(0, 500, 200_000) * 37).astype(np.int32)
+    piled = ora.Side(np.zeros(st.size, np.int32), st, st + np.int32(150))
+    q = rand_side(1634, 3_000, 1, 20_000, 400)
+    _fused_inner(eng_local, q, piled, 1)
+    _join_into(eng_local, q, piled, 1)
+    # a crowd of queries in one window (more than a block keeps in registers) inside a sparse table: that
+    # bucket is queued, the others run in LDS
+    reads2 = uniform_side(1635, 300_000, 2, 40_000_000, 150)
+    qs = np.concatenate([r.integers(0, 40_000_000, 4_000), r.integers(5_000_000, 5_030_000, 6_000)]).astype(np.int32)
+    ql = r.integers(50, 1_500, qs.size).astype(np.int32)
+    crowd = ora.Side(r.integers(0, 2, qs.size).astype(np.int32), qs, qs + ql)
+    _fused_inner(eng_local, crowd, reads2, 2)
+    _join_into(eng_local, crowd, reads2, 2)
+
+
+def test_bucket_join_with_buffers_too_small_reports_the_count_and_keeps_a_plan(eng_local):
+    from giql_amd import _lib
+
+    reads = uniform_side(1641, 300_000, 3, 20_000_000, 150)
+    peaks = rand_side(1642, 30_000, 3, 20_000_000, 3000)
+    want = ora.sort_pairs(*ora.c_inner(peaks, reads, "sweep"))
+    _fused_inner(eng_local, peaks, reads, 3)
+    ra = torch.full((want.shape[0] // 2,), -7, dtype=torch.int32, device="cuda:0")
+    rb = torch.full_like(ra, -7)
+    with pytest.raises(_lib.GiqlHipError) as exc:
+        eng_local.inner_join_into(dev(peaks), dev(reads), 3, ra, rb)
+    assert exc.value.code == _lib.GIQL_ERR_CAPACITY and eng_local.last_pairs == want.shape[0]
+    fa = torch.empty(want.shape[0], dtype=torch.int32, device="cuda:0")
+    fb = torch.empty_like(fa)
+    eng_local.inner_fill(fa, fb)                        # the plan behind the error is an ordinary one
+    assert np.array_equal(ora.sort_pairs(fa.cpu().numpy(), fb.cpu().numpy()), want)
+    _join_into(eng_local, peaks, reads, 3)              # and with room the same context joins in the bucket stage again
