@@ -138,10 +138,11 @@ def sort_bytes_model(sorts, local_min_rows=1 << 25):
     return scatter, local
 
 
-def inner_phase_bytes(n_a, n_b, n_out, form, span_hist, stats_bytes=None):
+def inner_phase_bytes(n_a, n_b, n_out, form, span_hist, stats_bytes=None, bucket_join=False):
     """Algorithmic (minimal) HBM bytes of every phase of one INNER join: read every input of a
     kernel once, write every output once (DESIGN.md section 3 states each figure).  The sort
-    phases take the library's own accounting (``stats.phase_bytes``) when it is there."""
+    phases take the library's own accounting (``stats.phase_bytes``) when it is there.
+    ``bucket_join``: the one-call form whose bucket stage writes the pairs itself (no count / scan / fill)."""
     n = n_a + n_b
     if form == "uniform_b":
         n_q, n_u = n_a, n_b
@@ -161,12 +162,27 @@ def inner_phase_bytes(n_a, n_b, n_out, form, span_hist, stats_bytes=None):
         count = 8.0 * n_q + 4.0 * n_u + 8.0 * n_q      # query (key, end) + the other side's keys -> lo, cnt
         scan = 12.0 * n_q
         fill = 8.0 * n_out + 16.0 * n_q + 4.0 * n_u    # pairs + {off, lo, rid} per query row + sorted rids
+    if bucket_join and form != "general":
+        # the bucket stage reads the sorted side's (key, rid), the queries' (key, end, rid) and writes the pairs;
+        # neither side is linearized (both sorted from their raw columns)
+        lo = 8.0 * n_u + 12.0 * n_q + 8.0 * n_out
+        count = scan = fill = 0.0
+        lin = 0.0
     out = {"span": 12.0 * n, "linearize": lin, "sort_scatter": sc, "sort_local": lo, "count": count,
            "scan": scan, "partition": 0.0, "fill": fill}
     for k in ("sort_scatter", "sort_local"):
         if stats_bytes and stats_bytes.get(k):
             out[k] = float(stats_bytes[k])
     return out
+
+
+DOMINANT_KERNEL = {
+    "sort_scatter": "k_onesweep (phase sort_scatter: the global radix passes of both sides)",
+    "sort_local": ("k_bucket_sort<1, 2> (phase sort_local: one block per 16-bit bucket sorts the bucket's rows in LDS "
+                   "and writes the bucket's pairs)"),
+    "fill": "k_fill (phase fill: pair materialisation)",
+    "span": "k_chrom_minmax (phase span: per-chromosome spans, lengths, digit histograms)",
+}
 
 
 def op_bytes(op, n_a, n_b, n_out):
@@ -578,7 +594,10 @@ def run_inner(args):
     light = bool(warm_phase_ms)
     phase_ms.clear()
     phase_launches.clear()
-    eng.set_profiling(2 if light else True)
+    # the dominant phase = the one that took longest in the last warm-up step (the global sort passes, or -- when
+    # the bucket stage writes the pairs itself -- that stage's one kernel)
+    dom_phase = max(warm_phase_ms, key=warm_phase_ms.get) if light else "sort_scatter"
+    eng.set_profiling(dom_phase if light else True)
     sync_all()
     split_ms[0] = split_ms[1] = split_ms[2] = 0.0
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -605,7 +624,7 @@ def run_inner(args):
     # per-rank view of a step (outside the timed region): local join, exchange, expansion, HBM fraction
     per_step_ms = {k: v / args.steps for k, v in phase_ms.items()}
     if light:
-        per_step_ms = {**warm_phase_ms, "sort_scatter": per_step_ms.get("sort_scatter", 0.0)}
+        per_step_ms = {**warm_phase_ms, dom_phase: per_step_ms.get(dom_phase, 0.0)}
     if exchange == "plan":   # the expansion's scan / partition / fill are timed by `expand_ms`, not as join phases
         per_step_ms = {k: v for k, v in per_step_ms.items() if k not in ("scan", "partition", "fill") or not used["plan"]}
     device_ms = sum(per_step_ms.values())
@@ -624,8 +643,9 @@ def run_inner(args):
     if rank == 0:
         per_step_launches = {k: v // args.steps for k, v in phase_launches.items()}
         form, span_hist = st["join_form"], bool(st.get("span_hist", False))
-        pbytes = inner_phase_bytes(loc_na, loc_nb, n_local, form, span_hist, st.get("phase_bytes"))
-        dom = "sort_scatter"   # the phase timed in the timed steps: the global sort passes (k_onesweep)
+        pbytes = inner_phase_bytes(loc_na, loc_nb, n_local, form, span_hist, st.get("phase_bytes"),
+                                   bool(st.get("bucket_join")))
+        dom = dom_phase   # the phase timed in the timed steps
         dom_ms = per_step_ms.get(dom, 0.0)
         dom_launches = max(per_step_launches.get(dom, 0), 1)
         dom_bytes = pbytes[dom]
@@ -643,7 +663,8 @@ def run_inner(args):
                           "frac": round(bts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if bts else None}
         roofline = {
             "bound": "hbm",
-            "kernel": "k_onesweep (phase sort_scatter: the global radix passes of both sides)",
+            "kernel": DOMINANT_KERNEL.get(dom, dom) if not (dom == "sort_local" and not st.get("bucket_join"))
+            else "k_bucket_sort (phase sort_local: every 16-bit bucket sorted in LDS)",
             "launches_per_step": dom_launches,
             "avg_launch_ms": round(dom_ms / dom_launches, 4),
             "algorithmic_bytes_per_launch": round(dom_bytes / dom_launches),
@@ -661,8 +682,8 @@ def run_inner(args):
                 "frac": round(join_bytes / (device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms > 0 else 0.0,
             },
             "kernels": kernels,
-            "phase_ms_source": ("sort_scatter: hipEvents in the timed steps; other phases: hipEvents in the last warm-up "
-                                "step (the timed steps record events around the global sort passes only)"
+            "phase_ms_source": (f"{dom}: hipEvents in the timed steps; other phases: hipEvents in the last warm-up "
+                                "step (the timed steps record events around the dominant phase only)"
                                 if light else "hipEvents in the timed steps"),
         }
 
@@ -717,6 +738,8 @@ def run_inner(args):
                 "span_hist": span_hist,
                 "sort": ("two global passes + in-LDS bucket sort for sides >= 32M rows" if st.get("sort_local")
                          else "four global passes"),
+                "pairs_written_by": ("the bucket stage of the sort (k_bucket_sort<1, 2>: no count / scan / fill kernel)"
+                                     if st.get("bucket_join") else "k_fill"),
             },
             "hbm_algorithmic_GBps": round(op_bytes("inner", tot_na, tot_nb, n_pairs) * args.steps / elapsed / 1e9, 1),
             "roofline": roofline,

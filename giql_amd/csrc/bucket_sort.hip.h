@@ -256,6 +256,12 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pay)[R], const u32 
                                                  const u32 (&jq_end)[BJ_QR]) {
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const u32 k0 = v << 16;
+#if defined(GIQL_BJ_ABLATE)  // timing-only builds (results invalid, tools/bj_ablate.sh): the tail stops after its k-th stage
+#define GIQL_BJ_STOP(k) do { if (GIQL_BJ_ABLATE == (k)) { if (pay[0] == 0x12345u && slot[0] == 77u) s_buf[0] = 1; return; } } while (0)
+#else
+#define GIQL_BJ_STOP(k) do { } while (0)
+#endif
+  GIQL_BJ_STOP(1);  // the sort alone
   // ranks of my queries' bounds inside this bucket, clamped to it
   u32 q_lo[BJ_QR], q_cnt[BJ_QR], q_rid[BJ_QR], incl[BJ_QR];
 #pragma unroll
@@ -274,6 +280,7 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pay)[R], const u32 
     if (lane == WAVE - 1) s_jtot[i * BS_NW + w] = incl[i];
   }
   bs_sync<2>();  // every rank has been read: s_buf and the cells are free; the wave totals are in
+  GIQL_BJ_STOP(2);  // + ranks
   // pairs of the block, and where each (slot, wave) group of queries starts among them
   u32 total = 0, q_off[BJ_QR];
 #pragma unroll
@@ -299,6 +306,7 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pay)[R], const u32 
   if (tid == 0) *s_jbase = base;
   bs_sync<2>();
   base = *s_jbase;
+  GIQL_BJ_STOP(3);  // + place in the output, ids staged
   if (base + total > fq.cap) return;  // the caller's buffers are too small: the count still adds up, nothing is written
   int32_t* const rq = fq.row_q + base;
   int32_t* const rs = fq.row_s + base;

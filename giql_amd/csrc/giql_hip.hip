@@ -190,7 +190,8 @@ struct giql_hip_ctx {
   size_t xplan_cap = 0;
 
   // profiling
-  int profiling = 0;          // 0 off, 1 every phase, 2 only the sort passes (the dominant kernel)
+  int profiling = 0;          // 0 off, 1 every phase, 2 only profile_phase (the dominant kernel's)
+  int profile_phase = GIQL_PH_SORT_SCATTER;
   std::vector<hipEvent_t> ev_pool;
   struct Span {
     int phase;
@@ -249,7 +250,7 @@ struct Phase {
   hipEvent_t a = nullptr, b = nullptr;
   Phase(giql_hip_ctx* c, hipStream_t s, int ph, int launches = 1) : ctx(c), stream(s), phase(ph) {
     ctx->stats.phase_launches[ph] += launches;
-    if (!ctx->profiling || (ctx->profiling == 2 && ph != GIQL_PH_SORT_SCATTER)) return;
+    if (!ctx->profiling || (ctx->profiling == 2 && ph != ctx->profile_phase)) return;
     while (ctx->ev_used + 2 > ctx->ev_pool.size()) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) return;
@@ -544,18 +545,39 @@ struct FuseCount {
   bool join = false;    // FUSE == 2: the bucket blocks write the pairs themselves (dev.row_q / row_s / cap / cursor)
 };
 
-// The bucket stage of a fused (key, rid) sort: bounds only (FUSE 1) or the whole join (FUSE 2).
-static void launch_bucket_stage_fused(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, const FuseCount& fuse) {
-  if (fuse.join) {
-    hipLaunchKernelGGL((k_bucket_sort<1, 2>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
-                       sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse.dev);
-    hipLaunchKernelGGL((k_bucket_sort_big<1, 2>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
-                       sb.rid[0], sb.key[1], (u32*)nullptr, sb.rid[1], ctx->bucket_bnd, ctx->bucket_big, fuse.dev);
-  } else {
-    hipLaunchKernelGGL((k_bucket_sort<1, 1>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
-                       sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse.dev);
-    hipLaunchKernelGGL((k_bucket_sort_big<1, 1>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
-                       sb.rid[0], sb.key[1], (u32*)nullptr, sb.rid[1], ctx->bucket_bnd, ctx->bucket_big, fuse.dev);
+static int64_t bucket_stage_fused_bytes(u32 n, const FuseCount& fuse);
+// The bucket stage of a fused (key, rid) sort: bounds only (FUSE 1) or the whole join (FUSE 2).  Three launches,
+// each a phase of its own so that the stage's ONE heavy kernel can be timed alone: the bucket boundaries and query
+// windows (COUNT), the bucket kernel (SORT_LOCAL), the queue of buckets it could not take (AUX; almost always an
+// empty launch).
+static void launch_bucket_stage_fused(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n, const u32* gbase,
+                                      const FuseCount& fuse) {
+  ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += bucket_stage_fused_bytes(n, fuse);
+  ctx->count_fused = true;
+  ctx->bucket_join = fuse.join;
+  {
+    Phase ph(ctx, st, GIQL_PH_COUNT, 1);
+    hipLaunchKernelGGL(k_bucket_bounds_fused, dim3(cdiv((u64)3 * BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
+                       gbase + 3 * OS_BINS, ctx->bucket_bnd, ctx->bucket_big, fuse.dev, fuse.nq_total, fuse.irr_q,
+                       fuse.gbq3, fuse.key_mask, fuse.len_max_q, fuse.zero_ptr, fuse.zero_words);
+  }
+  {
+    Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 1);
+    if (fuse.join)
+      hipLaunchKernelGGL((k_bucket_sort<1, 2>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
+                         sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse.dev);
+    else
+      hipLaunchKernelGGL((k_bucket_sort<1, 1>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
+                         sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse.dev);
+  }
+  {
+    Phase ph(ctx, st, GIQL_PH_AUX, 1);
+    if (fuse.join)
+      hipLaunchKernelGGL((k_bucket_sort_big<1, 2>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
+                         sb.rid[0], sb.key[1], (u32*)nullptr, sb.rid[1], ctx->bucket_bnd, ctx->bucket_big, fuse.dev);
+    else
+      hipLaunchKernelGGL((k_bucket_sort_big<1, 1>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
+                         sb.rid[0], sb.key[1], (u32*)nullptr, sb.rid[1], ctx->bucket_bnd, ctx->bucket_big, fuse.dev);
   }
 }
 // its algorithmic bytes up to the pairs (8 B each, added once the count is known): the rows' keys and ids read;
@@ -595,14 +617,7 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
     }
     if (!local_fused) return GIQL_OK;   // sorted already: the bucket stage only runs as the carrier of the fused count
     ctx->last_sort_local = true;
-    Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 3);
-    ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += bucket_stage_fused_bytes(n, *fuse);
-    ctx->count_fused = true;
-    ctx->bucket_join = fuse->join;
-    hipLaunchKernelGGL(k_bucket_bounds_fused, dim3(cdiv((u64)3 * BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
-                       gbase + 3 * OS_BINS, ctx->bucket_bnd, ctx->bucket_big, fuse->dev, fuse->nq_total, fuse->irr_q,
-                       fuse->gbq3, fuse->key_mask, fuse->len_max_q, fuse->zero_ptr, fuse->zero_words);
-    launch_bucket_stage_fused(ctx, st, sb, *fuse);
+    launch_bucket_stage_fused(ctx, st, sb, n, gbase, *fuse);
     return post_launch("bucket stage (sorted input, fused count)");
   }
   const bool local = sort_is_local(ctx, n);
@@ -668,14 +683,7 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
     if (fuse && mode == 1) {
       // (key, rid) rows + the query side's bounds: keys and rids read, rids written, the query rows' keys
       // and ends read and their two bounds written -- the sorted keys never leave the CU
-      Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 3);
-      ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += bucket_stage_fused_bytes(n, *fuse);
-      ctx->count_fused = true;
-      ctx->bucket_join = fuse->join;
-      hipLaunchKernelGGL(k_bucket_bounds_fused, dim3(cdiv((u64)3 * BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
-                         gbase + 3 * OS_BINS, ctx->bucket_bnd, ctx->bucket_big, fuse->dev, fuse->nq_total, fuse->irr_q,
-                         fuse->gbq3, fuse->key_mask, fuse->len_max_q, fuse->zero_ptr, fuse->zero_words);
-      launch_bucket_stage_fused(ctx, st, sb, *fuse);
+      launch_bucket_stage_fused(ctx, st, sb, n, gbase, *fuse);
       return post_launch("onesweep sort (fused count)");
     }
     HIP_TRY(hipMemsetAsync(ctx->bucket_big, 0, sizeof(u32), st));
@@ -1025,7 +1033,13 @@ int giql_hip_reserve(giql_hip_ctx* ctx, int64_t bytes) {
 
 int giql_hip_set_profiling(giql_hip_ctx* ctx, int enabled) {
   if (!ctx) return set_err(GIQL_ERR_INVALID, "ctx is NULL");
+  if (enabled >= 16 && enabled < 16 + GIQL_PH_N) {  // events around ONE phase only: 16 + its GIQL_PH_* number
+    ctx->profiling = 2;
+    ctx->profile_phase = enabled - 16;
+    return GIQL_OK;
+  }
   ctx->profiling = enabled < 0 ? 0 : (enabled > 2 ? 1 : enabled);
+  ctx->profile_phase = GIQL_PH_SORT_SCATTER;
   return GIQL_OK;
 }
 

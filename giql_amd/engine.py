@@ -117,7 +117,10 @@ class HipEngine:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def set_profiling(self, enabled) -> None:
-        """``False`` / ``True`` (hipEvent pairs around every phase) / ``2`` (only around the sort passes)."""
+        """``False`` / ``True`` (hipEvent pairs around every phase) / ``2`` (only around the sort passes) /
+        a phase name of ``_lib.PHASES`` (only around that phase)."""
+        if isinstance(enabled, str):
+            enabled = 16 + _lib.PHASES.index(enabled)
         _lib.check(self._L.giql_hip_set_profiling(self._h, int(enabled)))
 
     def reserve(self, nbytes: int) -> None:

@@ -147,8 +147,9 @@ int giql_hip_create(int device, giql_hip_ctx** out);
 int giql_hip_destroy(giql_hip_ctx* ctx);
 /* Pre-size the device arena (bytes); optional, the arena grows on demand. */
 int giql_hip_reserve(giql_hip_ctx* ctx, int64_t bytes);
-/* enabled: 0 = off, 1 = hipEvent pairs around every phase, 2 = only around the sort passes
- * (an event pair costs the stream a few microseconds of idle time per phase). */
+/* enabled: 0 = off, 1 = hipEvent pairs around every phase, 2 = only around the sort passes,
+ * 16 + p = only around phase p (GIQL_PH_*) -- an event pair costs the stream a few
+ * microseconds of idle time per phase. */
 int giql_hip_set_profiling(giql_hip_ctx* ctx, int enabled);
 int giql_hip_get_stats(giql_hip_ctx* ctx, giql_hip_stats* out);
 

@@ -3,7 +3,8 @@
 under profiles/: <tag>_kernel_stats.csv (the --stats view), <tag>_pmc_hbm_traffic.csv
 (FETCH_SIZE / WRITE_SIZE per kernel, raw counter x 1024 B) and profiles/pmc_traffic.json
 (HBM bytes per join and phase: FETCH_SIZE x 2 + WRITE_SIZE -- the x 2 is the gfx950
-correction of MI355X_MICROARCH.md, "HBM").  usage: pmc_summary.py <tag> [joins_in_pmc_run]"""
+correction of MI355X_MICROARCH.md, "HBM").  usage: pmc_summary.py <tag> [joins]   (joins = 1: only the LAST join
+of the PMC run is counted -- the settled form; n > 1: everything, divided by n)"""
 import csv
 import json
 import os
@@ -12,7 +13,7 @@ import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PHASE_OF = [("k_onesweep", "sort_scatter"), ("k_bucket_sort", "sort_local"), ("k_bucket_bounds", "sort_local"), ("k_linearize", "linearize"), ("k_digit_offsets", "linearize"), ("k_fold_top", "linearize"),
+PHASE_OF = [("k_onesweep", "sort_scatter"), ("k_bucket_sort_big", "aux"), ("k_bucket_sort", "sort_local"), ("k_bucket_bounds_fused", "count"), ("k_bucket_bounds", "sort_local"), ("k_linearize", "linearize"), ("k_digit_offsets", "linearize"), ("k_fold_top", "linearize"),
             ("k_init_minmax", "span"), ("k_chrom_minmax", "span"), ("k_chrom_offsets", "span"),
             ("k_range_count", "count"), ("k_count_partition", "count"), ("k_c1_count", "count"),
             ("k_scan_", "scan"), ("k_partition", "partition"), ("k_fill", "fill"), ("k_c1_emit", "fill")]
@@ -25,7 +26,7 @@ def short(name: str) -> str:
 
 def main() -> None:
     tag = sys.argv[1]
-    joins = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    joins = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     prof = os.path.join(ROOT, "profiles")
     stats_csv = os.path.join(src, "trace", "trace_kernel_stats.csv")
@@ -55,8 +56,14 @@ def main() -> None:
             cc_csv = os.path.join(src, f"pmc_{counter}", "pmc_counter_collection.csv")
             if os.path.exists(cc_csv):
                 with open(cc_csv) as fc:
-                    values = [(r["Kernel_Name"], float(r["Counter_Value"])) for r in csv.DictReader(fc)
-                              if r["Counter_Name"] == counter]
+                    recs = sorted((r for r in csv.DictReader(fc) if r["Counter_Name"] == counter),
+                                  key=lambda r: int(r["Dispatch_Id"]))
+                # every join starts with k_init_minmax: the LAST join of the run is the settled form (the first one of a
+                # context reads its guesses back and takes the ordinary kernels)
+                starts = [i for i, r in enumerate(recs) if "k_init_minmax" in r["Kernel_Name"]]
+                if joins == 1 and starts:
+                    recs = recs[max(starts[-1] - 1, 0):]   # (- 1: the memset that precedes it)
+                values = [(r["Kernel_Name"], float(r["Counter_Value"])) for r in recs]
             else:
                 db = sqlite3.connect(os.path.join(src, f"pmc_{counter}", "pmc_results.db"))
                 values = db.execute("select kernel_name, value from counters_collection where counter_name = ?",
