@@ -35,6 +35,9 @@ struct DevMeta {
   // 1 as soon as a row of the side is found out of (chrom id, start) order or irregular (k_chrom_minmax): a side
   // that stays 0 arrives sorted on the linear axis and needs no sort (coordinate-sorted BED / BAM-derived tables)
   u32 unsorted_a, unsorted_b;
+  // 1 as soon as a row of the side has its canonical end BELOW its canonical start (k_chrom_minmax): NEAREST rejects
+  // such a table (zero-length rows are fine there)
+  u32 inverted_a, inverted_b;
 };
 
 // XCD-aware block -> tile map.  Workgroups are dealt round-robin to the 8 XCDs, each

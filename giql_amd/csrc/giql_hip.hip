@@ -160,6 +160,8 @@ struct giql_hip_ctx {
   u64 last_span = 0;           // linearised span of the context's last call: the density guess of row_skip() / sort_is_local()
   double local_max_bucket_rows = 2800.0;  // three-stage sort only while a 16-bit bucket holds at most this many rows on average
   bool no_skip_digit = false;  // GIQL_HIP_NO_SKIP_DIGIT=1: query sides are sorted on every digit
+  bool no_coarse_b = false;    // GIQL_HIP_NO_COARSE_B=1: the fixed-length B of SEMI / ANTI / COUNT is sorted on every digit
+  double coarse_max_group_rows = 8.0;  // ... and coarsely only while the rows sharing their upper 24 key bits are at most this many on average
   bool local_sort = true;
   u64 local_min_rows = 1u << 25;
   int local_resorts = 0;      // calls repeated with the four-pass sort
@@ -802,6 +804,15 @@ static inline int row_skip(const giql_hip_ctx* ctx, size_t nb) {
   return (double)nb * 65536.0 / (double)ctx->last_span <= 1024.0 ? 2 : 1;
 }
 
+// Fixed-length B of the per-row operators (SEMI / ANTI / COUNT): sorted without its lowest digit (three passes
+// instead of four) when the rows sharing the upper 24 key bits are few enough to be looked at one by one
+// (aux_kernels.hip.h, "sorted COARSELY") -- by the density of the context's previous call, like row_skip(): a guess
+// that only costs speed.
+static inline bool coarse_b_ok(const giql_hip_ctx* ctx, size_t nb) {
+  if (ctx->no_coarse_b || ctx->no_skip_digit || ctx->last_span == 0 || sort_is_local(ctx, nb)) return false;
+  return (double)nb * 256.0 / (double)ctx->last_span <= ctx->coarse_max_group_rows;
+}
+
 // Fork / join of the context's second stream.  A side of a few million rows is a chain of ~10 launches
 // of 10-40 us each that do not fill the GPU (look-back latency, not bandwidth, bounds them): run beside
 // the other side's chain it costs almost nothing.  Work given to stream() is ordered after everything
@@ -946,6 +957,10 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->no_span_hist = nh && atoi(nh) != 0;
     const char* nsd = getenv("GIQL_HIP_NO_SKIP_DIGIT");
     ctx->no_skip_digit = nsd && atoi(nsd) != 0;
+    const char* ncb = getenv("GIQL_HIP_NO_COARSE_B");
+    ctx->no_coarse_b = ncb && atoi(ncb) != 0;
+    const char* cmb = getenv("GIQL_HIP_COARSE_MAX_GROUP_ROWS");
+    if (cmb && atof(cmb) > 0) ctx->coarse_max_group_rows = atof(cmb);
     const char* rsd = getenv("GIQL_HIP_ROW_SKIP_DIGITS");
     if (rsd && atoi(rsd) >= 0 && atoi(rsd) <= 3) ctx->row_skip_digits = atoi(rsd);
     const char* nfc = getenv("GIQL_HIP_NO_FUSE_COUNT");
@@ -1763,6 +1778,24 @@ struct OsScratch {
   u32* status = nullptr;
 };
 
+// ONE memset for everything two sides' histograms and sort passes need at zero, instead of one per histogram and per
+// sort (four launches of ~5 us on a path of ~60): `first` is carved right before `second`, so the range runs from
+// first's histograms to the end of second's four passes of status words.  Only for calls that sort each side ONCE (a
+// second sort through the same status words must zero them again: ctx->prezeroed makes the helpers skip theirs).
+struct PrezeroGuard {
+  giql_hip_ctx* c;
+  ~PrezeroGuard() { c->prezeroed = false; }
+};
+static int prezero_row_scratch(giql_hip_ctx* ctx, hipStream_t st, const OsScratch& first, const OsScratch& second,
+                               size_t n_second) {
+  char* const lo = reinterpret_cast<char*>(first.hist);
+  char* const hi = reinterpret_cast<char*>(second.status + 4 * os_pass_stride(ctx, n_second));
+  if (!first.hist || hi <= lo) return GIQL_OK;
+  HIP_TRY(hipMemsetAsync(lo, 0, (size_t)(hi - lo), st));
+  ctx->prezeroed = true;
+  return GIQL_OK;
+}
+
 static void os_scratch_sizes(Carver& c, size_t n_max, OsScratch& o) {
   o.hist = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
   o.hist_e = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
@@ -1782,6 +1815,7 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   ctx->planned = false;
+  ctx->prezeroed = false;  // (a repeated call -- a guess that missed -- starts over: the caller's frame may still hold its guard)
   reset_stats(ctx);
   ctx->stats.n_a = a->n;
   ctx->stats.n_b = b->n;
@@ -1806,8 +1840,8 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
       sbb.end[k] = c.take<u32>(nb ? nb : 1);
       sbb.rid[k] = nullptr;
     }
-    os_scratch_sizes(c, nb ? nb : 1, os);
     os_scratch_sizes(c, na, os_a);   // A's own histogram / status words: its chain may run beside B's
+    os_scratch_sizes(c, nb ? nb : 1, os);  // (right behind A's: prezero_row_scratch)
     bsums = c.take<u64>(cdiv(na, SCAN_TILE) + 2);
     flag = c.take<u32>(na);
     off = c.take<u64>(na + 1);
@@ -1818,11 +1852,14 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   };
   GIQL_TRY(ensure_arena(ctx, carve(nullptr), st));
   carve(ctx->arena);
+  PrezeroGuard prezero_guard{ctx};
+  GIQL_TRY(prezero_row_scratch(ctx, st, os_a, os, nb ? nb : 1));  // each side is sorted once, in either form
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, nch, lb));
   i64 uni_len = 0;
   bool speculated = false;
   if (nb > 0) GIQL_TRY(row_form_guess(ctx, st, uni_len, speculated));
+  const bool coarse_b = nb > 0 && uni_len > 0 && coarse_b_ok(ctx, nb);
   {
     // the query side's chain (linearize + sort) beside B's when it is small
     SideChain sc(ctx, st, nb > 0 ? na : 0, nb);
@@ -1834,7 +1871,8 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
     sbb.end[0] = sbb.end[1] = nullptr;
     GIQL_TRY(run_linearize(ctx, st, *b, nch, lb, sbb.key[0], nullptr, dummy_irr, 1, 1, os.hist, os.gbase,
                            nullptr, nullptr, /*skip_end=*/true));
-    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, false, nullptr, nullptr,
+                               /*skip_digits=*/coarse_b ? 1 : 0));
   } else if (nb > 0) {
     // every B row keeps its real key: the prefix-max test is exact for any row
     GIQL_TRY(run_linearize(ctx, st, *b, nch, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist,
@@ -1851,7 +1889,10 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   }
   {
     Phase ph(ctx, st, GIQL_PH_COUNT);
-    if (nb > 0 && uni_len > 0)
+    if (coarse_b)
+      hipLaunchKernelGGL(k_semi_flags_uniform_coarse, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0],
+                         sa.rid[0], (u32)na, ctx->d_meta, sbb.key[0], (u32)nb, uni_len, anti, flag);
+    else if (nb > 0 && uni_len > 0)
       hipLaunchKernelGGL(k_semi_flags_uniform, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0],
                          sa.rid[0], (u32)na, ctx->d_meta, sbb.key[0], (u32)nb, uni_len, anti, flag);
     else
@@ -1870,7 +1911,7 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   if (nb > 0 && !row_form_settled(ctx, uni_len, speculated))  // B is not fixed-length after all
     return giql_hip_semi_anti_dev_impl(ctx, a, b, n_chrom, anti, rows_out, n_out, stream);
   collect_spans(ctx);
-  ctx->stats.reserved = uni_len > 0 ? 1 : 0;  // form: fixed-length B or general
+  ctx->stats.reserved = (uni_len > 0 ? 1 : 0) | (coarse_b ? 0x10 : 0);  // form: fixed-length B or general; bit 4: B sorted coarsely (without its lowest digit)
   *n_out = (int64_t)ctx->h_meta->n_out;
   ctx->stats.n_out = *n_out;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
@@ -1893,6 +1934,7 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   ctx->planned = false;
+  ctx->prezeroed = false;  // (a repeated call -- a guess that missed -- starts over: the caller's frame may still hold its guard)
   reset_stats(ctx);
   ctx->stats.n_a = a->n;
   ctx->stats.n_b = b->n;
@@ -1918,8 +1960,8 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
       send.key[k] = c.take<u32>(nb);
       send.end[k] = send.rid[k] = nullptr;
     }
-    os_scratch_sizes(c, nb, os);
     os_scratch_sizes(c, na, os_a);   // A's chain may run beside B's (SideChain)
+    os_scratch_sizes(c, nb, os);     // (right behind A's: prezero_row_scratch)
     irr_a_list = c.take<u32>(na);
     irr_b_list = c.take<u32>(nb);
     return c.off;
@@ -1931,6 +1973,9 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
   i64 uni_len = 0;
   bool speculated = false;
   GIQL_TRY(row_form_guess(ctx, st, uni_len, speculated));
+  const bool coarse_b = uni_len > 0 && coarse_b_ok(ctx, nb);
+  PrezeroGuard prezero_guard{ctx};
+  if (uni_len > 0) GIQL_TRY(prezero_row_scratch(ctx, st, os_a, os, nb));  // (the general form sorts B twice through one set of status words)
   {
   SideChain sc(ctx, st, na, nb);
   GIQL_TRY(run_linearize(ctx, sc.stream(), *a, n_chrom, lb, sa.key[0], sa.end[0], irr_a_list, 0, 0, os_a.hist,
@@ -1941,7 +1986,8 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
     // fixed-length B: one sorted array (its sorted ends are its sorted starts + L)
     GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sstart.key[0], nullptr, irr_b_list, 1, 0, os.hist,
                            os.gbase, nullptr, nullptr, /*skip_end=*/true));
-    GIQL_TRY(run_sort_onesweep(ctx, st, sstart, (u32)nb, os.gbase, os.status));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sstart, (u32)nb, os.gbase, os.status, false, nullptr, nullptr,
+                               /*skip_digits=*/coarse_b ? 1 : 0));
   } else {
     GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sstart.key[0], send.key[0], irr_b_list, 1, 0,
                            os.hist, os.gbase, os.hist_e, os.gbase_e));
@@ -1954,13 +2000,13 @@ static int giql_hip_count_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const 
     Phase ph(ctx, st, GIQL_PH_COUNT);
     hipLaunchKernelGGL(k_count_rows, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0],
                        sa.rid[0], (u32)na, view_of(*a), view_of(*b), sstart.key[0], send.key[0], (u32)nb,
-                       irr_b_list, ctx->d_meta, counts_out, uni_len);
+                       irr_b_list, ctx->d_meta, counts_out, uni_len, coarse_b ? 1 : 0);
     GIQL_TRY(post_launch("count rows"));
   }
   GIQL_TRY(read_meta(ctx, st));
   if (!row_form_settled(ctx, uni_len, speculated))  // B is not fixed-length after all
     return giql_hip_count_dev_impl(ctx, a, b, n_chrom, counts_out, stream);
-  ctx->stats.reserved = uni_len > 0 ? 1 : 0;
+  ctx->stats.reserved = (uni_len > 0 ? 1 : 0) | (coarse_b ? 0x10 : 0);
   ctx->stats.n_irregular_a = ctx->h_meta->irr_a;
   ctx->stats.n_irregular_b = ctx->h_meta->irr_b;
   if (ctx->h_meta->irr_a > 0) {
@@ -1993,6 +2039,7 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
   ctx->planned = false;
+  ctx->prezeroed = false;  // (a repeated call -- a guess that missed -- starts over: the caller's frame may still hold its guard)
   reset_stats(ctx);
   ctx->stats.n_a = a->n;
   ctx->stats.n_b = b->n;
@@ -2015,8 +2062,8 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
     common_sizes(c, n_chrom, lb);
     sort_sizes(c, na, sa, true);
     sort_sizes(c, nb, sbb, true);
-    os_scratch_sizes(c, nb, os);
     os_scratch_sizes(c, na, os_a);   // A's chain may run beside B's (SideChain)
+    os_scratch_sizes(c, nb, os);     // (right behind A's: prezero_row_scratch)
     recs = c.take<NearestRec>(na);
     pmax = c.take<u32>(nb);
     bmax = c.take<u32>(cdiv(nb, PM_TILE) + 1);
@@ -2027,8 +2074,10 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
   GIQL_TRY(ensure_arena(ctx, carve(nullptr), st));
   carve(ctx->arena);
 
-  GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
   const bool two_sorts = ctx->nearest_two_sorts;
+  PrezeroGuard prezero_guard{ctx};
+  if (!two_sorts) GIQL_TRY(prezero_row_scratch(ctx, st, os_a, os, nb));  // (the two-sort plan reuses B's status words)
+  GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
   SideChain sc(ctx, st, na, nb);
   GIQL_TRY(run_linearize(ctx, sc.stream(), *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr + 8, 0, 1, os_a.hist,
                          os_a.gbase));
@@ -2036,11 +2085,7 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
                              /*skip_digits=*/row_skip(ctx, nb)));  // the query side's order only serves locality; every row keeps its real key here
   GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist,
                          os.gbase, two_sorts ? os.hist_e : nullptr, two_sorts ? os.gbase_e : nullptr));
-  {
-    Phase ph(ctx, st, GIQL_PH_AUX);
-    hipLaunchKernelGGL(k_check_not_inverted, dim3(cdiv(nb, 256)), dim3(256), 0, st, view_of(*b),
-                       ctx->d_meta);
-  }
+  // (an inverted B row -- NEAREST needs start <= end on both sides -- is reported by the span pass: DevMeta::inverted_b)
   if (two_sorts) {
     // (start, end) lexicographic order = stable sort by end, then stable sort by start
     SortBufs by_end = sbb;
@@ -2071,6 +2116,7 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
     GIQL_TRY(post_launch("nearest"));
   }
   GIQL_TRY(read_meta(ctx, st));
+  if (ctx->h_meta->inverted_b) return set_err(GIQL_ERR_INVALID, "NEAREST: a target row has end < start");
   if (!two_sorts && ctx->h_meta->aux0 != 0) {
     // a long run of equal starts (pile-ups): this table wants the two-sort plan
     ctx->nearest_two_sorts = true;
@@ -2144,10 +2190,6 @@ static int giql_hip_nearest_k_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist, os.gbase,
                          os.hist_e, os.gbase_e));
   {
-    Phase ph(ctx, st, GIQL_PH_AUX);
-    hipLaunchKernelGGL(k_check_not_inverted, dim3(cdiv(nb, 256)), dim3(256), 0, st, view_of(*b), ctx->d_meta);
-  }
-  {
     SortBufs by_end = sbb;
     for (int i = 0; i < 2; i++) {
       by_end.key[i] = sbb.end[i];
@@ -2180,6 +2222,7 @@ static int giql_hip_nearest_k_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
     GIQL_TRY(post_launch("nearest k"));
   }
   GIQL_TRY(read_meta(ctx, st));
+  if (ctx->h_meta->inverted_b) return set_err(GIQL_ERR_INVALID, "NEAREST: a target row has end < start");
   collect_spans(ctx);
   ctx->stats.n_out = a->n * (int64_t)k;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;

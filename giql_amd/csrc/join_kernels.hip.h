@@ -48,6 +48,8 @@ __global__ void k_init_minmax(int* __restrict__ gmin, int* __restrict__ gmax, in
     meta->aligned_ok = 0;
     meta->unsorted_a = 0;
     meta->unsorted_b = 0;
+    meta->inverted_a = 0;
+    meta->inverted_b = 0;
   }
 }
 
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
   // its predecessor, which is the previous LANE's row (consecutive lanes hold consecutive rows): a DPP shift,
   // no LDS; lane 0 of a wave loads its predecessor itself.  An irregular row (sentinel key) counts as out of order.
   bool inv = false;
+  bool neg = false;  // a row with canonical end < canonical start
   // (pc0, ps0: the predecessor of lane 0's row, loaded by the caller in the same batch as the rows themselves --
   // loaded here, after the rows had arrived, it was one more exposed round trip per item: 240 -> 267 us at 100M rows)
   auto order = [&](const int c, const int s, const int pc0, const int ps0, const bool ok) {
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
       } else {
         lmn = 0;  // an irregular row (canonical end <= start): this side is not uniform
         inv = true;
+        if ((i64)e - (i64)s + len_bias < 0) neg = true;
       }
       if (c < 0 || c >= n_chrom) {
         bad = true;
@@ -275,6 +279,7 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
   }
   if (bad) meta->status = -4;  // GIQL_ERR_CHROM
   if (__ballot(inv) != 0ull && lane_id() == 0) *(which ? &meta->unsorted_b : &meta->unsorted_a) = 1u;
+  if (__ballot(neg) != 0ull && lane_id() == 0) *(which ? &meta->inverted_b : &meta->inverted_a) = 1u;
   {
     // block-reduce the length range into this block's slot (no global atomics:
     // thousands of waves hitting two addresses serialise for ~0.2 ms)

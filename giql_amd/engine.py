@@ -134,6 +134,7 @@ class HipEngine:
                 "profiled")}
         out["join_form"] = {0: "general", 1: "uniform_b", 2: "uniform_a"}.get(int(st.reserved) & 0x0F, "?")
         out["span_hist"] = bool(int(st.reserved) & 0x10)  # fixed-length side sorted from its raw columns
+        out["coarse_b"] = out["span_hist"]  # (SEMI / ANTI / COUNT: the same bit says B was sorted without its lowest digit)
         out["sort_local"] = bool(int(st.reserved) & 0x20)   # a side was sorted in three stages (bucket_sort.hip.h)
         out["sort_resorted"] = bool(int(st.reserved) & 0x40)  # the context fell back to the four-pass sort
         out["swapped"] = bool(int(st.reserved) & 0x80)  # the INNER plan ran with the sides exchanged (larger side as B)
@@ -350,8 +351,9 @@ class HipEngine:
     def _nearest_once(self, a: DeviceSide, b: DeviceSide, n_chrom: int, signed: bool = False,
                       max_distance=None):
         torch = _torch()
-        idx = torch.full((a.n,), -1, dtype=torch.int32, device=self.device)
-        dist = torch.zeros(a.n, dtype=torch.int64, device=self.device)
+        # (no pre-fill: the library writes every slot -- k_nearest_unpack, or its own memsets for an empty B)
+        idx = torch.empty((a.n,), dtype=torch.int32, device=self.device)
+        dist = torch.empty(a.n, dtype=torch.int64, device=self.device)
         md = -1 if max_distance is None else int(max_distance)
         _lib.check(self._L.giql_hip_nearest_dev(
             self._h, a.c_struct(), b.c_struct(), int(n_chrom), int(bool(signed)), md,

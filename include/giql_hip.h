@@ -121,7 +121,9 @@ typedef struct giql_hip_stats {
   int32_t reserved;         /* bits 0-3: INNER join form (0 = general two-class join,
                                1 / 2 = uniform-length form with B / A as the fixed-
                                length side); bit 4: that side was sorted straight from
-                               its raw columns (digit histogram in the span pass); bit 5: a side
+                               its raw columns (digit histogram in the span pass) -- after SEMI / ANTI /
+                               COUNT: the fixed-length B was sorted without its lowest digit (three
+                               passes), equal upper 24 bits looked at row by row; bit 5: a side
                                was sorted in three stages (two global passes + the in-LDS
                                bucket sort); bit 6: the context fell back to the four-pass
                                sort (a bucket too large for LDS); bit 7: the INNER plan ran with

@@ -41,7 +41,8 @@ def cfg3():
 
 
 @pytest.mark.parametrize("env,form", [
-    ({}, "uniform_b"),                                   # fixed-length B: one sorted array, no prefix max
+    ({}, "uniform_b"),                                   # fixed-length B: one sorted array (coarsely sorted from the second call on), no prefix max
+    ({"GIQL_HIP_NO_COARSE_B": "1"}, "uniform_b"),        # ... sorted on every digit, binary searches
     ({"GIQL_HIP_NO_UNIFORM": "1"}, "general"),           # (key, end) sort + prefix max / two sorted arrays
     ({"GIQL_HIP_LOCAL_MIN_ROWS": "1"}, "uniform_b"),     # three-stage sort of both sides
     ({"GIQL_HIP_LOCAL_MIN_ROWS": "1", "GIQL_HIP_NO_UNIFORM": "1"}, "general"),
@@ -58,6 +59,7 @@ def test_config3_semi_anti_count_1m_x_10m(monkeypatch, cfg3, env, form):
             assert np.array_equal(e.count_overlaps(da, db, 24).cpu().numpy(), want["count"])
             assert e.stats()["join_form"] == form
         assert e.stats()["sort_local"] == ("GIQL_HIP_LOCAL_MIN_ROWS" in env) and not e.stats()["sort_resorted"]
+        assert e.stats()["coarse_b"] == (env == {})
     finally:
         e.close()
 

@@ -465,6 +465,42 @@ def test_row_ops_fixed_length_b(eng_fresh):
     assert _row_ops_equal(e, a, b, 3, "brute") == ("uniform_b", "uniform_b")
 
 
+def test_row_ops_fixed_length_b_sorted_coarsely(monkeypatch):
+    """SEMI / ANTI / COUNT against a fixed-length B sorted without its lowest digit, the rows sharing the upper 24 key
+    bits looked at one by one (forced at every density here): ranges inside one such group, across many (long A
+    rows), empty stretches, chromosome edges, every encoding of A, irregular A rows; the form is taken from the
+    context's second call on (the first has no density to go by)."""
+    from giql_amd.engine import HipEngine
+
+    monkeypatch.setenv("GIQL_HIP_COARSE_MAX_GROUP_ROWS", "1e12")
+    e = HipEngine(0)
+    monkeypatch.delenv("GIQL_HIP_COARSE_MAX_GROUP_ROWS")
+    try:
+        b = uniform_side(341, 200_000, 6, 3_000_000, 150)
+        a0 = rand_side(342, 30_000, 7, 3_000_000, 900)
+        assert _row_ops_equal(e, a0, b, 7) == ("uniform_b", "uniform_b")
+        for k, enc in enumerate(ora.ENCODING_OFFSETS):
+            a = rand_side(343 + k, 30_000, 7, 3_000_000, 900, min_len=-3, enc=enc)  # chrom 6 is A-only
+            assert _row_ops_equal(e, a, b, 7, "brute") == ("uniform_b", "uniform_b")
+            assert e.stats()["coarse_b"]
+        # long A rows (ranges over many buckets, some of them empty) on a sparse B
+        bs = uniform_side(350, 3_000, 3, 30_000_000, 100)
+        al = rand_side(351, 20_000, 3, 30_000_000, 400_000, min_len=1)
+        assert _row_ops_equal(e, al, bs, 3) == ("uniform_b", "uniform_b")
+        assert _row_ops_equal(e, al, bs, 3) == ("uniform_b", "uniform_b") and e.stats()["coarse_b"]
+        # chromosome edges: ranges reaching below a chromosome's first key must not leak
+        a = ora.Side(np.array([0, 1, 1, 2, 2], np.int32), np.array([0, 0, 5, 0, 120], np.int32),
+                     np.array([10, 3, 9, 1000, 121], np.int32))
+        b2 = ora.Side(np.array([0, 0, 1, 1, 2], np.int32), np.array([0, 990, 0, 2, 0], np.int32),
+                      np.array([100, 1090, 100, 102, 100], np.int32))
+        assert _row_ops_equal(e, a, b2, 3, "brute") == ("uniform_b", "uniform_b")
+        # B loses its fixed length: the guess misses, the call is repeated in the general form
+        b3 = rand_side(352, 150_000, 6, 3_000_000, 300)
+        assert _row_ops_equal(e, a0, b3, 7)[1] == "general" and not e.stats()["coarse_b"]
+    finally:
+        e.close()
+
+
 def test_row_ops_form_guess_misses_and_recovers(eng_fresh):
     """fixed-length B -> B with other lengths -> a different fixed length -> an irregular B row:
     a wrong "fixed-length" guess repeats the call, a wrong "general" guess is merely slower (the
