@@ -667,86 +667,182 @@ __global__ __launch_bounds__(256) void k_nearest_unpack(const NearestRec* __rest
 // (_distance.py:67-87).  One thread per A row (rows sorted by start: neighbouring lanes walk
 // neighbouring ranges); results go out as k 16-byte records per row, by row id.
 constexpr int NEAREST_K_MAX = 64;
+// Round 3: the block's bracket of lower_bound(b_keys, a.end) is staged in LDS as in k_nearest (keys, prefix max AND
+// ends of the (start, end) view: the overlap walk filters on the ends), so the ~20 dependent loads of every row's
+// search and its walk over the overlapping rows are LDS loads; the upstream view is only looked at by rows that
+// still lack candidates after the overlapping ones (its run heads found by galloping back: equal ends are short
+// runs), and from k = 16 on the results go straight to the output arrays (a row's k ids / k distances are 64+ / 128+
+// contiguous bytes) instead of through 16-byte records and an unpack pass.
+constexpr int NRK_CAP = 2560;  // staged B rows (keys + prefix max + ends: 30 KB)
 
-__global__ __launch_bounds__(256) void k_nearest_k(
+template <bool DIRECT>
+__global__ __launch_bounds__(NR_NT) void k_nearest_k(
     const u32* __restrict__ a_keys, const u32* __restrict__ a_ends, const u32* __restrict__ a_rids, u32 n_a,
     int n_chrom, const u32* __restrict__ chrom_first, const u32* __restrict__ chrom_lo,
     const u32* __restrict__ chrom_lo_e, const u32* __restrict__ b_keys, const u32* __restrict__ b_ends,
     const u32* __restrict__ b_pmax, const u32* __restrict__ b_rids, const u32* __restrict__ e_ends,
     const u32* __restrict__ e_starts, const u32* __restrict__ e_rids, u32 n_b, int k, int is_signed,
-    i64 max_distance, NearestRec* __restrict__ rec_out, DevMeta* __restrict__ meta) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_a) return;
+    i64 max_distance, NearestRec* __restrict__ rec_out, int32_t* __restrict__ idx_out, i64* __restrict__ dist_out,
+    DevMeta* __restrict__ meta) {
+  __shared__ u32 s_keys[NRK_CAP], s_pmax[NRK_CAP], s_ends[NRK_CAP];
+  __shared__ u32 s_min[NR_NT / WAVE], s_max[NR_NT / WAVE];
+  __shared__ u32 s_w[2];
+  __shared__ u32 s_cfirst[NR_CHROMS + 1], s_clo[NR_CHROMS + 1];
+  const u32 tid = threadIdx.x;
+  const u32 base = blockIdx.x * NR_TQ;
   const u32 sentinel = meta->sentinel;
-  const u32 qs = a_keys[i], qe = a_ends[i], r = a_rids[i];
-  NearestRec* out = rec_out + (size_t)r * (size_t)k;
-  int emitted = 0;
-  if (n_b > 0 && qs < sentinel) {
-    if (qe < qs && meta->status == 0) meta->status = -1;  // NEAREST needs start <= end
-    const u32 c = upper_bound_u32(chrom_first, 0, (u32)n_chrom + 1, qs) - 1;
-    const u32 blo = chrom_lo[c], bhi = chrom_lo[c + 1];
-    const u32 elo = chrom_lo_e[c], ehi = chrom_lo_e[c + 1];
-    if (bhi > blo) {
-      const u32 hi = lower_bound_u32(b_keys, blo, bhi, qe);  // rows [blo, hi) start before a.end
-      if (hi > blo && b_pmax[hi - 1] > qs) {
-        for (u32 j = gallop_back_upper_u32(b_pmax, blo, hi, qs); j < hi && emitted < k; j++) {
-          if (b_ends[j] > qs) {
-            NearestRec rec;
-            rec.dist = 0;
-            rec.idx = (int32_t)b_rids[j];
-            rec.pad = 0;
-            out[emitted++] = rec;
-          }
-        }
-      }
-      u32 dn = hi;
-      // upstream cursor: the run [run_lo, run_hi) of equal ends being emitted, `cur` inside it
-      u32 run_lo = upper_bound_u32(e_ends, elo, ehi, qs), run_hi = run_lo, cur = run_lo;
-      while (emitted < k) {
-        // next upstream candidate (skipping rows that are downstream by the CASE's first arm)
-        bool has_up = false;
-        u32 up_e = 0;
-        while (true) {
-          if (cur == run_hi) {
-            if (run_lo == elo) break;
-            const u32 last = run_lo - 1;
-            const u32 e = e_ends[last];
-            run_hi = run_lo;
-            run_lo = lower_bound_u32(e_ends, elo, last + 1, e);
-            cur = run_lo;
-          }
-          if (e_starts[cur] < qe) {
-            has_up = true;
-            up_e = e_ends[cur];
-            break;
-          }
-          cur++;
-        }
-        const bool has_dn = dn < bhi;
-        if (!has_up && !has_dn) break;
-        const i64 up_d = has_up ? (i64)qs - (i64)up_e + 1 : 0;
-        const i64 dn_d = has_dn ? (i64)b_keys[dn] - (i64)qe + 1 : 0;
-        const bool take_up = has_up && (!has_dn || up_d <= dn_d);
-        const i64 d = take_up ? up_d : dn_d;
-        if (max_distance >= 0 && d > max_distance) break;  // every later candidate is at least as far
-        NearestRec rec;
-        rec.dist = take_up ? (is_signed ? -d : d) : d;
-        rec.idx = (int32_t)(take_up ? e_rids[cur] : b_rids[dn]);
-        rec.pad = 0;
-        out[emitted++] = rec;
-        if (take_up)
-          cur++;
-        else
-          dn++;
-      }
+  const bool lds_chroms = n_chrom <= NR_CHROMS;
+  if (lds_chroms)
+    for (u32 c = tid; c <= (u32)n_chrom; c += NR_NT) {
+      s_cfirst[c] = chrom_first[c];
+      s_clo[c] = chrom_lo[c];
+    }
+  u32 qs[NR_ITEMS], qe[NR_ITEMS], rr[NR_ITEMS];
+  bool live[NR_ITEMS], srch[NR_ITEMS];
+  u32 emin = U32_MAX, emax = 0u;
+#pragma unroll
+  for (int u = 0; u < NR_ITEMS; u++) {
+    const u32 i = base + u * NR_NT + tid;
+    live[u] = i < n_a;
+    qs[u] = live[u] ? a_keys[i] : 0u;
+    qe[u] = live[u] ? a_ends[i] : 0u;
+    rr[u] = live[u] ? a_rids[i] : 0u;
+    srch[u] = live[u] && n_b > 0 && qs[u] < sentinel;
+    if (srch[u]) {
+      emin = qe[u] < emin ? qe[u] : emin;
+      emax = qe[u] > emax ? qe[u] : emax;
     }
   }
-  for (int t = emitted; t < k; t++) {
-    NearestRec rec;
-    rec.dist = 0;
-    rec.idx = -1;
-    rec.pad = 0;
-    out[t] = rec;
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) {
+    const u32 tmin = (u32)__shfl_xor((int)emin, d, WAVE), tmax = (u32)__shfl_xor((int)emax, d, WAVE);
+    emin = tmin < emin ? tmin : emin;
+    emax = tmax > emax ? tmax : emax;
+  }
+  if (lane_id() == 0) {
+    s_min[wave_id()] = emin;
+    s_max[wave_id()] = emax;
+  }
+  __syncthreads();
+  if (wave_id() == 0) {  // the block's bracket of lower_bound(b_keys, a.end)
+    u32 bmin = U32_MAX, bmax = 0u;
+#pragma unroll
+    for (int w = 0; w < NR_NT / WAVE; w++) {
+      bmin = s_min[w] < bmin ? s_min[w] : bmin;
+      bmax = s_max[w] > bmax ? s_max[w] : bmax;
+    }
+    u32 lo = 0, hi = n_b;
+    if (bmin <= bmax && n_b > 0) {
+      lo = wave_lower_bound_u32(b_keys, 0, n_b, bmin);
+      hi = wave_lower_bound_u32(b_keys, lo, n_b, bmax);
+    }
+    if (lane_id() == 0) {
+      s_w[0] = lo;
+      s_w[1] = hi;
+    }
+  }
+  __syncthreads();
+  const u32 w_lo = s_w[0], w_hi = s_w[1];
+  const u32 w0 = w_lo > NR_BACK ? w_lo - NR_BACK : 0u;
+  // k rows above: the downstream candidates of the last lookups
+  u32 w1 = w_hi + (u32)k < n_b ? w_hi + (u32)k : n_b;
+  if (w1 - w0 > (u32)NRK_CAP) w1 = w0;  // a bracket wider than the stage: everything from global memory
+  for (u32 t = tid; t < w1 - w0; t += NR_NT) {
+    s_keys[t] = b_keys[w0 + t];
+    s_pmax[t] = b_pmax[w0 + t];
+    s_ends[t] = b_ends[w0 + t];
+  }
+  __syncthreads();
+  const u32 wn = w1 - w0;
+  auto key_at = [&](u32 j) -> u32 { return (j - w0 < wn) ? s_keys[j - w0] : b_keys[j]; };
+  auto pmax_at = [&](u32 j) -> u32 { return (j - w0 < wn) ? s_pmax[j - w0] : b_pmax[j]; };
+  auto end_at = [&](u32 j) -> u32 { return (j - w0 < wn) ? s_ends[j - w0] : b_ends[j]; };
+  auto e_end_at = [&](u32 j) -> u32 { return e_ends[j]; };
+#pragma unroll 1
+  for (int u = 0; u < NR_ITEMS; u++) {
+    if (!live[u]) continue;
+    const size_t o = (size_t)rr[u] * (size_t)k;
+    int emitted = 0;
+    auto emit = [&](i64 d, u32 rid) {
+      if (DIRECT) {
+        idx_out[o + emitted] = (int32_t)rid;
+        dist_out[o + emitted] = d;
+      } else {
+        NearestRec rec;
+        rec.dist = d;
+        rec.idx = (int32_t)rid;
+        rec.pad = 0;
+        rec_out[o + emitted] = rec;
+      }
+      emitted++;
+    };
+    if (srch[u]) {
+      const u32 s = qs[u], e = qe[u];
+      if (e < s && meta->status == 0) meta->status = -1;  // NEAREST needs start <= end
+      const u32 c = upper_bound_u32(lds_chroms ? s_cfirst : chrom_first, 0, (u32)n_chrom + 1, s) - 1;
+      const u32 blo = lds_chroms ? s_clo[c] : chrom_lo[c];
+      const u32 bhi = lds_chroms ? s_clo[c + 1] : chrom_lo[c + 1];
+      if (bhi > blo) {
+        u32 hi = lower_bound_f(key_at, w_lo, w_hi, e);  // rows [blo, hi) start before a.end
+        hi = hi < blo ? blo : (hi > bhi ? bhi : hi);
+        if (hi > blo && pmax_at(hi - 1) > s) {
+          for (u32 j = gallop_back_upper_f(pmax_at, blo, hi, s); j < hi && emitted < k; j++)
+            if (end_at(j) > s) emit(0, b_rids[j]);
+        }
+        if (emitted < k) {
+          u32 dn = hi;
+          const u32 elo = chrom_lo_e[c], ehi = chrom_lo_e[c + 1];
+          // upstream cursor: the run [run_lo, run_hi) of equal ends being emitted, `cur` inside it
+          u32 run_lo = upper_bound_u32(e_ends, elo, ehi, s), run_hi = run_lo, cur = run_lo;
+          while (emitted < k) {
+            // next upstream candidate (skipping rows that are downstream by the CASE's first arm)
+            bool has_up = false;
+            u32 up_e = 0;
+            while (true) {
+              if (cur == run_hi) {
+                if (run_lo == elo) break;
+                const u32 last = run_lo - 1;
+                const u32 ee = e_ends[last];
+                run_hi = run_lo;
+                run_lo = gallop_back_lower_f(e_end_at, elo, last, ee);  // the head of the run that ends at `last`
+                cur = run_lo;
+              }
+              if (e_starts[cur] < e) {
+                has_up = true;
+                up_e = e_ends[cur];
+                break;
+              }
+              cur++;
+            }
+            const bool has_dn = dn < bhi;
+            if (!has_up && !has_dn) break;
+            const i64 up_d = has_up ? (i64)s - (i64)up_e + 1 : 0;
+            const i64 dn_d = has_dn ? (i64)key_at(dn) - (i64)e + 1 : 0;
+            const bool take_up = has_up && (!has_dn || up_d <= dn_d);
+            const i64 d = take_up ? up_d : dn_d;
+            if (max_distance >= 0 && d > max_distance) break;  // every later candidate is at least as far
+            emit(take_up ? (is_signed ? -d : d) : d, take_up ? e_rids[cur] : b_rids[dn]);
+            if (take_up)
+              cur++;
+            else
+              dn++;
+          }
+        }
+      }
+    }
+    while (emitted < k) {  // unused slots: idx -1
+      if (DIRECT) {
+        idx_out[o + emitted] = -1;
+        dist_out[o + emitted] = 0;
+      } else {
+        NearestRec rec;
+        rec.dist = 0;
+        rec.idx = -1;
+        rec.pad = 0;
+        rec_out[o + emitted] = rec;
+      }
+      emitted++;
+    }
   }
 }
 

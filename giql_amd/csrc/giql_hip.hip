@@ -2185,25 +2185,42 @@ static int giql_hip_nearest_k_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
   carve(ctx->arena);
 
   GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
-  // B by (start, end): the stable two-sort form (by end, then stably by start); its digit histograms
-  // of the starts AND of the ends come out of one linearize pass
+  // Two sorted views of B from ONE linearize pass (it counts the digits of the starts and of the ends):
+  //   by (start, end) and by (end, start).
   GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist, os.gbase,
                          os.hist_e, os.gbase_e));
-  {
-    SortBufs by_end = sbb;
-    for (int i = 0; i < 2; i++) {
-      by_end.key[i] = sbb.end[i];
-      by_end.end[i] = sbb.key[i];
+  const bool two_sorts = ctx->nearest_two_sorts;
+  if (two_sorts) {
+    // tables with long runs of equal starts or ends: stable two-key sorts -- (start, end) = by end, then stably by
+    // start; (end, start) = that order stably re-sorted by end
+    {
+      SortBufs by_end = sbb;
+      for (int i = 0; i < 2; i++) {
+        by_end.key[i] = sbb.end[i];
+        by_end.end[i] = sbb.key[i];
+      }
+      GIQL_TRY(run_sort_onesweep(ctx, st, by_end, (u32)nb, os.gbase_e, os.status));
+      GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, /*keep_rids=*/true));
     }
-    GIQL_TRY(run_sort_onesweep(ctx, st, by_end, (u32)nb, os.gbase_e, os.status));
-    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, /*keep_rids=*/true));
+    HIP_TRY(hipMemcpyAsync(se.key[0], sbb.end[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(se.end[0], sbb.key[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(se.rid[0], sbb.rid[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
+    GIQL_TRY(run_sort_onesweep(ctx, st, se, (u32)nb, os.gbase_e, os.status, /*keep_rids=*/true));
+  } else {
+    // ONE sort per view (eight passes instead of twelve): each view sorted on its first key from the linearized
+    // columns, the -- short -- runs of equal first keys ordered by the second key in place (k_fix_start_ties; a run
+    // too long for that flags the table for the two-key plan above, as in NEAREST k = 1)
+    HIP_TRY(hipMemcpyAsync(se.key[0], sbb.end[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(se.end[0], sbb.key[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status));
+    GIQL_TRY(run_sort_onesweep(ctx, st, se, (u32)nb, os.gbase_e, os.status));
+    Phase ph(ctx, st, GIQL_PH_AUX, 2);
+    hipLaunchKernelGGL(k_fix_start_ties, dim3(cdiv(nb, 256)), dim3(256), 0, st, sbb.key[0], sbb.end[0], sbb.rid[0],
+                       (u32)nb, ctx->d_meta);
+    hipLaunchKernelGGL(k_fix_start_ties, dim3(cdiv(nb, 256)), dim3(256), 0, st, se.key[0], se.end[0], se.rid[0],
+                       (u32)nb, ctx->d_meta);
   }
   GIQL_TRY(run_pmax(ctx, st, sbb.end[0], (u32)nb, pmax, bmax));
-  // B by (end, start): the (start, end) order, stably re-sorted by end
-  HIP_TRY(hipMemcpyAsync(se.key[0], sbb.end[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
-  HIP_TRY(hipMemcpyAsync(se.end[0], sbb.key[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
-  HIP_TRY(hipMemcpyAsync(se.rid[0], sbb.rid[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
-  GIQL_TRY(run_sort_onesweep(ctx, st, se, (u32)nb, os.gbase_e, os.status, /*keep_rids=*/true));
   GIQL_TRY(run_linearize(ctx, st, *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr, 0, 1, os.hist, os.gbase));
   GIQL_TRY(run_sort_onesweep(ctx, st, sa, (u32)na, os.gbase, os.status, false, nullptr, nullptr,
                              /*skip_digits=*/row_skip(ctx, nb)));  // the query side's order only serves locality; every row keeps its real key here
@@ -2213,15 +2230,28 @@ static int giql_hip_nearest_k_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
                        sbb.key[0], (u32)nb, chrom_lo);
     hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st, lb.chrom_first, n_chrom,
                        se.key[0], (u32)nb, chrom_lo_e);
-    hipLaunchKernelGGL(k_nearest_k, dim3(cdiv(na, 256)), dim3(256), 0, st, sa.key[0], sa.end[0], sa.rid[0], (u32)na,
-                       n_chrom, lb.chrom_first, chrom_lo, chrom_lo_e, sbb.key[0], sbb.end[0], pmax, sbb.rid[0],
-                       se.key[0], se.end[0], se.rid[0], (u32)nb, (int)k, is_signed, (i64)max_distance, recs,
-                       ctx->d_meta);
-    hipLaunchKernelGGL(k_nearest_unpack, dim3(cdiv(na * (size_t)k, 256)), dim3(256), 0, st, recs, (u32)(na * (size_t)k),
-                       idx_b_out, (i64*)dist_out);
+    if (k >= 16) {  // a row's k ids / distances are contiguous runs of 64+ / 128+ bytes: straight into the outputs
+                     // (at k = 8 the two scattered 32 / 64-byte runs cost what the 128-byte records + the unpack pass do)
+      hipLaunchKernelGGL(k_nearest_k<true>, dim3(cdiv(na, NR_TQ)), dim3(NR_NT), 0, st, sa.key[0], sa.end[0], sa.rid[0],
+                         (u32)na, n_chrom, lb.chrom_first, chrom_lo, chrom_lo_e, sbb.key[0], sbb.end[0], pmax,
+                         sbb.rid[0], se.key[0], se.end[0], se.rid[0], (u32)nb, (int)k, is_signed, (i64)max_distance,
+                         recs, idx_b_out, (i64*)dist_out, ctx->d_meta);
+    } else {
+      hipLaunchKernelGGL(k_nearest_k<false>, dim3(cdiv(na, NR_TQ)), dim3(NR_NT), 0, st, sa.key[0], sa.end[0], sa.rid[0],
+                         (u32)na, n_chrom, lb.chrom_first, chrom_lo, chrom_lo_e, sbb.key[0], sbb.end[0], pmax,
+                         sbb.rid[0], se.key[0], se.end[0], se.rid[0], (u32)nb, (int)k, is_signed, (i64)max_distance,
+                         recs, idx_b_out, (i64*)dist_out, ctx->d_meta);
+      hipLaunchKernelGGL(k_nearest_unpack, dim3(cdiv(na * (size_t)k, 256)), dim3(256), 0, st, recs,
+                         (u32)(na * (size_t)k), idx_b_out, (i64*)dist_out);
+    }
     GIQL_TRY(post_launch("nearest k"));
   }
   GIQL_TRY(read_meta(ctx, st));
+  if (!two_sorts && ctx->h_meta->aux0 != 0) {
+    // a long run of equal starts or ends (pile-ups): this table wants the two-key sorts
+    ctx->nearest_two_sorts = true;
+    return giql_hip_nearest_k_dev_impl(ctx, a, b, n_chrom, k, is_signed, max_distance, idx_b_out, dist_out, stream);
+  }
   if (ctx->h_meta->inverted_b) return set_err(GIQL_ERR_INVALID, "NEAREST: a target row has end < start");
   collect_spans(ctx);
   ctx->stats.n_out = a->n * (int64_t)k;

@@ -366,8 +366,9 @@ class HipEngine:
         torch = _torch()
         self._check_sides(a, b)
         k = int(k)
-        idx = torch.full((a.n, k), -1, dtype=torch.int32, device=self.device)
-        dist = torch.zeros((a.n, k), dtype=torch.int64, device=self.device)
+        # (no pre-fill: the library writes every slot, unused ones as idx -1 / distance 0)
+        idx = torch.empty((a.n, k), dtype=torch.int32, device=self.device)
+        dist = torch.empty((a.n, k), dtype=torch.int64, device=self.device)
         md = -1 if max_distance is None else int(max_distance)
         _lib.check(self._L.giql_hip_nearest_k_dev(
             self._h, a.c_struct(), b.c_struct(), int(n_chrom), k, int(bool(signed)), md,

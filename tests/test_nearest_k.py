@@ -87,3 +87,30 @@ def test_nearest_k_edge_cases(eng):
     inv = ora.Side(np.zeros(2, np.int32), np.array([10, 50], np.int32), np.array([5, 60], np.int32))
     with pytest.raises(GiqlHipError):
         eng.nearest_k(dev(a), dev(inv), 3, 2)
+
+
+def test_nearest_k_one_sort_per_view_and_the_fallback_for_long_tie_runs():
+    """Round 3: each sorted view of the targets takes ONE sort (by its first key) and orders the short runs of equal
+    first keys in place; a table with runs longer than that allows for (here: 2,000 targets on 25 starts / ends)
+    flags itself and the call is repeated with the stable two-key sorts -- same answers either way."""
+    from giql_amd.engine import HipEngine
+
+    e = HipEngine(0)
+    try:
+        a = rand_side(301, 3000, 2, 50_000, 300)
+        b = rand_side(302, 5000, 2, 50_000, 300)
+        for k in (2, 17):   # records + unpack (k < 16) and straight into the outputs (k >= 16)
+            idx, dist = e.nearest_k(dev(a), dev(b), 2, k, signed=True)
+            wi, wd = ora.c_nearest_k(a, b, k, signed=True)
+            assert _triples(idx.cpu().numpy(), dist.cpu().numpy(), b) == _triples(wi, wd, b)
+        r = np.random.default_rng(303)
+        st = (r.integers(0, 25, 2000) * 1000).astype(np.int32)
+        ln = (r.integers(1, 4, 2000) * 50).astype(np.int32)
+        piled = ora.Side(r.integers(0, 2, 2000).astype(np.int32), st, st + ln)
+        for k in (3, 8):
+            idx, dist = e.nearest_k(dev(a), dev(piled), 2, k)
+            wi, wd = ora.c_nearest_k(a, piled, k)
+            assert _triples(idx.cpu().numpy(), dist.cpu().numpy(), piled) == _triples(wi, wd, piled)
+            assert np.array_equal(idx.cpu().numpy() >= 0, wi >= 0)
+    finally:
+        e.close()
