@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void k_bucket_bounds_fused(const u32* __restri
                                                               const u32* __restrict__ irr_q,
                                                               const u32* __restrict__ gbq3, u32 key_mask,
                                                               const int* __restrict__ len_max_q,
-                                                              u32* __restrict__ zero_ptr, u32 zero_words) {
+                                                              u32* __restrict__ zero_ptr, u32 zero_words,
+                                                              const int* __restrict__ len_max_u = nullptr) {
   const u32 t = blockIdx.x * 256 + threadIdx.x;
   if (t == 0) big_list[0] = 0;  // the queue of buckets too large for LDS starts empty
   // the status words + ticket of the chained scan that follows the bucket sort (scan.hip.h) start at zero
@@ -125,7 +126,15 @@ __global__ __launch_bounds__(256) void k_bucket_bounds_fused(const u32* __restri
     const u32 w = lm < 0 ? 0u : ((u32)lm > BS_FUSE_WCAP ? BS_FUSE_WCAP : (u32)lm);
     target = k0 > w ? k0 - w : 0u;
   } else {
-    const u64 tmax = (u64)k0 + 65535ull + (u64)(-fq.lo_off);  // lo_off <= 0: keys up to K1 - 1 - lo_off
+    // fixed-length form (lo_off <= 0): query keys up to K1 - 1 - lo_off put their lower bound into the bucket; general
+    // form (len_max_u given): the queries double as the POINTS of the bucket rows' own ranges [u.start, u.end), which
+    // reach up to the longest row above the bucket
+    u64 reach = (u64)(-fq.lo_off);
+    if (len_max_u) {
+      const int lu = *len_max_u;
+      reach = lu < 0 ? 0ull : ((u32)lu > BS_FUSE_WCAP ? (u64)BS_FUSE_WCAP : (u64)lu);
+    }
+    const u64 tmax = (u64)k0 + 65535ull + reach;
     if (tmax >= (u64)U32_MAX) {
       fq.qwin[2 * v + 1] = nq;
       return;
@@ -244,16 +253,26 @@ constexpr int BS_QPRE = GIQL_BS_QPRE;  // probe rounds whose values are loaded w
 #ifndef GIQL_BJ_MIN_WAVES
 #define GIQL_BJ_MIN_WAVES 6  // the join form keeps its queries' ranks in registers next to the rows: 80 VGPRs, three blocks per CU
 #endif
+#ifndef GIQL_BJG_MIN_WAVES
+#define GIQL_BJG_MIN_WAVES 5  // ... the general form its rows' class-1 ranges as well
+#endif
 constexpr int BJ_QR = 4;
 constexpr u32 BJ_WCAP = BJ_QR * BS_NT;
 
 // The tail of a FUSE == 2 block (see above).  On entry every row knows its final place (slot), the bin table and
 // the gathered equal-key bins are still valid, and no barrier has passed since the last of them was read.
-template <int R>
-__device__ __forceinline__ void bucket_join_tail(const u32 (&pay)[R], const u32 (&slot)[R], u32 cnt, u32 v,
-                                                 u32* s_buf, const u64* s_cell, u32* s_jtot, const BsFuse& fq,
-                                                 u32 qw0, u32 nw, const u32 (&jq_key)[BJ_QR],
-                                                 const u32 (&jq_end)[BJ_QR]) {
+//
+// GENERAL (FUSE == 3, the two-class join of rows of ANY length; the bucket rows carry their end keys): the queries'
+// own ranges over the bucket's rows are class 2 exactly as above (range (q.start, q.end): lo_off = +1), and class 1
+// -- the queries that START inside a bucket row, q.start in [u.start, u.end) -- is answered from the other side: the
+// window's keys are staged in LDS (in the bin table's place, once the ranks are done), every bucket row searches
+// them for its own range (a lower bound and a short walk: 0.3 matches per row at 10M x 100M) and writes its few
+// pairs itself, behind the class-2 runs.  Every pair (q, u) leaves from the block of u's bucket.
+template <int R, bool GENERAL>
+__device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (&pay)[R], const u32 (&slot)[R], u32 cnt,
+                                                 u32 v, const u32* __restrict__ ep, u32* s_buf, u64* s_cell,
+                                                 u32* s_jtot, const BsFuse& fq, u32 qw0, u32 nw,
+                                                 const u32 (&jq_key)[BJ_QR], const u32 (&jq_end)[BJ_QR]) {
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const u32 k0 = v << 16;
 #if defined(GIQL_BJ_ABLATE)  // timing-only builds (results invalid, tools/bj_ablate.sh): the tail stops after its k-th stage
@@ -293,7 +312,58 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pay)[R], const u32 
     }
     q_off[i] = mine + incl[i] - q_cnt[i];
   }
-  if (total == 0) return;  // block-uniform: no query of the window reaches a row of this bucket
+  // class 1 (GENERAL): the window's keys into LDS, each of my rows against them
+  u32 c1[GENERAL ? R : 1];  // {first matching window row : 16 | matches : 16}
+  u32 off1 = 0;
+  const u32 total2 = total;
+  if (GENERAL) {
+    u32* const s_qkey = reinterpret_cast<u32*>(s_cell);
+#pragma unroll
+    for (int i = 0; i < BJ_QR; i++) {
+      const u32 j = i * BS_NT + tid;
+      if (j < nw) s_qkey[j] = jq_key[i];
+    }
+    u32 pe[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const u32 r = i * BS_NT + tid;
+      pe[i] = (i < R - 1 || r < cnt) ? ep[r] : 0u;
+    }
+    bs_sync<2>();
+    u32 t1 = 0;
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const u32 r = i * BS_NT + tid;
+      c1[i] = 0;
+      if (i < R - 1 || r < cnt) {
+        const u32 key = k0 | (pk[i] >> 12), end = pe[i];
+        u32 lo = 0, hi = nw;
+        while (lo < hi) {
+          const u32 mid = (lo + hi) >> 1;
+          if (s_qkey[mid] < key)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        u32 c = 0;
+        while (lo + c < nw && s_qkey[lo + c] < end) c++;
+        c1[i] = lo | (c << 16);
+        t1 += c;
+      }
+    }
+    const u32 incl1 = wave_incl_scan_add_u32(t1);
+    if (lane == WAVE - 1) s_jtot[BJ_QR * BS_NW + 4 + w] = incl1;
+    bs_sync<2>();
+    u32 mine1 = 0, total1 = 0;
+#pragma unroll
+    for (int k = 0; k < BS_NW; k++) {
+      if (k == (int)w) mine1 = total1;
+      total1 += s_jtot[BJ_QR * BS_NW + 4 + k];
+    }
+    off1 = total2 + mine1 + incl1 - t1;
+    total += total1;
+  }
+  if (total == 0) return;  // block-uniform: no query of the window meets a row of this bucket
   // the block's place in the output: one atomic, in flight while the row ids are staged by final place
   unsigned long long base = 0;
   if (tid == 0) base = atomicAdd(fq.cursor, (unsigned long long)total);
@@ -324,6 +394,17 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pay)[R], const u32 
       for (u32 k = lane; k < c; k += WAVE) {
         rq[off + k] = qr;
         rs[off + k] = (int32_t)s_buf[lo + k];
+      }
+    }
+  }
+  if (GENERAL) {  // class 1: a row's few pairs from its own thread
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const u32 lo = c1[i] & 0xFFFFu, c = c1[i] >> 16;
+      for (u32 k = 0; k < c; k++) {
+        rq[off1] = (int32_t)fq.qrid[qw0 + lo + k];
+        rs[off1] = (int32_t)pay[i];
+        off1++;
       }
     }
   }
@@ -364,8 +445,8 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
     if (FUSE == 1 && tid + k * BS_NT < n_probe) q_val[k] = q_src[qw0 + ((tid + k * BS_NT) >> 1)];
   }
   // the join form: one thread per query of the window, key and end key, up to BJ_QR rounds
-  u32 jq_key[FUSE == 2 ? BJ_QR : 1], jq_end[FUSE == 2 ? BJ_QR : 1];
-  if constexpr (FUSE == 2) {
+  u32 jq_key[FUSE >= 2 ? BJ_QR : 1], jq_end[FUSE >= 2 ? BJ_QR : 1];
+  if constexpr (FUSE >= 2) {
 #pragma unroll
     for (int k = 0; k < BJ_QR; k++) {
       const u32 j = k * BS_NT + tid;
@@ -471,8 +552,8 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
       }
     }
   }
-  if constexpr (FUSE == 2) {  // the pairs leave from here: no sorted array is stored
-    bucket_join_tail<R>(pay, slot, cnt, v, s_buf, s_cell, s_jtot, fq, qw0, qw1 - qw0, jq_key, jq_end);
+  if constexpr (FUSE >= 2) {  // the pairs leave from here: no sorted array is stored
+    bucket_join_tail<R, FUSE == 3>(pk, pay, slot, cnt, v, ep, s_buf, s_cell, s_jtot, fq, qw0, qw1 - qw0, jq_key, jq_end);
     return;
   }
   bs_sync<FUSE>();  // every gathered bin has been read: s_buf and the cells are free
@@ -612,18 +693,20 @@ __device__ __forceinline__ void bucket_sort_big(u32* __restrict__ k0, u32* __res
 }
 
 template <int PAYLOAD, int FUSE = 0>
-__global__ __launch_bounds__(BS_NT, FUSE == 2 ? GIQL_BJ_MIN_WAVES : GIQL_BS_MIN_WAVES) void k_bucket_sort(u32* __restrict__ keys, u32* __restrict__ ends,
+__global__ __launch_bounds__(BS_NT, FUSE == 3 ? GIQL_BJG_MIN_WAVES : (FUSE == 2 ? GIQL_BJ_MIN_WAVES : GIQL_BS_MIN_WAVES)) void k_bucket_sort(u32* __restrict__ keys, u32* __restrict__ ends,
                                                            u32* __restrict__ rids,
                                                            const u32* __restrict__ bnd,
                                                            DevMeta* __restrict__ meta,
                                                            u32* __restrict__ big_list, BsFuse fq = BsFuse()) {
   static_assert(BS_NB % BS_NT == 0, "bins must be a multiple of the block size");
   static_assert(BS_NB * sizeof(u64) >= BS_CAP * sizeof(uint16_t), "the cell table doubles as the 16-bit key stage");
+  static_assert(BS_NB * sizeof(u64) >= BJ_WCAP * sizeof(u32), "... and as the stage of a window's keys (general join form)");
   static_assert(BS_SUB_BITS == 5, "one 32-bit map of sub-values per bin");
   __shared__ u32 s_buf[BS_CAP + 4];  // + 4: the four-wide read of a gathered bin may run past the last row
   __shared__ u64 s_cell[BS_NB];  // {sub-value map : 32 | count : 32}, after the scan {map | dup, count, start}
   __shared__ u32 s_scan[BS_NW];
-  __shared__ u32 s_jtot[FUSE == 2 ? BJ_QR * BS_NW + 4 : 1];  // join form: wave totals of the pair counts + the block's output base
+  // join forms: wave totals of the class-2 pair counts, the block's output base (64 bits), wave totals of class 1
+  __shared__ __attribute__((aligned(8))) u32 s_jtot[FUSE >= 2 ? BJ_QR * BS_NW + 4 + BS_NW : 2];
   const u32 v = blockIdx.x;
   const u32 b0 = bnd[v];
   const u32 cnt = bnd[v + 1] - b0;
@@ -632,12 +715,12 @@ __global__ __launch_bounds__(BS_NT, FUSE == 2 ? GIQL_BJ_MIN_WAVES : GIQL_BS_MIN_
     qw0 = fq.qwin[2 * v];
     qw1 = fq.qwin[2 * v + 1];
   }
-  if (FUSE == 2) {
+  if (FUSE >= 2) {
     if (cnt == 0u || qw0 >= qw1) return;  // block-uniform: no row or no query, no pair (nothing else leaves this kernel)
   } else if (cnt < 2u && qw0 >= qw1) {
     return;  // block-uniform: nothing to sort, no bound to answer
   }
-  if (cnt > BS_CAP || (FUSE == 2 && qw1 - qw0 > BJ_WCAP)) {
+  if (cnt > BS_CAP || (FUSE >= 2 && qw1 - qw0 > BJ_WCAP)) {
     // too large for LDS: queued for k_bucket_sort_big (a launch of its own keeps this kernel free of
     // the big path's registers and scratch frame); past BS_BIG_MAX the whole call is repeated
     if (threadIdx.x == 0) {
@@ -685,7 +768,7 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ key
                              keys1 + b0, (PAYLOAD & 2) ? ends1 + b0 : nullptr, (PAYLOAD & 1) ? rids1 + b0 : nullptr, cnt,
                              s_wcnt, s_base, s_scan);
     __syncthreads();
-    if (FUSE == 2) {
+    if (FUSE >= 2) {
       // the join form of a queued bucket (too many rows for LDS, or too many queries in its window): the bucket is
       // sorted in global memory now; the window in chunks of one query per thread, each chunk's pairs placed by
       // one atomic and written as in bucket_join_tail
@@ -736,6 +819,43 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ key
           }
         }
         __syncthreads();  // s_scan and s_jbase are reused by the next chunk
+      }
+      if (FUSE == 3) {
+        // general form, class 1: the bucket's rows in chunks of one per thread, each against the window's keys
+        // (global memory here), a chunk's pairs placed by one atomic, every row writing its own
+        const u32* eb = ends + b0;
+        const u32* qk = fq.qkey + qw0;
+        const u32 nw = qw1 - qw0;
+        for (u32 r0 = 0; r0 < cnt; r0 += BS_NT) {  // block-uniform
+          const u32 r = r0 + threadIdx.x;
+          u32 lo1 = 0, c = 0;
+          if (r < cnt) {
+            lo1 = lower_bound_u32(qk, 0, nw, kb[r]);
+            const u32 end = eb[r];
+            while (lo1 + c < nw && qk[lo1 + c] < end) c++;
+          }
+          const u32 incl = wave_incl_scan_add_u32(c);
+          if (lane == WAVE - 1) s_scan[w] = incl;
+          __syncthreads();
+          u32 total = 0, mine = 0;
+#pragma unroll
+          for (int k = 0; k < BS_NW; k++) {
+            if (k == (int)w) mine = total;
+            total += s_scan[k];
+          }
+          if (threadIdx.x == 0) s_jbase = total ? atomicAdd(fq.cursor, (unsigned long long)total) : 0ull;
+          __syncthreads();
+          const unsigned long long base = s_jbase;
+          if (total != 0u && base + total <= fq.cap) {
+            unsigned long long o = base + mine + incl - c;
+            const int32_t mr = r < cnt ? (int32_t)rb[r] : 0;
+            for (u32 k = 0; k < c; k++, o++) {
+              fq.row_q[o] = (int32_t)fq.qrid[qw0 + lo1 + k];
+              fq.row_s[o] = mr;
+            }
+          }
+          __syncthreads();
+        }
       }
     } else if (FUSE) {
       // this bucket's keys are sorted in global memory now: the bounds of its query window by binary search

@@ -545,6 +545,8 @@ struct FuseCount {
   u32* zero_ptr;        // words the bounds kernel zeroes on the way (the chained scan's status + ticket)
   u32 zero_words;
   bool join = false;    // FUSE == 2: the bucket blocks write the pairs themselves (dev.row_q / row_s / cap / cursor)
+  bool general = false; // FUSE == 3: ... of the two-class join (rows of any length, (key, end, rid) sorts)
+  const int* len_max_u = nullptr;  // DevMeta: longest row of the sorted side (general form: how far the windows reach up)
 };
 
 static int64_t bucket_stage_fused_bytes(u32 n, const FuseCount& fuse);
@@ -561,7 +563,18 @@ static void launch_bucket_stage_fused(giql_hip_ctx* ctx, hipStream_t st, SortBuf
     Phase ph(ctx, st, GIQL_PH_COUNT, 1);
     hipLaunchKernelGGL(k_bucket_bounds_fused, dim3(cdiv((u64)3 * BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
                        gbase + 3 * OS_BINS, ctx->bucket_bnd, ctx->bucket_big, fuse.dev, fuse.nq_total, fuse.irr_q,
-                       fuse.gbq3, fuse.key_mask, fuse.len_max_q, fuse.zero_ptr, fuse.zero_words);
+                       fuse.gbq3, fuse.key_mask, fuse.len_max_q, fuse.zero_ptr, fuse.zero_words, fuse.len_max_u);
+  }
+  if (fuse.general) {
+    {
+      Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 1);
+      hipLaunchKernelGGL((k_bucket_sort<3, 3>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], sb.end[0], sb.rid[0],
+                         ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse.dev);
+    }
+    Phase ph(ctx, st, GIQL_PH_AUX, 1);
+    hipLaunchKernelGGL((k_bucket_sort_big<3, 3>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], sb.end[0], sb.rid[0],
+                       sb.key[1], sb.end[1], sb.rid[1], ctx->bucket_bnd, ctx->bucket_big, fuse.dev);
+    return;
   }
   {
     Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 1);
@@ -586,6 +599,7 @@ static void launch_bucket_stage_fused(giql_hip_ctx* ctx, hipStream_t st, SortBuf
 // bounds form: the ids written, the queries' keys and end keys read, two bounds each written; join form: the
 // queries' keys, end keys and ids read
 static int64_t bucket_stage_fused_bytes(u32 n, const FuseCount& fuse) {
+  if (fuse.general) return (int64_t)12 * n + (int64_t)12 * fuse.nq_total;  // (key, end, rid) of both sides read
   return fuse.join ? (int64_t)8 * n + (int64_t)12 * fuse.nq_total : (int64_t)12 * n + (int64_t)16 * fuse.nq_total;
 }
 
@@ -597,7 +611,7 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
   if (presorted) {
     // the side arrives sorted: no scatter pass, one streaming pass for what a sort would have left in buffer 0
     const int mode = (sb.rid[0] ? 1 : 0) | (sb.end[0] ? 2 : 0);
-    const bool local_fused = fuse && mode == 1 && sort_is_local(ctx, n);
+    const bool local_fused = fuse && mode == (fuse->general ? 3 : 1) && sort_is_local(ctx, n);
     {
       Phase ph(ctx, st, GIQL_PH_SORT_SCATTER, 1);
       u32 grid = cdiv(n, 256 * 8);
@@ -682,7 +696,7 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
   if (local) {
     // the rows are back in buffer 0, ordered by key >> 16: bucket boundaries, then one block per bucket
     const int mode = (sb.rid[0] ? 1 : 0) | (sb.end[0] ? 2 : 0);
-    if (fuse && mode == 1) {
+    if (fuse && mode == (fuse->general ? 3 : 1)) {
       // (key, rid) rows + the query side's bounds: keys and rids read, rids written, the query rows' keys
       // and ends read and their two bounds written -- the sorted keys never leave the CU
       launch_bucket_stage_fused(ctx, st, sb, n, gbase, *fuse);
@@ -1448,8 +1462,16 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     ctx->fuse_done = fused && ctx->h_meta->irr_a + ctx->h_meta->irr_b == 0 && ctx->n_reg <= ctx->fuse_cap;
     if (ctx->bucket_join) ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += (int64_t)8 * (int64_t)ctx->n_reg;  // the pairs
   } else {
-  // the smaller side's chain (linearize + sort) beside the larger side's when it is small
-  SideChain sc(ctx, st, onesweep ? (na < nb ? na : nb) : 0, na < nb ? nb : na);
+  // The join itself in B's bucket stage (bucket_sort.hip.h, FUSE == 3): one-call form, on the context's guesses (the
+  // general form again, no irregular row, no row longer than the windows allow for), B the three-stage side, the A
+  // rows -- fully sorted -- sparse enough for a bucket's window to stay in a block's registers.
+  const bool general_join = onesweep && !ctx->no_bucket_join && ctx->fuse_a && speculated && ctx->last_no_irr &&
+                            ctx->fuse_cap > 0 && nb >= na && sort_is_local(ctx, nb) && ctx->spec_fuse_len_ok &&
+                            ctx->last_span > 0 &&
+                            1.5 * (double)na * 65536.0 / (double)ctx->last_span <= 0.5 * (double)BJ_WCAP;
+  // the smaller side's chain (linearize + sort) beside the larger side's when it is small (not in the form above:
+  // B's last stage reads the sorted A)
+  SideChain sc(ctx, st, (onesweep && !general_join) ? (na < nb ? na : nb) : 0, na < nb ? nb : na);
   const bool a_small = na < nb;
   hipStream_t st_a = a_small ? sc.stream() : st, st_b = a_small ? st : sc.stream();
   const bool kg_a = keygen_g && !big_side, kg_b = keygen_g && big_side;
@@ -1475,13 +1497,43 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   if (onesweep) {
     GIQL_TRY(run_sort_onesweep(ctx, st_a, sa, (u32)na, gbase_a, a_small ? os_status2 : os_status,
                                false, kg_a ? a : nullptr, lb.abase, 0, nullptr, pre_a));
+    FuseCount fg;
+    if (general_join) {
+      fg.join = fg.general = true;
+      fg.zero_ptr = reinterpret_cast<u32*>(scan_chain);
+      fg.zero_words = 0;
+      fg.dev.qkey = sa.key[0];
+      fg.dev.qend = sa.end[0];
+      fg.dev.qrid = sa.rid[0];
+      fg.dev.qwin = ctx->bucket_qwin;
+      fg.dev.lo_out = fg.dev.hi_out = nullptr;
+      fg.dev.lo_off = 1;  // class 2: b.start in (a.start, a.end)
+      fg.dev.row_q = ctx->fuse_a;
+      fg.dev.row_s = ctx->fuse_b;
+      fg.dev.cap = ctx->fuse_cap;
+      fg.dev.cursor = reinterpret_cast<unsigned long long*>(&ctx->d_meta->n_out);  // zeroed by the span pass
+      fg.nq_total = (u32)na;
+      fg.irr_q = irr_a;
+      fg.gbq3 = gbase_a + 3 * OS_BINS;
+      fg.key_mask = 0xFFFFFFFFu;
+      fg.len_max_q = &ctx->d_meta->len_max_a;
+      fg.len_max_u = &ctx->d_meta->len_max_b;
+    }
     GIQL_TRY(run_sort_onesweep(ctx, st_b, sbb, (u32)nb, gbase_b, a_small ? os_status : os_status2,
-                               false, kg_b ? b : nullptr, lb.abase, 0, nullptr, pre_b));
+                               false, kg_b ? b : nullptr, lb.abase, 0, general_join ? &fg : nullptr, pre_b));
     GIQL_TRY(sc.join());
   } else {
     GIQL_TRY(run_sort(ctx, st, sa, (u32)na, tile_hist, bsums));
     GIQL_TRY(run_sort(ctx, st, sbb, (u32)nb, tile_hist, bsums));
   }
+  if (ctx->bucket_join) {
+    // the pairs are out already, counted in DevMeta::n_out
+    GIQL_TRY(read_meta(ctx, st));
+    ctx->n_c1 = 0;
+    ctx->n_reg = ctx->h_meta->n_out;
+    ctx->fuse_done = ctx->h_meta->irr_a + ctx->h_meta->irr_b == 0 && ctx->n_reg <= ctx->fuse_cap;
+    ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += (int64_t)8 * (int64_t)ctx->n_reg;  // the pairs
+  } else {
   // class 1 (count + the scan of its block totals) runs beside class 2 when both sides are small
   SideChain sc1(ctx, st, onesweep ? (na < nb ? na : nb) : 0, na < nb ? nb : na, 2);
   hipStream_t st1 = sc1.stream();
@@ -1527,6 +1579,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   ctx->n_c1 = ctx->h_meta->n_out_c1;
   ctx->n_reg = ctx->h_meta->n_out + ctx->n_c1;
   }
+  }
   if (onesweep) {
     int form;
     i64 len;
@@ -1540,7 +1593,9 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     if (keygen_wrong) ctx->last_no_irr = false;
     // the fused count's windows allow for query rows up to BS_FUSE_WCAP long (the query side of the form just decided)
     const int q_len_now = form == 1 ? ctx->h_meta->len_max_a : ctx->h_meta->len_max_b;
-    const bool fuse_len_ok_now = form != 0 && q_len_now <= (int)BS_FUSE_WCAP;
+    const bool fuse_len_ok_now = form != 0 ? q_len_now <= (int)BS_FUSE_WCAP
+                                           : (ctx->h_meta->len_max_a <= (int)BS_FUSE_WCAP &&
+                                              ctx->h_meta->len_max_b <= (int)BS_FUSE_WCAP);  // (general form: both sides' rows)
     const bool fuse_wrong = ctx->count_fused && !fuse_len_ok_now;
     ctx->spec_fuse_len_ok = fuse_len_ok_now;
     // a side taken as sorted must be: an out-of-order row was left where it was

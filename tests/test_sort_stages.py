@@ -446,3 +446,79 @@ def test_bucket_join_with_buffers_too_small_reports_the_count_and_keeps_a_plan(e
     eng_local.inner_fill(fa, fb)                        # the plan behind the error is an ordinary one
     assert np.array_equal(ora.sort_pairs(fa.cpu().numpy(), fb.cpu().numpy()), want)
     _join_into(eng_local, peaks, reads, 3)              # and with room the same context joins in the bucket stage again
+
+
+# ---- the general (two-class) join in the bucket stage: rows of any length (round 3) ----------------------------
+def _plain(e, a, b, nch):
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    got = _inner(e, a, b, nch)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_general_bucket_join_matches_the_oracle_in_both_argument_orders(eng_local):
+    reads = rand_side(1701, 400_000, 5, 30_000_000, 400, min_len=30)     # variable-length reads: the general form
+    peaks = rand_side(1702, 60_000, 5, 30_000_000, 2000, min_len=200)
+    _plain(eng_local, peaks, reads, 5)               # a first plan: the context learns form, span, lengths
+    st = _join_into(eng_local, peaks, reads, 5)
+    assert st["join_form"] == "general" and st["fused_fill"] and st["sort_local"]
+    _join_into(eng_local, peaks, reads, 5)
+    _plain(eng_local, reads, peaks, 5)
+    st = _join_into(eng_local, reads, peaks, 5)     # larger table first: planned with the sides exchanged
+    assert st["swapped"] and st["join_form"] == "general"
+    # equal starts on both sides (class 1 takes them, class 2 must not), starts at the bucket boundaries
+    r = np.random.default_rng(1703)
+    grid = (r.integers(0, 600, 50_000) * 65536 // 8).astype(np.int32)
+    b2 = ora.Side(np.zeros(grid.size, np.int32), grid, grid + r.integers(1, 20_000, grid.size).astype(np.int32))
+    a2 = ora.Side(np.zeros(8_000, np.int32), grid[:8_000].copy(), grid[:8_000] + r.integers(1, 30_000, 8_000).astype(np.int32))
+    _plain(eng_local, a2, b2, 1)
+    _join_into(eng_local, a2, b2, 1)
+
+
+def test_general_bucket_join_encodings_irregular_rows_and_long_rows(eng_local):
+    reads = rand_side(1711, 300_000, 3, 20_000_000, 300, min_len=20)
+    peaks = rand_side(1712, 30_000, 3, 20_000_000, 3000)
+    _plain(eng_local, peaks, reads, 3)
+    _join_into(eng_local, peaks, reads, 3)
+    joined = 0
+    for enc in ora.ENCODING_OFFSETS:
+        so, eo = ora.ENCODING_OFFSETS[enc]
+        side = ora.Side(reads.chrom, reads.start, reads.end, so, eo)
+        _join_into(eng_local, peaks, side, 3, expect_join=None)
+        joined += int(_join_into(eng_local, peaks, side, 3, expect_join=None)["bucket_join"])
+    assert joined >= 2
+    _join_into(eng_local, peaks, reads, 3, expect_join=None)
+    _join_into(eng_local, peaks, reads, 3)
+    # an irregular row on the larger side: the guess fails at the read-back, planned again the ordinary way
+    re = reads.end.copy()
+    re[::9] = reads.start[::9]
+    irr = ora.Side(reads.chrom, reads.start, re)
+    _join_into(eng_local, peaks, irr, 3, expect_join=False)
+    _join_into(eng_local, peaks, irr, 3, expect_join=False)
+    _join_into(eng_local, peaks, reads, 3, expect_join=False)
+    _join_into(eng_local, peaks, reads, 3)
+    # one row longer than the windows allow for: declined at the read-back, and from then on by the guess
+    long_ = rand_side(1713, 300_000, 3, 20_000_000, 300, min_len=20)
+    long_.end[17] = long_.start[17] + 2_000_000
+    _join_into(eng_local, peaks, long_, 3, expect_join=False)
+    _join_into(eng_local, peaks, long_, 3, expect_join=False)
+
+
+def test_general_bucket_join_queued_buckets_and_small_buffers(eng_local):
+    from giql_amd import _lib
+
+    # ~6,500 rows in every 65536-wide window: every bucket goes through the queue
+    reads = rand_side(1721, 700_000, 1, 7_000_000, 300, min_len=50)
+    peaks = rand_side(1722, 40_000, 1, 7_000_000, 2500)
+    _plain(eng_local, peaks, reads, 1)
+    _join_into(eng_local, peaks, reads, 1)
+    # buffers too small: the count comes back, the plan behind the error is an ordinary one
+    want = ora.sort_pairs(*ora.c_inner(peaks, reads, "sweep"))
+    ra = torch.full((want.shape[0] // 3,), -7, dtype=torch.int32, device="cuda:0")
+    rb = torch.full_like(ra, -7)
+    with pytest.raises(_lib.GiqlHipError) as exc:
+        eng_local.inner_join_into(dev(peaks), dev(reads), 1, ra, rb)
+    assert exc.value.code == _lib.GIQL_ERR_CAPACITY and eng_local.last_pairs == want.shape[0]
+    fa = torch.empty(want.shape[0], dtype=torch.int32, device="cuda:0")
+    fb = torch.empty_like(fa)
+    eng_local.inner_fill(fa, fb)
+    assert np.array_equal(ora.sort_pairs(fa.cpu().numpy(), fb.cpu().numpy()), want)
