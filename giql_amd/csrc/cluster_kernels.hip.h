@@ -18,6 +18,7 @@
 // is what the kernels below read.
 #pragma once
 #include "dev_common.hip.h"
+#include "select_kernels.hip.h"
 
 namespace giql {
 
@@ -38,6 +39,17 @@ __global__ __launch_bounds__(256) void k_cluster_flags(const u32* __restrict__ k
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || i == 0) return;
   if ((u64)pmax_incl[i - 1] + distance < (u64)keys[i]) flags[i] = 1;
+}
+
+// predicate := ... PREV(col) (src/giql/expanders/cluster.py:281-296, 587-640): a row stays in the running cluster only
+// when it is adjacent AND the predicate holds between it (operand side A) and its immediate sorted predecessor
+// (side B = the LAG over the same partition and order); a NULL operand makes the predicate not true, i.e. a new
+// cluster, as the emitted CASE's ELSE arm does.  A partition's first row is flagged already (its LAG is NULL).
+__global__ __launch_bounds__(256) void k_cluster_pred_flags(const u32* __restrict__ rids, u32 n, DevPreds ps,
+                                                            u32* __restrict__ flags) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || i == 0 || flags[i]) return;
+  if (!sel_eval(ps, (int)rids[i], (int)rids[i - 1])) flags[i] = 1;
 }
 
 // cluster id of every row, 1-based within its partition, scattered by row id

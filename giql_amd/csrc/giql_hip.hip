@@ -2335,7 +2335,8 @@ struct ClusterBufs {
 };
 
 static int cluster_front(giql_hip_ctx* ctx, hipStream_t st, const giql_side* s, int32_t n_chrom,
-                         int64_t distance, bool want_rids, bool want_heads, ClusterBufs& cb) {
+                         int64_t distance, bool want_rids, bool want_heads, ClusterBufs& cb,
+                         const DevPreds* preds = nullptr) {
   const size_t n = (size_t)s->n;
   auto carve = [&](char* base) {
     Carver c{base};
@@ -2380,6 +2381,9 @@ static int cluster_front(giql_hip_ctx* ctx, hipStream_t st, const giql_side* s, 
                        n_chrom, (u32)n, cb.flags);
     hipLaunchKernelGGL(k_cluster_flags, dim3(cdiv(n, 256)), dim3(256), 0, st, cb.sb.key[0], cb.pmax,
                        (u32)n, (u64)(distance > 0 ? distance : 0), cb.flags);
+    if (preds && preds->n > 0)  // (needs the row ids: want_rids)
+      hipLaunchKernelGGL(k_cluster_pred_flags, dim3(cdiv(n, 256)), dim3(256), 0, st, cb.sb.rid[0], (u32)n, *preds,
+                         cb.flags);
     GIQL_TRY(post_launch("cluster flags"));
   }
   GIQL_TRY(run_scan<u32>(ctx, st, GIQL_PH_SCAN, cb.flags, (u64)n, cb.excl, cb.bsums, cb.total));
@@ -2406,7 +2410,7 @@ static int cluster_status(giql_hip_ctx* ctx, hipStream_t st) {
 }
 
 static int giql_hip_cluster_dev_impl(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
-                         int64_t* cluster_id_out, void* stream) {
+                         int64_t* cluster_id_out, void* stream, const DevPreds* preds = nullptr) {
   GIQL_TRY(check_cluster_args(ctx, s, n_chrom));
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
@@ -2417,7 +2421,7 @@ static int giql_hip_cluster_dev_impl(giql_hip_ctx* ctx, const giql_side* s, int3
   if (!cluster_id_out) return set_err(GIQL_ERR_INVALID, "cluster_id_out is NULL");
   if (n_chrom == 0) return set_err(GIQL_ERR_CHROM, "rows but n_chrom = 0");
   ClusterBufs cb;
-  GIQL_TRY(cluster_front(ctx, st, s, n_chrom, distance, true, false, cb));
+  GIQL_TRY(cluster_front(ctx, st, s, n_chrom, distance, true, false, cb, preds));
   {
     Phase ph(ctx, st, GIQL_PH_FILL);
     hipLaunchKernelGGL(k_cluster_ids, dim3(cdiv((u64)s->n, 256)), dim3(256), 0, st, cb.sb.key[0],
@@ -2435,6 +2439,25 @@ static int giql_hip_cluster_dev_impl(giql_hip_ctx* ctx, const giql_side* s, int3
 int giql_hip_cluster_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
                          int64_t* cluster_id_out, void* stream) {
   return with_order_fallback(ctx, [&] { return giql_hip_cluster_dev_impl(ctx, s, n_chrom, distance, cluster_id_out, stream); });
+}
+
+static int check_operand(const giql_operand& o, int k, const char* which);
+
+int giql_hip_cluster_pred_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
+                              const giql_pred* preds, int32_t n_preds, int64_t* cluster_id_out, void* stream) {
+  if (n_preds < 0 || n_preds > SEL_MAX_PREDS || (n_preds && !preds))
+    return set_err(GIQL_ERR_INVALID, "bad predicates (at most %d)", SEL_MAX_PREDS);
+  DevPreds ps;
+  memset(&ps, 0, sizeof(ps));
+  ps.n = n_preds;
+  for (int k = 0; k < n_preds; k++) {
+    if (preds[k].op < GIQL_OP_EQ || preds[k].op > GIQL_OP_GE)
+      return set_err(GIQL_ERR_INVALID, "predicate %d: operator %d", k, preds[k].op);
+    GIQL_TRY(check_operand(preds[k].lhs, k, "lhs"));
+    GIQL_TRY(check_operand(preds[k].rhs, k, "rhs"));
+    memcpy(&ps.p[k], &preds[k], sizeof(DevPred));
+  }
+  return with_order_fallback(ctx, [&] { return giql_hip_cluster_dev_impl(ctx, s, n_chrom, distance, cluster_id_out, stream, &ps); });
 }
 
 static int giql_hip_merge_dev_impl(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,

@@ -407,10 +407,15 @@ class HipEngine:
         z = torch.empty(0, dtype=torch.int32, device=self.device)
         return DeviceSide(z, z.clone(), z.clone(), 0, 0)
 
-    def cluster(self, s: DeviceSide, n_chrom: int, distance: int = 0):
+    def cluster(self, s: DeviceSide, n_chrom: int, distance: int = 0, preds=None):
         """CLUSTER ids per row (int64, 1-based within each partition ``s.chrom``):
-        ``src/giql/expanders/cluster.py:210-300``.  Raw coordinates (offsets must be 0)."""
+        ``src/giql/expanders/cluster.py:210-300``.  Raw coordinates (offsets must be 0).
+        ``preds`` (``predicate := ... PREV(col)``, cluster.py:281-296): ``[(lhs, op, rhs)]`` as for
+        :meth:`select`, operand ``("a", column)`` = the current row's value, ``("b", column)`` = its sorted
+        predecessor's; columns are device tensors of ``s.n`` rows."""
         torch = _torch()
+        if preds:
+            return self._cluster_pred(s, n_chrom, distance, preds)
         try:
             return self._cluster_once(s, n_chrom, distance)
         except _lib.GiqlHipError as exc:
@@ -419,6 +424,27 @@ class HipEngine:
         ids = torch.zeros(s.n, dtype=torch.int64, device=self.device)
         for sub, rows, _sb, _rb in self._groups(s, self._empty_side(s), n_chrom):
             ids[rows] = self._cluster_once(sub, n_chrom, distance)
+        return ids
+
+    def _cluster_pred(self, s: DeviceSide, n_chrom: int, distance: int, preds):
+        torch = _torch()
+        k = len(preds)
+        c_preds = (_lib.CPred * max(k, 1))()
+        keep_alive = []
+        for j, (lhs, op, rhs) in enumerate(preds):
+            if op not in _lib.OPS:
+                raise ValueError(f"operator {op!r}")
+            for o in (lhs, rhs):
+                if o[0] in ("a", "b") and int(o[1].shape[0]) != s.n:
+                    raise ValueError("a predicate column must have one value per row of the table")
+            c_preds[j].lhs, ka = self._c_operand(lhs)
+            keep_alive.append(ka)
+            c_preds[j].rhs, ka = self._c_operand(rhs)
+            keep_alive.append(ka)
+            c_preds[j].op = _lib.OPS[op]
+        ids = torch.empty(s.n, dtype=torch.int64, device=self.device)
+        _lib.check(self._L.giql_hip_cluster_pred_dev(self._h, s.c_struct(), int(n_chrom), int(distance), c_preds, k,
+                                                     ids.data_ptr() if s.n else None, self._stream()))
         return ids
 
     def _cluster_once(self, s: DeviceSide, n_chrom: int, distance: int):

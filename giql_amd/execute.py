@@ -338,7 +338,13 @@ def _execute_cluster_merge(plan: JoinPlan, tables, eng: HipEngine, return_indice
         dev_side = _subset(eng, dev_side, keep)
 
     if plan.kind == "CLUSTER":
-        ids = eng.cluster(dev_side, n_part, plan.distance)
+        preds = None
+        if plan.cluster_predicate:
+            # predicate := ... PREV(col): both operand sides read the SAME table (the rows the WHERE kept), the current
+            # row through side "l", its sorted predecessor through side "r" (cluster.py:281-296, 587-640)
+            ptbl = tbl if keep is None else _rows_of(tbl, keep.cpu().numpy())
+            preds = _Residuals(plan, ptbl, ptbl, eng).preds(plan.cluster_predicate)
+        ids = eng.cluster(dev_side, n_part, plan.distance, preds=preds)
         if return_indices:
             return (keep.cpu().numpy() if keep is not None else np.arange(dev_side.n)), ids.cpu().numpy()
         is_arrow = isinstance(tbl, pa.Table)

@@ -103,6 +103,9 @@ class JoinPlan:
     distance: int = 0
     stranded: bool = False
     strand_col: str | None = None
+    # CLUSTER(..., predicate := <comparison> [AND ...]) (src/giql/expanders/cluster.py:281-296): operand kind "l" = the
+    # current row's column, "r" = PREV(column) -- the sorted predecessor's -- or a literal; clause "predicate"
+    cluster_predicate: tuple[Residual, ...] = field(default_factory=tuple)
     # the clauses that ride on the reference's outer SELECT wrapper (intersects_duckdb.py:1336-1400),
     # finished on the projected table: projection columns named "__giql_*" are carried for them only
     aggregates: tuple[Aggregate, ...] = field(default_factory=tuple)
@@ -124,6 +127,7 @@ class JoinPlan:
         d = asdict(self)
         d["projection"] = [asdict(p) for p in self.projection]
         d["residuals"] = [asdict(r) for r in self.residuals]
+        d["cluster_predicate"] = [asdict(r) for r in self.cluster_predicate]
         d["aggregates"] = [asdict(a) for a in self.aggregates]
         d["having"] = [asdict(h) for h in self.having]
         d["order_by"] = [list(o) for o in self.order_by]
@@ -143,6 +147,8 @@ class JoinPlan:
             residuals=tuple(Residual(r["clause"], Operand(**r["lhs"]), r["op"], Operand(**r["rhs"]))
                             for r in d.get("residuals", ())),
             distance=d.get("distance", 0), stranded=d.get("stranded", False), strand_col=d.get("strand_col"),
+            cluster_predicate=tuple(Residual(r["clause"], Operand(**r["lhs"]), r["op"], Operand(**r["rhs"]))
+                                    for r in d.get("cluster_predicate", ())),
             aggregates=tuple(Aggregate(**a) for a in d.get("aggregates", ())),
             having=tuple(Having(Operand(**h["lhs"]), h["op"], Operand(**h["rhs"])) for h in d.get("having", ())),
             group_by=tuple(d.get("group_by", ())),

@@ -582,13 +582,71 @@ def _has_cluster_or_merge(p: _Parser) -> bool:
     return False
 
 
+def _parse_prev_operand(p: _Parser):
+    """An operand of a CLUSTER predicate: ``PREV(<column>)`` (the sorted predecessor's value), a column of the
+    current row, or a literal.  ``PREV`` takes exactly one column and does not nest (cluster.py:623-633)."""
+    t = p.peek()
+    if t.kind == "id" and not t.quoted and t.text.upper() == "PREV" and p.peek(1).kind == "punct" and p.peek(1).text == "(":
+        p.next()
+        p.expect_punct("(")
+        if p.at_punct(")"):
+            raise ValueError("PREV() takes exactly one column argument; got 0.")
+        inner = p.peek()
+        if inner.kind == "id" and not inner.quoted and inner.text.upper() == "PREV" and p.peek(1).kind == "punct" \
+                and p.peek(1).text == "(":
+            raise ValueError("PREV() cannot be nested; a CLUSTER/MERGE predicate compares only the immediate predecessor.")
+        if inner.kind != "id":
+            raise _decline("PREV() of an expression")
+        ref = p.colref()
+        if p.at_punct(","):
+            raise ValueError("PREV() takes exactly one column argument; got 2.")
+        if not p.at_punct(")"):
+            raise _decline("PREV() of an expression")
+        p.expect_punct(")")
+        return ("prev", ref)
+    return _parse_operand(p)
+
+
+def _parse_cluster_predicate(p: _Parser):
+    """``<operand> op <operand> (AND ...)*`` up to the argument's end; OR / NOT / parentheses / arithmetic decline."""
+    terms = []
+    while True:
+        if p.at_kw("NOT") or p.at_punct("("):
+            raise _decline("NOT / parenthesised CLUSTER predicate")
+        lhs = _parse_prev_operand(p)
+        t = p.peek()
+        op = None
+        if t.kind == "punct" and t.text in "=<>!":
+            p.next()
+            op = t.text
+            n = p.peek()
+            if n.kind == "punct" and ((op == "<" and n.text in "=>") or (op == ">" and n.text == "=")
+                                      or (op == "!" and n.text == "=")):
+                p.next()
+                op += n.text
+        if op is None or op == "!":
+            raise _decline("CLUSTER predicate other than simple comparisons")
+        op = {"<>": "!=", "==": "="}.get(op, op)
+        rhs = _parse_prev_operand(p)
+        if p.peek().kind == "punct" and p.peek().text in "+-*/":
+            raise _decline("arithmetic in a CLUSTER predicate")
+        terms.append((lhs, op, rhs))
+        if p.at_kw("AND"):
+            p.next()
+            continue
+        if p.at_kw("OR"):
+            raise _decline("OR in a CLUSTER predicate")
+        return terms
+
+
 def _parse_cluster_call(p: _Parser):
-    """``CLUSTER(`` / ``MERGE(`` argument list -> ``(genomic colref, distance, stranded)``;
+    """``CLUSTER(`` / ``MERGE(`` argument list -> ``(genomic colref, distance, stranded, predicate terms)``;
     named arguments accept ``:=``, ``=`` and ``=>`` (tests/test_cluster_parsing.py:22-75)."""
     p.expect_punct("(")
     this = None
     distance = 0
     stranded = False
+    predicate = []
     n_pos = 0
     while not p.at_punct(")"):
         named = None
@@ -617,14 +675,16 @@ def _parse_cluster_call(p: _Parser):
             if p.peek().kind != "num" or "." in p.peek().text:
                 raise _decline("non-literal CLUSTER / MERGE distance")
             distance = int(p.next().text)
+        elif named == "predicate":
+            predicate = _parse_cluster_predicate(p)
         else:
-            raise _decline(f"CLUSTER / MERGE argument {named!r}")  # predicate := ... PREV(col)
+            raise _decline(f"CLUSTER / MERGE argument {named!r}")
         if p.at_punct(","):
             p.next()
     p.expect_punct(")")
     if this is None:
         raise ValueError("CLUSTER requires a genomic interval column as its first argument.")
-    return this, distance, stranded
+    return this, distance, stranded, predicate
 
 
 def _lower_cluster(p: _Parser, tbls: Tables) -> JoinPlan:
@@ -694,7 +754,9 @@ def _lower_cluster(p: _Parser, tbls: Tables) -> JoinPlan:
         raise ValueError("CLUSTER and MERGE cannot be combined in one SELECT")  # reject_cluster_merge_mix
     if len(ops) > 1:
         raise ValueError(f"Multiple {ops[0][0]} expressions not yet supported")  # cluster.py:176-181, merge.py:173-175
-    op, (this, distance, stranded), op_alias = ops[0]
+    op, (this, distance, stranded, predicate), op_alias = ops[0]
+    if predicate and op == "MERGE":
+        raise _decline("MERGE with a predicate")  # (the merged MAX(end) is then a segmented maximum: not built)
     if this.star or (this.table is not None and _norm(this.table, this.table_quoted) != side.alias) \
             or this.column != table.genomic_col:
         raise ValueError(f"{op} operand must be the table's genomic column ({table.genomic_col!r})")
@@ -756,8 +818,18 @@ def _lower_cluster(p: _Parser, tbls: Tables) -> JoinPlan:
         if a.kind != "l" and b.kind != "l":
             raise _decline("constant predicate")
         residuals.append(Residual("where", a, cmp_op, b))
+    cluster_pred = []
+    for lhs, cmp_op, rhs in predicate:
+        def pbind(o) -> Operand:
+            if o[0] == "lit":
+                v = o[1]
+                return Operand("str" if isinstance(v, str) else ("float" if isinstance(v, float) else "int"), v)
+            return Operand("r" if o[0] == "prev" else "l", own(o[1]))
+
+        cluster_pred.append(Residual("predicate", pbind(lhs), cmp_op, pbind(rhs)))
     return JoinPlan(op, side, None, tuple(proj), residuals=tuple(residuals), distance=distance,
-                    stranded=stranded, strand_col=table.strand_col if stranded else None)
+                    stranded=stranded, strand_col=table.strand_col if stranded else None,
+                    cluster_predicate=tuple(cluster_pred))
 
 
 def build_plan(giql: str, tables=None) -> JoinPlan:

@@ -220,6 +220,17 @@ int giql_hip_chrom_spans_dev(giql_hip_ctx* ctx, const giql_side* a,
  * need start <= end (GIQL_ERR_INVALID otherwise). */
 int giql_hip_cluster_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom,
                          int64_t distance, int64_t* cluster_id_out, void* stream);
+/* CLUSTER(interval[, d], predicate := <conjunction of comparisons over columns and PREV(col)>),
+ * src/giql/expanders/cluster.py:281-296, 587-640: a row stays in the running cluster only when
+ * it is adjacent AND every predicate holds between it and its immediate predecessor in the
+ * partition's start order (the LAG the reference emits).  giql_pred (declared below, with the
+ * residual predicates) reads the current row through operand side A and the predecessor through
+ * side B -- both DEVICE columns of s->n rows, addressed by row id; a NULL operand starts a new
+ * cluster (the CASE's ELSE arm).  Rows of equal start keep their input order. */
+struct giql_pred;
+int giql_hip_cluster_pred_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom,
+                              int64_t distance, const struct giql_pred* preds, int32_t n_preds,
+                              int64_t* cluster_id_out, void* stream);
 /* MERGE: src/giql/expanders/merge.py:186-330 -- GROUP BY chrom, cluster id ->
  * chrom, MIN(start), MAX(end) [, COUNT(*) when out_count != NULL], ordered by
  * (chrom, start).  Outputs have `capacity` entries (s->n always suffices);

@@ -345,6 +345,30 @@ def c_cluster(s: Side, distance: int = 0) -> np.ndarray:
     return ids
 
 
+def py_cluster_predicate(part, start, end, distance, holds) -> np.ndarray:
+    """CLUSTER with ``predicate := ...`` restated (src/giql/expanders/cluster.py:210-300, 281-296): per partition
+    (``part``: any hashable per row), rows in start order (equal starts: input order -- upstream leaves that to the
+    engine), a row opens a new cluster unless the running MAX(end) of the partition's preceding rows + distance
+    reaches its start AND ``holds(row, predecessor_row)`` is true; ids count from 1 inside a partition.  ``holds``
+    gets row indices and must return False where the SQL predicate is NULL.  Pure Python: small cases only."""
+    n = len(start)
+    ids = np.zeros(n, np.int64)
+    groups: dict = {}
+    for i in range(n):
+        groups.setdefault(part[i], []).append(i)
+    for rows in groups.values():
+        rows.sort(key=lambda i: (start[i], i))
+        cid, run_max, prev = 0, None, None
+        for i in rows:
+            keep = prev is not None and run_max + max(int(distance), 0) >= start[i] and holds(i, prev)
+            if not keep:
+                cid += 1
+            ids[i] = cid
+            run_max = end[i] if run_max is None else max(run_max, end[i])
+            prev = i
+    return ids
+
+
 def c_merge(s: Side, distance: int = 0):
     n = ctypes.c_int64(0)
     pc, ps, pe, pn = (ctypes.c_void_p() for _ in range(4))

@@ -1,0 +1,114 @@
+"""CLUSTER(interval, ..., predicate := <comparisons over columns and PREV(col)>): the reference's
+src/giql/expanders/cluster.py:281-296, 587-640 (tests/test_cluster_predicate_transpilation.py pins the emitted SQL).
+Golden cluster ids: tests/golden/cluster_predicate.json, minted by sqlite3 executing that window SQL
+(tests/golden/make_cluster_predicate.py).  CPU: the oracle's restatement and the plan builder; GPU: execute()."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from giql_amd.transpile import HipDeclined, build_plan
+from oracle import pyoracle as ora
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = json.load(open(os.path.join(HERE, "golden", "cluster_predicate.json")))["cases"]
+COLS = ["chrom", "start", "end", "strand", "depth", "name", "score"]
+
+
+def _query(case) -> str:
+    args = ["interval"] + ([str(case["distance"])] if case["distance"] else []) \
+        + (["stranded := true"] if case["stranded"] else []) + [f"predicate := {case['predicate']}"]
+    return f"SELECT *, CLUSTER({', '.join(args)}) AS cid FROM features"
+
+
+def _holds(plan, rows):
+    """The plan's predicate as a Python function of (row, predecessor): SQL comparison, NULL -> False."""
+    import operator
+
+    ops = {"=": operator.eq, "!=": operator.ne, "<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge}
+
+    def value(o, i, j):
+        if o.kind in ("l", "r"):
+            return rows[i if o.kind == "l" else j][COLS.index(o.value)]
+        return o.value
+
+    def holds(i, j):
+        for r in plan.cluster_predicate:
+            a, b = value(r.lhs, i, j), value(r.rhs, i, j)
+            if a is None or b is None or not ops[r.op](a, b):
+                return False
+        return True
+
+    return holds
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_oracle_restatement_matches_the_sqlite_minted_ids(case):
+    plan = build_plan(_query(case), ["features"])
+    assert plan.kind == "CLUSTER" and plan.cluster_predicate and plan.stranded == case["stranded"]
+    rows = case["rows"]
+    part = [(r[0], r[3]) if case["stranded"] else r[0] for r in rows]
+    got = ora.py_cluster_predicate(part, [r[1] for r in rows], [r[2] for r in rows], case["distance"], _holds(plan, rows))
+    assert got.tolist() == case["ids"]
+
+
+def test_predicate_plan_shape_and_the_reference_s_errors():
+    p = build_plan("SELECT *, CLUSTER(interval, predicate := depth = PREV(depth)) AS cid FROM peaks", ["peaks"])
+    (r,) = p.cluster_predicate
+    assert (r.lhs.kind, r.lhs.value, r.op, r.rhs.kind, r.rhs.value) == ("l", "depth", "=", "r", "depth")
+    p = build_plan("SELECT *, CLUSTER(interval, 10, stranded := true, predicate := end = PREV(start) AND score > 0.5) "
+                   "AS cid FROM peaks", ["peaks"])
+    assert p.distance == 10 and p.stranded and [(r.lhs.value, r.op, r.rhs.kind) for r in p.cluster_predicate] == \
+        [("end", "=", "r"), ("score", ">", "float")]
+    # the plan's string form carries the predicate
+    from giql_amd.plan import JoinPlan
+
+    assert JoinPlan.from_string(p.to_string()).cluster_predicate == p.cluster_predicate
+    # PREV() takes exactly one column and does not nest (cluster.py:623-633)
+    with pytest.raises(ValueError, match="exactly one column"):
+        build_plan("SELECT *, CLUSTER(interval, predicate := depth = PREV(depth, name)) AS cid FROM peaks", ["peaks"])
+    with pytest.raises(ValueError, match="cannot be nested"):
+        build_plan("SELECT *, CLUSTER(interval, predicate := depth = PREV(PREV(depth))) AS cid FROM peaks", ["peaks"])
+    # shapes this target has no evaluator for decline (the reference inlines arbitrary SQL text there)
+    for q in ("SELECT *, CLUSTER(interval, predicate := depth = PREV(depth) OR name = PREV(name)) AS cid FROM peaks",
+              "SELECT *, CLUSTER(interval, predicate := (depth = PREV(depth))) AS cid FROM peaks",
+              "SELECT *, CLUSTER(interval, predicate := depth + 1 = PREV(depth)) AS cid FROM peaks",
+              "SELECT MERGE(interval, predicate := depth = PREV(depth)) FROM peaks"):
+        with pytest.raises(HipDeclined):
+            build_plan(q, ["peaks"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_execute_cluster_predicate_golden(case):
+    pa = pytest.importorskip("pyarrow")
+    pytest.importorskip("torch")
+    from giql_amd.execute import execute
+
+    rows = case["rows"]
+    types = [pa.string(), pa.int32(), pa.int32(), pa.string(), pa.int64(), pa.string(), pa.float64()]
+    tbl = pa.table({c: pa.array([r[k] for r in rows], type=t) for k, (c, t) in enumerate(zip(COLS, types))})
+    out = execute(_query(case), {"features": tbl}, giql_tables=["features"])
+    assert out.column("cid").to_pylist() == case["ids"]
+    assert out.column("start").to_pylist() == [r[1] for r in rows]
+
+
+@pytest.mark.gpu
+def test_execute_cluster_predicate_behind_a_where_filter():
+    pa = pytest.importorskip("pyarrow")
+    pytest.importorskip("torch")
+    from giql_amd.execute import execute
+
+    r = np.random.default_rng(5)
+    n = 5000
+    start = np.sort(r.choice(2_000_000, n, replace=False)).astype(np.int32)
+    tbl = pa.table({"chrom": pa.array(r.choice(["chr1", "chr2"], n).tolist()), "start": start,
+                    "end": (start + r.integers(50, 900, n)).astype(np.int32), "depth": r.integers(0, 3, n).astype(np.int64)})
+    q = "SELECT *, CLUSTER(interval, 100, predicate := depth = PREV(depth)) AS cid FROM t WHERE depth < 2"
+    out = execute(q, {"t": tbl}, giql_tables=["t"])
+    keep = np.nonzero(tbl.column("depth").to_numpy() < 2)[0]
+    d = tbl.column("depth").to_numpy()[keep]
+    want = ora.py_cluster_predicate(np.asarray(tbl.column("chrom").to_pylist())[keep].tolist(), start[keep].tolist(),
+                                    tbl.column("end").to_numpy()[keep].tolist(), 100, lambda i, j: d[i] == d[j])
+    assert out.column("cid").to_pylist() == want.tolist()
