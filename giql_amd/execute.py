@@ -549,15 +549,14 @@ def _rows_of(table, rows: np.ndarray):
 
 
 def _strand_codes(col, null_code: int) -> np.ndarray:
-    """'+' -> 0, '-' -> 1, NULL -> ``null_code`` (a NULL strand never equals anything)."""
+    """'+' -> 0, '-' -> 1, '.' -> 2, '?' -> 3, NULL -> ``null_code`` (a NULL strand never equals anything)."""
     v = np.asarray(_to_numpy_obj(col), dtype=object)
     out = np.full(v.shape[0], null_code, np.int32)
-    out[v == "+"] = 0
-    out[v == "-"] = 1
-    bad = ~np.isin(out, (0, 1)) & np.array([x is not None for x in v], dtype=bool)
+    for code, sym in enumerate("+-.?"):
+        out[v == sym] = code
+    bad = ~np.isin(out, (0, 1, 2, 3)) & np.array([x is not None for x in v], dtype=bool)
     if bad.any():
-        raise ValueError("stranded NEAREST: strands other than '+' / '-' (the reference yields a NULL "
-                         "distance for '.' / '?') are not supported by dialect='hip'")
+        raise ValueError("stranded NEAREST: strands other than '+' / '-' / '.' / '?' are not supported by dialect='hip'")
     return out
 
 
@@ -594,7 +593,7 @@ def _join_piece(plan: JoinPlan, lt, rt, ia: np.ndarray, ib: np.ndarray, n_chrom:
         # is ~6.2e9 > 2^32); the distance of a '-' reference row flips its sign
         # (_distance.py:88-117).
         ls, rs = (plan.strand_col or "strand,strand").split(",")
-        ca, cb = _strand_codes(_column(lt, ls), 2), _strand_codes(_column(rt, rs), 3)
+        ca, cb = _strand_codes(_column(lt, ls), 4), _strand_codes(_column(rt, rs), 5)
         sa = _int32_column(_column(lt, plan.left.start_col), f"{plan.left.table}.{plan.left.start_col}")
         ea = _int32_column(_column(lt, plan.left.end_col), f"{plan.left.table}.{plan.left.end_col}")
         sb = _int32_column(_column(rt, plan.right.start_col), f"{plan.right.table}.{plan.right.start_col}")
@@ -607,11 +606,41 @@ def _join_piece(plan: JoinPlan, lt, rt, ia: np.ndarray, ib: np.ndarray, n_chrom:
             a = DeviceSide.from_numpy(ia[ra_], sa[ra_], ea[ra_], plan.left.encoding, device=eng.device)
             b = DeviceSide.from_numpy(ib[rb_], sb[rb_], eb[rb_], plan.right.encoding, device=eng.device)
             keep, ib_keep, dn = _nearest_rows(plan, a, b, n_chrom, eng)
-            parts.append((ra_[keep.cpu().numpy()], rb_[ib_keep.cpu().numpy()], dn * sign))
+            parts.append((ra_[keep.cpu().numpy()], rb_[ib_keep.cpu().numpy()], np.ma.masked_array(dn * sign, mask=False)))
+        # '.' / '?' strands: the strand filter pairs such a reference row with the targets of ITS strand symbol, and the
+        # distance CASE yields NULL for every one of them (_distance.py:88-117) -- so the ORDER BY falls through to
+        # (start, end): the row's k targets are the first k of its chromosome in that order, distance NULL; under
+        # max_distance there is none (NULL <= d is not true).  "First k by (start, end)" is asked of the NEAREST
+        # kernel itself: one probe row per chromosome placed below every target sees them all downstream, nearest
+        # = smallest start first, ties by (start, end) -- the same order.
+        for code in (2, 3):
+            ra_, rb_ = np.nonzero(ca == code)[0], np.nonzero(cb == code)[0]
+            if not ra_.size or not rb_.size or plan.max_distance is not None:
+                continue
+            chroms = np.unique(ib[rb_])
+            lo = int(sb[rb_].min()) - 2
+            probe = DeviceSide.from_numpy(chroms.astype(np.int32), np.full(chroms.size, lo, np.int32),
+                                          np.full(chroms.size, lo + 1, np.int32), plan.right.encoding, device=eng.device)
+            b = DeviceSide.from_numpy(ib[rb_], sb[rb_], eb[rb_], plan.right.encoding, device=eng.device)
+            if plan.k == 1:
+                first = eng.nearest(probe, b, n_chrom)[0].cpu().numpy().reshape(-1, 1)
+            else:
+                first = eng.nearest_k(probe, b, n_chrom, plan.k)[0].cpu().numpy()
+            slot = np.full(int(n_chrom), -1, np.int64)
+            slot[chroms] = np.arange(chroms.size)
+            rows = slot[ia[ra_]]                      # the probe row of each reference row's chromosome (-1: no target there)
+            ok = rows >= 0
+            cand = first[rows[ok]]                    # [n, k] target rows (indices into rb_), -1 = fewer than k
+            hit = cand >= 0
+            ka_ = np.repeat(ra_[ok], hit.sum(axis=1))
+            parts.append((ka_, rb_[cand[hit]], np.ma.masked_array(np.zeros(ka_.size, np.int64), mask=True)))
         if parts:
             ka = np.concatenate([p[0] for p in parts])
             order = np.argsort(ka, kind="stable")   # A rows ascending; a row's k matches keep their order
-            ka, kb, dn = ka[order], np.concatenate([p[1] for p in parts])[order], np.concatenate([p[2] for p in parts])[order]
+            ka, kb = ka[order], np.concatenate([p[1] for p in parts])[order]
+            dn = np.ma.concatenate([p[2] for p in parts])[order]
+            if not np.ma.getmaskarray(dn).any():
+                dn = np.asarray(dn.data)
         else:
             ka = kb = np.zeros(0, np.int64)
             dn = np.zeros(0, np.int64)
@@ -679,7 +708,14 @@ def _project(plan: JoinPlan, lt, rt, idx: dict, extra: dict, eng: HipEngine, dev
             cols.append(_take(lt if p.side == "l" else rt, p.column, idx_h[p.side]))
     if pa is None:  # pragma: no cover
         return dict(zip(names, cols))
-    arrays = [c if isinstance(c, (pa.Array, pa.ChunkedArray)) else pa.array(c) for c in cols]
+    def as_arrow(c):
+        if isinstance(c, (pa.Array, pa.ChunkedArray)):
+            return c
+        if isinstance(c, np.ma.MaskedArray):   # NULL distances ('.' / '?' strands under stranded := true)
+            return pa.array(np.asarray(c.data), mask=np.ma.getmaskarray(c))
+        return pa.array(c)
+
+    arrays = [as_arrow(c) for c in cols]
     if not arrays:   # e.g. SELECT COUNT(*): no column to carry, only the row count
         n_rows = int(next(iter(idx.values())).shape[0])
         names, arrays = ["__giql_rows"], [pa.nulls(n_rows, pa.int8())]
@@ -755,7 +791,9 @@ def _execute_sharded(plan: JoinPlan, lt, rt, ia, ib, n_chrom, devices, return_in
             return np.sort(np.concatenate(rows)).astype(np.int32) if rows else np.zeros(0, np.int32)
         ka = np.concatenate([shards[r][0][pieces[r][0]] for r in have]) if have else np.zeros(0, np.int64)
         kb = np.concatenate([shards[r][1][pieces[r][1]] for r in have]) if have else np.zeros(0, np.int64)
-        dn = np.concatenate([pieces[r][2] for r in have]) if have else np.zeros(0, np.int64)
+        ds = [pieces[r][2] for r in have]   # (masked where the distance is NULL: '.' / '?' strands)
+        dn = ((np.ma.concatenate(ds) if any(isinstance(x, np.ma.MaskedArray) for x in ds) else np.concatenate(ds))
+              if have else np.zeros(0, np.int64))
         order = np.argsort(ka, kind="stable")
         return ka[order].astype(np.int32), kb[order].astype(np.int32), dn[order]
     import pyarrow as pa
@@ -775,8 +813,9 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
     unspecified row order, as upstream), or ``{column: array}`` when pyarrow is
     absent.  ``return_indices=True`` returns the raw row indices instead:
     ``(row_a, row_b)`` for INNER, ``rows_a`` for SEMI/ANTI,
-    ``(rows_a, idx_b, distance)`` for NEAREST and the per-left-row counts for
-    count_overlaps.  ``device_projection`` (default) gathers the projected columns
+    ``(rows_a, idx_b, distance)`` for NEAREST (``distance`` a numpy masked array when
+    ``stranded := true`` met '.' / '?' strands: those rows' distance is NULL) and the
+    per-left-row counts for count_overlaps.  ``device_projection`` (default) gathers the projected columns
     on the GPU from the device-resident row ids; ``False`` ships the ids to the
     host and takes there.
 

@@ -96,6 +96,29 @@ def main():
         json.dump({"_source": __doc__.strip().splitlines()[0] + " -- see tests/golden/make_nearest_k.py", "cases": cases}, f)
     print(f"wrote nearest_k.json: {len(cases)} cases")
 
+    # stranded := true with '.' / '?' strands (round 3): the strand filter pairs a '.' reference row with the '.'
+    # targets of its chromosome, the distance CASE yields NULL for them (_distance.py:88-117), so the k rows are the
+    # first k by (start, end) with a NULL distance -- and none at all under max_distance (NULL <= d is not true)
+    rng = random.Random(20261005)
+    dot = []
+    for idx, (k, signed, md) in enumerate([(1, False, None), (2, True, None), (3, False, None), (2, False, 500),
+                                           (5, True, None), (4, False, None)]):
+        def rows(n, chroms):
+            out = []
+            for _ in range(n):
+                s = rng.randint(0, 600)
+                out.append([rng.choice(chroms), s, s + rng.randint(0, 60), rng.choice("+-.?")])
+            return out
+        a = rows(rng.randint(6, 14), ["chr1", "chr2", "chr3"])
+        b = rows(rng.randint(10, 40), ["chr1", "chr2"])
+        dot.append({"name": f"dot_strands_{idx}", "source": "sqlite3 over the reference's distance CASE",
+                    "a": a, "b": b, "k": k, "signed": signed, "max_distance": md, "stranded": True,
+                    "expected": run(dm, a, b, k, signed, md, True)})
+    assert any(r[3] is None for c in dot for rows_ in c["expected"] for r in rows_)
+    with open(os.path.join(HERE, "nearest_dot_strands.json"), "w") as f:
+        json.dump({"_source": "stranded NEAREST with '.' / '?' strands -- see tests/golden/make_nearest_k.py", "cases": dot}, f)
+    print(f"wrote nearest_dot_strands.json: {len(dot)} cases")
+
 
 if __name__ == "__main__":
     main()

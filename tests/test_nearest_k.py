@@ -114,3 +114,38 @@ def test_nearest_k_one_sort_per_view_and_the_fallback_for_long_tie_runs():
             assert np.array_equal(idx.cpu().numpy() >= 0, wi >= 0)
     finally:
         e.close()
+
+
+DOT_CASES = G.load("nearest_dot_strands.json")["cases"]
+
+
+@pytest.mark.parametrize("case", DOT_CASES, ids=lambda c: c["name"])
+def test_stranded_nearest_with_dot_and_question_mark_strands(case):
+    """``stranded := true`` over tables with '.' / '?' strands (golden rows minted by sqlite3 over the reference's own
+    distance CASE, _distance.py:88-117): such a reference row pairs with the targets of its own strand symbol, every
+    distance is NULL, the k rows are the first k by (start, end); none under ``max_distance``.  Through execute(),
+    on one device and fanned out over two contexts."""
+    pa = pytest.importorskip("pyarrow")
+    from giql_amd.execute import execute
+
+    def table(rows):
+        return pa.table({"chrom": pa.array([r[0] for r in rows], type=pa.string()),
+                         "start": pa.array([r[1] for r in rows], type=pa.int32()),
+                         "end": pa.array([r[2] for r in rows], type=pa.int32()),
+                         "strand": pa.array([r[3] for r in rows], type=pa.string()),
+                         "rid": pa.array(list(range(len(rows))), type=pa.int64())})
+
+    args = [f"k := {case['k']}", "stranded := true"] + (["signed := true"] if case["signed"] else []) \
+        + ([f"max_distance := {case['max_distance']}"] if case["max_distance"] is not None else [])
+    q = ("SELECT a.rid AS a_rid, b.start AS b_start, b.end AS b_end, b.distance AS d FROM peaks a "
+         f"CROSS JOIN LATERAL NEAREST(genes, reference := a.interval, {', '.join(args)}) b")
+    tables = {"peaks": table(case["a"]), "genes": table(case["b"])}
+    want = [(i, r[1], r[2], r[3]) for i, rows in enumerate(case["expected"]) for r in rows]
+    for devices in (None, [0, 0]):
+        out = execute(q, tables, giql_tables=["peaks", "genes"], devices=devices)
+        got = list(zip(out.column("a_rid").to_pylist(), out.column("b_start").to_pylist(),
+                       out.column("b_end").to_pylist(), out.column("d").to_pylist()))
+        key = lambda t: (t[0], t[3] is None, abs(t[3]) if t[3] is not None else 0, t[1], t[2])  # noqa: E731
+        assert sorted(got, key=key) == sorted(want, key=key), devices
+        # a row's k matches come in the reference's order
+        assert [t for t in got if t[0] == got[0][0]] == [t for t in want if t[0] == got[0][0]] if got else True
