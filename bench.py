@@ -828,9 +828,10 @@ def inner_extras(eng, dev_index, a, b, ha, hb, n_chrom, n_pairs, alloc_out, join
         ms, n = eng.inner_join_host_timed(ha, hb, n_chrom)
         out["t_e2e_ms"] = round(ms, 1)
         out["t_e2e_first_call_ms"] = round(first_ms, 1)
-        out["t_e2e_note"] = ("giql_hip_inner: pageable host columns -> device, join, pairs -> pinned host memory; the "
-                             "first call also page-locks the output arrays, later calls reuse them (the library's "
-                             "pool); never the headline value")
+        out["t_e2e_note"] = ("giql_hip_inner: pageable host columns -> device, join, pairs -> pinned host memory, the "
+                             "larger table uploaded in blocks of 4M rows so that a block's pairs travel out while the "
+                             "next block travels in; the first call also page-locks the output arrays, later calls "
+                             "reuse them (the library's pool); never the headline value")
     except Exception as exc:
         out["t_e2e_ms"] = None
         out["t_e2e_error"] = str(exc)[:200]

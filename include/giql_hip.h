@@ -326,7 +326,11 @@ int giql_hip_select_dev(giql_hip_ctx* ctx, const giql_pred* preds, int32_t n_pre
 int giql_hip_mark_dev(giql_hip_ctx* ctx, const int32_t* idx, int64_t n,
                       uint8_t* flags, int64_t n_rows, void* stream);
 
-/* ---- host-buffer entry points (Arrow buffers in host memory) ------------ */
+/* ---- host-buffer entry points (Arrow buffers in host memory) ------------
+ * giql_hip_inner: columns of both tables in host memory in, the pairs out in pinned host arrays the
+ * library owns (giql_hip_free_host).  A table of 8M rows and more is uploaded in blocks of 4M rows
+ * (GIQL_HIP_E2E_BLOCK_ROWS; 0 = one shot): an INNER join is the union of the joins of its row
+ * blocks, so block j's pairs travel to the host while block j + 1 travels to the device. */
 int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
                    int32_t n_chrom, int64_t* n_pairs, int32_t** row_a,
                    int32_t** row_b);

@@ -1394,3 +1394,22 @@ def test_sorted_inputs_with_the_three_stage_sort_and_the_fused_count(monkeypatch
         assert np.array_equal(gpu_inner(e, a1, b1, 5), want)
     finally:
         e.close()
+
+
+def test_host_entry_pipelined_over_row_blocks_of_the_larger_table(monkeypatch, eng):
+    """giql_hip_inner with the larger table uploaded block by block (round 3): the union of the blocks' joins, the
+    blocked table's row ids offset per block -- whichever table is the larger one, blocks that yield nothing, an
+    irregular row (the literal path reads the uploaded columns again at fill time), a ragged last block."""
+    monkeypatch.setenv("GIQL_HIP_E2E_BLOCK_ROWS", "7000")
+    a = rand_side(1801, 3_000, 4, 600_000, 900)
+    b = rand_side(1802, 40_000, 4, 600_000, 400, min_len=0)       # zero-length rows: the irregular path
+    b.start[30_000:37_000] = 5_000_000                            # a whole block far from every A row
+    b.end[30_000:37_000] = 5_000_100
+    want = ora.sort_pairs(*ora.c_inner(a, b, "sweep"))
+    for x, y, flip in ((a, b, False), (b, a, True)):
+        ra, rb = eng.inner_join_host((x.chrom, x.start, x.end), (y.chrom, y.start, y.end), 4)
+        got = ora.sort_pairs(rb, ra) if flip else ora.sort_pairs(ra, rb)
+        assert got.shape == want.shape and np.array_equal(got, want)
+    monkeypatch.setenv("GIQL_HIP_E2E_BLOCK_ROWS", "0")            # one shot: the same pairs
+    ra, rb = eng.inner_join_host((a.chrom, a.start, a.end), (b.chrom, b.start, b.end), 4)
+    assert np.array_equal(ora.sort_pairs(ra, rb), want)
