@@ -251,12 +251,19 @@ constexpr int BS_QPRE = GIQL_BS_QPRE;  // probe rounds whose values are loaded w
 // A window holds at most BJ_QR queries per thread (their ranks live in registers while the bin table is reused);
 // denser windows, like buckets too large for LDS, go to the queue of k_bucket_sort_big.
 #ifndef GIQL_BJ_MIN_WAVES
-#define GIQL_BJ_MIN_WAVES 6  // the join form keeps its queries' ranks in registers next to the rows: 80 VGPRs, three blocks per CU
+#define GIQL_BJ_MIN_WAVES 7  // the join form keeps its queries' ranks in registers next to the rows: 69 VGPRs, three blocks per CU
 #endif
 #ifndef GIQL_BJG_MIN_WAVES
-#define GIQL_BJG_MIN_WAVES 5  // ... the general form its rows' class-1 ranges as well
+#define GIQL_BJG_MIN_WAVES 6  // ... the general form its rows' class-1 ranges as well (82 VGPRs)
 #endif
-constexpr int BJ_QR = 4;
+// Queries a thread ranks (window cap = BJ_QR x 512).  Every round costs its instructions whether the window fills it or
+// not, and its ranks live in registers: at the headline sizes (636 queries per window) 4 rounds / 78 VGPRs ran the
+// kernel in 1.02 ms, 3 rounds / 69 VGPRs in 0.93, 2 rounds / 64 VGPRs (four blocks per CU) in 0.91 -- but a 1024-query
+// cap is 1.6x the AVERAGE window there, and a window over the cap sends its bucket to the slow queue.
+#ifndef GIQL_BJ_QR
+#define GIQL_BJ_QR 3
+#endif
+constexpr int BJ_QR = GIQL_BJ_QR;
 constexpr u32 BJ_WCAP = BJ_QR * BS_NT;
 
 // The tail of a FUSE == 2 block (see above).  On entry every row knows its final place (slot), the bin table and
