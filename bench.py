@@ -596,7 +596,10 @@ def run_inner(args):
     phase_launches.clear()
     # the dominant phase = the one that took longest in the last warm-up step (the global sort passes, or -- when
     # the bucket stage writes the pairs itself -- that stage's one kernel)
-    dom_phase = max(warm_phase_ms, key=warm_phase_ms.get) if light else "sort_scatter"
+    # (in the join-in-the-bucket-stage form that stage's kernel IS the largest single kernel -- rocprofv3's top line;
+    # the four global passes are three different kernels -- whatever the warm-up's event overhead made of the phases)
+    dom_phase = ("sort_local" if (warm or {}).get("bucket_join") else max(warm_phase_ms, key=warm_phase_ms.get)) if light \
+        else "sort_scatter"
     eng.set_profiling(dom_phase if light else True)
     sync_all()
     split_ms[0] = split_ms[1] = split_ms[2] = 0.0

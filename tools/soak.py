@@ -71,6 +71,9 @@ while time.time() - t0 < budget:
     ob = torch.empty(cap, dtype=torch.int32, device="cuda:0")
     n = eng.inner_join_into(da, db, nch, oa, ob)
     assert n == want.shape[0] and np.array_equal(ora.sort_pairs(oa[:n].cpu().numpy(), ob[:n].cpu().numpy()), want), ("into", it)
+    st2 = eng.stats()
+    if st2["bucket_join"]:   # the pairs came straight from the bucket stage (round 3), of either join form
+        forms[("bucket_join", st2["join_form"])] = forms.get(("bucket_join", st2["join_form"]), 0) + 1
     # NEAREST k = 1 (rows with start <= end only: the operator rejects inverted rows)
     if not (np.any(a.end + a.end_off < a.start + a.start_off) or np.any(b.end + b.end_off < b.start + b.start_off)):
         signed = bool(rng.random() < 0.5)
@@ -81,6 +84,8 @@ while time.time() - t0 < budget:
         hit = gi >= 0
         assert np.array_equal(b.start[gi[hit]], b.start[wi[hit]]) and np.array_equal(b.end[gi[hit]], b.end[wi[hit]]), ("nearest rows", it)
     assert np.array_equal(eng.semi_join(da, db, nch).cpu().numpy(), ora.c_semi_anti(a, b, False)), ("semi", it)
+    if eng.stats()["coarse_b"]:
+        forms[("coarse_b", True)] = forms.get(("coarse_b", True), 0) + 1
     assert np.array_equal(eng.anti_join(da, db, nch).cpu().numpy(), ora.c_semi_anti(a, b, True)), ("anti", it)
     assert np.array_equal(eng.count_overlaps(da, db, nch).cpu().numpy(),
                           ora.c_count(a, b, "brute" if na * nb < 3e8 else "sweep")), ("count", it)
@@ -90,6 +95,10 @@ while time.time() - t0 < budget:
 def label(k):
     if k[0] == "swapped":
         return "sides exchanged" if k[1] else "sides as given"
+    if k[0] == "bucket_join":
+        return f"pairs written by the bucket stage ({k[1]})"
+    if k[0] == "coarse_b":
+        return "SEMI with B sorted without its lowest digit"
     return f"{k[0]}/{'span_hist' if k[1] else 'linearize'}"
 
 
