@@ -247,14 +247,6 @@ __global__ __launch_bounds__(256) void k_semi_flags_uniform_coarse(const u32* __
   flag[a_rids[i]] = (hit != (anti != 0)) ? 1u : 0u;
 }
 
-// rows_out[off[i]] = i for flagged rows (ascending row ids).
-__global__ __launch_bounds__(256) void k_compact(const u32* __restrict__ flag,
-                                                  const u64* __restrict__ off, u32 n,
-                                                  int32_t* __restrict__ rows_out) {
-  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && flag[i]) rows_out[off[i]] = (int32_t)i;
-}
-
 // ------------------------------------------------------------------- COUNT
 // Regular rows: count(a) = #{b.start < a.end} - #{b.end <= a.start} over the
 // regular B rows (two sorted arrays, no candidate is touched); irregular rows on

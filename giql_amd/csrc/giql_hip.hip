@@ -1955,12 +1955,15 @@ static int giql_hip_semi_anti_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
                          sa.rid[0], (u32)na, ctx->d_meta, sbb.key[0], pmax, (u32)nb, anti, flag);
     GIQL_TRY(post_launch("semi flags"));
   }
-  GIQL_TRY(run_scan<u64>(ctx, st, GIQL_PH_SCAN, flag, na, off, bsums, off + na));
-  HIP_TRY(hipMemcpyAsync(&ctx->d_meta->n_out, off + na, sizeof(u64), hipMemcpyDeviceToDevice, st));
   {
-    Phase ph(ctx, st, GIQL_PH_FILL);
-    hipLaunchKernelGGL(k_compact, dim3(cdiv(na, 256)), dim3(256), 0, st, flag, off, (u32)na, rows_out);
-    GIQL_TRY(post_launch("compact"));
+    // scan of the flags with the compaction in its down-sweep, the count straight into DevMeta::n_out
+    // (three launches; were five: scan x 3, a device-to-device copy of the total, compact)
+    const u32 nbk = cdiv(na, SCAN_TILE);
+    Phase ph(ctx, st, GIQL_PH_SCAN, 3);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nbk), dim3(SCAN_NT), 0, st, flag, (u64)na, bsums);
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, st, bsums, nbk, off + na, &ctx->d_meta->n_out);
+    hipLaunchKernelGGL(k_scan_down_compact, dim3(nbk), dim3(SCAN_NT), 0, st, flag, (u64)na, bsums, rows_out);
+    GIQL_TRY(post_launch("scan + compact"));
   }
   GIQL_TRY(read_meta(ctx, st));
   if (nb > 0 && !row_form_settled(ctx, uni_len, speculated))  // B is not fixed-length after all

@@ -287,6 +287,28 @@ __global__ __launch_bounds__(SC_NT) void k_scan_chain_diff(const u32* __restrict
   }
 }
 
+// The down-sweep of a scan of 0 / 1 flags with the compaction folded in: rows_out[exclusive offset] = row for the
+// flagged rows (ascending row ids) -- SEMI / ANTI's last two launches (offsets written, then read by a compact
+// kernel) in one, the offsets never stored.
+__global__ __launch_bounds__(SCAN_NT) void k_scan_down_compact(const u32* __restrict__ flag, u64 n,
+                                                                const u64* __restrict__ bsums,
+                                                                int32_t* __restrict__ rows_out) {
+  __shared__ u64 lds[SCAN_NT / WAVE + 1];
+  const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  u32 x[SCAN_ITEMS];
+  scan_load(flag, n, base, x);
+  u64 s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) s += x[k];
+  u64 total;
+  u64 run = bsums[blockIdx.x] + block_excl_scan<u64, SCAN_NT>(s, lds, total);
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    if (x[k]) rows_out[run] = (int32_t)(base + k);
+    run += x[k];
+  }
+}
+
 template <typename TOut>
 __global__ __launch_bounds__(SCAN_NT) void k_scan_down(const u32* __restrict__ in, u64 n,
                                                         const u64* __restrict__ bsums,

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
 from giql_amd.engine import DeviceSide, HipEngine
 _op, ha, hb, n_chrom = bench.make_inputs("cfg4_10Mx100M_24chrom")
