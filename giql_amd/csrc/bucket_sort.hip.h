@@ -251,20 +251,27 @@ constexpr int BS_QPRE = GIQL_BS_QPRE;  // probe rounds whose values are loaded w
 // A window holds at most BJ_QR queries per thread (their ranks live in registers while the bin table is reused);
 // denser windows, like buckets too large for LDS, go to the queue of k_bucket_sort_big.
 #ifndef GIQL_BJ_MIN_WAVES
-#define GIQL_BJ_MIN_WAVES 7  // the join form keeps its queries' ranks in registers next to the rows: 69 VGPRs, three blocks per CU
+#define GIQL_BJ_MIN_WAVES 8  // the join form keeps its queries' ranks in registers next to the rows: 64 VGPRs at two rounds, four blocks per CU
 #endif
 #ifndef GIQL_BJG_MIN_WAVES
 #define GIQL_BJG_MIN_WAVES 6  // ... the general form its rows' class-1 ranges as well (82 VGPRs)
 #endif
 // Queries a thread ranks (window cap = BJ_QR x 512).  Every round costs its instructions whether the window fills it or
-// not, and its ranks live in registers: at the headline sizes (636 queries per window) 4 rounds / 78 VGPRs ran the
-// kernel in 1.02 ms, 3 rounds / 69 VGPRs in 0.93, 2 rounds / 64 VGPRs (four blocks per CU) in 0.91 -- but a 1024-query
-// cap is 1.6x the AVERAGE window there, and a window over the cap sends its bucket to the slow queue.
+// not, and its ranks live in registers: at the headline sizes (636 queries per window on average) 4 rounds / 78 VGPRs
+// ran the kernel in 1.02 ms, 3 rounds / 69 VGPRs in 0.93-0.98, 2 rounds / 64 VGPRs (four blocks per CU) in 0.91-0.93.
+// Two it is: a window over the 1024-query cap is not lost to the slow path but runs the same body with BJ_QR_CROWD
+// rounds in the queue kernel (below).
 #ifndef GIQL_BJ_QR
-#define GIQL_BJ_QR 3
+#define GIQL_BJ_QR 2
 #endif
 constexpr int BJ_QR = GIQL_BJ_QR;
 constexpr u32 BJ_WCAP = BJ_QR * BS_NT;
+// A window over that cap but within BJ_QR_CROWD rounds (real query tables are clustered: a promoter-dense stretch
+// holds many times the average) still runs in LDS -- the same body with more rounds per thread, one block per such
+// bucket, in the queue kernel (k_bucket_sort_big), where occupancy does not matter; only beyond that does a bucket
+// take the global-memory path.
+constexpr int BJ_QR_CROWD = 8;
+constexpr u32 BJ_WCAP_CROWD = BJ_QR_CROWD * BS_NT;
 
 // The tail of a FUSE == 2 block (see above).  On entry every row knows its final place (slot), the bin table and
 // the gathered equal-key bins are still valid, and no barrier has passed since the last of them was read.
@@ -275,11 +282,11 @@ constexpr u32 BJ_WCAP = BJ_QR * BS_NT;
 // window's keys are staged in LDS (in the bin table's place, once the ranks are done), every bucket row searches
 // them for its own range (a lower bound and a short walk: 0.3 matches per row at 10M x 100M) and writes its few
 // pairs itself, behind the class-2 runs.  Every pair (q, u) leaves from the block of u's bucket.
-template <int R, bool GENERAL>
+template <int R, bool GENERAL, int QR>
 __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (&pay)[R], const u32 (&slot)[R], u32 cnt,
                                                  u32 v, const u32* __restrict__ ep, u32* s_buf, u64* s_cell,
                                                  u32* s_jtot, const BsFuse& fq, u32 qw0, u32 nw,
-                                                 const u32 (&jq_key)[BJ_QR], const u32 (&jq_end)[BJ_QR]) {
+                                                 const u32 (&jq_key)[QR], const u32 (&jq_end)[QR]) {
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const u32 k0 = v << 16;
 #if defined(GIQL_BJ_ABLATE)  // timing-only builds (results invalid, tools/bj_ablate.sh): the tail stops after its k-th stage
@@ -289,9 +296,9 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
 #endif
   GIQL_BJ_STOP(1);  // the sort alone
   // ranks of my queries' bounds inside this bucket, clamped to it
-  u32 q_lo[BJ_QR], q_cnt[BJ_QR], q_rid[BJ_QR], incl[BJ_QR];
+  u32 q_lo[QR], q_cnt[QR], q_rid[QR], incl[QR];
 #pragma unroll
-  for (int i = 0; i < BJ_QR; i++) {
+  for (int i = 0; i < QR; i++) {
     const u32 j = i * BS_NT + tid;
     q_lo[i] = q_cnt[i] = q_rid[i] = 0;
     if (j < nw) {
@@ -308,9 +315,9 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
   bs_sync<2>();  // every rank has been read: s_buf and the cells are free; the wave totals are in
   GIQL_BJ_STOP(2);  // + ranks
   // pairs of the block, and where each (slot, wave) group of queries starts among them
-  u32 total = 0, q_off[BJ_QR];
+  u32 total = 0, q_off[QR];
 #pragma unroll
-  for (int i = 0; i < BJ_QR; i++) {
+  for (int i = 0; i < QR; i++) {
     u32 mine = 0;
 #pragma unroll
     for (int k = 0; k < BS_NW; k++) {
@@ -326,7 +333,7 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
   if (GENERAL) {
     u32* const s_qkey = reinterpret_cast<u32*>(s_cell);
 #pragma unroll
-    for (int i = 0; i < BJ_QR; i++) {
+    for (int i = 0; i < QR; i++) {
       const u32 j = i * BS_NT + tid;
       if (j < nw) s_qkey[j] = jq_key[i];
     }
@@ -359,13 +366,13 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
       }
     }
     const u32 incl1 = wave_incl_scan_add_u32(t1);
-    if (lane == WAVE - 1) s_jtot[BJ_QR * BS_NW + 4 + w] = incl1;
+    if (lane == WAVE - 1) s_jtot[QR * BS_NW + 4 + w] = incl1;
     bs_sync<2>();
     u32 mine1 = 0, total1 = 0;
 #pragma unroll
     for (int k = 0; k < BS_NW; k++) {
       if (k == (int)w) mine1 = total1;
-      total1 += s_jtot[BJ_QR * BS_NW + 4 + k];
+      total1 += s_jtot[QR * BS_NW + 4 + k];
     }
     off1 = total2 + mine1 + incl1 - t1;
     total += total1;
@@ -379,7 +386,7 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
     const u32 r = i * BS_NT + tid;
     if (i < R - 1 || r < cnt) s_buf[slot[i]] = pay[i];
   }
-  unsigned long long* s_jbase = reinterpret_cast<unsigned long long*>(s_jtot + BJ_QR * BS_NW);
+  unsigned long long* s_jbase = reinterpret_cast<unsigned long long*>(s_jtot + QR * BS_NW);
   if (tid == 0) *s_jbase = base;
   bs_sync<2>();
   base = *s_jbase;
@@ -389,7 +396,7 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
   int32_t* const rs = fq.row_s + base;
   // one query per wave iteration: its numbers come from the lane that ranked it
 #pragma unroll
-  for (int i = 0; i < BJ_QR; i++) {
+  for (int i = 0; i < QR; i++) {
     u64 m = __ballot(q_cnt[i] != 0u);
     while (m) {
       const int l = __ffsll((long long)m) - 1;
@@ -418,7 +425,7 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
 }
 
 
-template <int PAYLOAD, int R, int FUSE = 0>
+template <int PAYLOAD, int R, int FUSE = 0, int QR = BJ_QR>
 __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __restrict__ pp,
                                                  u32* __restrict__ ep, u32 cnt, u32 v, u32* s_buf,
                                                  u64* s_cell, u32* s_scan, const BsFuse& fq,
@@ -451,11 +458,11 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
     q_val[k] = 0;
     if (FUSE == 1 && tid + k * BS_NT < n_probe) q_val[k] = q_src[qw0 + ((tid + k * BS_NT) >> 1)];
   }
-  // the join form: one thread per query of the window, key and end key, up to BJ_QR rounds
-  u32 jq_key[FUSE >= 2 ? BJ_QR : 1], jq_end[FUSE >= 2 ? BJ_QR : 1];
+  // the join form: one thread per query of the window, key and end key, up to QR rounds
+  u32 jq_key[FUSE >= 2 ? QR : 1], jq_end[FUSE >= 2 ? QR : 1];
   if constexpr (FUSE >= 2) {
 #pragma unroll
-    for (int k = 0; k < BJ_QR; k++) {
+    for (int k = 0; k < QR; k++) {
       const u32 j = k * BS_NT + tid;
       const bool in = j < qw1 - qw0;
       jq_key[k] = in ? fq.qkey[qw0 + j] : 0u;
@@ -560,7 +567,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
     }
   }
   if constexpr (FUSE >= 2) {  // the pairs leave from here: no sorted array is stored
-    bucket_join_tail<R, FUSE == 3>(pk, pay, slot, cnt, v, ep, s_buf, s_cell, s_jtot, fq, qw0, qw1 - qw0, jq_key, jq_end);
+    bucket_join_tail<R, FUSE == 3, QR>(pk, pay, slot, cnt, v, ep, s_buf, s_cell, s_jtot, fq, qw0, qw1 - qw0, jq_key, jq_end);
     return;
   }
   bs_sync<FUSE>();  // every gathered bin has been read: s_buf and the cells are free
@@ -729,12 +736,14 @@ __global__ __launch_bounds__(BS_NT, FUSE == 3 ? GIQL_BJG_MIN_WAVES : (FUSE == 2 
   }
   if (cnt > BS_CAP || (FUSE >= 2 && qw1 - qw0 > BJ_WCAP)) {
     // too large for LDS: queued for k_bucket_sort_big (a launch of its own keeps this kernel free of
-    // the big path's registers and scratch frame); past BS_BIG_MAX the whole call is repeated
+    // the big path's registers and scratch frame); past BS_BIG_MAX the whole call is repeated.
+    // Bit 31 of the entry: only the WINDOW is too large for this kernel's rounds -- the bucket still runs in LDS there
     if (threadIdx.x == 0) {
       if (cnt > BS_BIG_MAX || !big_list)
         meta->status = GIQL_STATUS_RESORT;
       else
-        big_list[1 + atomicAdd(&big_list[0], 1u)] = v;
+        big_list[1 + atomicAdd(&big_list[0], 1u)] =
+            v | ((FUSE >= 2 && cnt <= BS_CAP && qw1 - qw0 <= BJ_WCAP_CROWD) ? 0x80000000u : 0u);
     }
     return;
   }
@@ -766,11 +775,40 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ key
   __shared__ u32 s_wcnt[BS_NW * OS_BINS];
   __shared__ u32 s_base[OS_BINS];
   __shared__ u32 s_scan[BS_NW];
+  // join forms: the LDS body with BJ_QR_CROWD rounds for the buckets whose window alone was too large
+  __shared__ u32 s_buf[FUSE >= 2 ? BS_CAP + 4 : 1];
+  __shared__ u64 s_cell[FUSE >= 2 ? BS_NB : 1];
+  __shared__ __attribute__((aligned(8))) u32 s_jtot[FUSE >= 2 ? BJ_QR_CROWD * BS_NW + 4 + BS_NW : 2];
+  static_assert(BS_NB * sizeof(u64) >= BJ_WCAP_CROWD * sizeof(u32), "the cell table holds a crowded window's keys");
   const u32 n_big = big_list[0];
   for (u32 i = blockIdx.x; i < n_big; i += gridDim.x) {
-    const u32 v = big_list[1 + i];
+    const u32 entry = big_list[1 + i];
+    const u32 v = entry & 0xFFFFu;
     const u32 b0 = bnd[v];
     const u32 cnt = bnd[v + 1] - b0;
+    if constexpr (FUSE >= 2) {
+      if (entry >> 31) {  // block-uniform
+        u32* kp = keys + b0;
+        u32* pp = rids + b0;
+        u32* ep = (PAYLOAD == 3) ? ends + b0 : nullptr;
+        const u32 qw0 = fq.qwin[2 * v], qw1 = fq.qwin[2 * v + 1];
+#define GIQL_BS_BODY(RR) \
+  bucket_sort_body<PAYLOAD, RR, FUSE, BJ_QR_CROWD>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan, fq, b0, qw0, qw1, s_jtot)
+        switch ((cnt + BS_NT - 1) / BS_NT) {
+          case 0: case 1: GIQL_BS_BODY(1); break;
+          case 2: GIQL_BS_BODY(2); break;
+          case 3: GIQL_BS_BODY(3); break;
+          case 4: GIQL_BS_BODY(4); break;
+          case 5: GIQL_BS_BODY(5); break;
+          case 6: GIQL_BS_BODY(6); break;
+          case 7: GIQL_BS_BODY(7); break;
+          default: GIQL_BS_BODY(8); break;
+        }
+#undef GIQL_BS_BODY
+        __syncthreads();  // the LDS arrays are reused by the block's next bucket
+        continue;
+      }
+    }
     bucket_sort_big<PAYLOAD>(keys + b0, (PAYLOAD & 2) ? ends + b0 : nullptr, (PAYLOAD & 1) ? rids + b0 : nullptr,
                              keys1 + b0, (PAYLOAD & 2) ? ends1 + b0 : nullptr, (PAYLOAD & 1) ? rids1 + b0 : nullptr, cnt,
                              s_wcnt, s_base, s_scan);

@@ -1374,7 +1374,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     // registers: a window covers three 65536-key buckets of the coarsely grouped query side
     const bool join_in_buckets = fuse_cnt && !ctx->no_bucket_join && ctx->fuse_a && speculated && ctx->last_no_irr &&
                                  ctx->fuse_cap > 0 && ctx->last_span > 0 &&
-                                 3.0 * (double)nqr * 65536.0 / (double)ctx->last_span <= 0.5 * (double)BJ_WCAP;
+                                 3.0 * (double)nqr * 65536.0 / (double)ctx->last_span <= 0.75 * (double)BJ_WCAP;
     FuseCount fc;
     if (fuse_cnt) {
       if (join_in_buckets) {
@@ -1468,7 +1468,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   const bool general_join = onesweep && !ctx->no_bucket_join && ctx->fuse_a && speculated && ctx->last_no_irr &&
                             ctx->fuse_cap > 0 && nb >= na && sort_is_local(ctx, nb) && ctx->spec_fuse_len_ok &&
                             ctx->last_span > 0 &&
-                            1.5 * (double)na * 65536.0 / (double)ctx->last_span <= 0.5 * (double)BJ_WCAP;
+                            1.5 * (double)na * 65536.0 / (double)ctx->last_span <= 0.75 * (double)BJ_WCAP;
   // the smaller side's chain (linearize + sort) beside the larger side's when it is small (not in the form above:
   // B's last stage reads the sorted A)
   SideChain sc(ctx, st, (onesweep && !general_join) ? (na < nb ? na : nb) : 0, na < nb ? nb : na);

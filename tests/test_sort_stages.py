@@ -419,10 +419,12 @@ def test_bucket_join_queued_buckets_equal_keys_and_crowded_windows(eng_local):
     q = rand_side(1634, 3_000, 1, 20_000, 400)
     _fused_inner(eng_local, q, piled, 1)
     _join_into(eng_local, q, piled, 1)
-    # a crowd of queries in one window (more than a block keeps in registers) inside a sparse table: that
-    # bucket is queued, the others run in LDS
+    # crowds of queries in one window inside a sparse table: 2,500 of them (more than the bucket kernel's three rounds
+    # hold: the bucket runs the LDS body with eight rounds in the queue kernel) and 6,000 (past that too: the
+    # global-memory path); the other buckets run in the bucket kernel
     reads2 = uniform_side(1635, 300_000, 2, 40_000_000, 150)
-    qs = np.concatenate([r.integers(0, 40_000_000, 4_000), r.integers(5_000_000, 5_030_000, 6_000)]).astype(np.int32)
+    qs = np.concatenate([r.integers(0, 40_000_000, 4_000), r.integers(5_000_000, 5_030_000, 6_000),
+                         r.integers(9_000_000, 9_030_000, 2_500)]).astype(np.int32)
     ql = r.integers(50, 1_500, qs.size).astype(np.int32)
     crowd = ora.Side(r.integers(0, 2, qs.size).astype(np.int32), qs, qs + ql)
     _fused_inner(eng_local, crowd, reads2, 2)
@@ -511,6 +513,14 @@ def test_general_bucket_join_queued_buckets_and_small_buffers(eng_local):
     peaks = rand_side(1722, 40_000, 1, 7_000_000, 2500)
     _plain(eng_local, peaks, reads, 1)
     _join_into(eng_local, peaks, reads, 1)
+    # crowded windows in the general form (2,500 and 6,000 A rows inside one bucket's reach)
+    r = np.random.default_rng(1723)
+    reads2 = rand_side(1724, 300_000, 2, 40_000_000, 300, min_len=40)
+    qs = np.concatenate([r.integers(0, 40_000_000, 4_000), r.integers(5_000_000, 5_030_000, 6_000),
+                         r.integers(9_000_000, 9_030_000, 2_500)]).astype(np.int32)
+    crowd = ora.Side(r.integers(0, 2, qs.size).astype(np.int32), qs, qs + r.integers(50, 1_500, qs.size).astype(np.int32))
+    _plain(eng_local, crowd, reads2, 2)
+    _join_into(eng_local, crowd, reads2, 2)
     # buffers too small: the count comes back, the plan behind the error is an ordinary one
     want = ora.sort_pairs(*ora.c_inner(peaks, reads, "sweep"))
     ra = torch.full((want.shape[0] // 3,), -7, dtype=torch.int32, device="cuda:0")
