@@ -206,12 +206,38 @@ class HipEngine:
     def inner_join(self, a: DeviceSide, b: DeviceSide, n_chrom: int, out=None):
         """All ``(row_a, row_b)`` with ``a INTERSECTS b``; two int32 device tensors."""
         torch = _torch()
+        # A context that has joined before gets ONE call (giql_hip_inner_join_dev): buffers sized from its previous
+        # result -- for large tables the pairs are then written by the sort's last stage itself, with no count /
+        # scan / fill kernels and no read-back in between.  A result that does not fit comes back as
+        # GIQL_ERR_CAPACITY with the exact count and a plan behind it: the ordinary fill follows.
+        guess = getattr(self, "_pairs_guess", 0)
+        if out is None and guess > 0 and a.n and b.n:
+            cap = int(guess * 1.05) + 4096
+            row_a = torch.empty(cap, dtype=torch.int32, device=self.device)
+            row_b = torch.empty(cap, dtype=torch.int32, device=self.device)
+            try:
+                n = self.inner_join_into(a, b, n_chrom, row_a, row_b)
+                self._pairs_guess = n
+                return row_a[:n], row_b[:n]
+            except _lib.GiqlHipError as exc:
+                if exc.code == _lib.GIQL_ERR_SPAN:
+                    return self._inner_by_groups(a, b, n_chrom)
+                if exc.code != _lib.GIQL_ERR_CAPACITY:
+                    raise
+                n = int(self.last_pairs)
+                del row_a, row_b
+                row_a = torch.empty(n, dtype=torch.int32, device=self.device)
+                row_b = torch.empty(n, dtype=torch.int32, device=self.device)
+                self.inner_fill(row_a, row_b)
+                self._pairs_guess = n
+                return row_a, row_b
         try:
             n = self.inner_plan(a, b, n_chrom)
         except _lib.GiqlHipError as exc:
             if exc.code != _lib.GIQL_ERR_SPAN:
                 raise
             return self._inner_by_groups(a, b, n_chrom)
+        self._pairs_guess = n
         if out is not None and out[0].shape[0] >= n:
             row_a, row_b = out[0][:n], out[1][:n]
         else:

@@ -532,3 +532,20 @@ def test_general_bucket_join_queued_buckets_and_small_buffers(eng_local):
     fb = torch.empty_like(fa)
     eng_local.inner_fill(fa, fb)
     assert np.array_equal(ora.sort_pairs(fa.cpu().numpy(), fb.cpu().numpy()), want)
+
+
+def test_engine_inner_join_takes_the_one_call_form_from_its_second_call(eng_local):
+    """HipEngine.inner_join (what execute() calls): buffers sized from the context's previous result, one C-ABI call --
+    so the product API gets the join in the bucket stage too; a result that outgrows the guess falls back to the
+    exact-size fill behind GIQL_ERR_CAPACITY."""
+    reads = uniform_side(1901, 300_000, 3, 20_000_000, 150)
+    peaks = rand_side(1902, 30_000, 3, 20_000_000, 3000)
+    _plain(eng_local, peaks, reads, 3)
+    assert not eng_local.stats()["bucket_join"]          # first call: plan + fill
+    _plain(eng_local, peaks, reads, 3)
+    _plain(eng_local, peaks, reads, 3)
+    assert eng_local.stats()["bucket_join"] and eng_local.stats()["fused_fill"]
+    wide = rand_side(1903, 30_000, 3, 20_000_000, 30_000, min_len=10_000)   # ten times the pairs: the guess is too small
+    _plain(eng_local, wide, reads, 3)
+    _plain(eng_local, wide, reads, 3)
+    assert eng_local.stats()["bucket_join"]
