@@ -134,6 +134,10 @@ struct giql_hip_ctx {
   bool no_swap = false;  // GIQL_HIP_NO_SWAP=1: plan the sides as given
   bool last_no_irr = false;   // the previous plan met no irregular row
   bool nearest_two_sorts = false;  // NEAREST: a B table with long equal-start runs was seen
+  // NEAREST k = 1: both sides sorted straight from their raw columns (digits counted in the span pass, aligned layout;
+  // no linearize pass) -- -1: not known yet (the next call probes the layout), 0: this data does not take the aligned
+  // layout, 1: the previous call did (a guess, validated at the read-back)
+  int nearest_aligned = -1;
   bool spec_valid = false;    // INNER: the previous plan's form decision, speculated on next time
   int spec_form = 0;
   i64 spec_len = 0;
@@ -2121,6 +2125,9 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
     sort_sizes(c, na, sa, true);
     sort_sizes(c, nb, sbb, true);
     os_scratch_sizes(c, na, os_a);   // A's chain may run beside B's (SideChain)
+    lb.top_partial = c.take<u32>((size_t)LIN_HIST_REPLICAS * MM_TOP_WORDS);   // (inside the range prezero_row_scratch zeroes)
+    lb.top_partial2 = c.take<u32>((size_t)LIN_HIST_REPLICAS * MM_TOP_WORDS);
+    lb.abase = c.take<u32>(MM_HIST_CHROMS);
     os_scratch_sizes(c, nb, os);     // (right behind A's: prezero_row_scratch)
     recs = c.take<NearestRec>(na);
     pmax = c.take<u32>(nb);
@@ -2135,14 +2142,36 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
   const bool two_sorts = ctx->nearest_two_sorts;
   PrezeroGuard prezero_guard{ctx};
   if (!two_sorts) GIQL_TRY(prezero_row_scratch(ctx, st, os_a, os, nb));  // (the two-sort plan reuses B's status words)
-  GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb));
+  // Both sides sorted from their raw columns (round 3): with every chromosome base a multiple of 2^24 the span pass
+  // counts the digits of the keys itself (k_chrom_minmax<1>, "Histogram in the span pass"), and the first sort pass
+  // of each side builds key and end key from (chrom, start, end) -- no linearize pass (2 x 49 us at 10M x 10M against
+  // ~2 x 22 more in the span pass and the first sort pass).  Every NEAREST row keeps its real key, zero-length rows
+  // included, so the only guess is the layout: taken when the previous call's data took it, validated at the
+  // read-back; a first call probes it (digits counted for B only) and sorts the ordinary way.
+  const bool hist_ok = !two_sorts && ctx->prezeroed && !ctx->no_span_hist && ctx->os_variant == 0 &&
+                       n_chrom <= MM_HIST_CHROMS && !sort_is_local(ctx, na) && !sort_is_local(ctx, nb);
+  const bool keygen = hist_ok && ctx->nearest_aligned == 1;
+  const bool probe = hist_ok && ctx->nearest_aligned == -1;
+  if (keygen) lb.hist_partial2 = os_a.hist;
+  if (!(keygen || probe)) lb.abase = nullptr;  // (run_spans: no digit counting)
+  GIQL_TRY(run_spans(ctx, st, *a, *b, n_chrom, lb, (keygen || probe) ? 1 : -1, os.hist));
+  if (keygen) {
+    Phase ph(ctx, st, GIQL_PH_LINEARIZE, 2);
+    hipLaunchKernelGGL(k_fold_top2, dim3(MM_HIST_CHROMS, 2), dim3(256), 0, st, lb.top_partial, lb.top_partial2, lb.abase,
+                       os.hist, os_a.hist);
+    hipLaunchKernelGGL(k_digit_offsets2, dim3(4, 2), dim3(256), 0, st, os.hist, os_a.hist, (u32)LIN_HIST_REPLICAS,
+                       os.gbase, os_a.gbase);
+    GIQL_TRY(post_launch("digit offsets (span histogram, NEAREST)"));
+  }
   SideChain sc(ctx, st, na, nb);
-  GIQL_TRY(run_linearize(ctx, sc.stream(), *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr + 8, 0, 1, os_a.hist,
-                         os_a.gbase));
-  GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sa, (u32)na, os_a.gbase, os_a.status, false, nullptr, nullptr,
-                             /*skip_digits=*/row_skip(ctx, nb)));  // the query side's order only serves locality; every row keeps its real key here
-  GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist,
-                         os.gbase, two_sorts ? os.hist_e : nullptr, two_sorts ? os.gbase_e : nullptr));
+  if (!keygen)
+    GIQL_TRY(run_linearize(ctx, sc.stream(), *a, n_chrom, lb, sa.key[0], sa.end[0], dummy_irr + 8, 0, 1, os_a.hist,
+                           os_a.gbase));
+  GIQL_TRY(run_sort_onesweep(ctx, sc.stream(), sa, (u32)na, os_a.gbase, os_a.status, false, keygen ? a : nullptr,
+                             lb.abase, /*skip_digits=*/row_skip(ctx, nb)));  // the query side's order only serves locality; every row keeps its real key here
+  if (!keygen)
+    GIQL_TRY(run_linearize(ctx, st, *b, n_chrom, lb, sbb.key[0], sbb.end[0], dummy_irr, 1, 1, os.hist,
+                           os.gbase, two_sorts ? os.hist_e : nullptr, two_sorts ? os.gbase_e : nullptr));
   // (an inverted B row -- NEAREST needs start <= end on both sides -- is reported by the span pass: DevMeta::inverted_b)
   if (two_sorts) {
     // (start, end) lexicographic order = stable sort by end, then stable sort by start
@@ -2155,7 +2184,7 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
     GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, /*keep_rids=*/true));
   } else {
     // one sort by start; the (short) runs of equal starts are ordered by end in place
-    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status));
+    GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, false, keygen ? b : nullptr, lb.abase));
     Phase ph(ctx, st, GIQL_PH_AUX);
     hipLaunchKernelGGL(k_fix_start_ties, dim3(cdiv(nb, 256)), dim3(256), 0, st, sbb.key[0], sbb.end[0],
                        sbb.rid[0], (u32)nb, ctx->d_meta);
@@ -2174,6 +2203,12 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
     GIQL_TRY(post_launch("nearest"));
   }
   GIQL_TRY(read_meta(ctx, st));
+  if (keygen || probe) {
+    const bool aligned_now = ctx->h_meta->aligned_ok != 0;
+    ctx->nearest_aligned = aligned_now ? 1 : 0;
+    if (keygen && !aligned_now)  // the layout did not hold for this data: its keys were built on bases that overlap
+      return giql_hip_nearest_dev_impl(ctx, a, b, n_chrom, is_signed, max_distance, idx_b_out, dist_out, stream);
+  }
   if (ctx->h_meta->inverted_b) return set_err(GIQL_ERR_INVALID, "NEAREST: a target row has end < start");
   if (!two_sorts && ctx->h_meta->aux0 != 0) {
     // a long run of equal starts (pile-ups): this table wants the two-sort plan

@@ -1413,3 +1413,35 @@ def test_host_entry_pipelined_over_row_blocks_of_the_larger_table(monkeypatch, e
     monkeypatch.setenv("GIQL_HIP_E2E_BLOCK_ROWS", "0")            # one shot: the same pairs
     ra, rb = eng.inner_join_host((a.chrom, a.start, a.end), (b.chrom, b.start, b.end), 4)
     assert np.array_equal(ora.sort_pairs(ra, rb), want)
+
+
+def test_nearest_sorts_both_sides_from_their_raw_columns_once_the_layout_is_known(eng_fresh):
+    """NEAREST k = 1 (round 3): the first call of a context probes the aligned layout, later calls build the keys in the
+    first sort pass of each side (no linearize pass) -- same answers, with every encoding, zero-length rows, signed
+    and max_distance; data the layout cannot take (a negative coordinate) repeats the call the ordinary way."""
+    e = eng_fresh
+
+    def check(a, b, nch, **kw):
+        idx, dist = e.nearest(dev(a), dev(b), nch, **kw)
+        oi, od = ora.c_nearest_k1(a, b, method="sweep", **kw)
+        idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+        assert np.array_equal(dist, od) and np.array_equal(idx >= 0, oi >= 0)
+        m = oi >= 0
+        assert np.array_equal(b.start[idx[m]], b.start[oi[m]]) and np.array_equal(b.end[idx[m]], b.end[oi[m]])
+
+    a = rand_side(1951, 60_000, 7, 4_000_000, 900, min_len=0)
+    b = rand_side(1952, 90_000, 6, 4_000_000, 400, min_len=0)     # chrom 6 has no target
+    check(a, b, 7)                                                 # probe
+    for kw in ({}, {"signed": True}, {"signed": True, "max_distance": 700}):
+        check(a, b, 7, **kw)                                       # keys from the raw columns
+    for enc in ora.ENCODING_OFFSETS:
+        so, eo = ora.ENCODING_OFFSETS[enc]
+        check(ora.Side(a.chrom, a.start + 5, a.end + 5, so, eo), ora.Side(b.chrom, b.start + 5, b.end + 5, so, eo), 7)
+    neg = ora.Side(a.chrom, a.start - 1000, a.end - 1000)        # canonical coordinates below zero: no aligned layout
+    check(neg, b, 7)
+    check(a, b, 7)
+    # more chromosomes than the layout's table holds
+    a40 = rand_side(1953, 20_000, 40, 500_000, 300)
+    b40 = rand_side(1954, 30_000, 40, 500_000, 300)
+    check(a40, b40, 40)
+    check(a40, b40, 40)
