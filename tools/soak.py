@@ -71,8 +71,13 @@ while time.time() - t0 < budget:
     ob = torch.empty(cap, dtype=torch.int32, device="cuda:0")
     n = eng.inner_join_into(da, db, nch, oa, ob)
     assert n == want.shape[0] and np.array_equal(ora.sort_pairs(oa[:n].cpu().numpy(), ob[:n].cpu().numpy()), want), ("into", it)
+    # ... and once more on the same data: now every guess of the context holds, which is when the pairs come straight
+    # from the bucket stage of the sort (round 3; either join form, the LDS body, the crowded and the queued buckets)
+    oa.fill_(-1)
+    n = eng.inner_join_into(da, db, nch, oa, ob)
+    assert n == want.shape[0] and np.array_equal(ora.sort_pairs(oa[:n].cpu().numpy(), ob[:n].cpu().numpy()), want), ("into again", it)
     st2 = eng.stats()
-    if st2["bucket_join"]:   # the pairs came straight from the bucket stage (round 3), of either join form
+    if st2["bucket_join"]:
         forms[("bucket_join", st2["join_form"])] = forms.get(("bucket_join", st2["join_form"]), 0) + 1
     # NEAREST k = 1 (rows with start <= end only: the operator rejects inverted rows)
     if not (np.any(a.end + a.end_off < a.start + a.start_off) or np.any(b.end + b.end_off < b.start + b.start_off)):
