@@ -286,7 +286,8 @@ template <int R, bool GENERAL, int QR>
 __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (&pay)[R], const u32 (&slot)[R], u32 cnt,
                                                  u32 v, const u32* __restrict__ ep, u32* s_buf, u64* s_cell,
                                                  u32* s_jtot, const BsFuse& fq, u32 qw0, u32 nw,
-                                                 const u32 (&jq_key)[QR], const u32 (&jq_end)[QR]) {
+                                                 const u32 (&jq_key)[QR], const u32 (&jq_end)[QR],
+                                                 u32* s_bend = nullptr) {
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const u32 k0 = v << 16;
 #if defined(GIQL_BJ_ABLATE)  // timing-only builds (results invalid, tools/bj_ablate.sh): the tail stops after its k-th stage
@@ -295,6 +296,29 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
 #define GIQL_BJ_STOP(k) do { } while (0)
 #endif
   GIQL_BJ_STOP(1);  // the sort alone
+  if (GENERAL) {
+    // class 1 is answered from the queries' side too (below): the rows' end keys by final place, and the bucket's
+    // longest row (how far below a query's start a row that still covers it can begin)
+    u32 lmax = 0, pe[R];
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const u32 r = i * BS_NT + tid;
+      pe[i] = (i < R - 1 || r < cnt) ? s_bend[r] : 0u;  // parked by input place (bucket_sort_body)
+    }
+    bs_sync<2>();
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const u32 r = i * BS_NT + tid;
+      if (i < R - 1 || r < cnt) {
+        const u32 key = k0 | (pk[i] >> 12);
+        s_bend[slot[i]] = pe[i];
+        const u32 len = pe[i] > key ? pe[i] - key : 0u;
+        lmax = len > lmax ? len : lmax;
+      }
+    }
+    lmax = wave_reduce_max_u32(lmax);
+    if (lane == 0) s_jtot[QR * BS_NW + 4 + w] = lmax;  // (read behind the barrier that ends the ranking)
+  }
   // ranks of my queries' bounds inside this bucket, clamped to it
   u32 q_lo[QR], q_cnt[QR], q_rid[QR], incl[QR];
 #pragma unroll
@@ -326,56 +350,54 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
     }
     q_off[i] = mine + incl[i] - q_cnt[i];
   }
-  // class 1 (GENERAL): the window's keys into LDS, each of my rows against them
-  u32 c1[GENERAL ? R : 1];  // {first matching window row : 16 | matches : 16}
-  u32 off1 = 0;
-  const u32 total2 = total;
+  // class 1 (GENERAL): the bucket rows that COVER a query's start, q.start in [u.start, u.end).  Asked from the
+  // query's side: such a row starts in (q.start - longest row of the bucket, q.start] -- a contiguous stretch of the
+  // sorted bucket, both ends one bin-table read -- and is kept when its end key (staged above by final place) lies
+  // beyond q.start.  A handful of candidates per query at read lengths; asked from the rows' side (every row
+  // binary-searching the window's keys) it was a third of the kernel: 0.50 of 1.39 ms.
+  u32 c_lo[GENERAL ? QR : 1], c_hi[GENERAL ? QR : 1], c_cnt[GENERAL ? QR : 1], c_off[GENERAL ? QR : 1];
   if (GENERAL) {
-    u32* const s_qkey = reinterpret_cast<u32*>(s_cell);
+    u32 lmax = 0;
+#pragma unroll
+    for (int k = 0; k < BS_NW; k++) lmax = s_jtot[QR * BS_NW + 4 + k] > lmax ? s_jtot[QR * BS_NW + 4 + k] : lmax;
+    u32 incl1[QR];
 #pragma unroll
     for (int i = 0; i < QR; i++) {
       const u32 j = i * BS_NT + tid;
-      if (j < nw) s_qkey[j] = jq_key[i];
-    }
-    u32 pe[R];
-#pragma unroll
-    for (int i = 0; i < R; i++) {
-      const u32 r = i * BS_NT + tid;
-      pe[i] = (i < R - 1 || r < cnt) ? ep[r] : 0u;
-    }
-    bs_sync<2>();
-    u32 t1 = 0;
-#pragma unroll
-    for (int i = 0; i < R; i++) {
-      const u32 r = i * BS_NT + tid;
-      c1[i] = 0;
-      if (i < R - 1 || r < cnt) {
-        const u32 key = k0 | (pk[i] >> 12), end = pe[i];
-        u32 lo = 0, hi = nw;
-        while (lo < hi) {
-          const u32 mid = (lo + hi) >> 1;
-          if (s_qkey[mid] < key)
-            lo = mid + 1;
-          else
-            hi = mid;
+      c_lo[i] = c_hi[i] = c_cnt[i] = 0;
+      if (j < nw && jq_key[i] >= k0) {
+        const u32 x = jq_key[i];
+        // rows with key <= x, and rows with key <= x - lmax (those end at or before x)
+        const u32 hi_p = (x >> 16) != v ? cnt : ((x & 0xFFFFu) == 0xFFFFu ? cnt : bs_rank16((x & 0xFFFFu) + 1u, s_cell, s_buf));
+        u32 lo_p = 0;
+        if (x - k0 >= lmax) {  // y = x - lmax >= K0
+          const u32 y = x - lmax;
+          lo_p = (y >> 16) != v ? cnt : ((y & 0xFFFFu) == 0xFFFFu ? cnt : bs_rank16((y & 0xFFFFu) + 1u, s_cell, s_buf));
         }
         u32 c = 0;
-        while (lo + c < nw && s_qkey[lo + c] < end) c++;
-        c1[i] = lo | (c << 16);
-        t1 += c;
+        for (u32 p = lo_p; p < hi_p; p++) c += (u32)(s_bend[p] > x);
+        c_lo[i] = lo_p;
+        c_hi[i] = hi_p;
+        c_cnt[i] = c;
+        if (c && !q_cnt[i]) q_rid[i] = fq.qrid[qw0 + j];
       }
+      incl1[i] = wave_incl_scan_add_u32(c_cnt[i]);
     }
-    const u32 incl1 = wave_incl_scan_add_u32(t1);
-    if (lane == WAVE - 1) s_jtot[QR * BS_NW + 4 + w] = incl1;
-    bs_sync<2>();
-    u32 mine1 = 0, total1 = 0;
+    bs_sync<2>();  // every lmax has been read: the slots are the class-1 wave totals' now
 #pragma unroll
-    for (int k = 0; k < BS_NW; k++) {
-      if (k == (int)w) mine1 = total1;
-      total1 += s_jtot[QR * BS_NW + 4 + k];
+    for (int i = 0; i < QR; i++)
+      if (lane == WAVE - 1) s_jtot[i * BS_NW + w] = incl1[i];  // (the class-2 totals were consumed above)
+    bs_sync<2>();
+#pragma unroll
+    for (int i = 0; i < QR; i++) {
+      u32 mine = 0;
+#pragma unroll
+      for (int k = 0; k < BS_NW; k++) {
+        if (k == (int)w) mine = total;
+        total += s_jtot[i * BS_NW + k];
+      }
+      c_off[i] = mine + incl1[i] - c_cnt[i];
     }
-    off1 = total2 + mine1 + incl1 - t1;
-    total += total1;
   }
   if (total == 0) return;  // block-uniform: no query of the window meets a row of this bucket
   // the block's place in the output: one atomic, in flight while the row ids are staged by final place
@@ -411,14 +433,19 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
       }
     }
   }
-  if (GENERAL) {  // class 1: a row's few pairs from its own thread
+  if (GENERAL) {  // class 1: a query's few pairs from its own thread, behind the class-2 runs
 #pragma unroll
-    for (int i = 0; i < R; i++) {
-      const u32 lo = c1[i] & 0xFFFFu, c = c1[i] >> 16;
-      for (u32 k = 0; k < c; k++) {
-        rq[off1] = (int32_t)fq.qrid[qw0 + lo + k];
-        rs[off1] = (int32_t)pay[i];
-        off1++;
+    for (int i = 0; i < QR; i++) {
+      if (c_cnt[i]) {
+        const u32 x = jq_key[i];
+        u32 o = c_off[i];
+        for (u32 p = c_lo[i]; p < c_hi[i]; p++) {
+          if (s_bend[p] > x) {
+            rq[o] = (int32_t)q_rid[i];
+            rs[o] = (int32_t)s_buf[p];
+            o++;
+          }
+        }
       }
     }
   }
@@ -429,7 +456,8 @@ template <int PAYLOAD, int R, int FUSE = 0, int QR = BJ_QR>
 __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __restrict__ pp,
                                                  u32* __restrict__ ep, u32 cnt, u32 v, u32* s_buf,
                                                  u64* s_cell, u32* s_scan, const BsFuse& fq,
-                                                 u32 b0, u32 qw0, u32 qw1, u32* s_jtot = nullptr) {
+                                                 u32 b0, u32 qw0, u32 qw1, u32* s_jtot = nullptr,
+                                                 u32* s_bend = nullptr) {
   constexpr int BIN_SHIFT = 12 + BS_SUB_BITS;
   constexpr int PER = BS_NB / BS_NT;  // cells scanned per thread
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -442,6 +470,16 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
     pk[i] = ok ? kp[r] : 0u;
     pay[i] = (PAYLOAD && ok) ? pp[r] : 0u;  // used at the very end: the load flies under everything
     slot[i] = 0;
+  }
+  // general join form: the end keys ride in with the rows and wait in LDS by INPUT place (bucket_join_tail moves
+  // them to their final places); loaded in the tail they were a second exposed round trip per block
+  u32 pe0[FUSE == 3 ? R : 1];
+  if constexpr (FUSE == 3) {
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const u32 r = i * BS_NT + tid;
+      pe0[i] = GIQL_BS_OK(i, r) ? ep[r] : 0u;
+    }
   }
   // fused count: this thread's first query of the window, loaded in the same round trip as the rows (every
   // __syncthreads drains the wave's outstanding loads: issued any later, the round trip stands exposed)
@@ -482,6 +520,13 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
       const u32 sub = (pk[i] >> 12) & 31u;
       const u64 add = ((u64)(1u << sub) << 32) | 1ull;
       slot[i] = (u32)atomicAdd((unsigned long long*)&s_cell[pk[i] >> BIN_SHIFT], (unsigned long long)add);
+    }
+  }
+  if constexpr (FUSE == 3) {
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const u32 r = i * BS_NT + tid;
+      if (GIQL_BS_OK(i, r)) s_bend[r] = pe0[i];
     }
   }
   bs_sync<FUSE>();
@@ -567,7 +612,8 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
     }
   }
   if constexpr (FUSE >= 2) {  // the pairs leave from here: no sorted array is stored
-    bucket_join_tail<R, FUSE == 3, QR>(pk, pay, slot, cnt, v, ep, s_buf, s_cell, s_jtot, fq, qw0, qw1 - qw0, jq_key, jq_end);
+    bucket_join_tail<R, FUSE == 3, QR>(pk, pay, slot, cnt, v, ep, s_buf, s_cell, s_jtot, fq, qw0, qw1 - qw0, jq_key, jq_end,
+                                       s_bend);
     return;
   }
   bs_sync<FUSE>();  // every gathered bin has been read: s_buf and the cells are free
@@ -714,13 +760,13 @@ __global__ __launch_bounds__(BS_NT, FUSE == 3 ? GIQL_BJG_MIN_WAVES : (FUSE == 2 
                                                            u32* __restrict__ big_list, BsFuse fq = BsFuse()) {
   static_assert(BS_NB % BS_NT == 0, "bins must be a multiple of the block size");
   static_assert(BS_NB * sizeof(u64) >= BS_CAP * sizeof(uint16_t), "the cell table doubles as the 16-bit key stage");
-  static_assert(BS_NB * sizeof(u64) >= BJ_WCAP * sizeof(u32), "... and as the stage of a window's keys (general join form)");
   static_assert(BS_SUB_BITS == 5, "one 32-bit map of sub-values per bin");
   __shared__ u32 s_buf[BS_CAP + 4];  // + 4: the four-wide read of a gathered bin may run past the last row
   __shared__ u64 s_cell[BS_NB];  // {sub-value map : 32 | count : 32}, after the scan {map | dup, count, start}
   __shared__ u32 s_scan[BS_NW];
   // join forms: wave totals of the class-2 pair counts, the block's output base (64 bits), wave totals of class 1
   __shared__ __attribute__((aligned(8))) u32 s_jtot[FUSE >= 2 ? BJ_QR * BS_NW + 4 + BS_NW : 2];
+  __shared__ u32 s_bend[FUSE == 3 ? BS_CAP : 1];  // general join form: the rows' end keys by final place
   const u32 v = blockIdx.x;
   const u32 b0 = bnd[v];
   const u32 cnt = bnd[v + 1] - b0;
@@ -751,7 +797,7 @@ __global__ __launch_bounds__(BS_NT, FUSE == 3 ? GIQL_BJG_MIN_WAVES : (FUSE == 2 
   // the payload that rides along in registers: rid when there is one, else end
   u32* pp = (PAYLOAD & 1) ? rids + b0 : ((PAYLOAD & 2) ? ends + b0 : nullptr);
   u32* ep = (PAYLOAD == 3) ? ends + b0 : nullptr;  // a second payload array takes a round of its own
-#define GIQL_BS_BODY(RR) bucket_sort_body<PAYLOAD, RR, FUSE>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan, fq, b0, qw0, qw1, s_jtot)
+#define GIQL_BS_BODY(RR) bucket_sort_body<PAYLOAD, RR, FUSE>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan, fq, b0, qw0, qw1, s_jtot, s_bend)
   switch ((cnt + BS_NT - 1) / BS_NT) {  // rows per thread: 1..BS_ITEMS, block-uniform
     case 0: case 1: GIQL_BS_BODY(1); break;  // (0: an empty bucket with bounds to answer)
     case 2: GIQL_BS_BODY(2); break;
@@ -779,7 +825,7 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ key
   __shared__ u32 s_buf[FUSE >= 2 ? BS_CAP + 4 : 1];
   __shared__ u64 s_cell[FUSE >= 2 ? BS_NB : 1];
   __shared__ __attribute__((aligned(8))) u32 s_jtot[FUSE >= 2 ? BJ_QR_CROWD * BS_NW + 4 + BS_NW : 2];
-  static_assert(BS_NB * sizeof(u64) >= BJ_WCAP_CROWD * sizeof(u32), "the cell table holds a crowded window's keys");
+  __shared__ u32 s_bend[FUSE == 3 ? BS_CAP : 1];
   const u32 n_big = big_list[0];
   for (u32 i = blockIdx.x; i < n_big; i += gridDim.x) {
     const u32 entry = big_list[1 + i];
@@ -793,7 +839,7 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ key
         u32* ep = (PAYLOAD == 3) ? ends + b0 : nullptr;
         const u32 qw0 = fq.qwin[2 * v], qw1 = fq.qwin[2 * v + 1];
 #define GIQL_BS_BODY(RR) \
-  bucket_sort_body<PAYLOAD, RR, FUSE, BJ_QR_CROWD>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan, fq, b0, qw0, qw1, s_jtot)
+  bucket_sort_body<PAYLOAD, RR, FUSE, BJ_QR_CROWD>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan, fq, b0, qw0, qw1, s_jtot, s_bend)
         switch ((cnt + BS_NT - 1) / BS_NT) {
           case 0: case 1: GIQL_BS_BODY(1); break;
           case 2: GIQL_BS_BODY(2); break;
