@@ -683,6 +683,9 @@ def run_inner(args):
                 "device_ms": round(device_ms, 3),
                 "achieved": round(join_bytes / (device_ms * 1e-3) / 1e9, 1) if device_ms > 0 else 0.0,
                 "frac": round(join_bytes / (device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms > 0 else 0.0,
+                # ... and over the WALL time of a timed step (the phase table above comes from a warm-up step with an
+                # event pair around every phase, which costs the stream a few microseconds each)
+                "frac_of_wall_step": round(join_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4) if elapsed > 0 else 0.0,
             },
             "kernels": kernels,
             "phase_ms_source": (f"{dom}: hipEvents in the timed steps; other phases: hipEvents in the last warm-up "
