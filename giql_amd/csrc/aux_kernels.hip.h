@@ -665,7 +665,8 @@ constexpr int NEAREST_K_MAX = 64;
 // still lack candidates after the overlapping ones (its run heads found by galloping back: equal ends are short
 // runs), and from k = 16 on the results go straight to the output arrays (a row's k ids / k distances are 64+ / 128+
 // contiguous bytes) instead of through 16-byte records and an unpack pass.
-constexpr int NRK_CAP = 2560;  // staged B rows (keys + prefix max + ends: 30 KB)
+constexpr int NRK_CAP = 2048;  // staged B rows per view (keys + prefix max + ends of the (start, end) view, ends of the (end, start) view: 32 KB)
+constexpr u32 NRK_EBACK = 192;   // rows of the (end, start) view staged below the bracket (the upstream walk runs backwards)
 
 template <bool DIRECT>
 __global__ __launch_bounds__(NR_NT) void k_nearest_k(
@@ -676,9 +677,9 @@ __global__ __launch_bounds__(NR_NT) void k_nearest_k(
     const u32* __restrict__ e_starts, const u32* __restrict__ e_rids, u32 n_b, int k, int is_signed,
     i64 max_distance, NearestRec* __restrict__ rec_out, int32_t* __restrict__ idx_out, i64* __restrict__ dist_out,
     DevMeta* __restrict__ meta) {
-  __shared__ u32 s_keys[NRK_CAP], s_pmax[NRK_CAP], s_ends[NRK_CAP];
-  __shared__ u32 s_min[NR_NT / WAVE], s_max[NR_NT / WAVE];
-  __shared__ u32 s_w[2];
+  __shared__ u32 s_keys[NRK_CAP], s_pmax[NRK_CAP], s_ends[NRK_CAP], s_eends[NRK_CAP];
+  __shared__ u32 s_min[NR_NT / WAVE], s_max[NR_NT / WAVE], s_smin[NR_NT / WAVE], s_smax[NR_NT / WAVE];
+  __shared__ u32 s_w[4];
   __shared__ u32 s_cfirst[NR_CHROMS + 1], s_clo[NR_CHROMS + 1];
   const u32 tid = threadIdx.x;
   const u32 base = blockIdx.x * NR_TQ;
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(NR_NT) void k_nearest_k(
     }
   u32 qs[NR_ITEMS], qe[NR_ITEMS], rr[NR_ITEMS];
   bool live[NR_ITEMS], srch[NR_ITEMS];
-  u32 emin = U32_MAX, emax = 0u;
+  u32 emin = U32_MAX, emax = 0u, smin = U32_MAX, smax = 0u;
 #pragma unroll
   for (int u = 0; u < NR_ITEMS; u++) {
     const u32 i = base + u * NR_NT + tid;
@@ -703,17 +704,24 @@ __global__ __launch_bounds__(NR_NT) void k_nearest_k(
     if (srch[u]) {
       emin = qe[u] < emin ? qe[u] : emin;
       emax = qe[u] > emax ? qe[u] : emax;
+      smin = qs[u] < smin ? qs[u] : smin;
+      smax = qs[u] > smax ? qs[u] : smax;
     }
   }
 #pragma unroll
   for (int d = WAVE / 2; d > 0; d >>= 1) {
     const u32 tmin = (u32)__shfl_xor((int)emin, d, WAVE), tmax = (u32)__shfl_xor((int)emax, d, WAVE);
+    const u32 umin = (u32)__shfl_xor((int)smin, d, WAVE), umax = (u32)__shfl_xor((int)smax, d, WAVE);
     emin = tmin < emin ? tmin : emin;
     emax = tmax > emax ? tmax : emax;
+    smin = umin < smin ? umin : smin;
+    smax = umax > smax ? umax : smax;
   }
   if (lane_id() == 0) {
     s_min[wave_id()] = emin;
     s_max[wave_id()] = emax;
+    s_smin[wave_id()] = smin;
+    s_smax[wave_id()] = smax;
   }
   __syncthreads();
   if (wave_id() == 0) {  // the block's bracket of lower_bound(b_keys, a.end)
@@ -732,6 +740,22 @@ __global__ __launch_bounds__(NR_NT) void k_nearest_k(
       s_w[0] = lo;
       s_w[1] = hi;
     }
+  } else if (wave_id() == 1) {  // ... and of upper_bound(e_ends, a.start), the entry point of the upstream walk
+    u32 bmin = U32_MAX, bmax = 0u;
+#pragma unroll
+    for (int w = 0; w < NR_NT / WAVE; w++) {
+      bmin = s_smin[w] < bmin ? s_smin[w] : bmin;
+      bmax = s_smax[w] > bmax ? s_smax[w] : bmax;
+    }
+    u32 lo = 0, hi = n_b;
+    if (bmin <= bmax && n_b > 0) {
+      lo = wave_lower_bound_u32(e_ends, 0, n_b, bmin);
+      hi = bmax == U32_MAX ? n_b : wave_lower_bound_u32(e_ends, lo, n_b, bmax + 1u);  // = upper_bound(bmax)
+    }
+    if (lane_id() == 0) {
+      s_w[2] = lo;
+      s_w[3] = hi;
+    }
   }
   __syncthreads();
   const u32 w_lo = s_w[0], w_hi = s_w[1];
@@ -744,12 +768,18 @@ __global__ __launch_bounds__(NR_NT) void k_nearest_k(
     s_pmax[t] = b_pmax[w0 + t];
     s_ends[t] = b_ends[w0 + t];
   }
+  // the (end, start) view's ends around the upstream entry points (the walk runs backwards from them, run by run)
+  const u32 e_lo = s_w[2], e_hi = s_w[3];
+  const u32 e0 = e_lo > NRK_EBACK ? e_lo - NRK_EBACK : 0u;
+  u32 e1 = e_hi;
+  if (e1 - e0 > (u32)NRK_CAP) e1 = e0;
+  for (u32 t = tid; t < e1 - e0; t += NR_NT) s_eends[t] = e_ends[e0 + t];
   __syncthreads();
-  const u32 wn = w1 - w0;
+  const u32 wn = w1 - w0, en = e1 - e0;
   auto key_at = [&](u32 j) -> u32 { return (j - w0 < wn) ? s_keys[j - w0] : b_keys[j]; };
   auto pmax_at = [&](u32 j) -> u32 { return (j - w0 < wn) ? s_pmax[j - w0] : b_pmax[j]; };
   auto end_at = [&](u32 j) -> u32 { return (j - w0 < wn) ? s_ends[j - w0] : b_ends[j]; };
-  auto e_end_at = [&](u32 j) -> u32 { return e_ends[j]; };
+  auto e_end_at = [&](u32 j) -> u32 { return (j - e0 < en) ? s_eends[j - e0] : e_ends[j]; };
 #pragma unroll 1
   for (int u = 0; u < NR_ITEMS; u++) {
     if (!live[u]) continue;
@@ -785,7 +815,10 @@ __global__ __launch_bounds__(NR_NT) void k_nearest_k(
           u32 dn = hi;
           const u32 elo = chrom_lo_e[c], ehi = chrom_lo_e[c + 1];
           // upstream cursor: the run [run_lo, run_hi) of equal ends being emitted, `cur` inside it
-          u32 run_lo = upper_bound_u32(e_ends, elo, ehi, s), run_hi = run_lo, cur = run_lo;
+          // (inside the block's bracket; the ends of earlier / later chromosomes lie below / above every key of this one)
+          u32 run_lo = upper_bound_f(e_end_at, e_lo, e_hi, s);
+          run_lo = run_lo < elo ? elo : (run_lo > ehi ? ehi : run_lo);
+          u32 run_hi = run_lo, cur = run_lo;
           while (emitted < k) {
             // next upstream candidate (skipping rows that are downstream by the CASE's first arm)
             bool has_up = false;
@@ -794,14 +827,14 @@ __global__ __launch_bounds__(NR_NT) void k_nearest_k(
               if (cur == run_hi) {
                 if (run_lo == elo) break;
                 const u32 last = run_lo - 1;
-                const u32 ee = e_ends[last];
+                const u32 ee = e_end_at(last);
                 run_hi = run_lo;
                 run_lo = gallop_back_lower_f(e_end_at, elo, last, ee);  // the head of the run that ends at `last`
                 cur = run_lo;
               }
               if (e_starts[cur] < e) {
                 has_up = true;
-                up_e = e_ends[cur];
+                up_e = e_end_at(cur);
                 break;
               }
               cur++;
