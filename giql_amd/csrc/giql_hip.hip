@@ -1375,10 +1375,12 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     bool part_done = false;  // the scan wrote the fill's partition
     // ... and, when the other side's bucket stage answers the bounds anyway, the pairs are written right there
     // (bucket_sort.hip.h, FUSE == 2) -- as long as the query windows stay well inside what a block holds in
-    // registers: a window covers three 65536-key buckets of the coarsely grouped query side
+    // registers: a window covers the query buckets (coarsely grouped: whole 65536-key buckets) that a bucket's
+    // reach -- its own 65536 keys, the fixed length above it, the longest query below it -- touches
+    const double win_keys = 3.0 * 65536.0 + (double)uni_len;
     const bool join_in_buckets = fuse_cnt && !ctx->no_bucket_join && ctx->fuse_a && speculated && ctx->last_no_irr &&
                                  ctx->fuse_cap > 0 && ctx->last_span > 0 &&
-                                 3.0 * (double)nqr * 65536.0 / (double)ctx->last_span <= 0.75 * (double)BJ_WCAP;
+                                 (double)nqr * win_keys / (double)ctx->last_span <= 0.75 * (double)BJ_WCAP;
     FuseCount fc;
     if (fuse_cnt) {
       if (join_in_buckets) {
@@ -1472,7 +1474,10 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   const bool general_join = onesweep && !ctx->no_bucket_join && ctx->fuse_a && speculated && ctx->last_no_irr &&
                             ctx->fuse_cap > 0 && nb >= na && sort_is_local(ctx, nb) && ctx->spec_fuse_len_ok &&
                             ctx->last_span > 0 &&
-                            1.5 * (double)na * 65536.0 / (double)ctx->last_span <= 0.75 * (double)BJ_WCAP;
+                            // (a window = the A rows within the bucket's 65536 keys + the longest rows of either side: the
+                            // previous plan's maxima, like the guess they validate)
+                            (double)na * (65536.0 + (double)ctx->h_meta->len_max_a + (double)ctx->h_meta->len_max_b) /
+                                    (double)ctx->last_span <= 0.5 * (double)BJ_WCAP;
   // the smaller side's chain (linearize + sort) beside the larger side's when it is small (not in the form above:
   // B's last stage reads the sorted A)
   SideChain sc(ctx, st, (onesweep && !general_join) ? (na < nb ? na : nb) : 0, na < nb ? nb : na);
