@@ -211,10 +211,16 @@ class HipEngine:
         # scan / fill kernels and no read-back in between.  A result that does not fit comes back as
         # GIQL_ERR_CAPACITY with the exact count and a plan behind it: the ordinary fill follows.
         guess = getattr(self, "_pairs_guess", 0)
+        row_a = row_b = None
         if out is None and guess > 0 and a.n and b.n:
             cap = int(guess * 1.05) + 4096
-            row_a = torch.empty(cap, dtype=torch.int32, device=self.device)
-            row_b = torch.empty(cap, dtype=torch.int32, device=self.device)
+            try:   # (a guess left over from a much larger join must not be what runs the device out of memory)
+                row_a = torch.empty(cap, dtype=torch.int32, device=self.device)
+                row_b = torch.empty(cap, dtype=torch.int32, device=self.device)
+            except RuntimeError:
+                row_a = row_b = None
+                self._pairs_guess = 0
+        if row_a is not None and row_b is not None:
             try:
                 n = self.inner_join_into(a, b, n_chrom, row_a, row_b)
                 self._pairs_guess = n
