@@ -549,3 +549,45 @@ def test_engine_inner_join_takes_the_one_call_form_from_its_second_call(eng_loca
     _plain(eng_local, wide, reads, 3)
     _plain(eng_local, wide, reads, 3)
     assert eng_local.stats()["bucket_join"]
+
+
+def test_bucket_join_with_a_fixed_length_longer_than_a_bucket(eng_local):
+    # L = 150,000 > 65536: every query's range [q.start - L + 1, q.end) spans three and more buckets (whole
+    # buckets in the middle), the windows reach that far above each bucket
+    reads = uniform_side(1961, 120_000, 2, 60_000_000, 150_000)
+    peaks = rand_side(1962, 3_000, 2, 60_000_000, 5_000)
+    _fused_inner(eng_local, peaks, reads, 2)
+    _join_into(eng_local, peaks, reads, 2, expect_join=None)
+    _join_into(eng_local, peaks, reads, 2, expect_join=None)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_bucket_join_randomized_sweep(eng_local, seed):  # noqa: C901
+    """Random shapes through the one-call form twice in a row (the second call runs on the context's settled
+    guesses: the join in the bucket stage whenever the shape allows it), fixed-length and general forms, both
+    argument orders, every encoding, clustered queries, more chromosomes than the aligned layout holds."""
+    r = np.random.default_rng(7700 + seed)
+    n_chrom = int(r.choice([1, 3, 24, 40]))
+    span = int(r.choice([300_000, 20_000_000, 2_000_000_000 // n_chrom]))
+    nq, nu = int(r.choice([700, 9_000, 60_000])), int(r.choice([30_000, 250_000]))
+    fixed = int(r.choice([0, 36, 150, 90_000]))
+    encs = list(ora.ENCODING_OFFSETS)
+    u = (uniform_side(7800 + seed, nu, n_chrom, span, fixed) if fixed
+         else rand_side(7800 + seed, nu, n_chrom, span, int(r.choice([60, 3_000])), min_len=1))
+    q = rand_side(7900 + seed, nq, n_chrom, span, int(r.choice([50, 4_000, 30_000])), min_len=1, enc=encs[int(r.integers(0, 4))])
+    if r.random() < 0.5:   # a crowd of queries in one stretch
+        k = nq // 2
+        q.start[:k] = (span // 3 + r.integers(0, 40_000, k)).astype(np.int32)
+        q.end[:k] = q.start[:k] + r.integers(1, 2_000, k).astype(np.int32)
+    a, b = (q, u) if r.random() < 0.5 else (u, q)
+    for _ in range(3):
+        st = _join_into(eng_local, a, b, n_chrom, expect_join=None)
+    _SWEEP_JOINED.append(bool(st["bucket_join"]))
+
+
+_SWEEP_JOINED: list = []
+
+
+def test_bucket_join_randomized_sweep_engaged_the_bucket_stage():
+    # (the sweep above is only worth its name if a good part of its shapes took the form under test)
+    assert len(_SWEEP_JOINED) == 10 and sum(_SWEEP_JOINED) >= 4, _SWEEP_JOINED
