@@ -109,10 +109,10 @@ class COperand(ctypes.Structure):
 class CPred(ctypes.Structure):
     """``giql_pred`` (include/giql_hip.h)."""
 
-    _fields_ = [("lhs", COperand), ("rhs", COperand), ("op", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+    _fields_ = [("lhs", COperand), ("rhs", COperand), ("op", ctypes.c_int32), ("group", ctypes.c_int32)]
 
 
-OPS = {"=": 0, "==": 0, "!=": 1, "<>": 1, "<": 2, "<=": 3, ">": 4, ">=": 5}
+OPS = {"=": 0, "==": 0, "!=": 1, "<>": 1, "<": 2, "<=": 3, ">": 4, ">=": 5, "isnull": 6, "notnull": 7}
 SIDE_A, SIDE_B, SIDE_LIT = 0, 1, 2
 T_I32, T_I64, T_F32, T_F64, T_U8 = range(5)
 

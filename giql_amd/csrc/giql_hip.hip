@@ -2486,20 +2486,37 @@ int giql_hip_cluster_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom,
 
 static int check_operand(const giql_operand& o, int k, const char* which);
 
+// giql_pred[] -> the by-value kernel argument; uses[side] = a column of that side is read
+static int convert_preds(const giql_pred* preds, int32_t n_preds, DevPreds& ps, bool* uses) {
+  static_assert(sizeof(giql_operand) == sizeof(DevOperand), "giql_operand layout");
+  static_assert(sizeof(giql_pred) == sizeof(DevPred), "giql_pred layout");
+  memset(&ps, 0, sizeof(ps));
+  ps.n = n_preds;
+  for (int k = 0; k < n_preds; k++) {
+    const bool unary = preds[k].op == GIQL_OP_IS_NULL || preds[k].op == GIQL_OP_NOT_NULL;
+    if (preds[k].op < GIQL_OP_EQ || preds[k].op > GIQL_OP_NOT_NULL)
+      return set_err(GIQL_ERR_INVALID, "predicate %d: operator %d", k, preds[k].op);
+    if (preds[k].group < 0) return set_err(GIQL_ERR_INVALID, "predicate %d: group %d", k, preds[k].group);
+    GIQL_TRY(check_operand(preds[k].lhs, k, "lhs"));
+    if (!unary) GIQL_TRY(check_operand(preds[k].rhs, k, "rhs"));
+    memcpy(&ps.p[k], &preds[k], sizeof(DevPred));
+    if (unary) {  // the right operand is not read: make it a harmless literal
+      memset(&ps.p[k].rhs, 0, sizeof(DevOperand));
+      ps.p[k].rhs.side = GIQL_SIDE_LIT;
+    }
+    if (uses)
+      for (const giql_operand* o : {&preds[k].lhs, unary ? &preds[k].lhs : &preds[k].rhs})
+        if (o->side != GIQL_SIDE_LIT) uses[o->side] = true;
+  }
+  return GIQL_OK;
+}
+
 int giql_hip_cluster_pred_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
                               const giql_pred* preds, int32_t n_preds, int64_t* cluster_id_out, void* stream) {
   if (n_preds < 0 || n_preds > SEL_MAX_PREDS || (n_preds && !preds))
     return set_err(GIQL_ERR_INVALID, "bad predicates (at most %d)", SEL_MAX_PREDS);
   DevPreds ps;
-  memset(&ps, 0, sizeof(ps));
-  ps.n = n_preds;
-  for (int k = 0; k < n_preds; k++) {
-    if (preds[k].op < GIQL_OP_EQ || preds[k].op > GIQL_OP_GE)
-      return set_err(GIQL_ERR_INVALID, "predicate %d: operator %d", k, preds[k].op);
-    GIQL_TRY(check_operand(preds[k].lhs, k, "lhs"));
-    GIQL_TRY(check_operand(preds[k].rhs, k, "rhs"));
-    memcpy(&ps.p[k], &preds[k], sizeof(DevPred));
-  }
+  GIQL_TRY(convert_preds(preds, n_preds, ps, nullptr));
   return with_order_fallback(ctx, [&] { return giql_hip_cluster_dev_impl(ctx, s, n_chrom, distance, cluster_id_out, stream, &ps); });
 }
 
@@ -3025,21 +3042,9 @@ int giql_hip_select_dev(giql_hip_ctx* ctx, const giql_pred* preds, int32_t n_pre
       (n_preds && !preds) || n_rows_a < 0 || n_rows_b < 0 || n_rows_a > 0x7FFFFFFFll ||
       n_rows_b > 0x7FFFFFFFll)
     return set_err(GIQL_ERR_INVALID, "bad arguments (at most %d predicates, n < 2^31)", SEL_MAX_PREDS);
-  static_assert(sizeof(giql_operand) == sizeof(DevOperand), "giql_operand layout");
-  static_assert(sizeof(giql_pred) == sizeof(DevPred), "giql_pred layout");
   DevPreds ps;
-  memset(&ps, 0, sizeof(ps));
-  ps.n = n_preds;
   bool uses[2] = {false, false};
-  for (int k = 0; k < n_preds; k++) {
-    if (preds[k].op < GIQL_OP_EQ || preds[k].op > GIQL_OP_GE)
-      return set_err(GIQL_ERR_INVALID, "predicate %d: operator %d", k, preds[k].op);
-    GIQL_TRY(check_operand(preds[k].lhs, k, "lhs"));
-    GIQL_TRY(check_operand(preds[k].rhs, k, "rhs"));
-    memcpy(&ps.p[k], &preds[k], sizeof(DevPred));
-    for (const giql_operand* o : {&preds[k].lhs, &preds[k].rhs})
-      if (o->side != GIQL_SIDE_LIT) uses[o->side] = true;
-  }
+  GIQL_TRY(convert_preds(preds, n_preds, ps, uses));
   // a side given neither ids nor a row count is addressed by the candidate index
   if (!idx_a && n_rows_a == 0 && !uses[0]) n_rows_a = n;
   if (!idx_b && n_rows_b == 0 && !uses[1]) n_rows_b = n;

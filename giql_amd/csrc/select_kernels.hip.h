@@ -19,7 +19,7 @@ namespace giql {
 constexpr int SEL_NT = 256;
 constexpr int SEL_ITEMS = 8;
 constexpr int SEL_TILE = SEL_NT * SEL_ITEMS;
-constexpr int SEL_MAX_PREDS = 8;
+constexpr int SEL_MAX_PREDS = 16;
 
 // mirrors giql_operand / giql_pred of include/giql_hip.h
 struct DevOperand {
@@ -34,8 +34,8 @@ struct DevOperand {
 };
 struct DevPred {
   DevOperand lhs, rhs;
-  int op;  // 0 ==, 1 !=, 2 <, 3 <=, 4 >, 5 >=
-  int pad;
+  int op;     // 0 ==, 1 !=, 2 <, 3 <=, 4 >, 5 >=, 6 IS NULL, 7 IS NOT NULL (lhs only)
+  int group;  // != 0 and equal to the predecessor's: OR-ed with it; otherwise a new AND-ed clause
 };
 struct DevPreds {
   DevPred p[SEL_MAX_PREDS];
@@ -85,20 +85,38 @@ __device__ __forceinline__ bool sel_cmp(T a, T b, int op) {
   }
 }
 
-// SQL three-valued logic collapsed for a filter: NULL on either side -> not kept.
+// SQL three-valued logic collapsed for a filter: a comparison with a NULL operand is
+// not true.  The predicates form a conjunction of clauses; a clause is a run of
+// predicates sharing one non-zero group id, OR-ed (a NOT has been pushed into the
+// comparisons by the caller, so "not true" and "false" need no telling apart:
+// AND / OR are monotone).
 __device__ __forceinline__ bool sel_eval(const DevPreds& ps, int ia, int ib) {
-  bool keep = true;
+  bool keep = true, acc = true;
+  int prev = 0;
   for (int k = 0; k < ps.n; k++) {
+    const int op = ps.p[k].op;
     const SelValue a = sel_load(ps.p[k].lhs, ia, ib);
-    const SelValue b = sel_load(ps.p[k].rhs, ia, ib);
     bool t;
-    if (a.is_float || b.is_float)
-      t = sel_cmp<double>(a.is_float ? a.f : (double)a.i, b.is_float ? b.f : (double)b.i, ps.p[k].op);
-    else
-      t = sel_cmp<i64>(a.i, b.i, ps.p[k].op);
-    keep = keep && t && !a.null && !b.null;
+    if (op >= 6) {
+      t = (op == 6) == a.null;
+    } else {
+      const SelValue b = sel_load(ps.p[k].rhs, ia, ib);
+      if (a.is_float || b.is_float)
+        t = sel_cmp<double>(a.is_float ? a.f : (double)a.i, b.is_float ? b.f : (double)b.i, op);
+      else
+        t = sel_cmp<i64>(a.i, b.i, op);
+      t = t && !a.null && !b.null;
+    }
+    const int g = ps.p[k].group;
+    if (g != 0 && g == prev) {
+      acc = acc || t;
+    } else {
+      keep = keep && acc;
+      acc = t;
+    }
+    prev = g;
   }
-  return keep;
+  return keep && acc;
 }
 
 // pass 1: ballot masks (one 64-bit word per 64 consecutive candidates) + block counts.

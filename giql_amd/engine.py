@@ -460,20 +460,11 @@ class HipEngine:
 
     def _cluster_pred(self, s: DeviceSide, n_chrom: int, distance: int, preds):
         torch = _torch()
-        k = len(preds)
-        c_preds = (_lib.CPred * max(k, 1))()
-        keep_alive = []
-        for j, (lhs, op, rhs) in enumerate(preds):
-            if op not in _lib.OPS:
-                raise ValueError(f"operator {op!r}")
-            for o in (lhs, rhs):
+        for p in preds:
+            for o in (p[0], p[2]):
                 if o[0] in ("a", "b") and int(o[1].shape[0]) != s.n:
                     raise ValueError("a predicate column must have one value per row of the table")
-            c_preds[j].lhs, ka = self._c_operand(lhs)
-            keep_alive.append(ka)
-            c_preds[j].rhs, ka = self._c_operand(rhs)
-            keep_alive.append(ka)
-            c_preds[j].op = _lib.OPS[op]
+        c_preds, k, _keep_alive = self._c_preds(preds)
         ids = torch.empty(s.n, dtype=torch.int64, device=self.device)
         _lib.check(self._L.giql_hip_cluster_pred_dev(self._h, s.c_struct(), int(n_chrom), int(distance), c_preds, k,
                                                      ids.data_ptr() if s.n else None, self._stream()))
@@ -581,6 +572,26 @@ class HipEngine:
         return out_off, out
 
     # ----------------------------------------------------- residual predicates
+    def _c_preds(self, preds):
+        """``[(lhs, op, rhs[, group])]`` -> (``giql_pred`` array, its length, the tensors to keep alive).
+        Predicates are AND-ed; adjacent ones sharing a non-zero ``group`` are OR-ed (one CNF clause)."""
+        k = len(preds)
+        if k > 16:
+            raise ValueError("at most 16 predicates per call")
+        c_preds = (_lib.CPred * max(k, 1))()
+        keep_alive = []
+        for j, p in enumerate(preds):
+            lhs, op, rhs = p[0], p[1], p[2]
+            if op not in _lib.OPS:
+                raise ValueError(f"operator {op!r}")
+            c_preds[j].lhs, ka = self._c_operand(lhs)
+            keep_alive.append(ka)
+            c_preds[j].rhs, ka = self._c_operand(rhs if op not in ("isnull", "notnull") else ("lit", 0))
+            keep_alive.append(ka)
+            c_preds[j].op = _lib.OPS[op]
+            c_preds[j].group = int(p[3]) if len(p) > 3 else 0
+        return c_preds, k, keep_alive
+
     def _c_operand(self, spec):
         """``("a" | "b", tensor[, valid_u8_tensor])`` or ``("lit", int | float)`` -> COperand."""
         torch = _torch()
@@ -617,28 +628,19 @@ class HipEngine:
         return o, (t, valid)
 
     def select(self, preds, idx_a=None, idx_b=None, n=None, n_rows_a=0, n_rows_b=0, want=("a", "b")):
-        """Stable filter by a conjunction of residual predicates (the extra ON / WHERE
-        conjuncts the reference inlines beside the INTERSECTS,
-        ``intersects_duckdb.py:1164-1177, 1239-1243``).
+        """Stable filter by residual predicates (the extra ON / WHERE conditions the
+        reference inlines beside the INTERSECTS, ``intersects_duckdb.py:1164-1177,
+        1239-1243``), given in conjunctive normal form.
 
-        ``preds`` = ``[(lhs, op, rhs)]`` with operands ``("a" | "b", column[, valid])`` or
-        ``("lit", value)`` and ``op`` one of ``= != <> < <= > >=``.  Candidates are the
+        ``preds`` = ``[(lhs, op, rhs[, group])]`` with operands ``("a" | "b", column[, valid])``
+        or ``("lit", value)`` and ``op`` one of ``= != <> < <= > >= isnull notnull``; the
+        predicates are AND-ed, adjacent ones sharing a non-zero ``group`` are OR-ed.  Candidates are the
         pairs ``(idx_a[i], idx_b[i])``; a missing id array means "the candidate index".
         Returns the kept ``(ids_a, ids_b)`` (``None`` for a side not in ``want``)."""
         torch = _torch()
         if n is None:
             n = int((idx_a if idx_a is not None else idx_b).shape[0])
-        k = len(preds)
-        c_preds = (_lib.CPred * max(k, 1))()
-        keep_alive = []
-        for j, (lhs, op, rhs) in enumerate(preds):
-            if op not in _lib.OPS:
-                raise ValueError(f"operator {op!r}")
-            c_preds[j].lhs, ka = self._c_operand(lhs)
-            keep_alive.append(ka)
-            c_preds[j].rhs, ka = self._c_operand(rhs)
-            keep_alive.append(ka)
-            c_preds[j].op = _lib.OPS[op]
+        c_preds, k, _keep_alive = self._c_preds(preds)
         for t in (idx_a, idx_b):
             if t is not None and (t.dtype != torch.int32 or not t.is_contiguous() or int(t.shape[0]) != n):
                 raise ValueError("id arrays must be contiguous int32 tensors of n rows")

@@ -149,8 +149,20 @@ class _Residuals:
         self._cache: dict = {}
 
     @staticmethod
-    def sides(res) -> set:
-        return {o.kind for o in (res.lhs, res.rhs) if o.kind in ("l", "r")}
+    def sides(clause) -> set:
+        """The tables a clause (a list of OR-ed residuals) reads."""
+        return {o.kind for res in clause for o in (res.lhs, res.rhs) if o.kind in ("l", "r")}
+
+    @staticmethod
+    def clauses(residuals) -> list:
+        """Residuals are AND-ed; neighbours sharing a non-zero group form one OR clause."""
+        out: list = []
+        for r in residuals:
+            if out and r.group and out[-1][-1].group == r.group:
+                out[-1].append(r)
+            else:
+                out.append([r])
+        return out
 
     def _arrow(self, side: str, column: str):
         import pyarrow as pa
@@ -218,6 +230,10 @@ class _Residuals:
 
         ops = (res.lhs, res.rhs)
         eside = {"l": "a", "r": "b"}
+        if res.op in ("isnull", "notnull"):   # reads the validity of lhs only, whatever the column's type
+            col = self._arrow(res.lhs.kind, res.lhs.value)
+            data = torch.zeros(len(col), dtype=torch.uint8, device=self.eng.device)
+            return (eside[res.lhs.kind], data, self._valid(col)), res.op, ("lit", 0), res.group
         if any(self._is_string(o) for o in ops):
             if not all(self._is_string(o) for o in ops):
                 raise ValueError(f"cannot compare a string with a number in {res.lhs.value!r} {res.op} {res.rhs.value!r}")
@@ -240,7 +256,7 @@ class _Residuals:
                     col = self._arrow(o.kind, o.value)
                     specs.append((eside[o.kind], torch.from_numpy(np.ascontiguousarray(codes)).to(self.eng.device),
                                   self._valid(col)))
-            return specs[0], res.op, specs[1]
+            return specs[0], res.op, specs[1], res.group
         specs = []
         for o in ops:
             if o.kind in ("int", "float"):
@@ -251,10 +267,11 @@ class _Residuals:
                     raise ValueError(f"column {o.value!r}: type {self._arrow(o.kind, o.value).type} is not supported "
                                      "in a dialect='hip' predicate")
                 specs.append((eside[o.kind], nv[0], nv[1]))
-        return specs[0], res.op, specs[1]
+        return specs[0], res.op, specs[1], res.group
 
-    def preds(self, residuals):
-        return [self.pred(r) for r in residuals]
+    def preds(self, clauses):
+        """The predicates of a list of clauses (or of plain residuals), in order."""
+        return [self.pred(r) for c in clauses for r in (c if isinstance(c, list) else [c])]
 
 
 def _subset(eng: HipEngine, side: DeviceSide, ids):
@@ -275,11 +292,12 @@ def _join_with_residuals(plan: JoinPlan, lt, rt, a: DeviceSide, b: DeviceSide, n
     intersects_duckdb.py:1164-1177)."""
     rb_ = _Residuals(plan, lt, rt, eng)
     semi = plan.kind in ("SEMI", "ANTI")
-    joinside = [r for r in plan.residuals if not (semi and r.clause == "where")]
-    outer = [r for r in plan.residuals if semi and r.clause == "where"]
-    left_only = [r for r in joinside if rb_.sides(r) == {"l"}]
-    right_only = [r for r in joinside if rb_.sides(r) == {"r"}]
-    both = [r for r in joinside if rb_.sides(r) == {"l", "r"}]
+    clauses = rb_.clauses(plan.residuals)   # every member of a clause comes from the same SQL clause
+    joinside = [c for c in clauses if not (semi and c[0].clause == "where")]
+    outer = [c for c in clauses if semi and c[0].clause == "where"]
+    left_only = [c for c in joinside if rb_.sides(c) == {"l"}]
+    right_only = [c for c in joinside if rb_.sides(c) == {"r"}]
+    both = [c for c in joinside if rb_.sides(c) == {"l", "r"}]
     ids_a = eng.select(rb_.preds(left_only), n=a.n, n_rows_a=a.n, want=("a",))[0] if left_only else None
     ids_b = eng.select(rb_.preds(right_only), n=b.n, n_rows_b=b.n, want=("b",))[1] if right_only else None
     a_sub, b_sub = _subset(eng, a, ids_a), _subset(eng, b, ids_b)

@@ -59,8 +59,9 @@ class Residual:
 
     clause: str    # "on" | "where"
     lhs: Operand
-    op: str        # = != < <= > >=
+    op: str        # = != < <= > >= isnull notnull (the last two read lhs only)
     rhs: Operand
+    group: int = 0  # residuals are AND-ed; those sharing a non-zero group are OR-ed (one CNF clause)
 
 
 @dataclass(frozen=True)
@@ -144,10 +145,10 @@ class JoinPlan:
             projection=tuple(Projection(**p) for p in d["projection"]),
             distinct=d.get("distinct", False), k=d.get("k", 1),
             max_distance=d.get("max_distance"), signed=d.get("signed", False),
-            residuals=tuple(Residual(r["clause"], Operand(**r["lhs"]), r["op"], Operand(**r["rhs"]))
+            residuals=tuple(Residual(r["clause"], Operand(**r["lhs"]), r["op"], Operand(**r["rhs"]), r.get("group", 0))
                             for r in d.get("residuals", ())),
             distance=d.get("distance", 0), stranded=d.get("stranded", False), strand_col=d.get("strand_col"),
-            cluster_predicate=tuple(Residual(r["clause"], Operand(**r["lhs"]), r["op"], Operand(**r["rhs"]))
+            cluster_predicate=tuple(Residual(r["clause"], Operand(**r["lhs"]), r["op"], Operand(**r["rhs"]), r.get("group", 0))
                                     for r in d.get("cluster_predicate", ())),
             aggregates=tuple(Aggregate(**a) for a in d.get("aggregates", ())),
             having=tuple(Having(Operand(**h["lhs"]), h["op"], Operand(**h["rhs"])) for h in d.get("having", ())),

@@ -47,7 +47,8 @@ import re
 from dataclasses import dataclass
 
 from .plan import PlanSide
-from .shape import AGG_FUNCS, ColRef, HipDeclined, JoinShape, OrderKey, SelItem, TableRef, decline, lower_join_shape, norm
+from .shape import (AGG_FUNCS, ColRef, HipDeclined, JoinShape, OrderKey, SelItem, TableRef, condition_terms, decline,
+                    lower_join_shape, norm)
 
 SPATIAL_KEYS = ("intersects", "contains", "within", "spatialsetpredicate")
 SPATIAL_PREDICATE_META = "giql_spatial_predicate"   # what the generic spatial expanders stamp on their output
@@ -186,24 +187,53 @@ def _conjuncts(n):
         yield n
 
 
+def _cond_tree(n):
+    """A condition node -> the tree ``shape.condition_terms`` normalises (AND / OR / NOT / parentheses over
+    INTERSECTS, comparisons, BETWEEN, IN (literals), IS [NOT] NULL).  The reference inlines any extra that
+    holds no INTERSECTS / sub-query / aggregate / window as SQL text (``_classify_extras``,
+    intersects_duckdb.py:889-912); what has no evaluator here -- LIKE, arithmetic, functions, sub-queries,
+    TRUE -- declines, so the naive predicate runs the query."""
+    k = _key(n)
+    if k in ("and", "or"):
+        _only(n, ("this", "expression"), k.upper())
+        return (k, [_cond_tree(_arg(n, "this")), _cond_tree(_arg(n, "expression"))])
+    if k == "not":
+        _only(n, ("this",), "NOT")
+        return ("not", _cond_tree(_arg(n, "this")))
+    if k == "paren":
+        _only(n, ("this",), "parentheses")
+        return _cond_tree(_arg(n, "this"))
+    if k == "intersects":
+        l, r = _arg(n, "this"), _arg(n, "expression")
+        if _key(l) != "column" or _key(r) != "column":
+            raise decline("INTERSECTS operand that is not a column")
+        return ("leaf", ("intersects", _colref(l), _colref(r)))
+    if k in _CMP:
+        return ("leaf", ("cmp", _operand(_arg(n, "this")), _CMP[k], _operand(_arg(n, "expression"))))
+    if k == "between":
+        _only(n, ("this", "low", "high"), "BETWEEN")
+        x = _operand(_arg(n, "this"))
+        return ("and", [("leaf", ("cmp", x, ">=", _operand(_arg(n, "low")))),
+                        ("leaf", ("cmp", x, "<=", _operand(_arg(n, "high"))))])
+    if k == "in":
+        _only(n, ("this", "expressions"), "IN")      # IN (sub-query) / IN UNNEST(...) carry other args
+        x = _operand(_arg(n, "this"))
+        values = [_literal(v) for v in (_arg(n, "expressions") or [])]
+        if not values or any(v is None for v in values):
+            raise decline("IN list with a non-literal member")
+        return ("or", [("leaf", ("cmp", x, "=", v)) for v in values])
+    if k == "is":
+        _only(n, ("this", "expression"), "IS")
+        if _key(_arg(n, "expression")) != "null" or _key(_arg(n, "this")) != "column":
+            raise decline("IS predicate other than <column> IS [NOT] NULL")
+        return ("leaf", ("cmp", ("col", _colref(_arg(n, "this"))), "isnull", ("lit", 0)))
+    if k in ("contains", "within"):
+        raise decline(f"{k.upper()} predicate")
+    raise decline(f"join condition of kind {k!r}")
+
+
 def _terms(cond):
-    out = []
-    for c in _conjuncts(cond):
-        k = _key(c)
-        if k == "intersects":
-            l, r = _arg(c, "this"), _arg(c, "expression")
-            if _key(l) != "column" or _key(r) != "column":
-                raise decline("INTERSECTS operand that is not a column")
-            out.append(("intersects", _colref(l), _colref(r)))
-        elif k in _CMP:
-            out.append(("cmp", _operand(_arg(c, "this")), _CMP[k], _operand(_arg(c, "expression"))))
-        elif k in ("contains", "within"):
-            raise decline(f"{k.upper()} predicate")
-        else:
-            # OR / NOT / parentheses / IN / BETWEEN / LIKE / IS / functions / sub-queries / TRUE:
-            # _classify_extras routes these to the naive plan (intersects_duckdb.py:889-912)
-            raise decline(f"join condition of kind {k!r}")
-    return out
+    return condition_terms(_cond_tree(cond)) if cond is not None else []
 
 
 def _select_item(n) -> SelItem:

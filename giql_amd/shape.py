@@ -44,6 +44,70 @@ def decline(reason: str) -> HipDeclined:
         "giql.transpile(...) for a SQL engine instead")
 
 
+# ------------------------------------------------------- boolean conditions -> CNF
+# Both front ends hand a condition over as a tree -- ("leaf", term) | ("and", [nodes]) |
+# ("or", [nodes]) | ("not", node), a term being ("intersects", ...), ("intersects_lit", ...)
+# or ("cmp", lhs, op, rhs) -- and get the terms of its conjunctive normal form back: the
+# select kernel evaluates an AND of ORs (include/giql_hip.h, giql_pred.group).  The
+# reference inlines such extras as SQL text (_classify_extras, intersects_duckdb.py:889-912).
+NEGATED_OP = {"=": "!=", "!=": "=", "<": ">=", ">=": "<", ">": "<=", "<=": ">", "isnull": "notnull",
+              "notnull": "isnull"}
+MAX_CONDITION_LEAVES = 12   # a select call takes 16 predicates; a literal-range filter adds three of its own
+
+
+def _nnf(node, neg: bool = False):
+    """Push NOT down to the comparisons.  Exact under three-valued logic: a filter keeps TRUE
+    only, De Morgan holds in Kleene logic and NOT (x < y) is TRUE exactly when x >= y is."""
+    k = node[0]
+    if k == "leaf":
+        if not neg:
+            return node
+        t = node[1]
+        if t[0] != "cmp":
+            raise decline("NOT over a spatial predicate")
+        return ("leaf", ("cmp", t[1], NEGATED_OP[t[2]], t[3]))
+    if k == "not":
+        return _nnf(node[1], not neg)
+    kids = [_nnf(c, neg) for c in node[1]]
+    return (("or" if k == "and" else "and") if neg else k, kids)
+
+
+def _cnf(node) -> list:
+    k = node[0]
+    if k == "leaf":
+        return [[node[1]]]
+    if k == "and":
+        return [cl for c in node[1] for cl in _cnf(c)]
+    acc = [[]]
+    for c in node[1]:
+        acc = [a + cl for a in acc for cl in _cnf(c)]
+        if sum(len(a) for a in acc) > 4 * MAX_CONDITION_LEAVES:
+            raise decline("condition too large once normalised")
+    return acc
+
+
+def condition_terms(tree) -> list:
+    """The condition's CNF as terms: a one-leaf clause is the leaf itself, a longer one
+    ``("or", [cmp, ...])``.  A spatial predicate must be a conjunct of its own (under OR / NOT
+    the reference falls back too: ``_classify_extras``)."""
+    out, leaves = [], 0
+    for clause in _cnf(_nnf(tree)):
+        uniq = []
+        for t in clause:
+            if t not in uniq:
+                uniq.append(t)
+        if len(uniq) == 1:
+            out.append(uniq[0])
+        else:
+            if any(t[0] != "cmp" for t in uniq):
+                raise decline("spatial predicate under OR")
+            out.append(("or", uniq))
+        leaves += sum(t[0] == "cmp" for t in uniq)
+    if leaves > MAX_CONDITION_LEAVES:
+        raise decline("condition too large once normalised")
+    return out
+
+
 def norm(name: str, quoted: bool = False) -> str:
     # unquoted identifiers are case-insensitive (intersects_duckdb.py:119-128)
     return name if quoted else name.casefold()
@@ -95,7 +159,8 @@ class JoinShape:
     join_ref: TableRef
     kind: str = "INNER"                      # INNER (also CROSS / comma) | SEMI | ANTI | LEFT
     on_seen: bool = False
-    on_terms: list = field(default_factory=list)      # ("intersects", ColRef, ColRef) | ("cmp", lhs, op, rhs)
+    # ("intersects", ColRef, ColRef) | ("cmp", lhs, op, rhs) | ("or", [cmp, ...]): see condition_terms
+    on_terms: list = field(default_factory=list)
     where_terms: list = field(default_factory=list)
     using: list[str] = field(default_factory=list)
     distinct: bool = False
@@ -165,7 +230,20 @@ def resolve_projection(items, left: PlanSide, right: PlanSide, left_only: bool,
     return tuple(out)
 
 
-def resolve_residual(clause: str, term, left: PlanSide, right: PlanSide, kind: str) -> Residual:
+def resolve_residuals(clause_terms, left: PlanSide, right: PlanSide, kind: str) -> tuple:
+    """``[(clause, term)]`` -> residuals.  A term is a comparison ``("cmp", lhs, op, rhs)`` or
+    a disjunction ``("or", [cmp, ...])``; the members of one disjunction share a fresh group id."""
+    out, group = [], 0
+    for clause, t in clause_terms:
+        if t[0] == "or":
+            group += 1
+            out.extend(resolve_residual(clause, leaf, left, right, kind, group) for leaf in t[1])
+        else:
+            out.append(resolve_residual(clause, t, left, right, kind))
+    return tuple(out)
+
+
+def resolve_residual(clause: str, term, left: PlanSide, right: PlanSide, kind: str, group: int = 0) -> Residual:
     """Bind a comparison's operands to the two sides; qualifier mistakes are user
     errors, as in ``_validate_extra_qualifiers`` (intersects_duckdb.py:914-959)."""
     _, lhs, op, rhs = term
@@ -195,7 +273,7 @@ def resolve_residual(clause: str, term, left: PlanSide, right: PlanSide, kind: s
     a, b = bind(lhs), bind(rhs)
     if a.kind not in ("l", "r") and b.kind not in ("l", "r"):
         raise decline("constant predicate in the join condition")
-    return Residual(clause, a, op, b)
+    return Residual(clause, a, op, b, group)
 
 
 def resolve_count_projection(items, group_cols, left: PlanSide, right: PlanSide):
@@ -430,7 +508,8 @@ def lower_join_shape(shape: JoinShape, tables: Tables) -> JoinPlan:
     if kind in ("SEMI", "ANTI") and not any(t[0] == "intersects" for t in on_terms):
         raise decline("SEMI/ANTI join with its INTERSECTS outside ON")  # #201
     _, lhs, rhs = [t for t in on_terms + where_terms if t[0] == "intersects"][0]
-    cmp_terms = [("on", t) for t in on_terms if t[0] == "cmp"] + [("where", t) for t in where_terms if t[0] == "cmp"]
+    cmp_terms = ([("on", t) for t in on_terms if t[0] in ("cmp", "or")]
+                 + [("where", t) for t in where_terms if t[0] in ("cmp", "or")])
     if kind == "COUNT" and (cmp_terms or where_terms):
         raise decline("count_overlaps with predicates beside the INTERSECTS")  # bare ON only (:432-548)
     if kind == "COUNT" and not shape.group_by:
@@ -478,7 +557,7 @@ def lower_join_shape(shape: JoinShape, tables: Tables) -> JoinPlan:
         proj, aggs, groups = resolve_projection(items, left, right, left_only), (), ()
         visible_aggs = ()
     hidden, order = _resolve_order(shape, proj, visible_aggs, left, right, left_only, grouped)
-    residuals = tuple(resolve_residual(clause, t, left, right, kind) for clause, t in cmp_terms)
+    residuals = resolve_residuals(cmp_terms, left, right, kind)
     return JoinPlan(kind, left, right, tuple(proj) + hidden, shape.distinct, residuals=residuals,
                     aggregates=aggs, group_by=groups, having=having, order_by=order,
                     limit=shape.limit, offset=shape.offset, output=output)

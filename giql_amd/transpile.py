@@ -36,6 +36,7 @@ from dataclasses import dataclass
 
 from .plan import JoinPlan, Operand, PlanSide, Projection, Residual
 from .shape import AGG_FUNCS, ColRef as _ColRef, HipDeclined, JoinShape, OrderKey, SelItem, TableRef as _TableRef
+from .shape import condition_terms as _condition_terms
 from .shape import decline as _decline
 from .shape import genomic_col as _genomic_col
 from .shape import lower_join_shape, resolve_projection
@@ -61,7 +62,7 @@ _KEYWORDS = {
     "SELECT", "DISTINCT", "FROM", "JOIN", "INNER", "CROSS", "SEMI", "ANTI", "LEFT", "RIGHT",
     "FULL", "OUTER", "NATURAL", "ON", "USING", "WHERE", "AND", "OR", "NOT", "AS", "INTERSECTS",
     "CONTAINS", "WITHIN", "GROUP", "ORDER", "BY", "HAVING", "LIMIT", "OFFSET", "LATERAL",
-    "NEAREST", "WITH", "UNION", "ANY", "ALL", "EXISTS", "TRUE", "FALSE",
+    "NEAREST", "WITH", "UNION", "ANY", "ALL", "EXISTS", "TRUE", "FALSE", "BETWEEN", "IN", "IS", "NULL", "LIKE",
 }
 
 
@@ -203,62 +204,159 @@ def _parse_operand(p: _Parser):
     return ("col", ref)
 
 
-def _parse_conjunction(p: _Parser, allow_literal: bool = False):
-    """``term (AND term)*`` where a term is ``<col> INTERSECTS <col>`` or a comparison
-    ``<operand> op <operand>``.  Everything else (OR, NOT, parentheses, arithmetic,
-    IN / BETWEEN / LIKE / IS, sub-queries) declines: the reference either routes those
-    to the naive plan (``_classify_extras``, intersects_duckdb.py:889-912) or inlines
-    SQL text this target has no evaluator for."""
-    terms = []
-    while True:
-        if p.at_kw("NOT", "EXISTS") or p.at_punct("("):
-            raise _decline("NOT / parenthesised / EXISTS condition")
-        lhs = _parse_operand(p)
-        if p.at_kw("INTERSECTS"):
-            p.next()
-            if lhs[0] != "col":
-                raise _decline("INTERSECTS with a literal on the left")
-            if p.peek().kind == "str":
-                if not allow_literal:
-                    raise _decline("literal-range INTERSECTS inside a join")
-                terms.append(("intersects_lit", lhs[1], p.next().text))
-                if p.at_kw("AND"):
-                    p.next()
-                    continue
-                if p.at_kw("OR"):
-                    raise _decline("OR in the condition")
-                return terms
-            if p.at_kw("ANY", "ALL"):
-                raise _decline("INTERSECTS ANY/ALL")
-            if p.peek().kind != "id":
-                raise _decline("INTERSECTS operand that is not a column")
-            terms.append(("intersects", lhs[1], p.colref()))
-        elif p.at_kw("CONTAINS", "WITHIN"):
-            raise _decline(f"{p.peek().text} predicate")
-        else:
-            op = None
-            t = p.peek()
-            if t.kind == "punct" and t.text in "=<>!":
+def _parse_comparison_op(p: _Parser):
+    t = p.peek()
+    if t.kind != "punct" or t.text not in "=<>!":
+        return None
+    p.next()
+    op = t.text
+    n = p.peek()
+    if n.kind == "punct" and ((op == "<" and n.text in "=>") or (op == ">" and n.text == "=")
+                              or (op == "!" and n.text == "=") or (op == "=" and n.text == "=")):
+        p.next()
+        op += n.text
+    if op == "!":
+        return None
+    return {"<>": "!=", "==": "="}.get(op, op)
+
+
+def _no_arithmetic(p: _Parser) -> None:
+    if p.peek().kind == "punct" and p.peek().text in "+-*/":
+        raise _decline("arithmetic in a join condition")
+
+
+def _parse_predicate(p: _Parser, allow_literal: bool, operand=None):
+    """One predicate -> a condition tree node (``shape.condition_terms``): ``<col> INTERSECTS
+    <col | 'chr:lo-hi'>``, ``<operand> op <operand>``, ``[NOT] BETWEEN``, ``[NOT] IN (literals)``,
+    ``IS [NOT] NULL``.  LIKE, arithmetic, functions, sub-queries decline."""
+    if p.at_kw("EXISTS"):
+        raise _decline("EXISTS condition")
+    operand = operand or _parse_operand     # a CLUSTER predicate also reads PREV(col)
+    lhs = operand(p)
+    if p.at_kw("INTERSECTS"):
+        p.next()
+        if lhs[0] != "col":
+            raise _decline("INTERSECTS with a literal on the left")
+        if p.peek().kind == "str":
+            if not allow_literal:
+                raise _decline("literal-range INTERSECTS inside a join")
+            return ("leaf", ("intersects_lit", lhs[1], p.next().text))
+        if p.at_kw("ANY", "ALL"):
+            raise _decline("INTERSECTS ANY/ALL")
+        if p.peek().kind != "id":
+            raise _decline("INTERSECTS operand that is not a column")
+        return ("leaf", ("intersects", lhs[1], p.colref()))
+    if p.at_kw("CONTAINS", "WITHIN"):
+        raise _decline(f"{p.peek().text} predicate")
+    _no_arithmetic(p)
+    negated = False
+    if p.at_kw("NOT") and p.peek(1).kind == "kw" and p.peek(1).text in ("BETWEEN", "IN", "LIKE"):
+        p.next()
+        negated = True
+    if p.at_kw("LIKE"):
+        raise _decline("LIKE predicate")
+    if p.at_kw("BETWEEN"):
+        p.next()
+        lo = operand(p)
+        _no_arithmetic(p)
+        p.expect_kw("AND")
+        hi = operand(p)
+        _no_arithmetic(p)
+        node = ("and", [("leaf", ("cmp", lhs, ">=", lo)), ("leaf", ("cmp", lhs, "<=", hi))])
+    elif p.at_kw("IN"):
+        p.next()
+        p.expect_punct("(")
+        if p.at_kw("SELECT", "WITH"):
+            raise _decline("IN (sub-query)")
+        values = []
+        while True:
+            v = operand(p)
+            if v[0] != "lit":
+                raise _decline("IN list with a non-literal member")
+            values.append(v)
+            if p.at_punct(","):
                 p.next()
-                op = t.text
-                n = p.peek()
-                if n.kind == "punct" and ((op == "<" and n.text in "=>") or (op == ">" and n.text == "=")
-                                          or (op == "!" and n.text == "=")):
-                    p.next()
-                    op += n.text
-            if op is None or op == "!":
-                raise _decline("join condition other than INTERSECTS / simple comparisons")
-            op = {"<>": "!=", "==": "="}.get(op, op)
-            rhs = _parse_operand(p)
-            if p.peek().kind == "punct" and p.peek().text in "+-*/":
-                raise _decline("arithmetic in a join condition")
-            terms.append(("cmp", lhs, op, rhs))
-        if p.at_kw("AND"):
+                continue
+            break
+        p.expect_punct(")")
+        node = ("or", [("leaf", ("cmp", lhs, "=", v)) for v in values])
+    elif p.at_kw("IS"):
+        p.next()
+        is_not = False
+        if p.at_kw("NOT"):
             p.next()
-            continue
-        if p.at_kw("OR"):
-            raise _decline("OR in the join condition")
-        return terms
+            is_not = True
+        if not p.at_kw("NULL"):
+            raise _decline("IS predicate other than IS [NOT] NULL")
+        p.next()
+        if lhs[0] == "lit":
+            raise _decline("IS NULL over a literal")
+        return ("leaf", ("cmp", lhs, "notnull" if is_not else "isnull", ("lit", 0)))
+    else:
+        op = _parse_comparison_op(p)
+        if op is None:
+            raise _decline("join condition other than INTERSECTS / simple comparisons")
+        rhs = operand(p)
+        _no_arithmetic(p)
+        return ("leaf", ("cmp", lhs, op, rhs))
+    return ("not", node) if negated else node
+
+
+def _parse_bool(p: _Parser, allow_literal: bool, level: int = 0, operand=None):
+    """``OR`` < ``AND`` < ``NOT`` < ``( ... )`` | predicate."""
+    if level == 0 or level == 1:
+        word, kind = ("OR", "or") if level == 0 else ("AND", "and")
+        kids = [_parse_bool(p, allow_literal, level + 1, operand)]
+        while p.at_kw(word):
+            p.next()
+            kids.append(_parse_bool(p, allow_literal, level + 1, operand))
+        return kids[0] if len(kids) == 1 else (kind, kids)
+    if p.at_kw("NOT"):
+        p.next()
+        return ("not", _parse_bool(p, allow_literal, 2, operand))
+    if p.at_punct("("):
+        if p.peek(1).kind == "kw" and p.peek(1).text in ("SELECT", "WITH"):
+            raise _decline("sub-query in a condition")
+        p.next()
+        node = _parse_bool(p, allow_literal, 0, operand)
+        p.expect_punct(")")
+        if p.peek().kind == "punct" and p.peek().text in "+-*/=<>!":
+            raise _decline("parenthesised expression as a comparison operand")
+        return node
+    return _parse_predicate(p, allow_literal, operand)
+
+
+def _parse_conjunction(p: _Parser, allow_literal: bool = False):
+    """A boolean condition -> the terms of its conjunctive normal form: ``("intersects", ...)``,
+    ``("cmp", lhs, op, rhs)`` and ``("or", [cmp, ...])`` (``shape.condition_terms``).  The
+    reference inlines any such extra beside the INTERSECTS as SQL text (``_classify_extras``,
+    intersects_duckdb.py:889-912); arithmetic, functions, LIKE and sub-queries have no
+    evaluator here and decline, as does a spatial predicate under OR / NOT (where the
+    reference falls back too)."""
+    return _condition_terms(_parse_bool(p, allow_literal))
+
+
+def _own_table_residuals(terms, own) -> list:
+    """WHERE terms over ONE table (literal-range filter, CLUSTER / MERGE) -> residuals; ``own``
+    checks a column's qualifier and returns its name."""
+    def bind(o) -> Operand:
+        if o[0] == "lit":
+            v = o[1]
+            return Operand("str" if isinstance(v, str) else ("float" if isinstance(v, float) else "int"), v)
+        return Operand("l", own(o[1]))
+
+    out, group = [], 0
+    for t in terms:
+        leaves, g = ([t], 0)
+        if t[0] == "or":
+            group += 1
+            leaves, g = t[1], group
+        for _, lhs, op, rhs in leaves:
+            a, b = bind(lhs), bind(rhs)
+            if a.kind != "l" and b.kind != "l":
+                raise _decline("constant predicate")
+            out.append(Residual("where", a, op, b, g))
+    return out
 
 
 _UNSUPPORTED_TAIL = ("GROUP", "ORDER", "HAVING", "LIMIT", "OFFSET", "UNION")
@@ -543,21 +641,7 @@ def _lower_filter(p: _Parser, tbls: Tables) -> JoinPlan:
     residuals = [Residual("where", Operand("l", side.chrom_col), "=", Operand("str", m.group("chr"))),
                  Residual("where", Operand("l", side.start_col), "<", Operand("int", hi)),
                  Residual("where", Operand("l", side.end_col), ">", Operand("int", lo))]
-    for t in terms:
-        if t[0] != "cmp":
-            continue
-        _, lhs, op, rhs = t
-
-        def bind(o) -> Operand:
-            if o[0] == "lit":
-                v = o[1]
-                return Operand("str" if isinstance(v, str) else ("float" if isinstance(v, float) else "int"), v)
-            return Operand("l", own(o[1]))
-
-        a, b = bind(lhs), bind(rhs)
-        if a.kind != "l" and b.kind != "l":
-            raise _decline("constant predicate")
-        residuals.append(Residual("where", a, op, b))
+    residuals += _own_table_residuals([t for t in terms if t[0] in ("cmp", "or")], own)
     proj = []
     for refc, alias in items:
         if refc.star:
@@ -608,35 +692,13 @@ def _parse_prev_operand(p: _Parser):
 
 
 def _parse_cluster_predicate(p: _Parser):
-    """``<operand> op <operand> (AND ...)*`` up to the argument's end; OR / NOT / parentheses / arithmetic decline."""
-    terms = []
-    while True:
-        if p.at_kw("NOT") or p.at_punct("("):
-            raise _decline("NOT / parenthesised CLUSTER predicate")
-        lhs = _parse_prev_operand(p)
-        t = p.peek()
-        op = None
-        if t.kind == "punct" and t.text in "=<>!":
-            p.next()
-            op = t.text
-            n = p.peek()
-            if n.kind == "punct" and ((op == "<" and n.text in "=>") or (op == ">" and n.text == "=")
-                                      or (op == "!" and n.text == "=")):
-                p.next()
-                op += n.text
-        if op is None or op == "!":
-            raise _decline("CLUSTER predicate other than simple comparisons")
-        op = {"<>": "!=", "==": "="}.get(op, op)
-        rhs = _parse_prev_operand(p)
-        if p.peek().kind == "punct" and p.peek().text in "+-*/":
-            raise _decline("arithmetic in a CLUSTER predicate")
-        terms.append((lhs, op, rhs))
-        if p.at_kw("AND"):
-            p.next()
-            continue
-        if p.at_kw("OR"):
-            raise _decline("OR in a CLUSTER predicate")
-        return terms
+    """The ``predicate :=`` argument up to its end -> the terms of its conjunctive normal form, ``("cmp", lhs, op,
+    rhs)`` / ``("or", [cmp, ...])`` over columns, ``PREV(col)`` and literals (the reference inlines the text into its
+    adjacency CASE, cluster.py:281-296; NULL -> not adjacent either way).  Arithmetic / functions decline."""
+    terms = _condition_terms(_parse_bool(p, False, 0, _parse_prev_operand))
+    if any(t[0] not in ("cmp", "or") for t in terms):
+        raise _decline("spatial predicate inside a CLUSTER predicate")
+    return terms
 
 
 def _parse_cluster_call(p: _Parser):
@@ -740,7 +802,7 @@ def _lower_cluster(p: _Parser, tbls: Tables) -> JoinPlan:
     if p.at_kw("WHERE"):
         p.next()
         where_terms = _parse_conjunction(p)
-        if any(t[0] != "cmp" for t in where_terms):
+        if any(t[0] not in ("cmp", "or") for t in where_terms):
             raise _decline("spatial predicate beside CLUSTER / MERGE")
     if p.peek().kind == "kw" or p.at_punct(","):
         raise _decline(f"{p.peek().text} clause with CLUSTER / MERGE")
@@ -804,29 +866,21 @@ def _lower_cluster(p: _Parser, tbls: Tables) -> JoinPlan:
         if len(set(names)) != len(names) or set(names) & {side.chrom_col.lower(), side.start_col.lower(),
                                                           side.end_col.lower()}:
             raise ValueError("MERGE cannot project a column that collides with chrom/start/end")  # merge.py:317-323
-    residuals = []
-    for t in where_terms:
-        _, lhs, cmp_op, rhs = t
+    residuals = _own_table_residuals(where_terms, own)
+    def pbind(o) -> Operand:
+        if o[0] == "lit":
+            v = o[1]
+            return Operand("str" if isinstance(v, str) else ("float" if isinstance(v, float) else "int"), v)
+        return Operand("r" if o[0] == "prev" else "l", own(o[1]))
 
-        def bind(o) -> Operand:
-            if o[0] == "lit":
-                v = o[1]
-                return Operand("str" if isinstance(v, str) else ("float" if isinstance(v, float) else "int"), v)
-            return Operand("l", own(o[1]))
-
-        a, b = bind(lhs), bind(rhs)
-        if a.kind != "l" and b.kind != "l":
-            raise _decline("constant predicate")
-        residuals.append(Residual("where", a, cmp_op, b))
-    cluster_pred = []
-    for lhs, cmp_op, rhs in predicate:
-        def pbind(o) -> Operand:
-            if o[0] == "lit":
-                v = o[1]
-                return Operand("str" if isinstance(v, str) else ("float" if isinstance(v, float) else "int"), v)
-            return Operand("r" if o[0] == "prev" else "l", own(o[1]))
-
-        cluster_pred.append(Residual("predicate", pbind(lhs), cmp_op, pbind(rhs)))
+    cluster_pred, pgroup = [], 0
+    for t in predicate:
+        leaves, g = ([t], 0)
+        if t[0] == "or":
+            pgroup += 1
+            leaves, g = t[1], pgroup
+        for _, lhs, cmp_op, rhs in leaves:
+            cluster_pred.append(Residual("predicate", pbind(lhs), cmp_op, pbind(rhs), g))
     return JoinPlan(op, side, None, tuple(proj), residuals=tuple(residuals), distance=distance,
                     stranded=stranded, strand_col=table.strand_col if stranded else None,
                     cluster_predicate=tuple(cluster_pred))
@@ -951,7 +1005,8 @@ def _lower(giql: str, tables, want_sql: bool):
     shape = JoinShape(items=items, from_ref=from_ref, join_ref=join_ref, kind=kind, on_seen=on_seen, using=using,
                       distinct=distinct)
     if on_seen:
-        if p.peek().kind not in ("id", "num", "str") and not p.at_punct("-"):
+        if p.peek().kind not in ("id", "num", "str") and not p.at_punct("-") and not p.at_punct("(") \
+                and not p.at_kw("NOT"):
             raise _decline("join condition other than INTERSECTS / simple comparisons")
         shape.on_terms = _parse_conjunction(p)
     if p.at_kw("WHERE"):

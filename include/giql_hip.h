@@ -288,7 +288,8 @@ int giql_hip_take_utf8_fill_dev(giql_hip_ctx* ctx, const int32_t* offsets,
  * column of side A / side B (DEVICE pointer, addressed through the candidate's
  * row id) or a literal.  Integers compare as int64, anything involving a float
  * as double; a NULL operand (valid[row] == 0) makes the predicate not true. */
-enum { GIQL_OP_EQ = 0, GIQL_OP_NE = 1, GIQL_OP_LT = 2, GIQL_OP_LE = 3, GIQL_OP_GT = 4, GIQL_OP_GE = 5 };
+enum { GIQL_OP_EQ = 0, GIQL_OP_NE = 1, GIQL_OP_LT = 2, GIQL_OP_LE = 3, GIQL_OP_GT = 4, GIQL_OP_GE = 5,
+       GIQL_OP_IS_NULL = 6, GIQL_OP_NOT_NULL = 7 /* unary: lhs only, rhs ignored */ };
 enum { GIQL_T_I32 = 0, GIQL_T_I64 = 1, GIQL_T_F32 = 2, GIQL_T_F64 = 3, GIQL_T_U8 = 4 };
 enum { GIQL_SIDE_A = 0, GIQL_SIDE_B = 1, GIQL_SIDE_LIT = 2 };
 
@@ -306,10 +307,20 @@ typedef struct giql_operand {
 typedef struct giql_pred {
   giql_operand lhs, rhs;
   int32_t op;            /* GIQL_OP_*                                            */
-  int32_t reserved;
+  int32_t group;         /* 0: a conjunct of its own; g != 0: OR-ed with the     */
+                         /* neighbouring predicates that carry the same g        */
 } giql_pred;
 
-/* Stable filter of n candidates by the conjunction of n_preds (<= 8) predicates.
+/* The reference inlines ANY residual expression as SQL text (_classify_extras,
+ * intersects_duckdb.py:889-912: only a nested INTERSECTS, sub-queries, aggregates
+ * and window functions fall back).  Here the caller hands over the expression in
+ * conjunctive normal form: predicates are AND-ed, except that a run of adjacent
+ * predicates sharing one non-zero `group` forms ONE clause whose members are OR-ed.
+ * NOT is pushed into the comparisons by the caller (NOT (x < y) = x >= y, De Morgan
+ * for AND / OR; exact under SQL's three-valued logic because a filter keeps TRUE
+ * only and AND / OR are monotone), BETWEEN and IN (list) are spelt as comparisons.
+ *
+ * Stable filter of n candidates by n_preds (<= 16) predicates.
  * Candidate i addresses side A by idx_a[i] (i itself when idx_a is NULL) and side
  * B by idx_b[i] likewise; the kept candidates' ids are written, in input order,
  * to out_a / out_b (capacity n each; either may be NULL) and *n_kept receives

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Mint tests/golden/boolean_residuals.json: INTERSECTS joins whose extra ON / WHERE conditions use OR, NOT,
+parentheses, BETWEEN, IN (list) and IS [NOT] NULL.  The reference inlines such an extra verbatim, as SQL text,
+into the per-chromosome join's ON clause (`_classify_extras` -> "inline", src/giql/expanders/intersects_duckdb.py:889-912,
+1164-1177, 1239-1243), so its rows are the rows of the plain overlap join filtered by that SQL condition -- which
+is what sqlite3 computes here from the same condition text (three-valued logic included: `score`, `name` hold NULLs).
+SEMI / ANTI: the ON extras take part in the existence test, the WHERE extras filter the left rows (#200,
+intersects_duckdb.py:1164-1177, 1254-1282).  Needs only the standard library (no reference code is imported)."""
+import json
+import os
+import random
+import sqlite3
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OVERLAP = 'a.chrom = b.chrom AND a."start" < b."end" AND a."end" > b."start"'
+
+# (join kind, extra ON condition or "", WHERE condition or "")
+CONDITIONS = [
+    ("INNER", "(a.score > 3 OR b.score < 2)", ""),
+    ("INNER", "NOT a.score > 3", ""),
+    ("INNER", "NOT (a.score > 3 OR b.score <= 2)", ""),
+    ("INNER", "", "NOT (a.score = 3 AND NOT b.score <> 2)"),
+    ("INNER", "", "(a.score > 1 AND b.score > 2) OR a.score = 0"),
+    ("INNER", "a.score BETWEEN 2 AND 4", "b.score NOT BETWEEN 1 AND 3"),
+    ("INNER", "a.score IN (1, 2, 5)", "b.name NOT IN ('g1', 'g2', 'g3')"),
+    ("INNER", "a.name IS NOT NULL AND b.score IS NULL", ""),
+    ("INNER", "", "a.score IS NULL OR b.score IS NULL OR a.score = b.score"),
+    ("INNER", "(a.strand = b.strand OR a.name = 'p4') AND (b.score >= 2 OR a.score < b.score)", "NOT a.name IS NULL"),
+    ("INNER", "", "a.name = 'p1' OR a.name = 'p2' OR b.name <> a.name"),
+    ("INNER", "a.score = 2.0 OR b.score > 3.5", ""),
+    ("INNER", "((a.score < 2 OR a.score > 4) AND (b.score < 2 OR b.score > 4)) OR a.strand <> b.strand", ""),
+    ("INNER", "NOT (a.score BETWEEN 1 AND 4 AND b.name IN ('g0', 'g5'))", ""),
+    ("SEMI", "(a.score > 3 OR b.score < 2)", ""),
+    ("SEMI", "b.score IN (0, 5) OR a.strand = b.strand", "a.score IS NOT NULL AND (a.score < 2 OR a.name = 'p3')"),
+    ("ANTI", "(a.score > 3 OR b.score < 2)", ""),
+    ("ANTI", "NOT (a.strand = b.strand)", "a.score NOT BETWEEN 2 AND 3 OR a.name IS NULL"),
+    ("ANTI", "b.score IS NULL", "NOT (a.score = 1 OR a.score = 4)"),
+]
+
+
+def giql_query(kind: str, on: str, where: str) -> str:
+    join = {"INNER": "JOIN", "SEMI": "SEMI JOIN", "ANTI": "ANTI JOIN"}[kind]
+    cols = "a.name AS an, a.start AS s, b.name AS bn, b.end AS e" if kind == "INNER" else "a.name, a.start, a.score"
+    q = f"SELECT {cols} FROM peaks a {join} genes b ON a.interval INTERSECTS b.interval"
+    if on:
+        q += f" AND ({on})"
+    if where:
+        q += f" WHERE {where}"
+    return q
+
+
+def sqlite_rows(conn, kind: str, on: str, where: str):
+    quote = lambda t: t.replace("a.start", 'a."start"').replace("b.start", 'b."start"').replace("b.end", 'b."end"')
+    cond = OVERLAP + (f" AND ({quote(on)})" if on else "")
+    if kind == "INNER":
+        sql = f'SELECT a.name, a."start", b.name, b."end" FROM peaks a JOIN genes b ON {cond}'
+        if where:
+            sql += f" WHERE {quote(where)}"
+    else:
+        ex = "EXISTS" if kind == "SEMI" else "NOT EXISTS"
+        sql = f'SELECT a.name, a."start", a.score FROM peaks a WHERE {ex} (SELECT 1 FROM genes b WHERE {cond})'
+        if where:
+            sql += f" AND ({quote(where)})"
+    return conn.execute(sql).fetchall()
+
+
+def rand_rows(rng, n, tag):
+    out = []
+    for i in range(n):
+        s = rng.randrange(0, 1500)
+        score = None if rng.random() < 0.15 else rng.randrange(0, 6)
+        name = None if rng.random() < 0.1 else f"{tag}{i % 7}"
+        out.append((rng.choice(["chr1", "chr2", "chr3"]), s, s + rng.randrange(1, 300), name, score, rng.choice("+-")))
+    return out
+
+
+def main() -> None:
+    rng = random.Random(20261006)
+    cases = []
+    for kind, on, where in CONDITIONS:
+        for n_p, n_g in [(6, 5), (60, 45)]:
+            peaks, genes = rand_rows(rng, n_p, "p"), rand_rows(rng, n_g, "g")
+            if kind != "INNER":
+                peaks.append(("chr9", 5, 50, "p1", 3, "+"))   # a chromosome only the left table has
+            conn = sqlite3.connect(":memory:")
+            for t, rows in (("peaks", peaks), ("genes", genes)):
+                conn.execute(f'CREATE TABLE {t} (chrom TEXT, "start" INTEGER, "end" INTEGER, name TEXT, score INTEGER, strand TEXT)')
+                conn.executemany(f"INSERT INTO {t} VALUES (?, ?, ?, ?, ?, ?)", rows)
+            got = sqlite_rows(conn, kind, on, where)
+            conn.close()
+            key = lambda r: tuple((x is None, x) for x in r)
+            cases.append({"kind": kind, "query": giql_query(kind, on, where), "peaks": [list(r) for r in peaks],
+                          "genes": [list(r) for r in genes], "rows": [list(r) for r in sorted(got, key=key)]})
+    assert sum(1 for c in cases if c["rows"]) >= len(cases) * 2 // 3
+    doc = {"_source": "tests/golden/make_boolean_residuals.py: sqlite3 evaluates the overlap join AND the condition "
+                      "text the reference would inline (intersects_duckdb.py:889-912, 1239-1243); rows sorted with NULLs last "
+                      "per column; table rows are (chrom, start, end, name, score, strand)",
+           "cases": cases}
+    with open(os.path.join(HERE, "boolean_residuals.json"), "w") as f:
+        json.dump(doc, f, separators=(",", ":"))
+    print(len(cases), "cases,", sum(len(c["rows"]) for c in cases), "rows")
+
+
+if __name__ == "__main__":
+    main()

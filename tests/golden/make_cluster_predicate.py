@@ -28,7 +28,7 @@ def cluster_pred_sql(distance: int, stranded: bool, pred) -> str:
             return f'LAG("{v}") {lag}'
         return repr(v) if not isinstance(v, str) else "'" + v + "'"
 
-    text = " AND ".join(f"{operand(l)} {op} {operand(r)}" for l, op, r in pred)
+    text = render(pred, operand)
     inner = (f'SELECT *, CASE WHEN {edge} >= "start" AND ({text}) THEN 0 ELSE 1 END AS __giql_is_new_cluster '
              "FROM features")
     return (f'SELECT *, SUM(__giql_is_new_cluster) OVER ({part} ORDER BY "start" NULLS LAST) '
@@ -45,11 +45,32 @@ def run(rows, distance, stranded, pred):
     return [r[1] for r in ids]
 
 
+def render(pred, operand) -> str:
+    """A predicate as text: a list of (lhs, op, rhs) comparisons is their conjunction; a tuple is a tree node --
+    ("and" | "or", [nodes]), ("not", node), ("cmp", lhs, op, rhs), ("null" | "notnull", operand),
+    ("between" | "notbetween", x, lo, hi), ("in" | "notin", x, [literals])."""
+    if isinstance(pred, list):
+        return " AND ".join(f"{operand(l)} {op} {operand(r)}" for l, op, r in pred)
+    k = pred[0]
+    if k in ("and", "or"):
+        return "(" + f" {k.upper()} ".join(render(c, operand) for c in pred[1]) + ")"
+    if k == "not":
+        return "NOT " + render(pred[1], operand)
+    if k == "cmp":
+        return f"{operand(pred[1])} {pred[2]} {operand(pred[3])}"
+    if k in ("null", "notnull"):
+        return f"{operand(pred[1])} IS {'NOT ' if k == 'notnull' else ''}NULL"
+    if k in ("between", "notbetween"):
+        return f"{operand(pred[1])} {'NOT ' if k == 'notbetween' else ''}BETWEEN {operand(pred[2])} AND {operand(pred[3])}"
+    assert k in ("in", "notin"), k
+    return f"{operand(pred[1])} {'NOT ' if k == 'notin' else ''}IN ({', '.join(operand(('lit', v)) for v in pred[2])})"
+
+
 def giql_text(pred) -> str:
     def operand(o):
         kind, v = o
         return v if kind == "col" else (f"PREV({v})" if kind == "prev" else (repr(v) if not isinstance(v, str) else f"'{v}'"))
-    return " AND ".join(f"{operand(l)} {op} {operand(r)}" for l, op, r in pred)
+    return render(pred, operand)
 
 
 PREDICATES = [
@@ -59,6 +80,14 @@ PREDICATES = [
     [(("col", "depth"), ">=", ("prev", "depth")), (("col", "score"), "<", ("lit", 0.75))],
     [(("prev", "depth"), "!=", ("lit", 3))],
     [(("col", "score"), ">", ("prev", "score"))],                               # floats, with NULLs
+    # boolean forms: the reference inlines the text as it stands; the hip target normalises it (AND of OR-groups)
+    ("or", [("cmp", ("col", "depth"), "=", ("prev", "depth")), ("cmp", ("col", "name"), "=", ("prev", "name"))]),
+    ("not", ("or", [("cmp", ("col", "depth"), "<", ("prev", "depth")), ("cmp", ("col", "score"), ">=", ("lit", 0.5))])),
+    ("and", [("or", [("null", ("prev", "score")), ("cmp", ("col", "score"), "<=", ("prev", "score"))]),
+             ("notnull", ("col", "name"))]),
+    ("or", [("and", [("between", ("col", "depth"), ("lit", 1), ("lit", 2)), ("in", ("prev", "name"), ["x", "y"])]),
+            ("notbetween", ("prev", "depth"), ("lit", 1), ("col", "depth"))]),
+    ("not", ("and", [("notin", ("col", "depth"), [1, 3]), ("not", ("cmp", ("col", "name"), "!=", ("prev", "name")))])),
 ]
 
 

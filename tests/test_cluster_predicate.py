@@ -33,12 +33,22 @@ def _holds(plan, rows):
             return rows[i if o.kind == "l" else j][COLS.index(o.value)]
         return o.value
 
+    def leaf(r, i, j):
+        a = value(r.lhs, i, j)
+        if r.op in ("isnull", "notnull"):
+            return (a is None) == (r.op == "isnull")
+        b = value(r.rhs, i, j)
+        return a is not None and b is not None and ops[r.op](a, b)
+
     def holds(i, j):
+        # an AND of clauses; neighbours sharing a non-zero group are one OR clause (giql_pred.group)
+        clauses = []
         for r in plan.cluster_predicate:
-            a, b = value(r.lhs, i, j), value(r.rhs, i, j)
-            if a is None or b is None or not ops[r.op](a, b):
-                return False
-        return True
+            if clauses and r.group and clauses[-1][-1].group == r.group:
+                clauses[-1].append(r)
+            else:
+                clauses.append([r])
+        return all(any(leaf(r, i, j) for r in c) for c in clauses)
 
     return holds
 
@@ -71,8 +81,12 @@ def test_predicate_plan_shape_and_the_reference_s_errors():
     with pytest.raises(ValueError, match="cannot be nested"):
         build_plan("SELECT *, CLUSTER(interval, predicate := depth = PREV(PREV(depth))) AS cid FROM peaks", ["peaks"])
     # shapes this target has no evaluator for decline (the reference inlines arbitrary SQL text there)
-    for q in ("SELECT *, CLUSTER(interval, predicate := depth = PREV(depth) OR name = PREV(name)) AS cid FROM peaks",
-              "SELECT *, CLUSTER(interval, predicate := (depth = PREV(depth))) AS cid FROM peaks",
+    p = build_plan("SELECT *, CLUSTER(interval, predicate := (depth = PREV(depth) OR NOT name = PREV(name)) AND "
+                   "PREV(score) IS NOT NULL) AS cid FROM peaks", ["peaks"])
+    assert [(r.lhs.kind, r.lhs.value, r.op, r.group) for r in p.cluster_predicate] == \
+        [("l", "depth", "=", 1), ("l", "name", "!=", 1), ("r", "score", "notnull", 0)]
+    for q in ("SELECT *, CLUSTER(interval, predicate := depth LIKE PREV(depth)) AS cid FROM peaks",
+              "SELECT *, CLUSTER(interval, predicate := ABS(depth) = PREV(depth)) AS cid FROM peaks",
               "SELECT *, CLUSTER(interval, predicate := depth + 1 = PREV(depth)) AS cid FROM peaks",
               "SELECT MERGE(interval, predicate := depth = PREV(depth)) FROM peaks"):
         with pytest.raises(HipDeclined):

@@ -339,6 +339,12 @@ def test_literal_range_filter_runs_on_the_gpu():
     q = "SELECT name, score AS s FROM peaks p WHERE p.interval INTERSECTS 'chr2:100-900' AND p.score >= 3 AND p.strand = '-'"
     got = rows_of(execute(transpile(q, tables=["peaks"], dialect="hip"), t))
     assert got == sorted((r[3], r[4]) for r in rows if r[0] == "chr2" and r[1] < 900 and r[2] > 100 and r[4] >= 3 and r[5] == "-")
+    q = ("SELECT name, score FROM peaks WHERE interval INTERSECTS 'chr2:100-900' AND (score >= 4 OR strand = '-') "
+         "AND NOT name IN ('p1', 'p2') AND score BETWEEN 1 AND 4")
+    got = rows_of(execute(transpile(q, tables=["peaks"], dialect="hip"), t))
+    want = sorted((r[3], r[4]) for r in rows if r[0] == "chr2" and r[1] < 900 and r[2] > 100 and (r[4] >= 4 or r[5] == "-")
+                  and r[3] not in ("p1", "p2") and 1 <= r[4] <= 4)
+    assert got == want and len(want) > 3
     none = execute(transpile("SELECT * FROM peaks WHERE interval INTERSECTS 'chrZ:1-2'", tables=["peaks"], dialect="hip"), t)
     assert none.num_rows == 0 and none.column_names == t["peaks"].column_names
 

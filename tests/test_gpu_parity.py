@@ -774,6 +774,49 @@ def test_select_rows_every_operator(eng, op):
     assert np.array_equal(got.cpu().numpy(), np.nonzero(_NP_OPS[op](col, 4.5))[0])
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_select_or_groups_and_null_tests_match_numpy(eng, seed):
+    # giql_pred.group: an AND of clauses, a clause = neighbours sharing a non-zero group, OR-ed; IS [NOT] NULL read
+    # the left operand's validity only; up to 16 predicates per call
+    rng = np.random.default_rng(100 + seed)
+    n, na, nb = 30_000, 900, 1100
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    cols = {"a": [rng.integers(0, 6, na).astype(np.int32), rng.standard_normal(na)],
+            "b": [rng.integers(0, 6, nb).astype(np.int64), rng.standard_normal(nb).astype(np.float32)]}
+    valid = {"a": rng.random(na) > 0.25, "b": rng.random(nb) > 0.25}
+    ia, ib = rng.integers(0, na, n).astype(np.int32), rng.integers(0, nb, n).astype(np.int32)
+    idx = {"a": ia, "b": ib}
+    preds, want, group = [], np.ones(n, bool), 0
+    while len(preds) < 16:
+        width = int(min(rng.integers(1, 5), 16 - len(preds)))
+        group += 1
+        clause = np.zeros(n, bool)
+        for _ in range(width):
+            side = "ab"[rng.integers(0, 2)]
+            which = int(rng.integers(0, 2))
+            col, with_valid = cols[side][which], rng.random() < 0.6
+            vals = col[idx[side]].astype(np.float64)
+            ok = valid[side][idx[side]] if with_valid else np.ones(n, bool)
+            spec = (side, d(col), d(valid[side].astype(np.uint8))) if with_valid else (side, d(col))
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                op = ["isnull", "notnull"][rng.integers(0, 2)]
+                t = ~ok if op == "isnull" else ok
+                preds.append((spec, op, ("lit", 0), group if width > 1 else 0))
+            else:
+                op = sorted(_NP_OPS)[rng.integers(0, 6)]
+                lit = int(rng.integers(0, 6)) if which == 0 else float(rng.standard_normal())
+                t = _NP_OPS[op](vals, lit) & ok
+                preds.append((spec, op, ("lit", lit), group if width > 1 else 0))
+            clause |= t
+        want &= clause
+    assert len(preds) == 16
+    ga, gb = eng.select(preds, idx_a=d(ia), idx_b=d(ib), n_rows_a=na, n_rows_b=nb)
+    assert np.array_equal(ga.cpu().numpy(), ia[want]) and np.array_equal(gb.cpu().numpy(), ib[want])
+    with pytest.raises(ValueError, match="16"):
+        eng.select(preds + preds[:1], idx_a=d(ia), idx_b=d(ib), n_rows_a=na, n_rows_b=nb)
+
+
 def test_select_rejects_bad_ids_and_mark_flags(eng):
     from giql_amd._lib import GiqlHipError
 

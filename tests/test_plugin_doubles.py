@@ -129,9 +129,18 @@ def test_declined_shapes_defer_to_the_naive_predicate():
     _declined(*basic([A.agg("count", A.star("a"))]))                           # COUNT(a.*), #204
     _declined(*basic([A.N("add", this=A.col("a", "start"), expression=A.lit(1))]))   # a.start + 1, #205
     _declined(*basic([A.N("window", this=A.agg("sum", A.col("a", "score")))]))
-    _declined(*basic([A.col("a", "start")], on_extra=[A.N("or", this=A.cmp("gt", A.col("a", "score"), A.lit(1)),
-                                                            expression=A.cmp("lt", A.col("a", "score"), A.lit(0)))]))
-    _declined(*basic([A.col("a", "start")], on_extra=[A.N("paren", this=A.cmp("gt", A.col("a", "score"), A.lit(1)))]))
+    _declined(*basic([A.col("a", "start")], on_extra=[A.N("like", this=A.col("a", "name"), expression=A.lit("p%"))]))
+    _declined(*basic([A.col("a", "start")], on_extra=[A.N("is", this=A.col("a", "score"), expression=A.N("boolean", this=True))]))
+    _declined(*basic([A.col("a", "start")], on_extra=[A.N("in", this=A.col("a", "score"), query=A.N("subquery"))]))
+    _declined(*basic([A.col("a", "start")], on_extra=[A.N("in", this=A.col("a", "score"), expressions=[A.col("b", "score")])]))
+    _declined(*basic([A.col("a", "start")], on_extra=[A.N("between", this=A.col("a", "score"), low=A.lit(1), high=A.lit(2),
+                                                            symmetric=True)]))
+    # the INTERSECTS itself under OR / NOT: the reference falls back too (_classify_extras)
+    it = A.intersects(A.col("a", "interval"), A.col("b", "interval"))
+    _declined(A.select([A.col("a", "start")], A.tbl("peaks", "a"),
+                       [A.join(A.tbl("genes", "b"), on=A.N("or", this=it, expression=A.cmp("gt", A.col("a", "score"), A.lit(1))))]), it)
+    it = A.intersects(A.col("a", "interval"), A.col("b", "interval"))
+    _declined(A.select([A.col("a", "start")], A.tbl("peaks", "a"), [A.join(A.tbl("genes", "b"), on=A.N("not", this=it))]), it)
     _declined(*basic([A.col("a", "start")], distinct=A.N("distinct", on=A.N("tuple", expressions=[A.col("a", "chrom")]))))
     _declined(*basic([A.col("a", "start")], with_=A.N("with", expressions=[])))
     _declined(*basic([A.col("a", "start")], order=[(A.N("subquery", this=A.N("select", expressions=[])), False)]))
@@ -147,6 +156,30 @@ def test_declined_shapes_defer_to_the_naive_predicate():
     it = A.intersects(A.col("a", "interval"), A.col("b", "interval"))
     fn = A.N("table", this=A.N("anonymous", this="DISJOIN"), alias=A.N("tablealias", this=A.ident("b")))
     _declined(A.select([A.col("a", "start")], A.tbl("peaks", "a"), [A.join(fn, on=it)]), it)
+
+
+def test_boolean_extras_lower_to_the_same_plan_as_the_mirror():
+    # OR / NOT / parentheses / BETWEEN / IN / IS NULL beside the INTERSECTS: inlined by the reference
+    # (_classify_extras, intersects_duckdb.py:889-912), a conjunction of OR-groups here
+    a_s, b_s = A.col("a", "score"), A.col("b", "score")
+    extras = [
+        A.N("paren", this=A.N("or", this=A.cmp("gt", a_s, A.lit(5)), expression=A.cmp("lt", b_s, A.lit(2)))),
+        A.N("not", this=A.N("paren", this=A.N("and", this=A.cmp("eq", a_s, A.lit(3)), expression=A.cmp("neq", b_s, A.lit(4))))),
+        A.N("between", this=a_s, low=A.lit(1), high=A.lit(9)),
+        A.N("not", this=A.N("in", this=A.col("b", "name"), expressions=[A.lit("u"), A.lit("v")])),
+    ]
+    where = A.N("and", this=A.N("in", this=a_s, expressions=[A.lit(1), A.lit(2)]),
+                expression=A.N("not", this=A.N("is", this=A.col("a", "name"), expression=A.N("null"))))
+    root, it = basic([A.col("a", "name")], on_extra=extras, where=where)
+    out, ctx, calls = run(root, it, ["peaks", "genes"])
+    assert out is it and not calls
+    want = build_plan("SELECT a.name FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND (a.score > 5 OR b.score < 2) "
+                      "AND NOT (a.score = 3 AND b.score <> 4) AND a.score BETWEEN 1 AND 9 AND b.name NOT IN ('u', 'v') "
+                      "WHERE a.score IN (1, 2) AND a.name IS NOT NULL", ["peaks", "genes"])
+    got = JoinPlan.from_string(ctx.finalizers[0](root)[1])
+    assert got == want
+    assert [(r.op, r.group) for r in got.residuals] == [(">", 1), ("<", 1), ("!=", 2), ("=", 2), (">=", 0), ("<=", 0),
+                                                       ("!=", 0), ("!=", 0), ("=", 3), ("=", 3), ("notnull", 0)]
 
 
 def test_sibling_spatial_predicate_and_literal_ranges_defer():

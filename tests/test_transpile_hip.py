@@ -92,12 +92,18 @@ def test_case_insensitive_aliases():
     "SELECT a.start FROM peaks a JOIN peaks b ON a.interval INTERSECTS b.interval",
     "SELECT a.start FROM peaks a JOIN genes a ON a.interval INTERSECTS a.interval",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval OR a.score > 5",
-    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND (a.score > 5)",
-    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND NOT a.score > 5",
+    "SELECT a.start FROM peaks a JOIN genes b ON NOT a.interval INTERSECTS b.interval",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.name LIKE 'p%'",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score IS TRUE",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score IN (SELECT 1)",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score IN (1, b.score)",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND (a.score) > 5",
+    # 13 comparisons once in conjunctive normal form: the select kernel takes 12 beside a filter's own three
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score IN "
+    "(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score + 1 > 5",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND ABS(a.score) > 5",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND 1 = 1",
-    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval WHERE a.score IN (1, 2)",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.interval INTERSECTS b.interval",
     "SELECT a.start FROM peaks a JOIN genes b ON a.score > 5",
     "SELECT a.start + 1 FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
@@ -115,6 +121,51 @@ def test_case_insensitive_aliases():
 def test_valid_but_unsupported_shapes_decline(query):
     with pytest.raises(HipDeclined):
         build_plan(query, ["peaks", "genes"])
+
+
+def _res(plan):
+    return [(r.clause, r.lhs.value, r.op, r.rhs.value, r.group) for r in plan.residuals]
+
+
+def test_boolean_residuals_arrive_in_conjunctive_normal_form():
+    # the reference inlines any such extra as SQL text (_classify_extras, intersects_duckdb.py:889-912);
+    # here OR / NOT / parentheses / BETWEEN / IN / IS NULL become an AND of OR-groups of comparisons
+    base = "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval "
+    p = build_plan(base + "AND (a.score > 5)", ["peaks", "genes"])
+    assert _res(p) == [("on", "score", ">", 5, 0)]
+    p = build_plan(base + "AND NOT a.score > 5", ["peaks", "genes"])
+    assert _res(p) == [("on", "score", "<=", 5, 0)]
+    p = build_plan(base + "AND (a.score > 5 OR b.score < 2) WHERE a.name = 'x' OR a.name = 'y' OR b.name <> a.name",
+                   ["peaks", "genes"])
+    assert _res(p) == [("on", "score", ">", 5, 1), ("on", "score", "<", 2, 1),
+                       ("where", "name", "=", "x", 2), ("where", "name", "=", "y", 2), ("where", "name", "!=", "name", 2)]
+    # NOT over OR / AND: De Morgan, the comparisons flipped
+    p = build_plan(base + "AND NOT (a.score > 5 OR b.score <= 2)", ["peaks", "genes"])
+    assert _res(p) == [("on", "score", "<=", 5, 0), ("on", "score", ">", 2, 0)]
+    p = build_plan(base + "WHERE NOT (a.score = 5 AND NOT b.score <> 2)", ["peaks", "genes"])
+    assert _res(p) == [("where", "score", "!=", 5, 1), ("where", "score", "!=", 2, 1)]
+    # OR over AND distributes
+    p = build_plan(base + "WHERE (a.score > 1 AND b.score > 2) OR a.score = 0", ["peaks", "genes"])
+    assert _res(p) == [("where", "score", ">", 1, 1), ("where", "score", "=", 0, 1),
+                       ("where", "score", ">", 2, 2), ("where", "score", "=", 0, 2)]
+    p = build_plan(base + "AND a.score BETWEEN 2 AND 4 AND b.score NOT BETWEEN 1 AND 3", ["peaks", "genes"])
+    assert _res(p) == [("on", "score", ">=", 2, 0), ("on", "score", "<=", 4, 0),
+                       ("on", "score", "<", 1, 1), ("on", "score", ">", 3, 1)]
+    p = build_plan(base + "WHERE a.score IN (1, 2) AND b.name NOT IN ('u', 'v') AND a.name IS NOT NULL "
+                   "AND NOT b.name IS NULL AND a.score IS NULL", ["peaks", "genes"])
+    assert _res(p) == [("where", "score", "=", 1, 1), ("where", "score", "=", 2, 1),
+                       ("where", "name", "!=", "u", 0), ("where", "name", "!=", "v", 0),
+                       ("where", "name", "notnull", 0, 0), ("where", "name", "notnull", 0, 0),
+                       ("where", "score", "isnull", 0, 0)]
+    assert JoinPlan.from_string(p.to_string()) == p
+    # a parenthesised INTERSECTS is still the join's spatial predicate
+    p = build_plan("SELECT a.start FROM peaks a JOIN genes b ON (a.interval INTERSECTS b.interval) AND (a.score > 1)",
+                   ["peaks", "genes"])
+    assert p.kind == "INNER" and _res(p) == [("on", "score", ">", 1, 0)]
+    # SEMI / ANTI: the WHERE clause still cannot name the right side, inside an OR either
+    with pytest.raises(ValueError, match="right side"):
+        build_plan("SELECT a.start FROM peaks a SEMI JOIN genes b ON a.interval INTERSECTS b.interval "
+                   "WHERE a.score > 1 OR b.score > 1", ["peaks", "genes"])
 
 
 @pytest.mark.parametrize("query,match", [
