@@ -75,11 +75,36 @@ __global__ __launch_bounds__(256) void k_merge_heads(const u32* __restrict__ fla
   if (i < n && flags[i]) head_pos[excl[i]] = i;
 }
 
+// MERGE with a predicate: a region may end while the running maximum of the partition still lies
+// ahead of it, so MAX(end) is the maximum over the region's own rows.  Regions are runs of the
+// sorted order: a segmented maximum inside each wave (log steps over lanes of one region), then
+// one atomic per (wave, region) -- a region of any length costs n / 64 atomics at most.
+// seg_end: zero-initialised, one word per region.
+__global__ __launch_bounds__(256) void k_merge_segmax(const u32* __restrict__ ends,
+                                                      const u32* __restrict__ excl,
+                                                      const u32* __restrict__ flags, u32 n,
+                                                      u32* __restrict__ seg_end) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  const u32 g = live ? excl[i] + flags[i] - 1u : 0xFFFFFFFFu;  // (every partition's first row is a head)
+  u32 e = live ? ends[i] : 0u;
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const u32 oe = (u32)__shfl_up((int)e, d);
+    const u32 og = (u32)__shfl_up((int)g, d);
+    if (lane >= d && og == g && oe > e) e = oe;
+  }
+  const u32 ng = (u32)__shfl_down((int)g, 1);
+  if (live && (lane == WAVE - 1 || ng != g)) atomicMax(&seg_end[g], e);
+}
+
 // one merged region per thread: chrom, MIN(start) = the head's start (sorted by start),
-// MAX(end) = running max at the region's last row, COUNT(*) = its rows
+// MAX(end) = running max at the region's last row (seg_end[g] under a predicate), COUNT(*) = its rows
 __global__ __launch_bounds__(256) void k_merge_rows(const u32* __restrict__ head_pos, u32 m, u32 n,
                                                     const u32* __restrict__ keys,
                                                     const u32* __restrict__ pmax_incl,
+                                                    const u32* __restrict__ seg_end,
                                                     const u32* __restrict__ chrom_first,
                                                     const i64* __restrict__ chrom_base, int n_chrom,
                                                     int* __restrict__ out_chrom,
@@ -95,7 +120,7 @@ __global__ __launch_bounds__(256) void k_merge_rows(const u32* __restrict__ head
   const i64 b = chrom_base[c];
   out_chrom[g] = (int)c;
   out_start[g] = (int)((i64)key - b);
-  out_end[g] = (int)((i64)pmax_incl[i1 - 1] - b);
+  out_end[g] = (int)((i64)(seg_end ? seg_end[g] : pmax_incl[i1 - 1]) - b);
   if (out_count) out_count[g] = (i64)(i1 - i0);
 }
 

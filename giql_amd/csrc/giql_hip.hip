@@ -2375,6 +2375,7 @@ struct ClusterBufs {
   u32* dummy_irr = nullptr;
   u64 *bsums = nullptr, *total = nullptr;
   u32* head_pos = nullptr;
+  u32* seg_end = nullptr;  // MERGE under a predicate: MAX(end) per region
 };
 
 static int cluster_front(giql_hip_ctx* ctx, hipStream_t st, const giql_side* s, int32_t n_chrom,
@@ -2399,6 +2400,7 @@ static int cluster_front(giql_hip_ctx* ctx, hipStream_t st, const giql_side* s, 
     cb.total = c.take<u64>(1);
     cb.dummy_irr = c.take<u32>(16);
     cb.head_pos = want_heads ? c.take<u32>(n + 1) : nullptr;
+    cb.seg_end = want_heads && preds && preds->n > 0 ? c.take<u32>(n + 1) : nullptr;
     return c.off;
   };
   GIQL_TRY(ensure_arena(ctx, carve(nullptr), st));
@@ -2522,7 +2524,8 @@ int giql_hip_cluster_pred_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_c
 
 static int giql_hip_merge_dev_impl(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
                        int32_t* out_chrom, int32_t* out_start, int32_t* out_end,
-                       int64_t* out_count, int64_t capacity, int64_t* n_out, void* stream) {
+                       int64_t* out_count, int64_t capacity, int64_t* n_out, void* stream,
+                       const DevPreds* preds = nullptr) {
   GIQL_TRY(check_cluster_args(ctx, s, n_chrom));
   if (!n_out) return set_err(GIQL_ERR_INVALID, "n_out is NULL");
   HIP_TRY(hipSetDevice(ctx->device));
@@ -2535,7 +2538,8 @@ static int giql_hip_merge_dev_impl(giql_hip_ctx* ctx, const giql_side* s, int32_
   if (!out_chrom || !out_start || !out_end) return set_err(GIQL_ERR_INVALID, "output buffer is NULL");
   if (n_chrom == 0) return set_err(GIQL_ERR_CHROM, "rows but n_chrom = 0");
   ClusterBufs cb;
-  GIQL_TRY(cluster_front(ctx, st, s, n_chrom, distance, false, true, cb));
+  const bool pred = preds && preds->n > 0;
+  GIQL_TRY(cluster_front(ctx, st, s, n_chrom, distance, pred, true, cb, preds));
   u64 h_total = 0;
   HIP_TRY(hipMemcpyAsync(&h_total, cb.total, sizeof(u64), hipMemcpyDeviceToHost, st));
   GIQL_TRY(cluster_status(ctx, st));
@@ -2543,12 +2547,17 @@ static int giql_hip_merge_dev_impl(giql_hip_ctx* ctx, const giql_side* s, int32_
     return set_err(GIQL_ERR_CAPACITY, "%llu merged regions, capacity %lld",
                    (unsigned long long)h_total, (long long)capacity);
   {
-    Phase ph(ctx, st, GIQL_PH_FILL, 2);
+    Phase ph(ctx, st, GIQL_PH_FILL, pred ? 3 : 2);
     hipLaunchKernelGGL(k_merge_heads, dim3(cdiv((u64)s->n, 256)), dim3(256), 0, st, cb.flags, cb.excl,
                        (u32)s->n, cb.head_pos);
+    if (pred && h_total) {
+      HIP_TRY(hipMemsetAsync(cb.seg_end, 0, (size_t)h_total * sizeof(u32), st));
+      hipLaunchKernelGGL(k_merge_segmax, dim3(cdiv((u64)s->n, 256)), dim3(256), 0, st, cb.sb.end[0], cb.excl,
+                         cb.flags, (u32)s->n, cb.seg_end);
+    }
     if (h_total)
       hipLaunchKernelGGL(k_merge_rows, dim3(cdiv(h_total, 256)), dim3(256), 0, st, cb.head_pos,
-                         (u32)h_total, (u32)s->n, cb.sb.key[0], cb.pmax, cb.lb.chrom_first,
+                         (u32)h_total, (u32)s->n, cb.sb.key[0], cb.pmax, pred ? cb.seg_end : (u32*)nullptr, cb.lb.chrom_first,
                          cb.lb.chrom_base, n_chrom, out_chrom, out_start, out_end, (i64*)out_count);
     GIQL_TRY(post_launch("merge rows"));
   }
@@ -2564,6 +2573,16 @@ int giql_hip_merge_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, i
                        int32_t* out_chrom, int32_t* out_start, int32_t* out_end, int64_t* out_count,
                        int64_t capacity, int64_t* n_out, void* stream) {
   return with_order_fallback(ctx, [&] { return giql_hip_merge_dev_impl(ctx, s, n_chrom, distance, out_chrom, out_start, out_end, out_count, capacity, n_out, stream); });
+}
+
+int giql_hip_merge_pred_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom, int64_t distance,
+                            const giql_pred* preds, int32_t n_preds, int32_t* out_chrom, int32_t* out_start,
+                            int32_t* out_end, int64_t* out_count, int64_t capacity, int64_t* n_out, void* stream) {
+  if (n_preds < 0 || n_preds > SEL_MAX_PREDS || (n_preds && !preds))
+    return set_err(GIQL_ERR_INVALID, "bad predicates (at most %d)", SEL_MAX_PREDS);
+  DevPreds ps;
+  GIQL_TRY(convert_preds(preds, n_preds, ps, nullptr));
+  return with_order_fallback(ctx, [&] { return giql_hip_merge_dev_impl(ctx, s, n_chrom, distance, out_chrom, out_start, out_end, out_count, capacity, n_out, stream, &ps); });
 }
 
 // ------------------------------------------- distinct intervals + segment sums

@@ -477,10 +477,17 @@ class HipEngine:
                                                 ids.data_ptr() if s.n else None, self._stream()))
         return ids
 
-    def merge(self, s: DeviceSide, n_chrom: int, distance: int = 0):
+    def merge(self, s: DeviceSide, n_chrom: int, distance: int = 0, preds=None):
         """MERGE: ``(chrom, start, end, count)`` tensors of the merged regions ordered by
-        (chrom, start) (``src/giql/expanders/merge.py:186-330``)."""
+        (chrom, start) (``src/giql/expanders/merge.py:186-330``).  ``preds``: the ``predicate :=``
+        argument, as for :meth:`cluster` (merge.py:201-210 hands it to the CLUSTER underneath)."""
         torch = _torch()
+        if preds:
+            for p in preds:
+                for o in (p[0], p[2]):
+                    if o[0] in ("a", "b") and int(o[1].shape[0]) != s.n:
+                        raise ValueError("a predicate column must have one value per row of the table")
+            return self._merge_once(s, n_chrom, distance, preds)
         try:
             return self._merge_once(s, n_chrom, distance)
         except _lib.GiqlHipError as exc:
@@ -494,7 +501,7 @@ class HipEngine:
         order = torch.argsort(c.long() * (1 << 32) + (st.long() + (1 << 31)), stable=True)
         return c[order], st[order], en[order], cnt[order]
 
-    def _merge_once(self, s: DeviceSide, n_chrom: int, distance: int):
+    def _merge_once(self, s: DeviceSide, n_chrom: int, distance: int, preds=None):
         torch = _torch()
         n = s.n
         c = torch.empty(n, dtype=torch.int32, device=self.device)
@@ -502,10 +509,14 @@ class HipEngine:
         en = torch.empty(n, dtype=torch.int32, device=self.device)
         cnt = torch.empty(n, dtype=torch.int64, device=self.device)
         m = ctypes.c_int64(0)
-        _lib.check(self._L.giql_hip_merge_dev(
-            self._h, s.c_struct(), int(n_chrom), int(distance), c.data_ptr() if n else None,
-            st.data_ptr() if n else None, en.data_ptr() if n else None, cnt.data_ptr() if n else None,
-            n, ctypes.byref(m), self._stream()))
+        outs = (c.data_ptr() if n else None, st.data_ptr() if n else None, en.data_ptr() if n else None,
+                cnt.data_ptr() if n else None, n, ctypes.byref(m), self._stream())
+        if preds:
+            c_preds, k, _keep_alive = self._c_preds(preds)
+            _lib.check(self._L.giql_hip_merge_pred_dev(self._h, s.c_struct(), int(n_chrom), int(distance), c_preds, k,
+                                                       *outs))
+        else:
+            _lib.check(self._L.giql_hip_merge_dev(self._h, s.c_struct(), int(n_chrom), int(distance), *outs))
         k = int(m.value)
         return c[:k], st[:k], en[:k], cnt[:k]
 

@@ -355,13 +355,14 @@ def _execute_cluster_merge(plan: JoinPlan, tables, eng: HipEngine, return_indice
                           n_rows_a=dev_side.n, want=("a",))[0]
         dev_side = _subset(eng, dev_side, keep)
 
+    preds = None
+    if plan.cluster_predicate:
+        # predicate := ... PREV(col): both operand sides read the SAME table (the rows the WHERE kept), the current
+        # row through side "l", its sorted predecessor through side "r" (cluster.py:281-296, 587-640; MERGE hands
+        # its predicate to the CLUSTER underneath, merge.py:201-210)
+        ptbl = tbl if keep is None else _rows_of(tbl, keep.cpu().numpy())
+        preds = _Residuals(plan, ptbl, ptbl, eng).preds(plan.cluster_predicate)
     if plan.kind == "CLUSTER":
-        preds = None
-        if plan.cluster_predicate:
-            # predicate := ... PREV(col): both operand sides read the SAME table (the rows the WHERE kept), the current
-            # row through side "l", its sorted predecessor through side "r" (cluster.py:281-296, 587-640)
-            ptbl = tbl if keep is None else _rows_of(tbl, keep.cpu().numpy())
-            preds = _Residuals(plan, ptbl, ptbl, eng).preds(plan.cluster_predicate)
         ids = eng.cluster(dev_side, n_part, plan.distance, preds=preds)
         if return_indices:
             return (keep.cpu().numpy() if keep is not None else np.arange(dev_side.n)), ids.cpu().numpy()
@@ -384,7 +385,7 @@ def _execute_cluster_merge(plan: JoinPlan, tables, eng: HipEngine, return_indice
         arrays = [c if isinstance(c, (pa.Array, pa.ChunkedArray)) else pa.array(c) for c in cols]
         return pa.Table.from_arrays(arrays, names=names)
 
-    c, s, e, cnt = (t.cpu().numpy() for t in eng.merge(dev_side, n_part, plan.distance))
+    c, s, e, cnt = (t.cpu().numpy() for t in eng.merge(dev_side, n_part, plan.distance, preds=preds))
     chrom_out = chrom_dict[c // n_strand]
     cols = {side.chrom_col: pa.array(chrom_out.tolist() if chrom_out.dtype.kind in "US" else chrom_out)}
     if plan.stranded:

@@ -817,8 +817,6 @@ def _lower_cluster(p: _Parser, tbls: Tables) -> JoinPlan:
     if len(ops) > 1:
         raise ValueError(f"Multiple {ops[0][0]} expressions not yet supported")  # cluster.py:176-181, merge.py:173-175
     op, (this, distance, stranded, predicate), op_alias = ops[0]
-    if predicate and op == "MERGE":
-        raise _decline("MERGE with a predicate")  # (the merged MAX(end) is then a segmented maximum: not built)
     if this.star or (this.table is not None and _norm(this.table, this.table_quoted) != side.alias) \
             or this.column != table.genomic_col:
         raise ValueError(f"{op} operand must be the table's genomic column ({table.genomic_col!r})")

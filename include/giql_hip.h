@@ -239,6 +239,13 @@ int giql_hip_merge_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom,
                        int64_t distance, int32_t* out_chrom, int32_t* out_start,
                        int32_t* out_end, int64_t* out_count, int64_t capacity,
                        int64_t* n_out, void* stream);
+/* MERGE(..., predicate := ...): merge.py:201-210 hands the predicate to the CLUSTER it is built on, so a
+ * merged region is a cluster of giql_hip_cluster_pred_dev; its MAX(end) is taken over the region's own
+ * rows (a region may end while an earlier one still reaches further). */
+int giql_hip_merge_pred_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom,
+                            int64_t distance, const struct giql_pred* preds, int32_t n_preds,
+                            int32_t* out_chrom, int32_t* out_start, int32_t* out_end,
+                            int64_t* out_count, int64_t capacity, int64_t* n_out, void* stream);
 
 /* ---- the aggregate half of count_overlaps --------------------------------
  * GROUP BY the left interval + SUM of the per-row counts

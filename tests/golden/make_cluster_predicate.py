@@ -41,8 +41,12 @@ def run(rows, distance, stranded, pred):
                  "depth INTEGER, name TEXT, score REAL)")
     conn.executemany("INSERT INTO features VALUES (?, ?, ?, ?, ?, ?, ?, ?)", [(i, *r) for i, r in enumerate(rows)])
     ids = conn.execute(f"SELECT rid, __giql_cluster_id FROM ({cluster_pred_sql(distance, stranded, pred)}) ORDER BY rid").fetchall()
+    # MERGE(..., predicate := ...) is a GROUP BY over that clustered relation (merge.py:201-210, 253-330)
+    keys = '"chrom"' + (', "strand"' if stranded else "")
+    merged = conn.execute(f'SELECT {keys}, MIN("start"), MAX("end"), COUNT(*) FROM ({cluster_pred_sql(distance, stranded, pred)}) '
+                          f"GROUP BY {keys}, __giql_cluster_id ORDER BY {keys}, MIN(\"start\")").fetchall()
     conn.close()
-    return [r[1] for r in ids]
+    return [r[1] for r in ids], [list(r) for r in merged]
 
 
 def render(pred, operand) -> str:
@@ -97,10 +101,11 @@ def main() -> None:
     # the documentation's example shape: depth runs over abutting bins (docs/dialect/aggregation-operators.rst:40-75)
     doc = [("chr1", 0, 100, "+", 5, "a", 0.1), ("chr1", 100, 200, "+", 5, "a", 0.2), ("chr1", 200, 300, "+", 7, "b", 0.3),
            ("chr1", 300, 400, "+", 7, "b", None), ("chr1", 400, 500, "+", 5, "a", 0.5), ("chr2", 0, 100, "+", 5, "a", 0.6)]
-    ids = run(doc, 0, False, PREDICATES[0])
+    ids, merged = run(doc, 0, False, PREDICATES[0])
     assert ids == [1, 1, 2, 2, 3, 1], ids
+    assert merged == [["chr1", 0, 200, 2], ["chr1", 200, 400, 2], ["chr1", 400, 500, 1], ["chr2", 0, 100, 1]], merged
     cases.append({"name": "doc_depth_runs", "rows": [list(r) for r in doc], "distance": 0, "stranded": False,
-                  "predicate": giql_text(PREDICATES[0]), "ids": ids})
+                  "predicate": giql_text(PREDICATES[0]), "ids": ids, "merged": merged})
     idx = 0
     for stranded in (False, True):
         for distance in (0, 25):
@@ -115,9 +120,9 @@ def main() -> None:
                         used.add((c, st if stranded else "", s))
                         rows.append((c, s, s + rng.randint(1, ml), st, rng.choice([1, 2, 3, None]),
                                      rng.choice(["x", "y", None]), rng.choice([None, round(rng.random(), 3)])))
+                    ids, merged = run(rows, distance, stranded, pred)
                     cases.append({"name": f"fuzz_pred_{idx}", "rows": [list(r) for r in rows], "distance": distance,
-                                  "stranded": stranded, "predicate": giql_text(pred),
-                                  "ids": run(rows, distance, stranded, pred)})
+                                  "stranded": stranded, "predicate": giql_text(pred), "ids": ids, "merged": merged})
                     idx += 1
     with open(os.path.join(HERE, "cluster_predicate.json"), "w") as f:
         json.dump({"source": "tests/golden/make_cluster_predicate.py (sqlite3 over the reference's window SQL)",

@@ -87,10 +87,53 @@ def test_predicate_plan_shape_and_the_reference_s_errors():
         [("l", "depth", "=", 1), ("l", "name", "!=", 1), ("r", "score", "notnull", 0)]
     for q in ("SELECT *, CLUSTER(interval, predicate := depth LIKE PREV(depth)) AS cid FROM peaks",
               "SELECT *, CLUSTER(interval, predicate := ABS(depth) = PREV(depth)) AS cid FROM peaks",
-              "SELECT *, CLUSTER(interval, predicate := depth + 1 = PREV(depth)) AS cid FROM peaks",
-              "SELECT MERGE(interval, predicate := depth = PREV(depth)) FROM peaks"):
+              "SELECT *, CLUSTER(interval, predicate := depth + 1 = PREV(depth)) AS cid FROM peaks"):
         with pytest.raises(HipDeclined):
             build_plan(q, ["peaks"])
+    # MERGE hands its predicate to the CLUSTER underneath (merge.py:201-210)
+    p = build_plan("SELECT MERGE(interval, 5, predicate := depth = PREV(depth)), COUNT(*) AS n FROM peaks", ["peaks"])
+    assert p.kind == "MERGE" and p.distance == 5 and [(r.lhs.value, r.op, r.rhs.kind) for r in p.cluster_predicate] == \
+        [("depth", "=", "r")]
+
+
+def _merge_query(case) -> str:
+    args = ["interval"] + ([str(case["distance"])] if case["distance"] else []) \
+        + (["stranded := true"] if case["stranded"] else []) + [f"predicate := {case['predicate']}"]
+    return f"SELECT MERGE({', '.join(args)}), COUNT(*) AS n FROM features"
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_merged_regions_of_the_oracle_s_clusters_match_sqlite(case):
+    # MERGE = GROUP BY chrom[, strand], cluster id -> MIN(start), MAX(end), COUNT(*) (merge.py:253-330)
+    plan = build_plan(_merge_query(case), ["features"])
+    assert plan.kind == "MERGE" and plan.cluster_predicate
+    rows = case["rows"]
+    part = [(r[0], r[3]) if case["stranded"] else (r[0],) for r in rows]
+    ids = ora.py_cluster_predicate(part, [r[1] for r in rows], [r[2] for r in rows], case["distance"], _holds(plan, rows))
+    groups = {}
+    for p, cid, r in zip(part, ids.tolist(), rows):
+        g = groups.setdefault((p, cid), [r[1], r[2], 0])
+        g[0], g[1], g[2] = min(g[0], r[1]), max(g[1], r[2]), g[2] + 1
+    got = sorted([*p, *v] for (p, _cid), v in groups.items())
+    assert got == sorted(case["merged"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_execute_merge_predicate_golden(case):
+    pa = pytest.importorskip("pyarrow")
+    pytest.importorskip("torch")
+    from giql_amd.execute import execute
+
+    rows = case["rows"]
+    types = [pa.string(), pa.int32(), pa.int32(), pa.string(), pa.int64(), pa.string(), pa.float64()]
+    tbl = pa.table({c: pa.array([r[k] for r in rows], type=t) for k, (c, t) in enumerate(zip(COLS, types))})
+    out = execute(_merge_query(case), {"features": tbl}, giql_tables=["features"])
+    names = ["chrom"] + (["strand"] if case["stranded"] else []) + ["start", "end", "n"]
+    assert out.column_names == names
+    got = [list(r) for r in zip(*(out.column(c).to_pylist() for c in names))]
+    assert sorted(got) == sorted(case["merged"])
+    assert [r[0] for r in got] == sorted(r[0] for r in got)   # ORDER BY chrom, start (merge.py:320-330)
 
 
 @pytest.mark.gpu
@@ -126,3 +169,37 @@ def test_execute_cluster_predicate_behind_a_where_filter():
     want = ora.py_cluster_predicate(np.asarray(tbl.column("chrom").to_pylist())[keep].tolist(), start[keep].tolist(),
                                     tbl.column("end").to_numpy()[keep].tolist(), 100, lambda i, j: d[i] == d[j])
     assert out.column("cid").to_pylist() == want.tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["runs", "one_region", "long_shadow"])
+def test_execute_merge_predicate_on_regions_longer_than_a_wave(shape):
+    # regions that span waves and blocks (the segmented maximum's atomics), and regions that end
+    # below an earlier row's end (MAX(end) of the region's own rows, not the running maximum)
+    pa = pytest.importorskip("pyarrow")
+    pytest.importorskip("torch")
+    from giql_amd.execute import execute
+
+    r = np.random.default_rng(11)
+    n = 200_000
+    start = np.sort(r.choice(3_000_000, n, replace=False)).astype(np.int32)
+    end = (start + r.integers(20, 400, n)).astype(np.int32)
+    depth = np.repeat(r.integers(0, 3, n // 500 + 1), 500)[:n].astype(np.int64)      # runs of 500 rows
+    if shape == "one_region":
+        depth[:] = 1
+    if shape == "long_shadow":
+        end[0] = 3_100_000                                                         # every later row is "adjacent"
+    order = r.permutation(n)
+    tbl = pa.table({"chrom": pa.array(["chr1"] * n), "start": start[order], "end": end[order], "depth": depth[order]})
+    out = execute("SELECT MERGE(interval, predicate := depth = PREV(depth)), COUNT(*) AS k FROM t", {"t": tbl},
+                  giql_tables=["t"])
+    ids = ora.py_cluster_predicate(["chr1"] * n, start.tolist(), end.tolist(), 0, lambda i, j: depth[i] == depth[j])
+    heads = np.r_[0, np.nonzero(np.diff(ids))[0] + 1]                               # rows are in start order here
+    want_end = np.maximum.reduceat(end, heads)
+    assert out.column("start").to_pylist() == start[heads].tolist()
+    assert out.column("end").to_pylist() == want_end.tolist()
+    assert out.column("k").to_pylist() == np.diff(np.r_[heads, n]).tolist()
+    if shape == "long_shadow":
+        assert len(heads) > 100 and (want_end[1:] < end[0]).all()
+    if shape == "one_region":
+        assert len(heads) < len(ids) // 100

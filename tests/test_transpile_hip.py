@@ -244,7 +244,6 @@ def test_cluster_and_merge_shapes():
     ("SELECT *, *, CLUSTER(interval) AS c FROM peaks", ValueError, "multiple star"),          # cluster.py:182-196
     ("SELECT CLUSTER(stranded := true) AS c FROM peaks", ValueError, "genomic interval column"),
     ("SELECT *, CLUSTER(start) AS c FROM peaks", ValueError, "genomic column"),
-    ("SELECT MERGE(interval, predicate := depth = PREV(depth)) FROM peaks", HipDeclined, "predicate"),   # (CLUSTER takes one: tests/test_cluster_predicate.py)
     ("SELECT *, CLUSTER(interval) AS c FROM peaks ORDER BY chrom", HipDeclined, "ORDER"),
     ("SELECT *, CLUSTER(interval) FROM peaks", HipDeclined, "alias"),
     ("SELECT MERGE(interval), SUM(score) AS s FROM peaks", HipDeclined, "function call"),
