@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void k_nearest_unpack(const NearestRec* __rest
 // (zero-length a and b on one point) is downstream, as the distance CASE's first matching arm says
 // (_distance.py:67-87).  One thread per A row (rows sorted by start: neighbouring lanes walk
 // neighbouring ranges); results go out as k 16-byte records per row, by row id.
-constexpr int NEAREST_K_MAX = 64;
+constexpr int NEAREST_K_MAX = 1 << 20;  // (nothing in the walk depends on k: the cap only keeps n_a * k honest)
 // Round 3: the block's bracket of lower_bound(b_keys, a.end) is staged in LDS as in k_nearest (keys, prefix max AND
 // ends of the (start, end) view: the overlap walk filters on the ends), so the ~20 dependent loads of every row's
 // search and its walk over the overlapping rows are LDS loads; the upstream view is only looked at by rows that

@@ -520,8 +520,8 @@ def _parse_nearest(p: _Parser, tables: Tables, from_ref: _TableRef):
     k = int(args.get("k", 1))
     if k < 1:
         raise ValueError("NEAREST k must be a positive integer")
-    if k > 64:
-        raise _decline("NEAREST with k > 64")   # giql_hip_nearest_k_dev keeps k records per row
+    if k > 1 << 20:
+        raise _decline("NEAREST with k > 2^20")   # giql_hip_nearest_k_dev's cap (n_a * k must stay below 2^31)
     md = args.get("max_distance")
     return (_TableRef(target.text, alias, aq), (None if md is None else int(md)), bool(args.get("signed", False)), k,
             bool(args.get("stranded", False)))

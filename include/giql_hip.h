@@ -371,7 +371,7 @@ int giql_hip_pairs_checksum_dev(giql_hip_ctx* ctx, const int32_t* row_a,
 /* NEAREST k >= 1 (src/giql/expanders/nearest.py:240-252, 336-397): for A row i the k nearest B
  * rows on its chromosome in the reference's order ABS(distance), start, end land in
  * idx_b_out[i*k .. i*k+k) / dist_out[i*k ..) (row-major; unused slots -1 / 0), within
- * max_distance when >= 0.  1 <= k <= 64.  Rows tied on (distance, start, end) are
+ * max_distance when >= 0.  1 <= k <= 2^20 and n_a * k < 2^31.  Rows tied on (distance, start, end) are
  * order-ambiguous upstream too (nearest.py:366-372).  Requires start <= end rows. */
 int giql_hip_nearest_k_dev(giql_hip_ctx* ctx, const giql_side* a,
                            const giql_side* b, int32_t n_chrom, int32_t k,

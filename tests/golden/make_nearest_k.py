@@ -92,6 +92,21 @@ def main():
                                       "a": a, "b": b, "k": k, "signed": signed, "max_distance": md, "stranded": stranded,
                                       "expected": run(dm, a, b, k, signed, md, stranded)})
                         idx += 1
+    # k beyond 64 (round 3: the kernel's walk does not depend on k; the cap is n_a * k < 2^31)
+    rng2 = random.Random(20261007)
+    for k, signed, md, stranded in [(70, False, None, False), (100, True, None, False), (150, False, 900, True)]:
+        def rows2(n, chroms):
+            out = []
+            for _ in range(n):
+                s = rng2.randint(0, 3000)
+                out.append([rng2.choice(chroms), s, s + rng2.randint(0, 90), rng2.choice("+-")])
+            return out
+        a, b = rows2(12, ["chr1", "chr2", "chr3"]), rows2(260, ["chr1", "chr2"])
+        if not stranded:
+            a, b = [r[:3] for r in a], [r[:3] for r in b]
+        cases.append({"name": f"large_k_{k}", "source": "sqlite3 over the reference's distance CASE",
+                      "a": a, "b": b, "k": k, "signed": signed, "max_distance": md, "stranded": stranded,
+                      "expected": run(dm, a, b, k, signed, md, stranded)})
     with open(os.path.join(HERE, "nearest_k.json"), "w") as f:
         json.dump({"_source": __doc__.strip().splitlines()[0] + " -- see tests/golden/make_nearest_k.py", "cases": cases}, f)
     print(f"wrote nearest_k.json: {len(cases)} cases")

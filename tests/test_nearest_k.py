@@ -45,7 +45,8 @@ def test_nearest_k_golden(eng, case):
     assert got == [[(w[3], w[1], w[2]) for w in want] for want in case["expected"]]
 
 
-@pytest.mark.parametrize("k,signed,md", [(1, False, None), (2, True, None), (3, False, 500), (8, True, 90), (64, False, None)])
+@pytest.mark.parametrize("k,signed,md", [(1, False, None), (2, True, None), (3, False, 500), (8, True, 90), (64, False, None),
+                                         (65, True, None), (200, False, 4000), (1000, True, None)])
 def test_nearest_k_random_vs_brute_force(eng, k, signed, md):
     for seed, (na, nb, nch, ms, ml, min_len) in enumerate([
             (3000, 4000, 5, 2_000_000, 900, 0),      # sparse: mostly gaps
@@ -81,7 +82,7 @@ def test_nearest_k_edge_cases(eng):
     assert dist.cpu().numpy().tolist() == [[1, 0]] and idx.cpu().numpy().tolist() == [[0, -1]]
     from giql_amd._lib import GiqlHipError
     with pytest.raises(GiqlHipError):
-        eng.nearest_k(dev(a), dev(a), 3, 65)
+        eng.nearest_k(dev(a), dev(a), 3, (1 << 20) + 1)
     with pytest.raises(GiqlHipError):
         eng.nearest_k(dev(a), dev(a), 3, 0)
     inv = ora.Side(np.zeros(2, np.int32), np.array([10, 50], np.int32), np.array([5, 60], np.int32))

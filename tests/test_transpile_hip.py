@@ -116,7 +116,7 @@ def test_case_insensitive_aliases():
     "SELECT a.start FROM peaks a, genes b, exons c WHERE a.interval INTERSECTS b.interval",
     "WITH x AS (SELECT 1) SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS 'chr1:1-10'",
-    "SELECT a.start FROM peaks a CROSS JOIN LATERAL NEAREST(genes, reference := a.interval, k := 65) b",
+    "SELECT a.start FROM peaks a CROSS JOIN LATERAL NEAREST(genes, reference := a.interval, k := 1048577) b",
 ])
 def test_valid_but_unsupported_shapes_decline(query):
     with pytest.raises(HipDeclined):
