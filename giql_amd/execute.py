@@ -916,11 +916,19 @@ def _finish_outer(out, plan: JoinPlan):
 
         cmp = {"=": pc.equal, "!=": pc.not_equal, "<": pc.less, "<=": pc.less_equal, ">": pc.greater,
                ">=": pc.greater_equal}
-        mask = None
-        for h in plan.having:
+        mask, clause, prev = None, None, 0
+        for h in list(plan.having) + [None]:
+            if h is None or not (h.group and h.group == prev):    # a clause ends: AND it in
+                if clause is not None:
+                    mask = clause if mask is None else pc.and_kleene(mask, clause)
+                clause = None
+            if h is None:
+                break
             lhs, rhs = (out.column(o.value) if o.kind == "name" else pa.scalar(o.value) for o in (h.lhs, h.rhs))
-            m = cmp[h.op](lhs, rhs)
-            mask = m if mask is None else pc.and_kleene(mask, m)
+            m = (pc.is_null(lhs) if h.op == "isnull" else pc.is_valid(lhs)) if h.op in ("isnull", "notnull") \
+                else cmp[h.op](lhs, rhs)
+            clause = m if clause is None else pc.or_kleene(clause, m)   # members of one group are OR-ed
+            prev = h.group
         out = out.filter(mask)   # NULL comparisons drop the group, as SQL's HAVING does
     visible = [n for n in out.column_names if not n.startswith("__giql_")]
     if plan.distinct:

@@ -84,8 +84,9 @@ class Having:
     ``__giql_h<n>`` aggregate computed for this clause only) or a literal ("int", "float", "str")."""
 
     lhs: Operand
-    op: str        # = != < <= > >=
+    op: str        # = != < <= > >= isnull notnull
     rhs: Operand
+    group: int = 0  # conjuncts sharing a non-zero group are OR-ed (one clause of the normal form)
 
 
 @dataclass(frozen=True)
@@ -151,7 +152,8 @@ class JoinPlan:
             cluster_predicate=tuple(Residual(r["clause"], Operand(**r["lhs"]), r["op"], Operand(**r["rhs"]), r.get("group", 0))
                                     for r in d.get("cluster_predicate", ())),
             aggregates=tuple(Aggregate(**a) for a in d.get("aggregates", ())),
-            having=tuple(Having(Operand(**h["lhs"]), h["op"], Operand(**h["rhs"])) for h in d.get("having", ())),
+            having=tuple(Having(Operand(**h["lhs"]), h["op"], Operand(**h["rhs"]), h.get("group", 0))
+                         for h in d.get("having", ())),
             group_by=tuple(d.get("group_by", ())),
             order_by=tuple((o[0], bool(o[1]), bool(o[2]) if len(o) > 2 else not bool(o[1])) for o in d.get("order_by", ())),
             limit=d.get("limit"), offset=d.get("offset"), output=tuple(d.get("output", ())))

@@ -177,56 +177,48 @@ def _operand(n):
     raise decline(f"join condition operand of kind {_key(n)!r}")
 
 
-def _conjuncts(n):
-    if n is None:
-        return
-    if _key(n) == "and":
-        yield from _conjuncts(_arg(n, "this"))
-        yield from _conjuncts(_arg(n, "expression"))
-    else:
-        yield n
-
-
-def _cond_tree(n):
+def _cond_tree(n, operand=None):
     """A condition node -> the tree ``shape.condition_terms`` normalises (AND / OR / NOT / parentheses over
     INTERSECTS, comparisons, BETWEEN, IN (literals), IS [NOT] NULL).  The reference inlines any extra that
     holds no INTERSECTS / sub-query / aggregate / window as SQL text (``_classify_extras``,
     intersects_duckdb.py:889-912); what has no evaluator here -- LIKE, arithmetic, functions, sub-queries,
     TRUE -- declines, so the naive predicate runs the query."""
     k = _key(n)
+    operand = operand or _operand
     if k in ("and", "or"):
         _only(n, ("this", "expression"), k.upper())
-        return (k, [_cond_tree(_arg(n, "this")), _cond_tree(_arg(n, "expression"))])
+        return (k, [_cond_tree(_arg(n, "this"), operand), _cond_tree(_arg(n, "expression"), operand)])
     if k == "not":
         _only(n, ("this",), "NOT")
-        return ("not", _cond_tree(_arg(n, "this")))
+        return ("not", _cond_tree(_arg(n, "this"), operand))
     if k == "paren":
         _only(n, ("this",), "parentheses")
-        return _cond_tree(_arg(n, "this"))
+        return _cond_tree(_arg(n, "this"), operand)
     if k == "intersects":
         l, r = _arg(n, "this"), _arg(n, "expression")
         if _key(l) != "column" or _key(r) != "column":
             raise decline("INTERSECTS operand that is not a column")
         return ("leaf", ("intersects", _colref(l), _colref(r)))
     if k in _CMP:
-        return ("leaf", ("cmp", _operand(_arg(n, "this")), _CMP[k], _operand(_arg(n, "expression"))))
+        return ("leaf", ("cmp", operand(_arg(n, "this")), _CMP[k], operand(_arg(n, "expression"))))
     if k == "between":
         _only(n, ("this", "low", "high"), "BETWEEN")
-        x = _operand(_arg(n, "this"))
-        return ("and", [("leaf", ("cmp", x, ">=", _operand(_arg(n, "low")))),
-                        ("leaf", ("cmp", x, "<=", _operand(_arg(n, "high"))))])
+        x = operand(_arg(n, "this"))
+        return ("and", [("leaf", ("cmp", x, ">=", operand(_arg(n, "low")))),
+                        ("leaf", ("cmp", x, "<=", operand(_arg(n, "high"))))])
     if k == "in":
         _only(n, ("this", "expressions"), "IN")      # IN (sub-query) / IN UNNEST(...) carry other args
-        x = _operand(_arg(n, "this"))
+        x = operand(_arg(n, "this"))
         values = [_literal(v) for v in (_arg(n, "expressions") or [])]
         if not values or any(v is None for v in values):
             raise decline("IN list with a non-literal member")
         return ("or", [("leaf", ("cmp", x, "=", v)) for v in values])
     if k == "is":
         _only(n, ("this", "expression"), "IS")
-        if _key(_arg(n, "expression")) != "null" or _key(_arg(n, "this")) != "column":
+        x = operand(_arg(n, "this"))
+        if _key(_arg(n, "expression")) != "null" or x[0] == "lit":
             raise decline("IS predicate other than <column> IS [NOT] NULL")
-        return ("leaf", ("cmp", ("col", _colref(_arg(n, "this"))), "isnull", ("lit", 0)))
+        return ("leaf", ("cmp", x, "isnull", ("lit", 0)))
     if k in ("contains", "within"):
         raise decline(f"{k.upper()} predicate")
     raise decline(f"join condition of kind {k!r}")
@@ -408,11 +400,9 @@ def shape_from_ast(root, node, ctx) -> JoinShape:
                 raise decline("parenthesised / sub-query HAVING condition")
             return _operand(n)
 
-        for c in _conjuncts(_arg(having, "this")):
-            if _key(c) not in _CMP:
-                raise decline(f"HAVING condition of kind {_key(c)!r}")
-            shape.having.append(("cmp", having_operand(_arg(c, "this")), _CMP[_key(c)],
-                                 having_operand(_arg(c, "expression"))))
+        shape.having = condition_terms(_cond_tree(_arg(having, "this"), having_operand))
+        if any(t[0] not in ("cmp", "or") for t in shape.having):
+            raise decline("spatial predicate in HAVING")
     order = _arg(root, "order")
     if order is not None:
         _only(order, ("expressions",), "ORDER BY")   # ORDER SIBLINGS BY

@@ -165,7 +165,7 @@ class JoinShape:
     using: list[str] = field(default_factory=list)
     distinct: bool = False
     group_by: list[ColRef] = field(default_factory=list)
-    # HAVING conjuncts ("cmp", lhs, op, rhs); an operand is ("lit", value), ("col", ColRef) or ("agg", SelItem)
+    # HAVING terms ("cmp", lhs, op, rhs) | ("or", [cmp, ...]); an operand is ("lit", value), ("col", ColRef) or ("agg", SelItem)
     having: list = field(default_factory=list)
     order_by: list[OrderKey] = field(default_factory=list)
     limit: int | None = None
@@ -431,11 +431,17 @@ def _resolve_having(shape: JoinShape, proj, aggs, left: PlanSide, right: PlanSid
         aggs.append(hidden)
         return Operand("name", hidden.name)
 
-    for _tag, lhs, op, rhs in shape.having:
-        a, b = bind(lhs), bind(rhs)
-        if a.kind != "name" and b.kind != "name":
-            raise decline("constant HAVING predicate")
-        having.append(Having(a, op, b))
+    group = 0
+    for term in shape.having:
+        leaves, g = [term], 0
+        if term[0] == "or":
+            group += 1
+            leaves, g = term[1], group
+        for _tag, lhs, op, rhs in leaves:
+            a, b = bind(lhs), bind(rhs)
+            if a.kind != "name" and b.kind != "name":
+                raise decline("constant HAVING predicate")
+            having.append(Having(a, op, b, g))
     return tuple(aggs), tuple(having)
 
 

@@ -393,45 +393,24 @@ def _parse_aggregate_call(p: _Parser, where: str):
 
 
 def _parse_having(p: _Parser):
-    """``term (AND term)*`` with ``<operand> op <operand>``, an operand being a plain aggregate, a
-    column (qualified key or output name) or a literal (the reference hands HAVING to the engine
-    verbatim, intersects_duckdb.py:1336-1400; sub-queries, OR / NOT, arithmetic decline here)."""
+    """A boolean condition over comparisons ``<operand> op <operand>`` (also BETWEEN / IN / IS NULL), an operand
+    being a plain aggregate, a column (qualified key or output name) or a literal -> the terms of its conjunctive
+    normal form (the reference hands HAVING to the engine verbatim, intersects_duckdb.py:1336-1400; sub-queries
+    and arithmetic decline here)."""
 
-    def operand():
+    def operand(p: _Parser):
         t = p.peek()
-        if p.at_punct("(") or p.at_kw("NOT", "EXISTS", "SELECT"):
-            raise _decline("parenthesised / sub-query HAVING condition")
+        if p.at_kw("EXISTS", "SELECT"):
+            raise _decline("sub-query HAVING condition")
         if t.kind == "id" and not t.quoted and p.peek(1).kind == "punct" and p.peek(1).text == "(":
             func, distinct, ref = _parse_aggregate_call(p, "HAVING")
             return ("agg", SelItem(ref, None, func, distinct))
         return _parse_operand(p)
 
-    terms = []
-    while True:
-        lhs = operand()
-        t = p.peek()
-        op = None
-        if t.kind == "punct" and t.text in "=<>!":
-            p.next()
-            op = t.text
-            n = p.peek()
-            if n.kind == "punct" and ((op == "<" and n.text in "=>") or (op == ">" and n.text == "=")
-                                      or (op == "!" and n.text == "=")):
-                p.next()
-                op += n.text
-        if op is None or op == "!":
-            raise _decline("HAVING condition other than simple comparisons")
-        op = {"<>": "!=", "==": "="}.get(op, op)
-        rhs = operand()
-        if p.peek().kind == "punct" and p.peek().text in "+-*/":
-            raise _decline("arithmetic in HAVING")
-        terms.append(("cmp", lhs, op, rhs))
-        if p.at_kw("AND"):
-            p.next()
-            continue
-        if p.at_kw("OR"):
-            raise _decline("OR in HAVING")
-        return terms
+    terms = _condition_terms(_parse_bool(p, False, 0, operand))
+    if any(t[0] not in ("cmp", "or") for t in terms):
+        raise _decline("spatial predicate in HAVING")
+    return terms
 
 
 def _parse_projection(p: _Parser) -> list[SelItem]:

@@ -38,6 +38,19 @@ CONDITIONS = [
 ]
 
 
+# grouped queries with a boolean HAVING (handed to the engine verbatim upstream, intersects_duckdb.py:1336-1400):
+# (SELECT list, GROUP BY, HAVING) -- valid in GIQL and, with the overlap predicate spelt out, in sqlite
+HAVING = [
+    ("a.name, COUNT(*) AS n", "a.name", "COUNT(*) > 8 OR SUM(b.score) < 10"),
+    ("a.name, COUNT(*) AS n", "a.name", "NOT (COUNT(*) BETWEEN 3 AND 9) AND a.name IS NOT NULL"),
+    ("a.name, COUNT(*) AS n, MAX(b.score) AS m", "a.name",
+     "(MIN(b.score) IS NULL OR MAX(b.score) >= 5) AND COUNT(*) IN (1, 2, 3, 10, 11)"),
+    ("a.chrom, a.strand, COUNT(*) AS n, SUM(b.score) AS s", "a.chrom, a.strand",
+     "SUM(b.score) > 150 OR a.strand = '-' AND NOT COUNT(*) < 20"),
+    ("a.score, COUNT(*) AS n", "a.score", "a.score IS NULL OR NOT (a.score IN (1, 3) OR COUNT(*) <= 4)"),
+]
+
+
 def giql_query(kind: str, on: str, where: str) -> str:
     join = {"INNER": "JOIN", "SEMI": "SEMI JOIN", "ANTI": "ANTI JOIN"}[kind]
     cols = "a.name AS an, a.start AS s, b.name AS bn, b.end AS e" if kind == "INNER" else "a.name, a.start, a.score"
@@ -92,13 +105,30 @@ def main() -> None:
             cases.append({"kind": kind, "query": giql_query(kind, on, where), "peaks": [list(r) for r in peaks],
                           "genes": [list(r) for r in genes], "rows": [list(r) for r in sorted(got, key=key)]})
     assert sum(1 for c in cases if c["rows"]) >= len(cases) * 2 // 3
+    having = []
+    for sel, group, cond in HAVING:
+        for n_p, n_g in [(8, 6), (70, 60)]:
+            peaks, genes = rand_rows(rng, n_p, "p"), rand_rows(rng, n_g, "g")
+            conn = sqlite3.connect(":memory:")
+            for t, rows in (("peaks", peaks), ("genes", genes)):
+                conn.execute(f'CREATE TABLE {t} (chrom TEXT, "start" INTEGER, "end" INTEGER, name TEXT, score INTEGER, strand TEXT)')
+                conn.executemany(f"INSERT INTO {t} VALUES (?, ?, ?, ?, ?, ?)", rows)
+            got = conn.execute(f"SELECT {sel} FROM peaks a JOIN genes b ON {OVERLAP} GROUP BY {group} HAVING {cond}").fetchall()
+            conn.close()
+            key = lambda r: tuple((x is None, x) for x in r)
+            having.append({"query": f"SELECT {sel} FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval "
+                                    f"GROUP BY {group} HAVING {cond}",
+                           "peaks": [list(r) for r in peaks], "genes": [list(r) for r in genes],
+                           "rows": [list(r) for r in sorted(got, key=key)]})
+    assert sum(1 for c in having if c["rows"]) >= len(having) // 2
     doc = {"_source": "tests/golden/make_boolean_residuals.py: sqlite3 evaluates the overlap join AND the condition "
                       "text the reference would inline (intersects_duckdb.py:889-912, 1239-1243); rows sorted with NULLs last "
                       "per column; table rows are (chrom, start, end, name, score, strand)",
-           "cases": cases}
+           "cases": cases, "having": having}
     with open(os.path.join(HERE, "boolean_residuals.json"), "w") as f:
         json.dump(doc, f, separators=(",", ":"))
-    print(len(cases), "cases,", sum(len(c["rows"]) for c in cases), "rows")
+    print(len(cases), "cases,", sum(len(c["rows"]) for c in cases), "rows;", len(having), "HAVING cases,",
+          sum(len(c["rows"]) for c in having), "rows")
 
 
 if __name__ == "__main__":

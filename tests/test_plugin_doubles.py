@@ -239,7 +239,20 @@ def test_having_shapes_this_target_does_not_run_decline():
     sub = A.N("subquery", this=A.N("select"))
     _declined(*basic([A.col("a", "chrom")], group=[A.col("a", "chrom")], having=A.cmp("gt", A.agg("sum", A.col("a", "score")), sub)))
     _declined(*basic([A.col("a", "chrom")], group=[A.col("a", "chrom")],
-                     having=A.N("or", this=A.cmp("gt", A.agg("count"), A.lit(1)), expression=A.cmp("lt", A.agg("count"), A.lit(9)))))
+                     having=A.cmp("gt", A.N("add", this=A.agg("count"), expression=A.lit(1)), A.lit(1))))
+
+
+def test_boolean_having_lowers_to_the_same_plan_as_the_mirror():
+    having = A.N("and", this=A.N("paren", this=A.N("or", this=A.cmp("gt", A.agg("count"), A.lit(1)),
+                                                    expression=A.N("not", this=A.cmp("gte", A.agg("sum", A.col("b", "score")), A.lit(3))))),
+                 expression=A.N("not", this=A.N("is", this=A.agg("max", A.col("a", "score")), expression=A.N("null"))))
+    root, it = basic([A.col("a", "chrom"), A.alias(A.agg("count"), "n")], group=[A.col("a", "chrom")], having=having)
+    out, ctx, calls = run(root, it, ["peaks", "genes"])
+    assert out is it and not calls
+    want = build_plan("SELECT a.chrom, COUNT(*) AS n FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom "
+                      "HAVING (COUNT(*) > 1 OR NOT SUM(b.score) >= 3) AND MAX(a.score) IS NOT NULL", ["peaks", "genes"])
+    got = JoinPlan.from_string(ctx.finalizers[0](root)[1])
+    assert got == want and [(h.op, h.group) for h in got.having] == [(">", 1), ("<", 1), ("notnull", 0)]
 
 
 def test_clauses_the_lowering_does_not_read_decline_instead_of_being_dropped():

@@ -109,7 +109,7 @@ def test_case_insensitive_aliases():
     "SELECT a.start + 1 FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval",
     "SELECT a.start FROM peaks a JOIN genes b USING (chrom)",                      # USING without any INTERSECTS
     "SELECT a.chrom FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom "
-    "HAVING COUNT(*) > 1 OR COUNT(*) < 9",
+    "HAVING COUNT(*) + 1 > 1",
     "SELECT a.chrom FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom "
     "HAVING SUM(a.score) > (SELECT AVG(score) FROM peaks)",
     "SELECT a.start FROM peaks a SEMI JOIN genes b ON TRUE WHERE a.interval INTERSECTS b.interval",
@@ -121,6 +121,17 @@ def test_case_insensitive_aliases():
 def test_valid_but_unsupported_shapes_decline(query):
     with pytest.raises(HipDeclined):
         build_plan(query, ["peaks", "genes"])
+
+
+def test_boolean_having_arrives_in_conjunctive_normal_form():
+    # the reference hands HAVING to the engine verbatim (intersects_duckdb.py:1336-1400)
+    q = ("SELECT a.chrom, COUNT(*) AS n FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval GROUP BY a.chrom "
+         "HAVING (COUNT(*) > 5 OR NOT SUM(b.score) >= 3) AND a.chrom IN ('chr1', 'chr2') AND MAX(a.score) IS NOT NULL")
+    p = build_plan(q, ["peaks", "genes"])
+    assert [(h.lhs.value, h.op, h.rhs.value, h.group) for h in p.having] == \
+        [("n", ">", 5, 1), ("__giql_h0", "<", 3, 1), ("chrom", "=", "chr1", 2), ("chrom", "=", "chr2", 2),
+         ("__giql_h1", "notnull", 0, 0)]
+    assert JoinPlan.from_string(p.to_string()) == p
 
 
 def _res(plan):
