@@ -35,7 +35,7 @@ SYMBOLS = [
     "giql_hip_inner", "giql_hip_semi_anti", "giql_hip_count", "giql_hip_nearest",
     "giql_hip_free_host", "giql_hip_pairs_checksum_dev",
     "giql_hip_take_dev", "giql_hip_take_utf8_plan_dev", "giql_hip_take_utf8_fill_dev",
-    "giql_hip_select_dev", "giql_hip_mark_dev", "giql_hip_cluster_dev", "giql_hip_cluster_pred_dev", "giql_hip_merge_dev", "giql_hip_merge_pred_dev",
+    "giql_hip_select_dev", "giql_hip_select_expr_dev", "giql_hip_mark_dev", "giql_hip_cluster_dev", "giql_hip_cluster_pred_dev", "giql_hip_merge_dev", "giql_hip_merge_pred_dev",
     "giql_hip_group_rows_dev", "giql_hip_segment_sum_dev", "giql_hip_inner_join_dev",
     "giql_hip_inner_plan_export_dev", "giql_hip_fill_from_plan_dev", "giql_hip_copy_probe_dev",
     "giql_hip_nearest_k_dev",
@@ -113,7 +113,7 @@ class CPred(ctypes.Structure):
 
 
 OPS = {"=": 0, "==": 0, "!=": 1, "<>": 1, "<": 2, "<=": 3, ">": 4, ">=": 5, "isnull": 6, "notnull": 7}
-SIDE_A, SIDE_B, SIDE_LIT = 0, 1, 2
+SIDE_A, SIDE_B, SIDE_LIT, SIDE_EXPR = 0, 1, 2, 3
 T_I32, T_I64, T_F32, T_F64, T_U8 = range(5)
 
 _lib = None
@@ -171,6 +171,7 @@ def load() -> ctypes.CDLL:
     L.giql_hip_take_utf8_plan_dev.argtypes = [vp, vp, i64, vp, i64, vp, P(i64), vp]
     L.giql_hip_take_utf8_fill_dev.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, vp]
     L.giql_hip_select_dev.argtypes = [vp, P(CPred), i32, vp, i64, vp, i64, i64, vp, vp, P(i64), vp]
+    L.giql_hip_select_expr_dev.argtypes = [vp, P(CPred), i32, P(COperand), i32, vp, i64, vp, i64, i64, vp, vp, P(i64), vp]
     L.giql_hip_mark_dev.argtypes = [vp, vp, i64, vp, i64, vp]
     L.giql_hip_group_rows_dev.argtypes = [vp, P(CSide), i32, vp, vp, P(i64), vp]
     L.giql_hip_segment_sum_dev.argtypes = [vp, vp, vp, i64, vp, i64, vp]

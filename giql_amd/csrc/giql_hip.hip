@@ -2489,7 +2489,35 @@ int giql_hip_cluster_dev(giql_hip_ctx* ctx, const giql_side* s, int32_t n_chrom,
 static int check_operand(const giql_operand& o, int k, const char* which);
 
 // giql_pred[] -> the by-value kernel argument; uses[side] = a column of that side is read
-static int convert_preds(const giql_pred* preds, int32_t n_preds, DevPreds& ps, bool* uses) {
+// A well-formed postfix program: every operator finds its arguments, one value is left, the stack stays within
+// SEL_X_STACK.  uses[side] as in convert_preds.
+static int check_program(const giql_operand* nodes, int32_t n_nodes, int first, int count, int k, const char* which,
+                         bool* uses) {
+  if (!nodes || first < 0 || count < 1 || first + count > n_nodes)
+    return set_err(GIQL_ERR_INVALID, "predicate %d %s: expression nodes [%d, %d) outside the %d given", k, which, first,
+                   first + count, n_nodes);
+  int sp = 0;
+  for (int t = first; t < first + count; t++) {
+    const giql_operand& nd = nodes[t];
+    if (nd.side == GIQL_SIDE_A || nd.side == GIQL_SIDE_B || nd.side == GIQL_SIDE_LIT) {
+      GIQL_TRY(check_operand(nd, k, which));
+      if (uses && nd.side != GIQL_SIDE_LIT) uses[nd.side] = true;
+      if (++sp > SEL_X_STACK) return set_err(GIQL_ERR_INVALID, "predicate %d %s: expression deeper than %d", k, which, SEL_X_STACK);
+    } else if (nd.side == GIQL_X_NEG || nd.side == GIQL_X_ABS) {
+      if (sp < 1) return set_err(GIQL_ERR_INVALID, "predicate %d %s: malformed expression", k, which);
+    } else if (nd.side >= GIQL_X_ADD && nd.side <= GIQL_X_GREATEST) {
+      if (sp < 2) return set_err(GIQL_ERR_INVALID, "predicate %d %s: malformed expression", k, which);
+      sp--;
+    } else {
+      return set_err(GIQL_ERR_INVALID, "predicate %d %s: expression node kind %d", k, which, nd.side);
+    }
+  }
+  if (sp != 1) return set_err(GIQL_ERR_INVALID, "predicate %d %s: malformed expression", k, which);
+  return GIQL_OK;
+}
+
+static int convert_preds(const giql_pred* preds, int32_t n_preds, DevPreds& ps, bool* uses,
+                         const giql_operand* nodes = nullptr, int32_t n_nodes = 0, bool* any_expr = nullptr) {
   static_assert(sizeof(giql_operand) == sizeof(DevOperand), "giql_operand layout");
   static_assert(sizeof(giql_pred) == sizeof(DevPred), "giql_pred layout");
   memset(&ps, 0, sizeof(ps));
@@ -2499,16 +2527,21 @@ static int convert_preds(const giql_pred* preds, int32_t n_preds, DevPreds& ps, 
     if (preds[k].op < GIQL_OP_EQ || preds[k].op > GIQL_OP_NOT_NULL)
       return set_err(GIQL_ERR_INVALID, "predicate %d: operator %d", k, preds[k].op);
     if (preds[k].group < 0) return set_err(GIQL_ERR_INVALID, "predicate %d: group %d", k, preds[k].group);
-    GIQL_TRY(check_operand(preds[k].lhs, k, "lhs"));
-    if (!unary) GIQL_TRY(check_operand(preds[k].rhs, k, "rhs"));
+    for (int w = 0; w < (unary ? 1 : 2); w++) {
+      const giql_operand& o = w ? preds[k].rhs : preds[k].lhs;
+      if (o.side == GIQL_SIDE_EXPR) {
+        GIQL_TRY(check_program(nodes, n_nodes, (int)o.lit_i, o.type, k, w ? "rhs" : "lhs", uses));
+        if (any_expr) *any_expr = true;
+      } else {
+        GIQL_TRY(check_operand(o, k, w ? "rhs" : "lhs"));
+        if (uses && o.side != GIQL_SIDE_LIT) uses[o.side] = true;
+      }
+    }
     memcpy(&ps.p[k], &preds[k], sizeof(DevPred));
     if (unary) {  // the right operand is not read: make it a harmless literal
       memset(&ps.p[k].rhs, 0, sizeof(DevOperand));
       ps.p[k].rhs.side = GIQL_SIDE_LIT;
     }
-    if (uses)
-      for (const giql_operand* o : {&preds[k].lhs, unary ? &preds[k].lhs : &preds[k].rhs})
-        if (o->side != GIQL_SIDE_LIT) uses[o->side] = true;
   }
   return GIQL_OK;
 }
@@ -3057,13 +3090,26 @@ int giql_hip_select_dev(giql_hip_ctx* ctx, const giql_pred* preds, int32_t n_pre
                         const int32_t* idx_a, int64_t n_rows_a, const int32_t* idx_b,
                         int64_t n_rows_b, int64_t n, int32_t* out_a, int32_t* out_b,
                         int64_t* n_kept, void* stream) {
+  return giql_hip_select_expr_dev(ctx, preds, n_preds, nullptr, 0, idx_a, n_rows_a, idx_b, n_rows_b, n, out_a, out_b,
+                                  n_kept, stream);
+}
+
+int giql_hip_select_expr_dev(giql_hip_ctx* ctx, const giql_pred* preds, int32_t n_preds,
+                             const giql_operand* nodes, int32_t n_nodes,
+                             const int32_t* idx_a, int64_t n_rows_a, const int32_t* idx_b,
+                             int64_t n_rows_b, int64_t n, int32_t* out_a, int32_t* out_b,
+                             int64_t* n_kept, void* stream) {
   if (!ctx || !n_kept || n < 0 || n > 0x7FFFFFF0ll || n_preds < 0 || n_preds > SEL_MAX_PREDS ||
       (n_preds && !preds) || n_rows_a < 0 || n_rows_b < 0 || n_rows_a > 0x7FFFFFFFll ||
-      n_rows_b > 0x7FFFFFFFll)
-    return set_err(GIQL_ERR_INVALID, "bad arguments (at most %d predicates, n < 2^31)", SEL_MAX_PREDS);
+      n_rows_b > 0x7FFFFFFFll || n_nodes < 0 || n_nodes > SEL_MAX_NODES || (n_nodes && !nodes))
+    return set_err(GIQL_ERR_INVALID, "bad arguments (at most %d predicates and %d expression nodes, n < 2^31)",
+                   SEL_MAX_PREDS, SEL_MAX_NODES);
+  static_assert(GIQL_SIDE_EXPR == SEL_SIDE_EXPR && GIQL_X_ADD == SEL_X_ADD && GIQL_X_GREATEST == SEL_X_GREATEST &&
+                GIQL_X_NEG == SEL_X_NEG && GIQL_X_ABS == SEL_X_ABS && GIQL_X_DIV == SEL_X_DIV, "expression node kinds");
   DevPreds ps;
   bool uses[2] = {false, false};
-  GIQL_TRY(convert_preds(preds, n_preds, ps, uses));
+  bool any_expr = false;
+  GIQL_TRY(convert_preds(preds, n_preds, ps, uses, nodes, n_nodes, &any_expr));
   // a side given neither ids nor a row count is addressed by the candidate index
   if (!idx_a && n_rows_a == 0 && !uses[0]) n_rows_a = n;
   if (!idx_b && n_rows_b == 0 && !uses[1]) n_rows_b = n;
@@ -3074,11 +3120,13 @@ int giql_hip_select_dev(giql_hip_ctx* ctx, const giql_pred* preds, int32_t n_pre
   reset_stats(ctx);
   const u32 nb = cdiv((u64)n, SEL_TILE);
   Carver c{nullptr};
+  DevOperand* prog = nullptr;
   auto carve = [&](Carver& cv, u64*& mask, u32*& cnt, u64*& bsums, u64*& total) {
     mask = cv.take<u64>(((size_t)n + 63) / 64);
     cnt = cv.take<u32>(nb);
     bsums = cv.take<u64>(cdiv((u64)nb, SCAN_TILE) + 1);
     total = cv.take<u64>(1);
+    prog = cv.take<DevOperand>(SEL_MAX_NODES);
   };
   u64 *mask, *bsums, *total;
   u32* cnt;
@@ -3087,10 +3135,16 @@ int giql_hip_select_dev(giql_hip_ctx* ctx, const giql_pred* preds, int32_t n_pre
   c = Carver{ctx->arena};
   carve(c, mask, cnt, bsums, total);
   HIP_TRY(hipMemsetAsync(&ctx->d_meta->status, 0, sizeof(int), st));
+  if (any_expr)  // (pageable source: staged by the runtime before the call returns)
+    HIP_TRY(hipMemcpyAsync(prog, nodes, (size_t)n_nodes * sizeof(DevOperand), hipMemcpyHostToDevice, st));
   {
     Phase ph(ctx, st, GIQL_PH_COUNT);
-    hipLaunchKernelGGL(k_select_count, dim3(nb), dim3(SEL_NT), 0, st, ps, idx_a, (u32)n_rows_a, idx_b,
-                       (u32)n_rows_b, (u64)n, mask, cnt, ctx->d_meta);
+    if (any_expr)
+      hipLaunchKernelGGL((k_select_count<true>), dim3(nb), dim3(SEL_NT), 0, st, ps, (const DevOperand*)prog, idx_a,
+                         (u32)n_rows_a, idx_b, (u32)n_rows_b, (u64)n, mask, cnt, ctx->d_meta);
+    else
+      hipLaunchKernelGGL((k_select_count<false>), dim3(nb), dim3(SEL_NT), 0, st, ps, (const DevOperand*)nullptr, idx_a,
+                         (u32)n_rows_a, idx_b, (u32)n_rows_b, (u64)n, mask, cnt, ctx->d_meta);
     GIQL_TRY(post_launch("select_count"));
   }
   GIQL_TRY(run_scan<u32>(ctx, st, GIQL_PH_SCAN, cnt, (u64)nb, cnt, bsums, total));

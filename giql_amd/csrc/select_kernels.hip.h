@@ -85,22 +85,102 @@ __device__ __forceinline__ bool sel_cmp(T a, T b, int op) {
   }
 }
 
+// ---- arithmetic operands (round 3) ---------------------------------------------------------
+// An operand of side SEL_SIDE_EXPR is a postfix program over the node array `prog` (device
+// memory; DevOperand-shaped nodes): nodes of side 0 / 1 / 2 push a column value / a literal,
+// nodes of side >= SEL_X_ADD pop their arguments and push the result.  lit_i = first node,
+// type = node count.  The reference inlines such text into its join's ON clause verbatim
+// (intersects_duckdb.py:889-912, 1239-1243); the semantics are DuckDB's, its execution target:
+// integer + - * stay 64-bit integers, `/` is a floating division (NULL on a zero divisor), NULL
+// propagates through arithmetic, LEAST / GREATEST skip NULL arguments.
+constexpr int SEL_SIDE_EXPR = 3;
+constexpr int SEL_X_ADD = 16, SEL_X_SUB = 17, SEL_X_MUL = 18, SEL_X_DIV = 19, SEL_X_NEG = 20, SEL_X_ABS = 21,
+              SEL_X_LEAST = 22, SEL_X_GREATEST = 23;
+constexpr int SEL_X_STACK = 8;
+constexpr int SEL_MAX_NODES = 64;
+
+__device__ __forceinline__ double sel_as_f(const SelValue& v) { return v.is_float ? v.f : (double)v.i; }
+
+__device__ __noinline__ SelValue sel_eval_prog(const DevOperand* __restrict__ prog, int first, int count, int ia,
+                                               int ib) {
+  SelValue st[SEL_X_STACK];
+  int sp = 0;
+  for (int t = first; t < first + count; t++) {
+    const DevOperand nd = prog[t];
+    if (nd.side <= 2) {
+      st[sp++] = sel_load(nd, ia, ib);
+      continue;
+    }
+    if (nd.side == SEL_X_NEG || nd.side == SEL_X_ABS) {
+      SelValue& v = st[sp - 1];
+      if (nd.side == SEL_X_NEG) {
+        v.i = -v.i;
+        v.f = -v.f;
+      } else {
+        v.i = v.i < 0 ? -v.i : v.i;
+        v.f = fabs(v.f);
+      }
+      continue;
+    }
+    const SelValue b = st[--sp];
+    SelValue& a = st[sp - 1];
+    const bool fl = a.is_float || b.is_float;
+    if (nd.side == SEL_X_LEAST || nd.side == SEL_X_GREATEST) {
+      if (a.null) {
+        a = b;
+      } else if (!b.null) {
+        const bool least = nd.side == SEL_X_LEAST;
+        if (fl) {
+          const double x = sel_as_f(a), y = sel_as_f(b);
+          a.f = least ? (y < x ? y : x) : (y > x ? y : x);
+          a.is_float = true;
+        } else {
+          a.i = least ? (b.i < a.i ? b.i : a.i) : (b.i > a.i ? b.i : a.i);
+        }
+      }
+      continue;
+    }
+    a.null = a.null || b.null;
+    if (nd.side == SEL_X_DIV) {
+      const double y = sel_as_f(b);
+      a.f = sel_as_f(a) / (y == 0.0 ? 1.0 : y);
+      a.null = a.null || y == 0.0;
+      a.is_float = true;
+    } else if (fl) {
+      const double x = sel_as_f(a), y = sel_as_f(b);
+      a.f = nd.side == SEL_X_ADD ? x + y : (nd.side == SEL_X_SUB ? x - y : x * y);
+      a.is_float = true;
+    } else {
+      a.i = nd.side == SEL_X_ADD ? a.i + b.i : (nd.side == SEL_X_SUB ? a.i - b.i : a.i * b.i);
+    }
+  }
+  return st[0];
+}
+
+template <bool EXPR>
+__device__ __forceinline__ SelValue sel_operand(const DevOperand& o, const DevOperand* __restrict__ prog, int ia,
+                                                int ib) {
+  if (EXPR && o.side == SEL_SIDE_EXPR) return sel_eval_prog(prog, (int)o.lit_i, o.type, ia, ib);
+  return sel_load(o, ia, ib);
+}
+
 // SQL three-valued logic collapsed for a filter: a comparison with a NULL operand is
 // not true.  The predicates form a conjunction of clauses; a clause is a run of
 // predicates sharing one non-zero group id, OR-ed (a NOT has been pushed into the
 // comparisons by the caller, so "not true" and "false" need no telling apart:
 // AND / OR are monotone).
-__device__ __forceinline__ bool sel_eval(const DevPreds& ps, int ia, int ib) {
+template <bool EXPR = false>
+__device__ __forceinline__ bool sel_eval(const DevPreds& ps, int ia, int ib, const DevOperand* __restrict__ prog = nullptr) {
   bool keep = true, acc = true;
   int prev = 0;
   for (int k = 0; k < ps.n; k++) {
     const int op = ps.p[k].op;
-    const SelValue a = sel_load(ps.p[k].lhs, ia, ib);
+    const SelValue a = sel_operand<EXPR>(ps.p[k].lhs, prog, ia, ib);
     bool t;
     if (op >= 6) {
       t = (op == 6) == a.null;
     } else {
-      const SelValue b = sel_load(ps.p[k].rhs, ia, ib);
+      const SelValue b = sel_operand<EXPR>(ps.p[k].rhs, prog, ia, ib);
       if (a.is_float || b.is_float)
         t = sel_cmp<double>(a.is_float ? a.f : (double)a.i, b.is_float ? b.f : (double)b.i, op);
       else
@@ -121,7 +201,9 @@ __device__ __forceinline__ bool sel_eval(const DevPreds& ps, int ia, int ib) {
 
 // pass 1: ballot masks (one 64-bit word per 64 consecutive candidates) + block counts.
 // A row id outside its side's row count raises GIQL_ERR_INVALID and drops the pair.
-__global__ __launch_bounds__(SEL_NT) void k_select_count(DevPreds ps, const int* __restrict__ idx_a,
+template <bool EXPR>
+__global__ __launch_bounds__(SEL_NT) void k_select_count(DevPreds ps, const DevOperand* __restrict__ prog,
+                                                         const int* __restrict__ idx_a,
                                                          u32 n_rows_a,
                                                          const int* __restrict__ idx_b,
                                                          u32 n_rows_b, u64 n,
@@ -141,7 +223,7 @@ __global__ __launch_bounds__(SEL_NT) void k_select_count(DevPreds ps, const int*
       if (ia < 0 || (u32)ia >= n_rows_a || ib < 0 || (u32)ib >= n_rows_b)
         bad = true;
       else
-        keep = sel_eval(ps, ia, ib);
+        keep = sel_eval<EXPR>(ps, ia, ib, prog);
     }
     const u64 m = __ballot(keep);
     if (lane_id() == 0 && (base + (u64)j * SEL_NT + wave_id() * WAVE) < n) mask[i >> 6] = m;

@@ -464,7 +464,9 @@ class HipEngine:
             for o in (p[0], p[2]):
                 if o[0] in ("a", "b") and int(o[1].shape[0]) != s.n:
                     raise ValueError("a predicate column must have one value per row of the table")
-        c_preds, k, _keep_alive = self._c_preds(preds)
+        c_preds, k, _keep_alive, _nodes, n_nodes = self._c_preds(preds)
+        if n_nodes:
+            raise ValueError("arithmetic in a CLUSTER / MERGE predicate is not supported")
         ids = torch.empty(s.n, dtype=torch.int64, device=self.device)
         _lib.check(self._L.giql_hip_cluster_pred_dev(self._h, s.c_struct(), int(n_chrom), int(distance), c_preds, k,
                                                      ids.data_ptr() if s.n else None, self._stream()))
@@ -512,7 +514,9 @@ class HipEngine:
         outs = (c.data_ptr() if n else None, st.data_ptr() if n else None, en.data_ptr() if n else None,
                 cnt.data_ptr() if n else None, n, ctypes.byref(m), self._stream())
         if preds:
-            c_preds, k, _keep_alive = self._c_preds(preds)
+            c_preds, k, _keep_alive, _nodes, n_nodes = self._c_preds(preds)
+            if n_nodes:
+                raise ValueError("arithmetic in a CLUSTER / MERGE predicate is not supported")
             _lib.check(self._L.giql_hip_merge_pred_dev(self._h, s.c_struct(), int(n_chrom), int(distance), c_preds, k,
                                                        *outs))
         else:
@@ -583,25 +587,70 @@ class HipEngine:
         return out_off, out
 
     # ----------------------------------------------------- residual predicates
+    _XOPS = {"+": 16, "-": 17, "*": 18, "/": 19, "neg": 20, "abs": 21, "least": 22, "greatest": 23}
+
+    def _flatten_expr(self, tree, nodes, keep_alive) -> None:
+        """Append the postfix form of ``tree`` -- ``("a" | "b", column[, valid])``, ``("lit", v)`` or
+        ``(op, child, ...)`` with op one of ``+ - * / neg abs least greatest`` -- to ``nodes``."""
+        kind = tree[0]
+        if kind in ("a", "b", "lit"):
+            o, ka = self._c_operand(tree)
+            nodes.append(o)
+            keep_alive.append(ka)
+            return
+        if kind not in self._XOPS:
+            raise ValueError(f"expression operator {kind!r}")
+        args = tree[1:]
+        arity_ok = (len(args) == 1) if kind in ("neg", "abs") else (len(args) >= 1 if kind in ("least", "greatest")
+                                                                    else len(args) == 2)
+        if not arity_ok:
+            raise ValueError(f"{kind!r} with {len(args)} argument(s)")
+        self._flatten_expr(args[0], nodes, keep_alive)
+        op = _lib.COperand()
+        op.side = self._XOPS[kind]
+        if kind in ("neg", "abs"):
+            nodes.append(op)
+            return
+        for child in args[1:]:
+            self._flatten_expr(child, nodes, keep_alive)
+            nd = _lib.COperand()
+            nd.side = op.side
+            nodes.append(nd)
+
     def _c_preds(self, preds):
-        """``[(lhs, op, rhs[, group])]`` -> (``giql_pred`` array, its length, the tensors to keep alive).
-        Predicates are AND-ed; adjacent ones sharing a non-zero ``group`` are OR-ed (one CNF clause)."""
+        """``[(lhs, op, rhs[, group])]`` -> (``giql_pred`` array, its length, the tensors to keep alive, the
+        expression nodes as a ``giql_operand`` array, their number).  Predicates are AND-ed; adjacent ones
+        sharing a non-zero ``group`` are OR-ed (one CNF clause).  An operand ``("expr", tree)`` is arithmetic
+        over columns and literals (``giql_hip_select_expr_dev``)."""
         k = len(preds)
         if k > 16:
             raise ValueError("at most 16 predicates per call")
         c_preds = (_lib.CPred * max(k, 1))()
-        keep_alive = []
+        keep_alive, nodes = [], []
+
+        def operand(spec):
+            if spec[0] != "expr":
+                return self._c_operand(spec)
+            first = len(nodes)
+            self._flatten_expr(spec[1], nodes, keep_alive)
+            o = _lib.COperand()
+            o.side, o.lit_i, o.type = _lib.SIDE_EXPR, first, len(nodes) - first
+            return o, ()
+
         for j, p in enumerate(preds):
             lhs, op, rhs = p[0], p[1], p[2]
             if op not in _lib.OPS:
                 raise ValueError(f"operator {op!r}")
-            c_preds[j].lhs, ka = self._c_operand(lhs)
+            c_preds[j].lhs, ka = operand(lhs)
             keep_alive.append(ka)
-            c_preds[j].rhs, ka = self._c_operand(rhs if op not in ("isnull", "notnull") else ("lit", 0))
+            c_preds[j].rhs, ka = operand(rhs if op not in ("isnull", "notnull") else ("lit", 0))
             keep_alive.append(ka)
             c_preds[j].op = _lib.OPS[op]
             c_preds[j].group = int(p[3]) if len(p) > 3 else 0
-        return c_preds, k, keep_alive
+        if len(nodes) > 64:
+            raise ValueError("at most 64 expression nodes per call")
+        c_nodes = (_lib.COperand * max(len(nodes), 1))(*nodes)
+        return c_preds, k, keep_alive, c_nodes, len(nodes)
 
     def _c_operand(self, spec):
         """``("a" | "b", tensor[, valid_u8_tensor])`` or ``("lit", int | float)`` -> COperand."""
@@ -651,15 +700,15 @@ class HipEngine:
         torch = _torch()
         if n is None:
             n = int((idx_a if idx_a is not None else idx_b).shape[0])
-        c_preds, k, _keep_alive = self._c_preds(preds)
+        c_preds, k, _keep_alive, c_nodes, n_nodes = self._c_preds(preds)
         for t in (idx_a, idx_b):
             if t is not None and (t.dtype != torch.int32 or not t.is_contiguous() or int(t.shape[0]) != n):
                 raise ValueError("id arrays must be contiguous int32 tensors of n rows")
         out_a = torch.empty(n, dtype=torch.int32, device=self.device) if "a" in want else None
         out_b = torch.empty(n, dtype=torch.int32, device=self.device) if "b" in want else None
         kept = ctypes.c_int64(0)
-        _lib.check(self._L.giql_hip_select_dev(
-            self._h, c_preds, k,
+        _lib.check(self._L.giql_hip_select_expr_dev(
+            self._h, c_preds, k, c_nodes if n_nodes else None, n_nodes,
             idx_a.data_ptr() if idx_a is not None and n else None, int(n_rows_a),
             idx_b.data_ptr() if idx_b is not None and n else None, int(n_rows_b), int(n),
             out_a.data_ptr() if out_a is not None and n else None,

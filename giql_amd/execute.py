@@ -17,6 +17,7 @@ import numpy as np
 
 from .engine import ENCODING_OFFSETS, DeviceSide, HipEngine
 from .plan import JoinPlan, PlanSide, Projection, is_plan_string
+from .shape import operand_sides
 from .transpile import build_plan
 
 _ENGINES: dict[int, HipEngine] = {}
@@ -151,7 +152,7 @@ class _Residuals:
     @staticmethod
     def sides(clause) -> set:
         """The tables a clause (a list of OR-ed residuals) reads."""
-        return {o.kind for res in clause for o in (res.lhs, res.rhs) if o.kind in ("l", "r")}
+        return set().union(*[operand_sides(o) for res in clause for o in (res.lhs, res.rhs)])
 
     @staticmethod
     def clauses(residuals) -> list:
@@ -234,6 +235,8 @@ class _Residuals:
             col = self._arrow(res.lhs.kind, res.lhs.value)
             data = torch.zeros(len(col), dtype=torch.uint8, device=self.eng.device)
             return (eside[res.lhs.kind], data, self._valid(col)), res.op, ("lit", 0), res.group
+        if any(o.kind == "expr" for o in ops) and not any(self._is_string(o) for o in ops):
+            return self._spec(ops[0]), res.op, self._spec(ops[1]), res.group
         if any(self._is_string(o) for o in ops):
             if not all(self._is_string(o) for o in ops):
                 raise ValueError(f"cannot compare a string with a number in {res.lhs.value!r} {res.op} {res.rhs.value!r}")
@@ -257,17 +260,28 @@ class _Residuals:
                     specs.append((eside[o.kind], torch.from_numpy(np.ascontiguousarray(codes)).to(self.eng.device),
                                   self._valid(col)))
             return specs[0], res.op, specs[1], res.group
-        specs = []
-        for o in ops:
-            if o.kind in ("int", "float"):
-                specs.append(("lit", o.value))
-            else:
-                nv = self._numeric(o.kind, o.value)
-                if nv is None:
-                    raise ValueError(f"column {o.value!r}: type {self._arrow(o.kind, o.value).type} is not supported "
-                                     "in a dialect='hip' predicate")
-                specs.append((eside[o.kind], nv[0], nv[1]))
-        return specs[0], res.op, specs[1], res.group
+        return self._spec(ops[0]), res.op, self._spec(ops[1]), res.group
+
+    def _spec(self, o):
+        """A numeric operand as :meth:`HipEngine.select` takes it: a column, a literal, or ``("expr", tree)`` for
+        arithmetic (``giql_hip_select_expr_dev``)."""
+        eside = {"l": "a", "r": "b"}
+
+        def leaf(kind, value):
+            if kind in ("int", "float"):
+                return ("lit", value)
+            nv = self._numeric(kind, value)
+            if nv is None:
+                raise ValueError(f"column {value!r}: type {self._arrow(kind, value).type} is not supported "
+                                 "in a dialect='hip' predicate" + (" expression" if o.kind == "expr" else ""))
+            return (eside[kind], nv[0], nv[1])
+
+        def tree(t):
+            if t[0] == "fn":
+                return (t[1], *[tree(c) for c in t[2]])
+            return leaf(t[0], t[1])
+
+        return ("expr", tree(o.value)) if o.kind == "expr" else leaf(o.kind, o.value)
 
     def preds(self, clauses):
         """The predicates of a list of clauses (or of plain residuals), in order."""

@@ -166,15 +166,37 @@ def _literal(n):
     return ("lit", float(text) if "." in text else int(text))
 
 
+_ARITH = {"add": "+", "sub": "-", "mul": "*", "div": "/"}
+
+
 def _operand(n):
+    """A comparison operand: a literal, a column, or arithmetic over them (``+ - * /``, unary minus, parentheses,
+    LEAST / GREATEST / ABS: the overlap-fraction recipes, docs/recipes/intersect.rst:144-190) -> ``("lit", v)`` |
+    ``("col", ColRef)`` | ``("fn", op, [operands])``."""
     lit = _literal(n)
     if lit is not None:
         return lit
-    if _key(n) == "column":
+    k = _key(n)
+    if k == "column":
         return ("col", _colref(n))
-    if _key(n) == "boolean":
+    if k == "boolean":
         raise decline("boolean literal in a join condition")
-    raise decline(f"join condition operand of kind {_key(n)!r}")
+    if k in _ARITH:
+        _only(n, ("this", "expression"), "arithmetic")     # (Div carries typed / safe flags when a dialect sets them)
+        return ("fn", _ARITH[k], [_operand(_arg(n, "this")), _operand(_arg(n, "expression"))])
+    if k == "neg":
+        _only(n, ("this",), "unary minus")
+        return ("fn", "neg", [_operand(_arg(n, "this"))])
+    if k == "paren":
+        _only(n, ("this",), "parentheses")
+        return _operand(_arg(n, "this"))
+    if k in ("least", "greatest"):
+        _only(n, ("this", "expressions"), k.upper())
+        return ("fn", k, [_operand(_arg(n, "this"))] + [_operand(e) for e in (_arg(n, "expressions") or [])])
+    if k == "abs":
+        _only(n, ("this",), "ABS")
+        return ("fn", "abs", [_operand(_arg(n, "this"))])
+    raise decline(f"join condition operand of kind {k!r}")
 
 
 def _cond_tree(n, operand=None):

@@ -230,6 +230,39 @@ def resolve_projection(items, left: PlanSide, right: PlanSide, left_only: bool,
     return tuple(out)
 
 
+def bind_expression(o, bind_leaf) -> Operand:
+    """An operand term -- ``("lit", v)`` / a column term / ``("fn", op, [terms])`` -- as a plan operand; columns and
+    literals through ``bind_leaf``.  Arithmetic becomes ``Operand("expr", ["fn", op, [children]])`` whose leaves
+    are ``[kind, value]`` pairs (lists throughout: the plan's JSON form gives lists back)."""
+    if o[0] != "fn":
+        return bind_leaf(o)
+
+    def tree(t):
+        if t[0] == "fn":
+            return ["fn", t[1], [tree(c) for c in t[2]]]
+        leaf = bind_leaf(t)
+        if leaf.kind == "str":
+            raise ValueError(f"a string ({leaf.value!r}) cannot take part in arithmetic")
+        return [leaf.kind, leaf.value]
+
+    return Operand("expr", tree(o))
+
+
+def operand_sides(o: Operand) -> set:
+    """The tables ("l" / "r") an operand reads."""
+    if o.kind in ("l", "r"):
+        return {o.kind}
+    if o.kind != "expr":
+        return set()
+
+    def walk(t):
+        if t[0] == "fn":
+            return set().union(*[walk(c) for c in t[2]]) if t[2] else set()
+        return {t[0]} if t[0] in ("l", "r") else set()
+
+    return walk(o.value)
+
+
 def resolve_residuals(clause_terms, left: PlanSide, right: PlanSide, kind: str) -> tuple:
     """``[(clause, term)]`` -> residuals.  A term is a comparison ``("cmp", lhs, op, rhs)`` or
     a disjunction ``("or", [cmp, ...])``; the members of one disjunction share a fresh group id."""
@@ -270,8 +303,8 @@ def resolve_residual(clause: str, term, left: PlanSide, right: PlanSide, kind: s
         raise ValueError(f"dialect='hip' cannot inline the extra predicate: unknown table qualifier "
                          f"{ref.table!r}; expected {left.alias!r} or {right.alias!r}")
 
-    a, b = bind(lhs), bind(rhs)
-    if a.kind not in ("l", "r") and b.kind not in ("l", "r"):
+    a, b = bind_expression(lhs, bind), bind_expression(rhs, bind)
+    if not operand_sides(a) and not operand_sides(b):
         raise decline("constant predicate in the join condition")
     return Residual(clause, a, op, b, group)
 
@@ -406,6 +439,8 @@ def _resolve_having(shape: JoinShape, proj, aggs, left: PlanSide, right: PlanSid
                 raise ValueError(f"HAVING {ref.table}.{ref.column}: the column must appear in GROUP BY "
                                  "or inside an aggregate")
             return Operand("name", name)
+        if o[0] == "fn":
+            raise decline("arithmetic in HAVING")
         it: SelItem = o[1]
         if it.func not in AGG_FUNCS:
             raise decline(f"aggregate {it.func}")

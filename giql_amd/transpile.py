@@ -36,7 +36,9 @@ from dataclasses import dataclass
 
 from .plan import JoinPlan, Operand, PlanSide, Projection, Residual
 from .shape import AGG_FUNCS, ColRef as _ColRef, HipDeclined, JoinShape, OrderKey, SelItem, TableRef as _TableRef
+from .shape import bind_expression as _bind_expression
 from .shape import condition_terms as _condition_terms
+from .shape import operand_sides as _operand_sides
 from .shape import decline as _decline
 from .shape import genomic_col as _genomic_col
 from .shape import lower_join_shape, resolve_projection
@@ -53,7 +55,7 @@ _TOKEN = re.compile(
       | (?P<num>\d+(?:\.\d+)?)
       | (?P<assign>:=)
       | (?P<id>[A-Za-z_][A-Za-z_0-9]*)
-      | (?P<punct>[(),.*;=<>+\-/!])
+      | (?P<punct>[(),.*;=<>+\-/!%|&^~\[\]:])
     )""",
     re.X,
 )
@@ -180,8 +182,12 @@ _CLAUSE_END = ("WHERE", "GROUP", "ORDER", "HAVING", "LIMIT", "OFFSET", "UNION", 
                "RIGHT", "FULL", "CROSS", "SEMI", "ANTI", "NATURAL")
 
 
-def _parse_operand(p: _Parser):
-    """A residual operand: [-]number, 'string' or a column reference."""
+_ARITH_FUNCS = {"LEAST": "least", "GREATEST": "greatest", "ABS": "abs"}
+
+
+def _parse_atom(p: _Parser, expr=None):
+    """A residual operand without arithmetic: [-]number, 'string', a column reference, or -- when ``expr`` (the
+    parser of a full expression) is given -- ``LEAST / GREATEST / ABS ( ... )``."""
     neg = False
     if p.at_punct("-") and p.peek(1).kind == "num":
         p.next()
@@ -198,10 +204,46 @@ def _parse_operand(p: _Parser):
         raise _decline("boolean literal in a join condition")
     if t.kind != "id":
         raise _decline(f"join condition operand near {t.text!r}")
+    if expr is not None and not t.quoted and t.text.upper() in _ARITH_FUNCS and p.peek(1).kind == "punct" \
+            and p.peek(1).text == "(":
+        name = _ARITH_FUNCS[p.next().text.upper()]
+        p.expect_punct("(")
+        args = [expr(p)]
+        while p.at_punct(","):
+            p.next()
+            args.append(expr(p))
+        p.expect_punct(")")
+        if name == "abs" and len(args) != 1:
+            raise ValueError("Parse error: ABS takes one argument")
+        return ("fn", name, args)
     ref = p.colref()
     if p.at_punct("("):
         raise _decline("function call in a join condition")
     return ("col", ref)
+
+
+def _parse_operand(p: _Parser, level: int = 0):
+    """An arithmetic expression over columns and literals: ``+ -`` < ``* /`` < unary minus < ``( ... )``, LEAST /
+    GREATEST / ABS -- what the overlap-fraction recipes put beside the INTERSECTS (docs/recipes/intersect.rst:144-190;
+    the reference inlines the text, intersects_duckdb.py:889-912).  ``("lit", v)`` | ``("col", ref)`` | ``("fn", op, args)``."""
+    if level < 2:
+        ops = "+-" if level == 0 else "*/"
+        lhs = _parse_operand(p, level + 1)
+        while p.peek().kind == "punct" and p.peek().text in ops:
+            op = p.next().text
+            lhs = ("fn", op, [lhs, _parse_operand(p, level + 1)])
+        return lhs
+    if p.at_punct("-") and p.peek(1).kind != "num":
+        p.next()
+        return ("fn", "neg", [_parse_operand(p, 2)])
+    if p.at_punct("("):
+        if p.peek(1).kind == "kw" and p.peek(1).text in ("SELECT", "WITH"):
+            raise _decline("sub-query in a condition")
+        p.next()
+        v = _parse_operand(p, 0)
+        p.expect_punct(")")
+        return v
+    return _parse_atom(p, _parse_operand)
 
 
 def _parse_comparison_op(p: _Parser):
@@ -221,7 +263,7 @@ def _parse_comparison_op(p: _Parser):
 
 
 def _no_arithmetic(p: _Parser) -> None:
-    if p.peek().kind == "punct" and p.peek().text in "+-*/":
+    if p.peek().kind == "punct" and p.peek().text in "+-*/%|&^":
         raise _decline("arithmetic in a join condition")
 
 
@@ -317,12 +359,20 @@ def _parse_bool(p: _Parser, allow_literal: bool, level: int = 0, operand=None):
     if p.at_punct("("):
         if p.peek(1).kind == "kw" and p.peek(1).text in ("SELECT", "WITH"):
             raise _decline("sub-query in a condition")
-        p.next()
-        node = _parse_bool(p, allow_literal, 0, operand)
-        p.expect_punct(")")
-        if p.peek().kind == "punct" and p.peek().text in "+-*/=<>!":
-            raise _decline("parenthesised expression as a comparison operand")
-        return node
+        # a boolean group, or the opening parenthesis of an arithmetic operand ("(a.end - a.start) > 5"): try the
+        # group first; what follows its ")" tells
+        save = p.i
+        try:
+            p.next()
+            node = _parse_bool(p, allow_literal, 0, operand)
+            p.expect_punct(")")
+            t = p.peek()
+            if not ((t.kind == "punct" and t.text in "+-*/=<>!") or (t.kind == "kw" and t.text in ("BETWEEN", "IN", "IS", "LIKE"))
+                    or (t.kind == "kw" and t.text == "NOT" and p.peek(1).kind == "kw" and p.peek(1).text in ("BETWEEN", "IN", "LIKE"))):
+                return node
+        except ValueError:
+            pass
+        p.i = save
     return _parse_predicate(p, allow_literal, operand)
 
 
@@ -352,8 +402,8 @@ def _own_table_residuals(terms, own) -> list:
             group += 1
             leaves, g = t[1], group
         for _, lhs, op, rhs in leaves:
-            a, b = bind(lhs), bind(rhs)
-            if a.kind != "l" and b.kind != "l":
+            a, b = _bind_expression(lhs, bind), _bind_expression(rhs, bind)
+            if not _operand_sides(a) and not _operand_sides(b):
                 raise _decline("constant predicate")
             out.append(Residual("where", a, op, b, g))
     return out
@@ -405,7 +455,7 @@ def _parse_having(p: _Parser):
         if t.kind == "id" and not t.quoted and p.peek(1).kind == "punct" and p.peek(1).text == "(":
             func, distinct, ref = _parse_aggregate_call(p, "HAVING")
             return ("agg", SelItem(ref, None, func, distinct))
-        return _parse_operand(p)
+        return _parse_atom(p)
 
     terms = _condition_terms(_parse_bool(p, False, 0, operand))
     if any(t[0] not in ("cmp", "or") for t in terms):
@@ -667,7 +717,7 @@ def _parse_prev_operand(p: _Parser):
             raise _decline("PREV() of an expression")
         p.expect_punct(")")
         return ("prev", ref)
-    return _parse_operand(p)
+    return _parse_atom(p)
 
 
 def _parse_cluster_predicate(p: _Parser):

@@ -298,7 +298,11 @@ int giql_hip_take_utf8_fill_dev(giql_hip_ctx* ctx, const int32_t* offsets,
 enum { GIQL_OP_EQ = 0, GIQL_OP_NE = 1, GIQL_OP_LT = 2, GIQL_OP_LE = 3, GIQL_OP_GT = 4, GIQL_OP_GE = 5,
        GIQL_OP_IS_NULL = 6, GIQL_OP_NOT_NULL = 7 /* unary: lhs only, rhs ignored */ };
 enum { GIQL_T_I32 = 0, GIQL_T_I64 = 1, GIQL_T_F32 = 2, GIQL_T_F64 = 3, GIQL_T_U8 = 4 };
-enum { GIQL_SIDE_A = 0, GIQL_SIDE_B = 1, GIQL_SIDE_LIT = 2 };
+enum { GIQL_SIDE_A = 0, GIQL_SIDE_B = 1, GIQL_SIDE_LIT = 2,
+       GIQL_SIDE_EXPR = 3 /* an arithmetic expression: giql_hip_select_expr_dev */ };
+/* node kinds of an expression program (giql_operand.side of a node): 0 / 1 / 2 push a column value / a literal */
+enum { GIQL_X_ADD = 16, GIQL_X_SUB = 17, GIQL_X_MUL = 18, GIQL_X_DIV = 19, GIQL_X_NEG = 20, GIQL_X_ABS = 21,
+       GIQL_X_LEAST = 22, GIQL_X_GREATEST = 23 };
 
 typedef struct giql_operand {
   int32_t side;          /* GIQL_SIDE_*                                          */
@@ -338,6 +342,21 @@ int giql_hip_select_dev(giql_hip_ctx* ctx, const giql_pred* preds, int32_t n_pre
                         const int32_t* idx_b, int64_t n_rows_b, int64_t n,
                         int32_t* out_a, int32_t* out_b, int64_t* n_kept,
                         void* stream);
+/* The same with ARITHMETIC operands -- the overlap-fraction recipes of docs/recipes/intersect.rst:144-190
+ * ("(LEAST(a.end, b.end) - GREATEST(a.start, b.start)) >= 0.5 * (a.end - a.start)"), which the reference
+ * inlines into its join's ON clause as text (intersects_duckdb.py:889-912, 1239-1243).  An operand of side
+ * GIQL_SIDE_EXPR is a postfix program over `nodes` (a HOST array of n_nodes <= 64 giql_operand-shaped
+ * nodes): lit_i = its first node, type = its node count.  A node of side A / B / LIT pushes that value, a node
+ * of side GIQL_X_* pops its one (NEG, ABS) or two arguments and pushes the result; at most 8 values are
+ * live.  Semantics are those of the reference's execution target (DuckDB): integer + - * stay 64-bit
+ * integers, `/` is a floating division and NULL on a zero divisor, NULL propagates through arithmetic,
+ * LEAST / GREATEST skip NULL arguments. */
+int giql_hip_select_expr_dev(giql_hip_ctx* ctx, const giql_pred* preds, int32_t n_preds,
+                             const giql_operand* nodes, int32_t n_nodes,
+                             const int32_t* idx_a, int64_t n_rows_a,
+                             const int32_t* idx_b, int64_t n_rows_b, int64_t n,
+                             int32_t* out_a, int32_t* out_b, int64_t* n_kept,
+                             void* stream);
 /* flags[idx[i]] = 1 for i < n (flags: device, n_rows bytes, caller-initialised):
  * the left rows that keep at least one pair, for SEMI / ANTI with two-sided
  * residuals (src/giql/expanders/intersects_duckdb.py:1254-1282). */

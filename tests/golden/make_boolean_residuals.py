@@ -51,6 +51,24 @@ HAVING = [
 ]
 
 
+# arithmetic operands (the overlap-fraction recipes, docs/recipes/intersect.rst:144-190, and kin).  LEAST / GREATEST /
+# ABS are spelt min / max / abs for sqlite; their arguments are never NULL here (sqlite's min(x, NULL) is NULL where
+# the reference's DuckDB skips the NULL), `/` always has a floating operand (DuckDB's `/` is a floating division)
+ARITH = [
+    ("INNER", "", "(LEAST(a.end, b.end) - GREATEST(a.start, b.start)) >= 0.5 * (a.end - a.start)"),
+    ("INNER", "(LEAST(a.end, b.end) - GREATEST(a.start, b.start)) >= 0.5 * (b.end - b.start)", ""),
+    ("INNER", "", "(LEAST(a.end, b.end) - GREATEST(a.start, b.start)) >= 0.5 * (a.end - a.start) "
+                  "AND (LEAST(a.end, b.end) - GREATEST(a.start, b.start)) >= 0.5 * (b.end - b.start)"),
+    ("INNER", "ABS(a.score - b.score) <= 1", ""),
+    ("INNER", "", "a.score + b.score > 5 OR a.score * 2 < b.score"),
+    ("INNER", "-a.score < -2 AND (a.end - a.start) / 2.0 > b.end - b.start", ""),
+    ("INNER", "", "GREATEST(a.start, b.start, 700) - LEAST(a.end, b.end, 900) > -150"),
+    ("INNER", "(a.end - a.start) / (a.score - 2.0) > 50", ""),
+    ("SEMI", "(LEAST(a.end, b.end) - GREATEST(a.start, b.start)) * 2 >= a.end - a.start", "a.end - a.start BETWEEN 20 AND 250"),
+    ("ANTI", "ABS(a.start - b.start) < 60", "NOT a.score * a.score > 9"),
+]
+
+
 def giql_query(kind: str, on: str, where: str) -> str:
     join = {"INNER": "JOIN", "SEMI": "SEMI JOIN", "ANTI": "ANTI JOIN"}[kind]
     cols = "a.name AS an, a.start AS s, b.name AS bn, b.end AS e" if kind == "INNER" else "a.name, a.start, a.score"
@@ -63,7 +81,8 @@ def giql_query(kind: str, on: str, where: str) -> str:
 
 
 def sqlite_rows(conn, kind: str, on: str, where: str):
-    quote = lambda t: t.replace("a.start", 'a."start"').replace("b.start", 'b."start"').replace("b.end", 'b."end"')
+    quote = lambda t: (t.replace("a.start", 'a."start"').replace("b.start", 'b."start"').replace("b.end", 'b."end"')
+                       .replace("a.end", 'a."end"').replace("LEAST(", "min(").replace("GREATEST(", "max(").replace("ABS(", "abs("))
     cond = OVERLAP + (f" AND ({quote(on)})" if on else "")
     if kind == "INNER":
         sql = f'SELECT a.name, a."start", b.name, b."end" FROM peaks a JOIN genes b ON {cond}'
@@ -121,14 +140,28 @@ def main() -> None:
                            "peaks": [list(r) for r in peaks], "genes": [list(r) for r in genes],
                            "rows": [list(r) for r in sorted(got, key=key)]})
     assert sum(1 for c in having if c["rows"]) >= len(having) // 2
+    arith = []
+    for kind, on, where in ARITH:
+        for n_p, n_g in [(6, 5), (60, 45)]:
+            peaks, genes = rand_rows(rng, n_p, "p"), rand_rows(rng, n_g, "g")
+            conn = sqlite3.connect(":memory:")
+            for t, rows in (("peaks", peaks), ("genes", genes)):
+                conn.execute(f'CREATE TABLE {t} (chrom TEXT, "start" INTEGER, "end" INTEGER, name TEXT, score INTEGER, strand TEXT)')
+                conn.executemany(f"INSERT INTO {t} VALUES (?, ?, ?, ?, ?, ?)", rows)
+            got = sqlite_rows(conn, kind, on, where)
+            conn.close()
+            key = lambda r: tuple((x is None, x) for x in r)
+            arith.append({"kind": kind, "query": giql_query(kind, on, where), "peaks": [list(r) for r in peaks],
+                          "genes": [list(r) for r in genes], "rows": [list(r) for r in sorted(got, key=key)]})
+    assert sum(1 for c in arith if c["rows"]) >= len(arith) * 2 // 3
     doc = {"_source": "tests/golden/make_boolean_residuals.py: sqlite3 evaluates the overlap join AND the condition "
                       "text the reference would inline (intersects_duckdb.py:889-912, 1239-1243); rows sorted with NULLs last "
                       "per column; table rows are (chrom, start, end, name, score, strand)",
-           "cases": cases, "having": having}
+           "cases": cases, "having": having, "arith": arith}
     with open(os.path.join(HERE, "boolean_residuals.json"), "w") as f:
         json.dump(doc, f, separators=(",", ":"))
     print(len(cases), "cases,", sum(len(c["rows"]) for c in cases), "rows;", len(having), "HAVING cases,",
-          sum(len(c["rows"]) for c in having), "rows")
+          sum(len(c["rows"]) for c in having), "rows;", len(arith), "arithmetic cases,", sum(len(c["rows"]) for c in arith), "rows")
 
 
 if __name__ == "__main__":

@@ -12,9 +12,10 @@ import pytest
 
 from giql_amd.transpile import build_plan, transpile
 
-GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "boolean_residuals.json")))["cases"]
+_DOC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "boolean_residuals.json")))
+GOLDEN = _DOC["cases"] + _DOC["arith"]    # boolean combinations; arithmetic operands (the overlap-fraction recipes)
 COLS = ["chrom", "start", "end", "name", "score", "strand"]
-IDS = [f"{i}:{c['kind']}" for i, c in enumerate(GOLDEN)]
+IDS = [f"{i}:{c['kind']}" for i, c in enumerate(_DOC["cases"])] + [f"arith{i}:{c['kind']}" for i, c in enumerate(_DOC["arith"])]
 
 
 def _key(r):
@@ -24,7 +25,30 @@ def _key(r):
 def _value(o, p, g):
     if o.kind in ("l", "r"):
         return (p if o.kind == "l" else g)[COLS.index(o.value)]
+    if o.kind == "expr":
+        return _arith(o.value, p, g)
     return o.value
+
+
+def _arith(t, p, g):
+    """An expression tree of the plan in plain Python, with the reference's execution target's semantics: NULL
+    propagates, `/` is a floating division and NULL on a zero divisor, LEAST / GREATEST skip NULLs."""
+    if t[0] != "fn":
+        return (p if t[0] == "l" else g)[COLS.index(t[1])] if t[0] in ("l", "r") else t[1]
+    args = [_arith(c, p, g) for c in t[2]]
+    if t[1] in ("least", "greatest"):
+        vals = [a for a in args if a is not None]
+        return None if not vals else (min(vals) if t[1] == "least" else max(vals))
+    if any(a is None for a in args):
+        return None
+    if t[1] == "neg":
+        return -args[0]
+    if t[1] == "abs":
+        return abs(args[0])
+    a, b = args
+    if t[1] == "/":
+        return None if b == 0 else a / b
+    return {"+": a + b, "-": a - b, "*": a * b}[t[1]]
 
 
 def _leaf(res, p, g) -> bool:
@@ -85,7 +109,7 @@ def test_execute_gives_sqlites_rows(case):
     assert got == case["rows"]
 
 
-HAVING = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "boolean_residuals.json")))["having"]
+HAVING = _DOC["having"]
 
 
 @pytest.mark.gpu
@@ -105,3 +129,44 @@ def test_boolean_having_gives_sqlites_groups(case):
     out = execute(transpile(case["query"], tables=["peaks", "genes"], dialect="hip"), t)
     got = sorted(([*d.values()] for d in out.to_pylist()), key=_key)
     assert got == case["rows"]
+
+
+RECIPES = [
+    # docs/recipes/intersect.rst:120-190 of the reference, as written there (comma join, conditions in WHERE)
+    ("same strand", "AND a.strand = b.strand", lambda p, g: p[5] == g[5]),
+    ("opposite strands", "AND a.strand != b.strand AND a.strand IN ('+', '-') AND b.strand IN ('+', '-')",
+     lambda p, g: p[5] != g[5] and p[5] in "+-" and g[5] in "+-"),
+    ("half of A covered", "AND ( LEAST(a.end, b.end) - GREATEST(a.start, b.start) ) >= 0.5 * (a.end - a.start)",
+     lambda p, g: min(p[2], g[2]) - max(p[1], g[1]) >= 0.5 * (p[2] - p[1])),
+    ("half of B covered", "AND ( LEAST(a.end, b.end) - GREATEST(a.start, b.start) ) >= 0.5 * (b.end - b.start)",
+     lambda p, g: min(p[2], g[2]) - max(p[1], g[1]) >= 0.5 * (g[2] - g[1])),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,extra,pred", RECIPES, ids=[r[0] for r in RECIPES])
+def test_the_documented_recipes_run_on_the_gpu_path(name, extra, pred):
+    import numpy as np
+    import pyarrow as pa
+
+    from giql_amd.execute import execute
+
+    rng = np.random.default_rng(9)
+
+    def rows(n, tag):
+        out = []
+        for i in range(n):
+            s = int(rng.integers(0, 4000))
+            out.append(("chr%d" % rng.integers(1, 3), s, s + int(rng.integers(1, 500)), f"{tag}{i}", int(rng.integers(0, 9)),
+                        str(rng.choice(["+", "-", "."]))))
+        return out
+
+    peaks, genes = rows(400, "p"), rows(350, "g")
+    types = [pa.string(), pa.int32(), pa.int32(), pa.string(), pa.int32(), pa.string()]
+    t = {n: pa.table({c: pa.array(list(v), ty) for c, v, ty in zip(COLS, zip(*r), types)})
+         for n, r in (("features_a", peaks), ("features_b", genes))}
+    q = f"SELECT a.name, b.name AS b_name FROM features_a a, features_b b WHERE a.interval INTERSECTS b.interval {extra}"
+    out = execute(transpile(q, tables=["features_a", "features_b"], dialect="hip"), t)
+    got = sorted(zip(out.column("name").to_pylist(), out.column("b_name").to_pylist()))
+    want = sorted((p[3], g[3]) for p in peaks for g in genes if _overlap(p, g) and pred(p, g))
+    assert got == want and len(want) > 20

@@ -817,6 +817,55 @@ def test_select_or_groups_and_null_tests_match_numpy(eng, seed):
         eng.select(preds + preds[:1], idx_a=d(ia), idx_b=d(ib), n_rows_a=na, n_rows_b=nb)
 
 
+def test_select_arithmetic_operands_match_numpy(eng):
+    # giql_hip_select_expr_dev: postfix programs over columns and literals; integers stay 64-bit, `/` is a floating
+    # division (NULL on a zero divisor), NULL propagates, LEAST / GREATEST skip NULLs
+    rng = np.random.default_rng(77)
+    n, na, nb = 50_000, 3000, 2500
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    a_s = rng.integers(0, 100_000, na).astype(np.int32)
+    a_e = (a_s + rng.integers(1, 500, na)).astype(np.int32)
+    b_s = rng.integers(0, 100_000, nb).astype(np.int32)
+    b_e = (b_s + rng.integers(1, 500, nb)).astype(np.int32)
+    a_sc = rng.integers(-3, 4, na).astype(np.int64)
+    b_f = rng.standard_normal(nb)
+    va, vb = rng.random(na) > 0.2, rng.random(nb) > 0.2
+    ia, ib = rng.integers(0, na, n).astype(np.int32), rng.integers(0, nb, n).astype(np.int32)
+    A_s, A_e, B_s, B_e = (("a", d(a_s)), ("a", d(a_e)), ("b", d(b_s)), ("b", d(b_e)))
+    A_sc, B_f = ("a", d(a_sc), d(va.astype(np.uint8))), ("b", d(b_f), d(vb.astype(np.uint8)))
+    s_a, e_a, s_b, e_b = (x.astype(np.int64) for x in (a_s[ia], a_e[ia], b_s[ib], b_e[ib]))
+    ov = np.minimum(e_a, e_b) - np.maximum(s_a, s_b)
+    sc, f, ok_a, ok_b = a_sc[ia], b_f[ib], va[ia], vb[ib]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        cases = [
+            # the overlap-fraction recipe on raw columns
+            ([(("expr", ("-", ("least", A_e, B_e), ("greatest", A_s, B_s))), ">=",
+               ("expr", ("*", ("lit", 0.5), ("-", A_e, A_s))))], ov >= 0.5 * (e_a - s_a)),
+            # integer arithmetic, NULL propagation, a comparison with a plain column on the other side
+            ([(("expr", ("+", ("*", A_sc, ("lit", 3)), ("neg", A_sc))), "<", B_f)], (sc * 3 - sc < f) & ok_a & ok_b),
+            # division: floating, NULL on a zero divisor
+            ([(("expr", ("/", ("-", A_e, A_s), A_sc)), ">", ("lit", 40))],
+             (np.where(sc != 0, (e_a - s_a) / np.where(sc == 0, 1, sc), 0) > 40) & ok_a & (sc != 0)),
+            # LEAST / GREATEST skip a NULL argument; ABS; three arguments
+            ([(("expr", ("abs", ("-", ("greatest", A_sc, ("lit", 1), ("lit", -7)), ("least", B_f, ("lit", 0.25))))), "<=",
+               ("lit", 1.5))],
+             np.abs(np.where(ok_a, np.maximum(sc, 1), 1) - np.where(ok_b, np.minimum(f, 0.25), 0.25)) <= 1.5),
+            # two expression predicates in one OR group beside a plain conjunct
+            ([(("expr", ("-", A_e, A_s)), ">", ("lit", 400), 1), (("expr", ("*", B_f, B_f)), ">", ("lit", 2.0), 1),
+              (A_sc, ">=", ("lit", 0))],
+             (((e_a - s_a) > 400) | ((f * f > 2.0) & ok_b)) & (sc >= 0) & ok_a),
+        ]
+    for preds, want in cases:
+        ga, gb = eng.select(preds, idx_a=d(ia), idx_b=d(ib), n_rows_a=na, n_rows_b=nb)
+        assert np.array_equal(ga.cpu().numpy(), ia[want]) and np.array_equal(gb.cpu().numpy(), ib[want])
+    from giql_amd._lib import GiqlHipError
+    deep = ("lit", 1)
+    for _ in range(9):
+        deep = ("+", ("lit", 1), deep)                      # right-nested: nine values live at once
+    with pytest.raises(GiqlHipError):
+        eng.select([(("expr", deep), ">", ("lit", 0))], n=10, n_rows_a=10, want=("a",))
+
+
 def test_select_rejects_bad_ids_and_mark_flags(eng):
     from giql_amd._lib import GiqlHipError
 

@@ -182,6 +182,27 @@ def test_boolean_extras_lower_to_the_same_plan_as_the_mirror():
                                                        ("!=", 0), ("!=", 0), ("=", 3), ("=", 3), ("notnull", 0)]
 
 
+def test_arithmetic_extras_lower_to_the_same_plan_as_the_mirror():
+    # the overlap-fraction recipe (docs/recipes/intersect.rst:144-160): GTE(Paren(Sub(Least, Greatest)), Mul(0.5, Paren(Sub)))
+    a_s, a_e, b_s, b_e = A.col("a", "start"), A.col("a", "end"), A.col("b", "start"), A.col("b", "end")
+    ov = A.N("paren", this=A.N("sub", this=A.N("least", this=a_e, expressions=[b_e]),
+                               expression=A.N("greatest", this=a_s, expressions=[b_s])))
+    frac = A.N("mul", this=A.lit(0.5), expression=A.N("paren", this=A.N("sub", this=a_e, expression=a_s)))
+    other = A.cmp("lt", A.N("abs", this=A.N("sub", this=A.col("a", "score"), expression=A.col("b", "score"))),
+                  A.N("div", this=A.N("neg", this=A.col("b", "score")), expression=A.lit(-2.0)))
+    root, it = basic([A.col("a", "name")], on_extra=[A.cmp("gte", ov, frac)], where=other)
+    out, ctx, calls = run(root, it, ["peaks", "genes"])
+    assert out is it and not calls
+    want = build_plan("SELECT a.name FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND "
+                      "(LEAST(a.end, b.end) - GREATEST(a.start, b.start)) >= 0.5 * (a.end - a.start) "
+                      "WHERE ABS(a.score - b.score) < -b.score / -2.0", ["peaks", "genes"])
+    assert JoinPlan.from_string(ctx.finalizers[0](root)[1]) == want
+    # arithmetic this target has no evaluator for declines (modulo, functions), typed division flags too
+    _declined(*basic([A.col("a", "start")], on_extra=[A.cmp("gt", A.N("mod", this=a_s, expression=A.lit(2)), A.lit(0))]))
+    _declined(*basic([A.col("a", "start")], on_extra=[A.cmp("gt", A.N("sqrt", this=a_s), A.lit(2))]))
+    _declined(*basic([A.col("a", "start")], on_extra=[A.cmp("gt", A.N("div", this=a_s, expression=A.lit(2), typed=True), A.lit(2))]))
+
+
 def test_sibling_spatial_predicate_and_literal_ranges_defer():
     it = A.intersects(A.col("a", "interval"), A.col("b", "interval"))
     other = A.N("contains", this=A.col("a", "interval"), expression=A.col("b", "interval"))

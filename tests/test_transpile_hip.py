@@ -97,12 +97,12 @@ def test_case_insensitive_aliases():
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score IS TRUE",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score IN (SELECT 1)",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score IN (1, b.score)",
-    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND (a.score) > 5",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score % 2 = 1",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND 1 + 1 = 2",
     # 13 comparisons once in conjunctive normal form: the select kernel takes 12 beside a filter's own three
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score IN "
     "(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)",
-    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score + 1 > 5",
-    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND ABS(a.score) > 5",
+    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND SQRT(a.score) > 5",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND 1 = 1",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.interval INTERSECTS b.interval",
     "SELECT a.start FROM peaks a JOIN genes b ON a.score > 5",
@@ -132,6 +132,32 @@ def test_boolean_having_arrives_in_conjunctive_normal_form():
         [("n", ">", 5, 1), ("__giql_h0", "<", 3, 1), ("chrom", "=", "chr1", 2), ("chrom", "=", "chr2", 2),
          ("__giql_h1", "notnull", 0, 0)]
     assert JoinPlan.from_string(p.to_string()) == p
+
+
+def test_arithmetic_operands_become_expression_trees():
+    # the overlap-fraction recipes (docs/recipes/intersect.rst:144-190), inlined as text upstream
+    base = "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval "
+    p = build_plan(base + "AND (LEAST(a.end, b.end) - GREATEST(a.start, b.start)) >= 0.5 * (a.end - a.start)", ["peaks", "genes"])
+    (r,) = p.residuals
+    assert (r.lhs.kind, r.op, r.rhs.kind) == ("expr", ">=", "expr")
+    assert r.lhs.value == ["fn", "-", [["fn", "least", [["l", "end"], ["r", "end"]]], ["fn", "greatest", [["l", "start"], ["r", "start"]]]]]
+    assert r.rhs.value == ["fn", "*", [["float", 0.5], ["fn", "-", [["l", "end"], ["l", "start"]]]]]
+    assert JoinPlan.from_string(p.to_string()) == p
+    # precedence, unary minus, a parenthesised operand next to a parenthesised condition
+    p = build_plan(base + "AND (a.score) > 5 AND (a.score + 1 > 5 OR -a.score * 2 + b.score / 2.0 < ABS(b.score - 3))",
+                   ["peaks", "genes"])
+    assert [(r.lhs.kind, r.op, r.group) for r in p.residuals] == [("l", ">", 0), ("expr", ">", 1), ("expr", "<", 1)]
+    assert p.residuals[2].lhs.value == ["fn", "+", [["fn", "*", [["fn", "neg", [["l", "score"]]], ["int", 2]]],
+                                                    ["fn", "/", [["r", "score"], ["float", 2.0]]]]]
+    # SEMI / ANTI: a WHERE expression cannot read the right side either; strings do not take part in arithmetic
+    with pytest.raises(ValueError, match="right side"):
+        build_plan("SELECT a.start FROM peaks a SEMI JOIN genes b ON a.interval INTERSECTS b.interval WHERE a.score + b.score > 1",
+                   ["peaks", "genes"])
+    with pytest.raises(ValueError, match="arithmetic"):
+        build_plan(base + "AND a.score + 'x' > 1", ["peaks", "genes"])
+    # HAVING and CLUSTER predicates keep declining arithmetic
+    with pytest.raises(HipDeclined):
+        build_plan("SELECT *, CLUSTER(interval, predicate := depth + 1 = PREV(depth)) AS cid FROM peaks", ["peaks"])
 
 
 def _res(plan):
