@@ -404,3 +404,32 @@ def test_nearest_k_and_stranded_lower_to_the_plan():
                    [Table("peaks", strand_col=None), "genes"])
     with pytest.raises(ValueError, match="positive"):
         build_plan("SELECT a.start FROM peaks a CROSS JOIN LATERAL NEAREST(genes, reference := a.interval, k := 0) b", ["peaks", "genes"])
+
+
+def test_chrom_encoding_takes_arrows_hash_and_agrees_with_the_numpy_path():
+    # execute()'s host side: the shared chromosome dictionary of two Arrow string columns comes from Arrow's own
+    # dictionary_encode (a Python-level pass over 110M strings took minutes), sorted like numpy.unique sorts
+    np = pytest.importorskip("numpy")
+    pa = pytest.importorskip("pyarrow")
+    from giql_amd import execute as X
+
+    rng = np.random.default_rng(0)
+    names = np.array([f"chr{i}" for i in range(1, 25)] + ["chrX", "chrM"])
+    av, bv = names[rng.integers(0, 26, 5000)], names[rng.integers(3, 20, 700)]
+    want = X.encode_chroms(av, bv)                                    # numpy arrays: the generic path
+    for a, b in [(pa.array(av), pa.array(bv)),
+                 (pa.chunked_array([pa.array(av[:1000]), pa.array(av[1000:])]), pa.array(bv).dictionary_encode()),
+                 (pa.chunked_array([pa.array(av[:10]).dictionary_encode(), pa.array(av[10:]).dictionary_encode()]),
+                  pa.array(bv, pa.large_string()))]:
+        ia, ib, d = X.encode_chroms(a, b)
+        assert d == want[2] and (ia == want[0]).all() and (ib == want[1]).all() and ia.dtype == np.int32
+    ia, ib, d = X.encode_chroms(pa.array([], pa.string()), pa.array(["b", "a", "b"]))
+    assert ia.size == 0 and ib.tolist() == [1, 0, 1] and d == ["a", "b"]
+    with pytest.raises(ValueError, match="NULL"):
+        X.encode_chroms(pa.array(["x", None]), pa.array(["x"]))
+    with pytest.raises(ValueError, match="NULL"):
+        X.encode_chroms(pa.array(["x"]), pa.array(["x", None]).dictionary_encode())
+    assert X._strand_codes(pa.array(["+", "-", None, ".", "?"]), 4).tolist() == [0, 1, 4, 2, 3]
+    assert X._strand_codes(np.array(["+", "-", None], dtype=object), 5).tolist() == [0, 1, 5]
+    with pytest.raises(ValueError, match="strands other than"):
+        X._strand_codes(pa.array(["+", "*"]), 4)
