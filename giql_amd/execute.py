@@ -87,9 +87,43 @@ def _int32_column(col, what: str) -> np.ndarray:
     return np.ascontiguousarray(x, dtype=np.int32)
 
 
+_CODES_CACHE: "OrderedDict" = None      # (buffer addresses, offset, length, type, nulls_as) -> (the column, its codes)
+_CODES_CACHE_SLOTS = int(os.environ.get("GIQL_HIP_CODES_CACHE_SLOTS", "6"))   # 0: nothing is kept between calls
+_CODES_CACHE_MIN_ROWS = 1_000_000
+_CODES_LOCK = None
+
+
+def _cached_codes(col, nulls_as, compute):
+    """Arrow arrays are immutable: the codes of a long column are kept for the next query over the same table
+    (hashing 110M strings is ~1 s of a ~1.7 s INNER join of BASELINE size).  The entry holds the column, so its
+    buffers cannot be freed and their addresses reused while it is cached; a handful of slots, oldest out."""
+    global _CODES_CACHE, _CODES_LOCK
+    cols = col if isinstance(col, tuple) else (col,)          # (a pair: the shared encoding of two columns)
+    if sum(len(c) for c in cols) < _CODES_CACHE_MIN_ROWS or _CODES_CACHE_SLOTS <= 0:
+        return compute()
+    if _CODES_CACHE is None:
+        import threading
+        from collections import OrderedDict
+
+        _CODES_CACHE, _CODES_LOCK = OrderedDict(), threading.Lock()
+    key = (tuple((tuple((tuple(b.address if b is not None else 0 for b in c.buffers()), c.offset, len(c))
+                        for c in (one.chunks if hasattr(one, "chunks") else [one])), str(one.type)) for one in cols), nulls_as)
+    with _CODES_LOCK:
+        hit = _CODES_CACHE.get(key)
+        if hit is not None:
+            _CODES_CACHE.move_to_end(key)
+            return hit[1]
+    value = compute()
+    with _CODES_LOCK:
+        _CODES_CACHE[key] = (col, value)
+        while len(_CODES_CACHE) > _CODES_CACHE_SLOTS:
+            _CODES_CACHE.popitem(last=False)
+    return value
+
+
 def _arrow_codes(col, what: str, nulls_as=None):
     """An Arrow string / dictionary column as ``(int32 codes, dictionary values)`` through Arrow's own hash
-    (``pyarrow.compute.dictionary_encode``: ~0.4 s per 100M rows where a Python-level pass takes minutes), or
+    (``pyarrow.compute.dictionary_encode``: ~0.8 s per 100M rows where a Python-level pass takes minutes), or
     None when the column is not one.  NULLs are refused as everywhere unless ``nulls_as``
     names the value they are encoded as (the caller carries the validity beside)."""
     try:
@@ -97,27 +131,32 @@ def _arrow_codes(col, what: str, nulls_as=None):
         import pyarrow.compute as pc
     except ImportError:  # pragma: no cover
         return None
-    if isinstance(col, pa.ChunkedArray):
-        if col.num_chunks == 1:
-            col = col.chunk(0)
-        elif pa.types.is_dictionary(col.type):
-            col = col.unify_dictionaries().combine_chunks()
-        else:
-            col = col.combine_chunks()
-    if not isinstance(col, pa.Array):
+    if not isinstance(col, (pa.Array, pa.ChunkedArray)):
         return None
     t = col.type
     value_type = t.value_type if pa.types.is_dictionary(t) else t
     if not (pa.types.is_string(value_type) or pa.types.is_large_string(value_type)):
         return None
-    if col.null_count or (pa.types.is_dictionary(t) and col.dictionary.null_count):
-        if nulls_as is None:
-            raise ValueError(f"{what} contains NULLs: not supported by dialect='hip'")
-        col = (col.dictionary_decode() if pa.types.is_dictionary(t) else col).fill_null(nulls_as)
-        t = col.type
-    d = col if pa.types.is_dictionary(t) else pc.dictionary_encode(col)
-    codes = d.indices.to_numpy(zero_copy_only=False)
-    return codes, d.dictionary.to_pylist()
+
+    def compute():
+        c = col
+        if isinstance(c, pa.ChunkedArray):
+            if c.num_chunks == 1:
+                c = c.chunk(0)
+            elif pa.types.is_dictionary(t):
+                c = c.unify_dictionaries().combine_chunks()
+            else:
+                c = c.combine_chunks()
+        ty = c.type
+        if c.null_count or (pa.types.is_dictionary(ty) and c.dictionary.null_count):
+            if nulls_as is None:
+                raise ValueError(f"{what} contains NULLs: not supported by dialect='hip'")
+            c = (c.dictionary_decode() if pa.types.is_dictionary(ty) else c).fill_null(nulls_as)
+            ty = c.type
+        d = c if pa.types.is_dictionary(ty) else pc.dictionary_encode(c)
+        return d.indices.to_numpy(zero_copy_only=False), d.dictionary.to_pylist()
+
+    return _cached_codes(col, nulls_as, compute)
 
 
 def _sorted_union_codes(parts):
@@ -136,8 +175,14 @@ def encode_chroms(col_a, col_b):
     """Shared dictionary encoding of both chrom columns -> (ids_a, ids_b, dictionary)."""
     fast = [_arrow_codes(col_a, "left chrom column"), _arrow_codes(col_b, "right chrom column")]
     if fast[0] is not None and fast[1] is not None:
-        (ia, ib), dictionary = _sorted_union_codes(fast)
-        return ia, ib, dictionary
+        def shared():
+            (ia, ib), dictionary = _sorted_union_codes(fast)
+            ia.setflags(write=False)      # (shared by every later query over these tables)
+            ib.setflags(write=False)
+            return ia, ib, dictionary
+
+        ia, ib, dictionary = _cached_codes((col_a, col_b), "pair", shared)
+        return ia, ib, list(dictionary)
     a = _to_numpy(col_a, "left chrom column")
     b = _to_numpy(col_b, "right chrom column")
     if a.dtype.kind in "iu" and b.dtype.kind in "iu":

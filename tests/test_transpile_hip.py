@@ -433,3 +433,29 @@ def test_chrom_encoding_takes_arrows_hash_and_agrees_with_the_numpy_path():
     assert X._strand_codes(np.array(["+", "-", None], dtype=object), 5).tolist() == [0, 1, 5]
     with pytest.raises(ValueError, match="strands other than"):
         X._strand_codes(pa.array(["+", "*"]), 4)
+
+
+def test_codes_of_long_columns_are_kept_for_the_next_query():
+    np = pytest.importorskip("numpy")
+    pa = pytest.importorskip("pyarrow")
+    from giql_amd import execute as X
+
+    names = np.array(["chr1", "chr2", "chrX"])
+    rng = np.random.default_rng(1)
+    a = pa.chunked_array([pa.array(names[rng.integers(0, 3, 700_000)]), pa.array(names[rng.integers(0, 3, 400_000)])])
+    b = pa.array(names[rng.integers(1, 3, 50_000)])
+    old = (X._CODES_CACHE_SLOTS, X._CODES_CACHE)
+    try:
+        X._CODES_CACHE_SLOTS, X._CODES_CACHE = 3, None
+        r1 = X.encode_chroms(a, b)
+        r2 = X.encode_chroms(a, b)
+        assert r2[0] is r1[0] and r2[1] is r1[1] and r1[2] == ["chr1", "chr2", "chrX"] and not r1[0].flags.writeable
+        assert (r1[0] == np.searchsorted(r1[2], np.concatenate([c.to_numpy(zero_copy_only=False) for c in a.chunks]))).all()
+        r3 = X.encode_chroms(a.slice(5, 1_050_000), b)                 # other rows of the same buffers: another entry
+        assert r3[0] is not r1[0] and (r3[0] == r1[0][5:1_050_005]).all()
+        assert len(X._CODES_CACHE) <= 3                                # oldest out
+        X._CODES_CACHE_SLOTS, X._CODES_CACHE = 0, None
+        r4 = X.encode_chroms(a, b)
+        assert X._CODES_CACHE is None and (r4[0] == r1[0]).all()
+    finally:
+        X._CODES_CACHE_SLOTS, X._CODES_CACHE = old
