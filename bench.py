@@ -934,20 +934,27 @@ def run_rowop(args):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    eng.set_profiling(True)
+    # the phase events are recorded in ONE extra call AFTER the timed region: switching them off in front of it left
+    # a one-off ~1.1 ms in the first timed call (box-dependent; the calls themselves take 0.3 ms)
     res = None
     for _ in range(max(args.warmup, 1)):
         res = fn()
+    sync_all()
+    step_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        res = fn()
+        step_ms.append((time.perf_counter() - ts) * 1e3)   # (a call ends with its read-back: host time = step time)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    eng.set_profiling(True)
+    fn()
     torch.cuda.synchronize(dev)
     st = eng.stats()
     phases = {k: v for k, v in st["phase_ms"].items() if v > 0}
     eng.set_profiling(False)
     sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = fn()
-    sync_all()
-    elapsed = time.perf_counter() - t0
     loc_na, loc_nb = a.n, b.n
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
@@ -978,7 +985,7 @@ def run_rowop(args):
                                    "frac": round(alg / (device_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms else 0.0},
                 "phase_ms": {k: round(v, 3) for k, v in phases.items()},
                 "phase_launches": {k: v for k, v in st["phase_launches"].items() if v},
-                "phase_ms_source": "hipEvents in the last warm-up call (the timed calls run without events)"}
+                "phase_ms_source": "hipEvents in one extra call after the timed region (the timed calls run without events)"}
     if dom and dom_bytes:
         launches = max(st["phase_launches"].get(dom, 1), 1)
         ach = dom_bytes / (phases[dom] * 1e-3) / 1e9
@@ -1025,6 +1032,8 @@ def run_rowop(args):
         "value": round((g_na + g_nb) * args.steps / elapsed, 1),
         "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "ms_per_step_median": round(statistics.median(step_ms), 3) if step_ms else None,
+        "step_ms": [round(x, 3) for x in step_ms],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": wl, "n_a": g_na, "n_b": g_nb, "n_chrom": n_chrom, "rows_out": n_out,
                    "inputs": "resident in HBM before the timed region", "form": st.get("join_form"),
