@@ -71,8 +71,8 @@ METRIC = {
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true",

@@ -750,3 +750,19 @@ def test_stranded_nearest_on_a_genome_wider_than_half_the_axis():
         assert got[p["name"]][1] == d, p
         g = gi[got[p["name"]][0]]
         assert g["chrom"] == p["chrom"] and g["strand"] == p["strand"]
+
+
+def test_large_result_columns_come_back_through_pinned_memory(monkeypatch, peaks_genes):
+    # execute._to_host: results past a size threshold are copied into page-locked memory from torch's caching host
+    # allocator (the Arrow column wraps it); forced here for a small result, with and without NULLs in the column
+    from giql_amd import execute as X
+
+    q = "SELECT a.name, a.score, b.start AS s FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval"
+    plan = transpile(q, tables=["peaks", "genes"], dialect="hip")
+    genes = peaks_genes["genes"]
+    peaks = peaks_genes["peaks"].set_column(4, "score", pa.array([10, 20, None, 30, 35], pa.int32()))
+    t = {"peaks": peaks, "genes": genes}
+    want = rows_of(execute(plan, t))
+    monkeypatch.setattr(X, "_PINNED_MIN_BYTES", 1)
+    got = execute(plan, t)
+    assert rows_of(got) == want and len(want) > 0
