@@ -338,8 +338,9 @@ class _Residuals:
             for o in ops:
                 if o.kind == "str":
                     parts.append((np.zeros(1, np.int32), [o.value]))
-                else:
-                    parts.append(_arrow_codes(self._arrow(o.kind, o.value), o.value, nulls_as=""))
+                else:   # (the raw column first: its buffers are the cache's key; _arrow() may build a new array)
+                    coded = _arrow_codes(_column(self.tables[o.kind], o.value), o.value, nulls_as="")
+                    parts.append(coded if coded is not None else _arrow_codes(self._arrow(o.kind, o.value), o.value, nulls_as=""))
             coded, _dictionary = _sorted_union_codes(parts)   # ONE sorted dictionary: = / < on the codes is = / < on the strings
             specs = []
             for o, codes in zip(ops, coded):
@@ -498,10 +499,16 @@ def _execute_cluster_merge(plan: JoinPlan, tables, eng: HipEngine, return_indice
         return pa.Table.from_arrays(arrays, names=names)
 
     c, s, e, cnt = (t.cpu().numpy() for t in eng.merge(dev_side, n_part, plan.distance, preds=preds))
-    chrom_out = chrom_dict[c // n_strand]
-    cols = {side.chrom_col: pa.array(chrom_out.tolist() if chrom_out.dtype.kind in "US" else chrom_out)}
+    def named(dictionary, codes):
+        """The dictionary's values at ``codes`` as an Arrow column (a take on the Arrow side: a Python list of
+        millions of strings took longer than the merge)."""
+        if dictionary.dtype.kind in "US":
+            return pa.array(dictionary.tolist(), pa.string()).take(pa.array(codes))
+        return pa.array(dictionary[codes])
+
+    cols = {side.chrom_col: named(chrom_dict, c // n_strand)}
     if plan.stranded:
-        cols[plan.strand_col] = pa.array(strand_dict[c % n_strand].tolist())
+        cols[plan.strand_col] = named(strand_dict, c % n_strand)
     cols[side.start_col] = pa.array(s, type=pa.int32())
     cols[side.end_col] = pa.array(e, type=pa.int32())
     for p in plan.projection:

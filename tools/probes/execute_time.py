@@ -36,6 +36,17 @@ QUERIES = [
     ("count", 'SELECT a.chrom, a.start, a."end", COUNT(b.chrom) AS n FROM peaks a LEFT JOIN reads b ON a.interval INTERSECTS b.interval '
               'GROUP BY a.chrom, a.start, a."end"'),
 ]
+if os.environ.get("PROBE_SET") == "other":      # NEAREST / CLUSTER / MERGE instead of the joins
+    QUERIES = [
+        ("nearest k=1", "SELECT a.start AS s, b.start AS t, b.distance FROM peaks a CROSS JOIN LATERAL "
+                        "NEAREST(reads, reference := a.interval) b"),
+        ("nearest k=3", "SELECT a.start AS s, b.start AS t, b.distance FROM peaks a CROSS JOIN LATERAL "
+                        "NEAREST(reads, reference := a.interval, k := 3) b"),
+        ("cluster", "SELECT *, CLUSTER(interval, 100) AS cid FROM reads"),
+        ("merge", "SELECT MERGE(interval), COUNT(*) AS n FROM reads"),
+        ("cluster pred", "SELECT *, CLUSTER(interval, 100, predicate := score >= PREV(score)) AS cid FROM reads"),
+        ("filter", "SELECT * FROM reads WHERE interval INTERSECTS 'chr2:1000000-90000000' AND (score > 500 OR score < 10)"),
+    ]
 for name, q in QUERIES:
     plan = transpile(q, tables=["peaks", "reads"], dialect="hip")
     t = time.time()
