@@ -106,8 +106,12 @@ def _cached_codes(col, nulls_as, compute):
         from collections import OrderedDict
 
         _CODES_CACHE, _CODES_LOCK = OrderedDict(), threading.Lock()
-    key = (tuple((tuple((tuple(b.address if b is not None else 0 for b in c.buffers()), c.offset, len(c))
-                        for c in (one.chunks if hasattr(one, "chunks") else [one])), str(one.type)) for one in cols), nulls_as)
+    def ident(c):   # (a dictionary array's values live in buffers of their own: part of its identity)
+        own = (tuple(b.address if b is not None else 0 for b in c.buffers()), c.offset, len(c))
+        return own + ident(c.dictionary) if hasattr(c, "dictionary") else own
+
+    key = (tuple((tuple(ident(c) for c in (one.chunks if hasattr(one, "chunks") else [one])), str(one.type)) for one in cols),
+           nulls_as)
     with _CODES_LOCK:
         hit = _CODES_CACHE.get(key)
         if hit is not None:

@@ -362,6 +362,9 @@ def _parse_bool(p: _Parser, allow_literal: bool, level: int = 0, operand=None):
         # a boolean group, or the opening parenthesis of an arithmetic operand ("(a.end - a.start) > 5"): try the
         # group first; what follows its ")" tells
         save = p.i
+        p.depth = getattr(p, "depth", 0) + 1
+        if p.depth > 12:   # (each level may be parsed twice: bound the work on adversarial nesting)
+            raise _decline("condition nested too deeply")
         try:
             p.next()
             node = _parse_bool(p, allow_literal, 0, operand)
@@ -370,8 +373,13 @@ def _parse_bool(p: _Parser, allow_literal: bool, level: int = 0, operand=None):
             if not ((t.kind == "punct" and t.text in "+-*/=<>!") or (t.kind == "kw" and t.text in ("BETWEEN", "IN", "IS", "LIKE"))
                     or (t.kind == "kw" and t.text == "NOT" and p.peek(1).kind == "kw" and p.peek(1).text in ("BETWEEN", "IN", "LIKE"))):
                 return node
+        except HipDeclined as exc:
+            if "nested too deeply" in str(exc):
+                raise
         except ValueError:
             pass
+        finally:
+            p.depth -= 1
         p.i = save
     return _parse_predicate(p, allow_literal, operand)
 
