@@ -381,6 +381,12 @@ def _parse_bool(p: _Parser, allow_literal: bool, level: int = 0, operand=None):
         finally:
             p.depth -= 1
         p.i = save
+        try:
+            return _parse_predicate(p, allow_literal, operand)
+        except HipDeclined:
+            raise
+        except ValueError:   # e.g. "(a.x > 1) = TRUE": a condition used as a value -- valid SQL, no evaluator here
+            raise _decline("parenthesised condition used as a value")
     return _parse_predicate(p, allow_literal, operand)
 
 
