@@ -12,7 +12,8 @@ so both accept, decline and reject exactly the same queries.  It restates the wh
 * one column-to-column INTERSECTS between two distinct registered-or-default base tables, joined
   INNER / CROSS / comma / SEMI / ANTI (or the count_overlaps ``LEFT JOIN ... COUNT(b.col) ...
   GROUP BY`` shape, ``:432-548``), optionally ``USING (<chrom>)`` (``:727-735, 1190-1201``);
-* comparison residuals beside it (ON residuals join, WHERE residuals filter: ``:1164-1177``);
+* residual conditions beside it -- comparisons over columns, literals and arithmetic in conjunctive normal form
+  (ON residuals join, WHERE residuals filter: ``:889-912, 1164-1177``);
 * a projection of qualified columns and plain aggregates (``:1402-1644``); stars, expressions,
   windows, FILTER, sub-queries decline (#202, #204, #205);
 * DISTINCT / GROUP BY / ORDER BY / LIMIT / OFFSET over the result, which the reference lets "ride on

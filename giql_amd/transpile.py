@@ -1,9 +1,10 @@
 """``transpile(giql, tables, dialect="hip")`` -- host-side mirror of the reference's
 ``giql.transpile`` (``src/giql/transpile.py:55-214``) for the one path this
 backend executes: the column-to-column INTERSECTS join (INNER / SEMI / ANTI, with
-comparison residuals beside the INTERSECTS), the count_overlaps shape, the
-correlated NEAREST k=1 join, CLUSTER / MERGE over one table, and the single-table
-literal-range filter.
+residual conditions beside the INTERSECTS: comparisons over columns, literals and
+arithmetic, combined with AND / OR / NOT, BETWEEN, IN, IS NULL), the count_overlaps
+shape, the correlated NEAREST join (any k, stranded), CLUSTER / MERGE over one table
+(with a ``predicate :=``), and the single-table literal-range filter.
 
 The reference parses with sqlglot, which is not installable here, so this module
 carries a small hand-written parser for exactly the query shapes the reference's
@@ -15,8 +16,9 @@ IEJoin override engages on (the whitelist of
 * user mistakes (unqualified / unknown-alias columns, right-side columns under
   SEMI / ANTI)                                    -> ``ValueError``
   (``_UnqualifiedProjectionError`` -> ``ValueError``, intersects_duckdb.py:803-804);
-* valid GIQL the hip path does not execute (stars, outer joins, self-joins, OR / NOT /
-  arithmetic in the join condition, other aggregates, 3+ tables, ...)         -> :class:`HipDeclined`
+* valid GIQL the hip path does not execute (stars, outer joins, self-joins, an INTERSECTS
+  under OR / NOT, functions / LIKE / sub-queries in a condition, other aggregates,
+  3+ tables, ...)                                                            -> :class:`HipDeclined`
   (a ``ValueError``): the reference *declines* such shapes to the naive predicate
   (intersects_duckdb.py:1715); without sqlglot there is no naive emitter to fall
   back to, so the caller is told to use ``giql.transpile`` for that query.
