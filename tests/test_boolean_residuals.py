@@ -170,3 +170,20 @@ def test_the_documented_recipes_run_on_the_gpu_path(name, extra, pred):
     got = sorted(zip(out.column("name").to_pylist(), out.column("b_name").to_pylist()))
     want = sorted((p[3], g[3]) for p in peaks for g in genes if _overlap(p, g) and pred(p, g))
     assert got == want and len(want) > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [GOLDEN[i] for i in (1, 9, 19, 27, 33, 39, 41, 55)], ids=lambda c: c["kind"])
+def test_boolean_and_arithmetic_residuals_through_several_contexts(case):
+    # execute(devices=[0, 0]): chromosomes sharded over two contexts, every shard filters its own pairs
+    import pyarrow as pa
+
+    from giql_amd.execute import execute
+
+    def table(rows):
+        types = [pa.string(), pa.int32(), pa.int32(), pa.string(), pa.int32(), pa.string()]
+        return pa.table({c: pa.array(list(v), t) for c, v, t in zip(COLS, zip(*rows), types)})
+
+    t = {"peaks": table(case["peaks"]), "genes": table(case["genes"])}
+    out = execute(transpile(case["query"], tables=["peaks", "genes"], dialect="hip"), t, devices=[0, 0])
+    assert sorted(([*d.values()] for d in out.to_pylist()), key=_key) == case["rows"]
