@@ -243,9 +243,16 @@ class _Residuals:
     travel as byte columns: a NULL operand makes the predicate not true.
     """
 
-    def __init__(self, plan: JoinPlan, lt, rt, eng: HipEngine):
+    def __init__(self, plan: JoinPlan, lt, rt, eng: HipEngine, dev_sides=None):
         self.plan, self.tables, self.eng = plan, {"l": lt, "r": rt}, eng  # rt is None for CLUSTER / MERGE
         self._cache: dict = {}
+        # the genomic columns are on the device already (raw values, as SQL sees them): a condition over a.start /
+        # b.end -- the overlap-fraction recipes -- reads those tensors instead of uploading the columns again
+        for key, dev in (dev_sides or {}).items():
+            ps = plan.left if key == "l" else plan.right
+            if dev is not None and ps is not None and ps.start_col != ps.end_col:
+                self._cache[(key, ps.start_col)] = (dev.start, None)
+                self._cache[(key, ps.end_col)] = (dev.end, None)
 
     @staticmethod
     def sides(clause) -> set:
@@ -399,7 +406,7 @@ def _join_with_residuals(plan: JoinPlan, lt, rt, a: DeviceSide, b: DeviceSide, n
     intersects_duckdb.py:1239-1243).  For SEMI / ANTI only the ON residuals take part
     in the existence test; WHERE residuals filter the surviving left rows (#200,
     intersects_duckdb.py:1164-1177)."""
-    rb_ = _Residuals(plan, lt, rt, eng)
+    rb_ = _Residuals(plan, lt, rt, eng, dev_sides={"l": a, "r": b})
     semi = plan.kind in ("SEMI", "ANTI")
     clauses = rb_.clauses(plan.residuals)   # every member of a clause comes from the same SQL clause
     joinside = [c for c in clauses if not (semi and c[0].clause == "where")]

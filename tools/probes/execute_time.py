@@ -32,6 +32,8 @@ print(f"tables built in {time.time() - t0:.1f} s", flush=True)
 QUERIES = [
     ("pairs", "SELECT a.start AS s, b.start AS t FROM peaks a JOIN reads b ON a.interval INTERSECTS b.interval"),
     ("residual", "SELECT a.start AS s, b.score AS t FROM peaks a JOIN reads b ON a.interval INTERSECTS b.interval AND a.score > b.score"),
+    ("overlap fraction", "SELECT a.start AS s, b.start AS t FROM peaks a, reads b WHERE a.interval INTERSECTS b.interval "
+                         "AND (LEAST(a.end, b.end) - GREATEST(a.start, b.start)) >= 0.5 * (b.end - b.start)"),
     ("semi", "SELECT a.chrom, a.start FROM peaks a SEMI JOIN reads b ON a.interval INTERSECTS b.interval"),
     ("count", 'SELECT a.chrom, a.start, a."end", COUNT(b.chrom) AS n FROM peaks a LEFT JOIN reads b ON a.interval INTERSECTS b.interval '
               'GROUP BY a.chrom, a.start, a."end"'),
