@@ -766,3 +766,38 @@ def test_large_result_columns_come_back_through_pinned_memory(monkeypatch, peaks
     monkeypatch.setattr(X, "_PINNED_MIN_BYTES", 1)
     got = execute(plan, t)
     assert rows_of(got) == want and len(want) > 0
+
+
+def test_long_tables_are_uploaded_once(monkeypatch):
+    # execute._device_side keeps the device copy of a long Arrow table's (chrom id, start, end) for the next query
+    # over the same buffers; another table of the same shape is another entry
+    from giql_amd import execute as X
+    from giql_amd.engine import DeviceSide
+
+    rng = np.random.default_rng(3)
+    names = np.array(["chr1", "chr2", "chr3"])
+
+    def table(n, seed):
+        r = np.random.default_rng(seed)
+        s = r.integers(0, 50_000_000, n).astype(np.int32)
+        return pa.table({"chrom": pa.array(names[r.integers(0, 3, n)]), "start": s, "end": (s + r.integers(1, 300, n)).astype(np.int32),
+                         "name": pa.array(np.arange(n).astype(str)), "score": r.integers(0, 9, n).astype(np.int32),
+                         "strand": pa.array(np.array(["+", "-"])[r.integers(0, 2, n)])})
+
+    t = {"peaks": table(1_100_000, 1), "genes": table(1_050_000, 2)}
+    plan = transpile("SELECT a.start, a.score FROM peaks a SEMI JOIN genes b ON a.interval INTERSECTS b.interval AND a.strand = b.strand",
+                     tables=["peaks", "genes"], dialect="hip")
+    uploads = []
+    real = DeviceSide.from_numpy.__func__
+    monkeypatch.setattr(DeviceSide, "from_numpy", classmethod(lambda cls, *a, **k: uploads.append(1) or real(cls, *a, **k)))
+    monkeypatch.setattr(X, "_SIDES_CACHE", None)
+    first = execute(plan, t)
+    n1 = len(uploads)
+    second = execute(plan, t)
+    assert n1 == 2 and len(uploads) == 2 and second.equals(first) and first.num_rows > 1000
+    other = dict(t, genes=table(1_050_000, 5))
+    third = execute(plan, other)
+    # (both sides again: the chromosome ids belong to the PAIR's shared dictionary)
+    assert len(uploads) == 4 and not third.equals(first)
+    monkeypatch.setattr(X, "_SIDES_CACHE_SLOTS", 0)
+    assert execute(plan, t).equals(first) and len(uploads) == 6
