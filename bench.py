@@ -98,6 +98,12 @@ def parse_args():
                         "(the other ranks wait), checks the gathered result against it (count + multiset checksum) and "
                         "the run exits non-zero on a mismatch")
     p.add_argument("--master-port", type=int, default=29531)
+    p.add_argument("--shard-of", type=int, default=0,
+                   help="--gpus 1 only: measure what ONE rank of an N-rank run of the INNER headline executes -- rank "
+                        "--shard-rank's LPT share of the chromosomes through exactly the per-rank code (local plan + "
+                        "export; the local one-call join; the expansion of all N ranks' plan blocks), each verified "
+                        "against the CPU leg.  An extra line, never the headline")
+    p.add_argument("--shard-rank", type=int, default=0)
     a = p.parse_args()
     if a.no_gather:
         a.exchange = "none"
@@ -362,6 +368,165 @@ def cpu_baseline_inner(args, wl, n_chrom, rank_chroms=None, whole=False):
     elif dd is not None:
         out["duckdb_probe"] = dd["error"]
     return out, parity_ref
+
+
+# ------------------------------------------------- one rank's share, measured on one GPU
+def run_shard(args):
+    """``--shard-of N [--shard-rank r]``: the parts of a step of an N-rank run that need no second GPU, on the one
+    GPU this pool gives: (A) rank r's local plan + the export of its compact plan block with global
+    row ids -- what precedes the exchange; (B) the same shard through the one-call join (``--exchange none``,
+    ``execute(devices=[...])``: results stay sharded); (C) the expansion of ALL N ranks' plan blocks into the global
+    pairs -- what follows the exchange on every rank (the peers' blocks are made here, one shard after the other,
+    outside the timed region).  Wire time is not measured (DESIGN.md section 6 keeps a stated model for it).
+    Parity: (B) against the oracle on the shard's rows, (A) + (C) against the oracle on the whole workload."""
+    import numpy as np
+    import torch
+
+    from giql_amd import shard, synth
+    from giql_amd.engine import DeviceSide, HipEngine
+    from oracle import pyoracle as ora
+
+    wl = args.workload
+    op, (n_a, kind_a, seed_a), (n_b, kind_b, seed_b), genome = WORKLOADS[wl]
+    if op != "inner" or genome != HG38 or args.gpus != 1:
+        raise SystemExit("--shard-of measures a rank of the chromosome-sharded INNER workloads at --gpus 1")
+    N, r = int(args.shard_of), int(args.shard_rank)
+    if not 0 <= r < N:
+        raise SystemExit("--shard-rank must be in [0, --shard-of)")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    rows_a, rows_b = synth.rows_per_chrom(n_a, seed_a), synth.rows_per_chrom(n_b, seed_b)
+    assign = shard.lpt_assign((rows_a + rows_b).tolist(), N)
+    layout = [[c for c in range(len(assign)) if assign[c] == q] for q in range(N)]
+    size_a = [int(rows_a[layout[q]].sum()) for q in range(N)]
+    size_b = [int(rows_b[layout[q]].sum()) for q in range(N)]
+    base_a = [sum(size_a[:q]) for q in range(N)]     # the global table = the rows of lower ranks first
+    base_b = [sum(size_b[:q]) for q in range(N)]
+    n_chrom = len(synth.HG38_LENGTHS)
+    eng = HipEngine(0)
+
+    def shard_sides(q):
+        ha = workload_table(wl, n_a, seed_a, kind_a, layout[q])
+        hb = workload_table(wl, n_b, seed_b, kind_b, layout[q])
+        return ha, hb, DeviceSide.from_numpy(*ha, device=dev), DeviceSide.from_numpy(*hb, device=dev)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for k in range(steps):
+            fn()
+            ev[k + 1].record()
+        torch.cuda.synchronize(dev)
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]
+        return {"ms_per_step": round(wall, 3), "median_ms": round(statistics.median(ms), 3), "step_ms": [round(x, 3) for x in ms]}
+
+    def export_block(q_sides, q):
+        """Plan shard q and export its compact block with global ids: (n_pairs, q_is_a, [q_rid, lo, cnt, s_rid])."""
+        _ha, _hb, da, db = q_sides
+        n = eng.inner_plan(da, db, n_chrom)
+        q_is_a, n_q, n_s = eng.plan_sizes()
+        blk = [torch.empty(n_q, dtype=torch.int32, device=dev) for _ in range(3)] + \
+              [torch.empty(n_s, dtype=torch.int32, device=dev)]
+        eng.plan_export(*blk, rid_add_a=base_a[q], rid_add_b=base_b[q])
+        return n, q_is_a, blk
+
+    # ---- (A) this rank: local plan + export (the block is re-used as the send buffer, as PlanGather does)
+    t0 = time.time()
+    mine = shard_sides(r)
+    gen_s = time.time() - t0
+    ha, hb, a, b = mine
+    n_mine, qa_mine, blk_mine = export_block(mine, r)
+
+    def plan_export_step():
+        n = eng.inner_plan(a, b, n_chrom)
+        eng.plan_sizes()
+        eng.plan_export(*blk_mine, rid_add_a=base_a[r], rid_add_b=base_b[r])
+        return n
+
+    part_a = timed(plan_export_step, args.steps, args.warmup)
+    st_plan = eng.stats()
+    eng.set_profiling(True)
+    plan_export_step()
+    ph = eng.stats()
+    part_a["phase_ms"] = {k: round(v, 3) for k, v in ph["phase_ms"].items() if v > 0}
+    part_a["launches"] = int(sum(ph["phase_launches"].values()))
+    eng.set_profiling(False)
+
+    # ---- (B) the same shard through the one-call join (a context of its own: the form is the context's memory)
+    eng_b = HipEngine(0)
+    cap = (int(n_mine * 1.05) + 1024 + (1 << 19) - 1) >> 19 << 19
+    out = (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev))
+    n0 = eng_b.inner_plan(a, b, n_chrom)
+    eng_b.inner_fill(out[0][:n0], out[1][:n0])
+    part_b = timed(lambda: eng_b.inner_join_into(a, b, n_chrom, out[0], out[1]), args.steps, args.warmup)
+    st_join = eng_b.stats()
+    gpu_local = (n0, eng_b.pairs_checksum(out[0][:n0], out[1][:n0]))
+    eng_b.set_profiling(True)
+    eng_b.inner_join_into(a, b, n_chrom, out[0], out[1])
+    phb = eng_b.stats()
+    part_b["phase_ms"] = {k: round(v, 3) for k, v in phb["phase_ms"].items() if v > 0}
+    part_b["launches"] = int(sum(phb["phase_launches"].values()))
+    wa, wb = ora.c_inner(ora.Side(*ha), ora.Side(*hb), "sweep")
+    cpu_local = (int(wa.shape[0]), ora.c_pairs_checksum(wa, wb))
+    del wa, wb, out
+    eng_b.close()
+
+    # ---- (C) every rank's block (peers planned here one after the other), then the timed expansion of all of them
+    blocks = [None] * N
+    blocks[r] = (n_mine, qa_mine, blk_mine)
+    del mine, a, b
+    for q in range(N):
+        if q != r:
+            sides = shard_sides(q)
+            blocks[q] = export_block(sides, q)
+            del sides
+    total = sum(bk[0] for bk in blocks)
+    offs = [sum(bk[0] for bk in blocks[:q]) for q in range(N)]
+    gcap = (int(total) + (1 << 19) - 1) >> 19 << 19
+    gout = (torch.empty(gcap, dtype=torch.int32, device=dev), torch.empty(gcap, dtype=torch.int32, device=dev))
+
+    def expand_all():
+        for q, (n_q_pairs, q_is_a, blk) in enumerate(blocks):
+            if n_q_pairs == 0:
+                continue
+            rq, rs = (gout[0], gout[1]) if q_is_a else (gout[1], gout[0])
+            eng.fill_from_plan(blk[0], blk[1], blk[2], blk[3], rq[offs[q]:offs[q] + n_q_pairs],
+                               rs[offs[q]:offs[q] + n_q_pairs], n_pairs_expected=n_q_pairs)
+
+    part_c = timed(expand_all, args.steps, args.warmup)
+    gpu_all = (int(total), eng.pairs_checksum(gout[0][:total], gout[1][:total]))
+    parity = {"local_join_pairs_equal": gpu_local[0] == cpu_local[0] == n_mine,
+              "local_join_checksum_equal": gpu_local[1] == cpu_local[1]}
+    cpu_baseline = None
+    if not args.no_cpu_baseline:
+        cpu_baseline, ref = cpu_baseline_inner(args, wl, n_chrom, layout, whole=True)
+        parity.update({"expanded_pairs_equal": ref[0] == gpu_all[0], "expanded_checksum_equal": ref[1] == gpu_all[1]})
+        cpu_baseline["parity"] = parity
+    block_bytes = [4 * sum(int(t.numel()) for t in bk[2]) for bk in blocks]
+    line = {
+        "metric": f"per-rank parts of a step, rank {r} of {N}, {short(n_a)}x{short(n_b)} INTERSECTS inner join (ONE GPU; no wire)",
+        "value": round(n_mine / (part_b["ms_per_step"] * 1e-3), 1), "unit": "pairs/s (this rank's one-call join)",
+        "n_gpus": 1, "shard_of": N, "shard_rank": r, "steps": args.steps, "warmup": args.warmup,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": wl, "chromosomes": layout[r], "rows_a": size_a[r], "rows_b": size_b[r], "pairs": n_mine,
+                   "all_ranks_rows_b": size_b, "all_ranks_pairs": [bk[0] for bk in blocks]},
+        "local_plan_export": {**part_a, "sort_local": st_plan["sort_local"], "count_fused": st_plan["count_fused"],
+                              "join_form": st_plan["join_form"], "span_hist": st_plan["span_hist"]},
+        "local_one_call_join": {**part_b, "bucket_join": st_join["bucket_join"], "sort_local": st_join["sort_local"],
+                                "join_form": st_join["join_form"]},
+        "expand_all_blocks": {**part_c, "pairs": int(total), "blocks": N},
+        "plan_block_bytes": block_bytes,
+        "cpu_baseline": cpu_baseline,
+        "parity": parity,
+        "gen_seconds": round(gen_s, 1),
+    }
+    eng.close()
+    return line
 
 
 # ------------------------------------------------------------------------ the INNER run
@@ -746,7 +911,7 @@ def run_inner(args):
                 "join_form": form,
                 "presorted_side_skipped_its_sort": bool(st.get("presorted", False)),
                 "span_hist": span_hist,
-                "sort": ("two global passes + in-LDS bucket sort for sides >= 32M rows" if st.get("sort_local")
+                "sort": ("two global passes + in-LDS bucket sort for sides of 300-2800 rows per 16-bit bucket" if st.get("sort_local")
                          else "four global passes"),
                 "pairs_written_by": ("the bucket stage of the sort (k_bucket_sort<1, 2>: no count / scan / fill kernel)"
                                      if st.get("bucket_join") else "k_fill"),
@@ -782,7 +947,16 @@ def inner_extras(eng, dev_index, a, b, ha, hb, n_chrom, n_pairs, alloc_out, join
 
     out = {}
     try:
-        out["measured_copy_GBps"] = round(eng.copy_probe(), 1)
+        # the box's streaming ceiling by access shape (giql_hip_stream_probe_dev): best read-only / write-only / copy
+        # rate over {1, 4, 8 accesses in flight} x {default, non-temporal} x {4, 8, 16 blocks per CU}, every byte
+        # moved counted once, + hipMemcpyDtoDAsync as an outside reference; measured_copy16 is round 3's naive probe
+        # (one 16-byte load in flight per thread), kept for comparison
+        pr = eng.stream_probe(nbytes=1024 << 20, reps=3)
+        out["measured_read_GBps"], out["measured_write_GBps"] = pr["read"], pr["write"]
+        out["measured_copy_GBps"], out["measured_memcpy_d2d_GBps"] = pr["copy"], pr["memcpy_d2d"]
+        out["measured_best_shapes"] = {k: max((v, n) for n, v in pr["shapes"].items() if n.startswith(k + "/"))[1]
+                                       for k in ("read", "write", "copy")}
+        out["measured_copy16_GBps"] = round(eng.copy_probe(), 1)
     except Exception as exc:  # e.g. not enough free HBM next to the workload
         out["measured_copy_GBps"] = None
         out["measured_copy_error"] = str(exc)[:200]
@@ -1061,7 +1235,7 @@ def main() -> None:
     args = parse_args()
     self_launch(args)
     op = WORKLOADS[args.workload][0]
-    line = run_inner(args) if op == "inner" else run_rowop(args)
+    line = run_shard(args) if args.shard_of else (run_inner(args) if op == "inner" else run_rowop(args))
     if line is not None:
         print(json.dumps(line), flush=True)
         parity = ((line.get("cpu_baseline") or {}).get("parity") or {})

@@ -38,7 +38,7 @@ SYMBOLS = [
     "giql_hip_select_dev", "giql_hip_select_expr_dev", "giql_hip_mark_dev", "giql_hip_cluster_dev", "giql_hip_cluster_pred_dev", "giql_hip_merge_dev", "giql_hip_merge_pred_dev",
     "giql_hip_group_rows_dev", "giql_hip_segment_sum_dev", "giql_hip_inner_join_dev",
     "giql_hip_inner_plan_export_dev", "giql_hip_fill_from_plan_dev", "giql_hip_copy_probe_dev",
-    "giql_hip_nearest_k_dev",
+    "giql_hip_nearest_k_dev", "giql_hip_stream_probe_dev", "giql_hip_host_pool_trim",
 ]
 
 
@@ -180,6 +180,8 @@ def load() -> ctypes.CDLL:
     L.giql_hip_inner_plan_export_dev.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, P(i32), P(i64), P(i64), vp]
     L.giql_hip_fill_from_plan_dev.argtypes = [vp, vp, vp, vp, i64, vp, i64, vp, vp, i64, i64, vp, P(i64)]
     L.giql_hip_copy_probe_dev.argtypes = [vp, vp, vp, i64, i32, vp, P(ctypes.c_double)]
+    L.giql_hip_stream_probe_dev.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, i32, vp, P(ctypes.c_double)]
+    L.giql_hip_host_pool_trim.argtypes = [i64, P(i64)]
     L.giql_hip_merge_dev.argtypes = [vp, P(CSide), i32, i64, vp, vp, vp, vp, i64, P(i64), vp]
     L.giql_hip_merge_pred_dev.argtypes = [vp, P(CSide), i32, i64, P(CPred), i32, vp, vp, vp, vp, i64, P(i64), vp]
     _lib = L

@@ -25,6 +25,7 @@
 #include "bucket_sort.hip.h"
 #include "radix_sort.hip.h"
 #include "scan.hip.h"
+#include "probe_kernels.hip.h"
 
 using namespace giql;
 
@@ -163,11 +164,12 @@ struct giql_hip_ctx {
   int row_skip_digits = -1;    // GIQL_HIP_ROW_SKIP_DIGITS: low digits the per-row operators leave unsorted on their query side (-1: by density, row_skip())
   u64 last_span = 0;           // linearised span of the context's last call: the density guess of row_skip() / sort_is_local()
   double local_max_bucket_rows = 2800.0;  // three-stage sort only while a 16-bit bucket holds at most this many rows on average
+  double local_min_bucket_rows = 300.0;   // ... and at least this many (below: a block per bucket is mostly overhead)
   bool no_skip_digit = false;  // GIQL_HIP_NO_SKIP_DIGIT=1: query sides are sorted on every digit
   bool no_coarse_b = false;    // GIQL_HIP_NO_COARSE_B=1: the fixed-length B of SEMI / ANTI / COUNT is sorted on every digit
   double coarse_max_group_rows = 8.0;  // ... and coarsely only while the rows sharing their upper 24 key bits are at most this many on average
   bool local_sort = true;
-  u64 local_min_rows = 1u << 25;
+  u64 local_min_rows = 1u << 21;  // (round 4: a floor only; the density bounds above decide)
   int local_resorts = 0;      // calls repeated with the four-pass sort
   bool last_sort_local = false;  // the call in flight sorted at least one side in three stages
   // fused range count (fixed-length INNER form whose sorted side takes the three-stage sort): the bucket
@@ -529,8 +531,13 @@ static inline bool sort_is_local(const giql_hip_ctx* ctx, size_t n) {
   // only while the AVERAGE bucket is comfortably below that -- by the span of the context's previous call
   // (a human-genome-sized axis until one has run); denser tables take the four global passes.  The value is
   // constant during a call (updated when it ends), so every decision of one call agrees.
+  // Round 4: what decides is the DENSITY, not the row count -- a 12.5M-row shard of an 8-GPU run has the headline's
+  // ~2,100 rows per bucket on an eighth of the axis and takes the same path (fused count, join in the bucket stage);
+  // a 10M-row table over the whole genome (212 rows per bucket) does not: a block per bucket is mostly overhead there
+  // (0.135 ms against 0.106 for the two passes it replaces).
   const double span = ctx->last_span ? (double)ctx->last_span : 3.2e9;
-  return (double)n * 65536.0 / span <= ctx->local_max_bucket_rows;
+  const double per_bucket = (double)n * 65536.0 / span;
+  return per_bucket <= ctx->local_max_bucket_rows && per_bucket >= ctx->local_min_bucket_rows;
 }
 
 // skip_digits = 1 (four-pass form only): the lowest digit is left unsorted -- rows come out ordered
@@ -997,7 +1004,10 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     if (lm) {
       ctx->local_min_rows = strtoull(lm, nullptr, 10);
       ctx->local_max_bucket_rows = 1e30;  // a forced size threshold (tests, sweeps) is not second-guessed by density
+      ctx->local_min_bucket_rows = 0.0;
     }
+    const char* lnb = getenv("GIQL_HIP_LOCAL_MIN_BUCKET_ROWS");
+    if (lnb && atof(lnb) >= 0) ctx->local_min_bucket_rows = atof(lnb);
     const char* lmb = getenv("GIQL_HIP_LOCAL_MAX_BUCKET_ROWS");
     if (lmb && atof(lmb) > 0) ctx->local_max_bucket_rows = atof(lmb);
   }
@@ -2961,6 +2971,57 @@ int giql_hip_copy_probe_dev(giql_hip_ctx* ctx, const void* src, void* dst, int64
   return GIQL_OK;
 }
 
+// The same question asked properly (round 4): what does this device read / write / copy per second, by access
+// shape?  mode 0 read only, 1 write only, 2 copy, 3 hipMemcpyDtoDAsync (an outside reference); in_flight = 16-byte
+// accesses a thread keeps in flight (1, 2, 4 or 8); nontemporal = nt loads and stores; blocks_per_cu sizes the grid
+// (256-thread blocks).  *gbytes_per_s counts every byte moved: read for mode 0, written for 1, both for 2 / 3.
+int giql_hip_stream_probe_dev(giql_hip_ctx* ctx, const void* src, void* dst, int64_t bytes, int32_t mode,
+                              int32_t in_flight, int32_t nontemporal, int32_t blocks_per_cu, int32_t reps, void* stream,
+                              double* gbytes_per_s) {
+  if (!ctx || !src || !dst || !gbytes_per_s || bytes < (1 << 20) || reps < 1 || mode < 0 || mode > 3 ||
+      blocks_per_cu < 1 || blocks_per_cu > 64 || (in_flight != 1 && in_flight != 2 && in_flight != 4 && in_flight != 8))
+    return set_err(GIQL_ERR_INVALID, "bad arguments");
+  if (((uintptr_t)src | (uintptr_t)dst) & 15) return set_err(GIQL_ERR_INVALID, "buffers must be 16-byte aligned");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const u64 tile = (u64)256 * (u64)in_flight;
+  const u64 n16 = (u64)bytes / 16 / tile * tile;  // whole tiles only
+  const u32 grid = (u32)ctx->n_cu * (u32)blocks_per_cu;
+  auto once = [&]() {
+    const probe_u4* s = (const probe_u4*)src;
+    probe_u4* d = (probe_u4*)dst;
+    u32* sk = ctx->bucket_qwin;  // the read-only form's sink (256 words, rewritten by every join that reads them)
+    if (mode == 3) {
+      (void)hipMemcpyDtoDAsync((hipDeviceptr_t)dst, (hipDeviceptr_t)src, n16 * 16, st);
+    } else if (nontemporal) {
+      if (mode == 0) launch_stream_probe<0, true>(in_flight, grid, st, s, d, n16, sk);
+      else if (mode == 1) launch_stream_probe<1, true>(in_flight, grid, st, s, d, n16, sk);
+      else launch_stream_probe<2, true>(in_flight, grid, st, s, d, n16, sk);
+    } else {
+      if (mode == 0) launch_stream_probe<0, false>(in_flight, grid, st, s, d, n16, sk);
+      else if (mode == 1) launch_stream_probe<1, false>(in_flight, grid, st, s, d, n16, sk);
+      else launch_stream_probe<2, false>(in_flight, grid, st, s, d, n16, sk);
+    }
+  };
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  once();  // warm-up
+  (void)hipEventRecord(e0, st);
+  for (int r = 0; r < reps; r++) once();
+  (void)hipEventRecord(e1, st);
+  hipError_t e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return set_err(GIQL_ERR_HIP, "stream probe failed: %s", hipGetErrorString(e));
+  GIQL_TRY(post_launch("stream probe"));
+  const double moved = (mode >= 2 ? 2.0 : 1.0) * (double)(n16 * 16) * reps;
+  *gbytes_per_s = ms > 0.f ? moved / ((double)ms * 1e6) : 0.0;
+  return GIQL_OK;
+}
+
 // ------------------------------------------------ projection (Arrow take)
 int giql_hip_take_dev(giql_hip_ctx* ctx, const void* const* cols, const int32_t* elem_bytes,
                       int32_t n_cols, int64_t n_rows, const int32_t* idx, int64_t n,
@@ -3278,6 +3339,32 @@ static HostPool& host_pool() {
   return *pool;
 }
 static void* host_alloc(size_t bytes) { return host_pool().get(bytes ? bytes : 1); }
+
+int giql_hip_host_pool_trim(int64_t keep_bytes, int64_t* released) {
+  if (keep_bytes < 0) return set_err(GIQL_ERR_INVALID, "keep_bytes < 0");
+  HostPool& hp = host_pool();
+  std::vector<void*> drop;
+  size_t freed = 0;
+  {
+    std::lock_guard<std::mutex> g(hp.mu);
+    size_t idle = 0;
+    for (auto& b : hp.bufs)
+      if (b.idle) idle += b.bytes;
+    while (idle > (size_t)keep_bytes) {  // the largest first: they are what a trim is called for
+      size_t k = hp.bufs.size();
+      for (size_t i = 0; i < hp.bufs.size(); i++)
+        if (hp.bufs[i].idle && (k == hp.bufs.size() || hp.bufs[i].bytes > hp.bufs[k].bytes)) k = i;
+      if (k == hp.bufs.size()) break;
+      idle -= hp.bufs[k].bytes;
+      freed += hp.bufs[k].bytes;
+      drop.push_back(hp.bufs[k].p);
+      hp.bufs.erase(hp.bufs.begin() + (long)k);
+    }
+  }
+  for (void* d : drop) (void)hipHostFree(d);
+  if (released) *released = (int64_t)freed;
+  return GIQL_OK;
+}
 
 struct DevBuf {
   void* p = nullptr;

@@ -72,7 +72,16 @@ class DeviceSide:
         so, eo = ENCODING_OFFSETS[tuple(encoding)]
 
         def up(x):
-            return torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(device)
+            x = np.ascontiguousarray(x, dtype=np.int32)
+            if x.flags.writeable:
+                return torch.from_numpy(x).to(device)
+            # read-only memory (cached chromosome ids, read-only Arrow buffers): torch warns about aliasing it; the
+            # host tensor here is only ever READ, by the upload on the next line, and dropped
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", UserWarning)
+                return torch.from_numpy(x).to(device)
 
         return cls(up(chrom), up(start), up(end), so, eo)
 
@@ -210,10 +219,22 @@ class HipEngine:
         # result -- for large tables the pairs are then written by the sort's last stage itself, with no count /
         # scan / fill kernels and no read-back in between.  A result that does not fit comes back as
         # GIQL_ERR_CAPACITY with the exact count and a plan behind it: the ordinary fill follows.
+        # The guess belongs to the INPUTS it was made on: for tables of another size it is scaled by the product of
+        # the row counts (the same density assumed) and never exceeds n_a * n_b or a third of the free HBM -- a
+        # guess left by a 404M-pair join must not size the buffers of a 1,000-row sub-join.
         guess = getattr(self, "_pairs_guess", 0)
+        g_na, g_nb = getattr(self, "_pairs_guess_rows", (a.n, b.n))
+        if guess > 0 and a.n and b.n and (g_na, g_nb) != (a.n, b.n):
+            guess = int(guess * (a.n / max(g_na, 1)) * (b.n / max(g_nb, 1))) + 1
+        guess = min(guess, a.n * b.n)
         row_a = row_b = None
         if out is None and guess > 0 and a.n and b.n:
-            cap = int(guess * 1.05) + 4096
+            cap = min(int(guess * 1.05) + 4096, a.n * b.n)
+            try:
+                free = int(torch.cuda.mem_get_info(self.device)[0])
+                cap = min(cap, max(free // 24, 4096))     # two int32 arrays within a third of what is free
+            except Exception:  # pragma: no cover
+                pass
             try:   # (a guess left over from a much larger join must not be what runs the device out of memory)
                 row_a = torch.empty(cap, dtype=torch.int32, device=self.device)
                 row_b = torch.empty(cap, dtype=torch.int32, device=self.device)
@@ -223,7 +244,7 @@ class HipEngine:
         if row_a is not None and row_b is not None:
             try:
                 n = self.inner_join_into(a, b, n_chrom, row_a, row_b)
-                self._pairs_guess = n
+                self._pairs_guess, self._pairs_guess_rows = n, (a.n, b.n)
                 return row_a[:n], row_b[:n]
             except _lib.GiqlHipError as exc:
                 if exc.code == _lib.GIQL_ERR_SPAN:
@@ -235,7 +256,7 @@ class HipEngine:
                 row_a = torch.empty(n, dtype=torch.int32, device=self.device)
                 row_b = torch.empty(n, dtype=torch.int32, device=self.device)
                 self.inner_fill(row_a, row_b)
-                self._pairs_guess = n
+                self._pairs_guess, self._pairs_guess_rows = n, (a.n, b.n)
                 return row_a, row_b
         try:
             n = self.inner_plan(a, b, n_chrom)
@@ -243,7 +264,7 @@ class HipEngine:
             if exc.code != _lib.GIQL_ERR_SPAN:
                 raise
             return self._inner_by_groups(a, b, n_chrom)
-        self._pairs_guess = n
+        self._pairs_guess, self._pairs_guess_rows = n, (a.n, b.n)
         if out is not None and out[0].shape[0] >= n:
             row_a, row_b = out[0][:n], out[1][:n]
         else:
@@ -840,3 +861,41 @@ class HipEngine:
         _lib.check(self._L.giql_hip_copy_probe_dev(self._h, src.data_ptr(), dst.data_ptr(), int(src.numel()) * 4,
                                                    int(reps), self._stream(), ctypes.byref(g)))
         return float(g.value)
+
+    def stream_probe(self, nbytes: int = 1600 << 20, reps: int = 5, shapes=None) -> dict:
+        """What this device reads / writes / copies per second (GB/s, every byte moved counted once), by access
+        shape: ``{"read": best, "write": best, "copy": best, "memcpy_d2d": x, "shapes": {label: GB/s}}`` --
+        16 B per lane with 1 / 4 / 8 accesses in flight, default and non-temporal cache policy, grids of
+        ``n_cu x {4, 8, 16}`` blocks (``giql_hip_stream_probe_dev``).  The ceiling the kernels are held against."""
+        torch = _torch()
+        src = torch.empty(nbytes // 4, dtype=torch.int32, device=self.device)
+        dst = torch.empty_like(src)
+        src.fill_(1)
+        dst.fill_(2)
+        g = ctypes.c_double(0.0)
+
+        def run(mode, in_flight, nt, per_cu):
+            _lib.check(self._L.giql_hip_stream_probe_dev(
+                self._h, src.data_ptr(), dst.data_ptr(), int(src.numel()) * 4, mode, in_flight, int(nt), per_cu,
+                int(reps), self._stream(), ctypes.byref(g)))
+            return float(g.value)
+
+        if shapes is None:
+            shapes = [(u, nt, per_cu) for u in (1, 4, 8) for nt in (0, 1) for per_cu in (4, 8, 16)]
+        out = {"shapes": {}}
+        for name, mode in (("read", 0), ("write", 1), ("copy", 2)):
+            best = 0.0
+            for u, nt, per_cu in shapes:
+                v = run(mode, u, nt, per_cu)
+                out["shapes"][f"{name}/x{u}/{'nt' if nt else 'dflt'}/{per_cu}perCU"] = round(v, 1)
+                best = max(best, v)
+            out[name] = round(best, 1)
+        out["memcpy_d2d"] = round(run(3, 1, 0, 8), 1)
+        return out
+
+    @staticmethod
+    def host_pool_trim(keep_bytes: int = 0) -> int:
+        """Return idle page-locked output buffers of the host-buffer entry points to the OS; bytes released."""
+        freed = ctypes.c_int64(0)
+        _lib.check(_lib.load().giql_hip_host_pool_trim(int(keep_bytes), ctypes.byref(freed)))
+        return int(freed.value)

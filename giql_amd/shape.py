@@ -264,6 +264,52 @@ def operand_sides(o: Operand) -> set:
     return walk(o.value)
 
 
+#: what one call of the select kernel takes (``check_program`` in ``csrc/giql_hip.hip``: ``SEL_X_STACK`` values
+#: live, 64 postfix nodes per call): the gate declines what the target cannot run instead of failing at run time
+MAX_EXPR_DEPTH = 8
+MAX_EXPR_NODES = 64
+
+
+def expression_cost(o: Operand) -> tuple:
+    """``(postfix nodes, values live at once)`` of an operand as ``HipEngine._flatten_expr`` lays it out: a leaf is
+    one node and one value; an n-ary function folds pairwise (n - 1 operator nodes, its first argument's result
+    stays on the stack while the next is evaluated); a unary one adds a node."""
+    if o.kind != "expr":
+        return (0, 0)
+
+    def walk(t):
+        if t[0] != "fn":
+            return (1, 1)
+        kids = [walk(c) for c in t[2]]
+        if not kids:
+            return (1, 1)
+        nodes = sum(k[0] for k in kids) + max(len(kids) - 1, 1)
+        depth = max([kids[0][1]] + [1 + k[1] for k in kids[1:]])
+        return (nodes, depth)
+
+    return walk(o.value)
+
+
+def check_expression_sizes(residuals, kind: str) -> None:
+    """Decline (never a run-time error) a condition whose arithmetic one select call cannot hold: an operand deeper
+    than ``MAX_EXPR_DEPTH``, or more than ``MAX_EXPR_NODES`` nodes among the residuals ``execute()`` evaluates in
+    one call -- those reading the same tables (left only: before the join; right only; both: on the pairs), and
+    for SEMI / ANTI the WHERE residuals on their own."""
+    per_call: dict = {}
+    for r in residuals:
+        nodes = 0
+        for o in (r.lhs, r.rhs):
+            n, d = expression_cost(o)
+            if d > MAX_EXPR_DEPTH:
+                raise decline(f"expression too deep for the select kernel ({d} values live, at most {MAX_EXPR_DEPTH})")
+            nodes += n
+        sides = frozenset(operand_sides(r.lhs) | operand_sides(r.rhs))
+        call = ("where" if kind in ("SEMI", "ANTI") and r.clause == "where" else "on", sides)
+        per_call[call] = per_call.get(call, 0) + nodes
+        if per_call[call] > MAX_EXPR_NODES:
+            raise decline(f"expressions too large for one select call ({per_call[call]} nodes, at most {MAX_EXPR_NODES})")
+
+
 def resolve_residuals(clause_terms, left: PlanSide, right: PlanSide, kind: str) -> tuple:
     """``[(clause, term)]`` -> residuals.  A term is a comparison ``("cmp", lhs, op, rhs)`` or
     a disjunction ``("or", [cmp, ...])``; the members of one disjunction share a fresh group id."""
@@ -274,6 +320,7 @@ def resolve_residuals(clause_terms, left: PlanSide, right: PlanSide, kind: str) 
             out.extend(resolve_residual(clause, leaf, left, right, kind, group) for leaf in t[1])
         else:
             out.append(resolve_residual(clause, t, left, right, kind))
+    check_expression_sizes(out, kind)
     return tuple(out)
 
 

@@ -434,6 +434,25 @@ int giql_hip_copy_probe_dev(giql_hip_ctx* ctx, const void* src, void* dst,
                             int64_t bytes, int32_t reps, void* stream,
                             double* gbytes_per_s);
 
+/* What this device reads / writes / copies per second, by access shape (round 4:
+ * the measured ceiling the kernels are held against; SURVEY.md section 8d "verify
+ * on the box with a copy kernel").  mode 0 = read only, 1 = write only, 2 = copy,
+ * 3 = hipMemcpyDtoDAsync (an outside reference); in_flight = 16-byte accesses a
+ * thread keeps in flight (1 / 2 / 4 / 8); nontemporal = nt loads and stores;
+ * blocks_per_cu sizes the grid of 256-thread blocks.  *gbytes_per_s counts every
+ * byte moved (read for mode 0, written for mode 1, both for 2 / 3), / 1e9. */
+int giql_hip_stream_probe_dev(giql_hip_ctx* ctx, const void* src, void* dst,
+                              int64_t bytes, int32_t mode, int32_t in_flight,
+                              int32_t nontemporal, int32_t blocks_per_cu,
+                              int32_t reps, void* stream, double* gbytes_per_s);
+
+/* The host-buffer entry points (giql_hip_inner & co.) keep released page-locked
+ * output buffers for the next call (up to GIQL_HIP_HOST_POOL_MB, default 8192).
+ * This returns every idle one beyond keep_bytes to the OS; *released (optional)
+ * = bytes freed.  Buffers a caller still owns are untouched.  There is no
+ * reference counterpart: DuckDB owns its buffers (conn.execute(sql)). */
+int giql_hip_host_pool_trim(int64_t keep_bytes, int64_t* released);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,10 @@ ARITH = [
     ("INNER", "(a.end - a.start) / (a.score - 2.0) > 50", ""),
     ("SEMI", "(LEAST(a.end, b.end) - GREATEST(a.start, b.start)) * 2 >= a.end - a.start", "a.end - a.start BETWEEN 20 AND 250"),
     ("ANTI", "ABS(a.start - b.start) < 60", "NOT a.score * a.score > 9"),
+    # IS [NOT] NULL over an expression (accepted by the gate, crashed in execute())
+    ("INNER", "", "(a.score + 1) IS NULL OR (b.score - a.score) IS NOT NULL AND a.score > 2"),
+    ("INNER", "(a.score * b.score) IS NOT NULL", "(a.end - a.start) IS NOT NULL"),
+    ("ANTI", "(a.score + b.score) IS NULL", ""),
 ]
 
 

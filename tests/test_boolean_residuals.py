@@ -258,3 +258,42 @@ def test_random_conditions_normalise_to_what_three_valued_logic_gives(seed):
     for p in rows:
         for g in rows:
             assert _holds(plan.residuals, p, g) == (truth(p, g) is True), (text, p[4], g[4])
+
+
+# ---- what one select call holds: the gate declines, never a run-time error -------------------------
+def _nested_sum(depth_levels: int) -> str:
+    """1 + (2 + (... + (k + a.score))): a right-nested sum keeps one more value live per level."""
+    expr = "a.score"
+    for k in range(depth_levels, 0, -1):
+        expr = f"{k} + ({expr})"
+    return expr
+
+
+def test_expression_depth_and_size_limits_are_declined_at_plan_time():
+    from giql_amd.shape import MAX_EXPR_DEPTH, MAX_EXPR_NODES, HipDeclined, expression_cost
+
+    base = "SELECT a.name FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval WHERE "
+    # depth: k nested levels keep k + 1 values live
+    ok = build_plan(base + _nested_sum(MAX_EXPR_DEPTH - 1) + " > 3", ["peaks", "genes"])
+    nodes, depth = expression_cost(ok.residuals[0].lhs)
+    assert depth == MAX_EXPR_DEPTH and nodes == 2 * (MAX_EXPR_DEPTH - 1) + 1
+    with pytest.raises(HipDeclined, match="too deep"):
+        build_plan(base + _nested_sum(MAX_EXPR_DEPTH) + " > 3", ["peaks", "genes"])
+    # a LEFT-nested sum of any length keeps two values live: only the node count bounds it
+    flat = " + ".join(["a.score"] * 32)                      # 32 leaves + 31 operators = 63 nodes
+    p = build_plan(base + flat + " > b.score", ["peaks", "genes"])
+    assert expression_cost(p.residuals[0].lhs) == (63, 2)
+    with pytest.raises(HipDeclined, match="too large"):
+        build_plan(base + " + ".join(["a.score"] * 33) + " > b.score", ["peaks", "genes"])   # 65 nodes
+    # the nodes of ONE select call add up over its comparisons (here: all two-sided, AND-ed) ...
+    recipe = "(LEAST(a.end, b.end) - GREATEST(a.start, b.start)) >= 0.5 * (b.end - b.start)"   # 12 nodes
+    assert sum(expression_cost(o)[0] for o in (build_plan(base + recipe, ["peaks", "genes"]).residuals[0].lhs,
+                                               build_plan(base + recipe, ["peaks", "genes"]).residuals[0].rhs)) == 12
+    build_plan(base + " AND ".join(recipe.replace("0.5", f"0.{k}") for k in range(1, 6)), ["peaks", "genes"])      # 60 nodes
+    with pytest.raises(HipDeclined, match="too large"):
+        build_plan(base + " OR ".join(recipe.replace("0.5", f"0.{k}") for k in range(1, 7)), ["peaks", "genes"])   # 72 nodes
+    # ... but one-sided conditions run in calls of their own
+    left = " + ".join(["a.score"] * 30) + " > 0"                                             # 59 nodes, left only
+    right = " + ".join(["b.score"] * 30) + " > 0"                                            # 59 nodes, right only
+    assert len(build_plan(base + left + " AND " + right, ["peaks", "genes"]).residuals) == 2
+    assert MAX_EXPR_NODES == 64

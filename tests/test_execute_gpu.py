@@ -768,36 +768,139 @@ def test_large_result_columns_come_back_through_pinned_memory(monkeypatch, peaks
     assert rows_of(got) == want and len(want) > 0
 
 
-def test_long_tables_are_uploaded_once(monkeypatch):
-    # execute._device_side keeps the device copy of a long Arrow table's (chrom id, start, end) for the next query
-    # over the same buffers; another table of the same shape is another entry
+def _long_table(n, seed, backing="arrow"):
+    names = np.array(["chr1", "chr2", "chr3"])
+    r = np.random.default_rng(seed)
+    s = r.integers(0, 50_000_000, n).astype(np.int32)
+    e = (s + r.integers(1, 300, n)).astype(np.int32)
+    rest = {"name": pa.array(np.arange(n).astype(str)), "score": r.integers(0, 9, n).astype(np.int32),
+            "strand": pa.array(np.array(["+", "-"])[r.integers(0, 2, n)])}
+    cols = {"chrom": pa.array(names[r.integers(0, 3, n)]), "start": pa.array(s), "end": pa.array(e), **rest}
+    return pa.table(cols), s, e
+
+
+_SEMI_Q = ("SELECT a.start, a.score FROM peaks a SEMI JOIN genes b ON a.interval INTERSECTS b.interval "
+           "AND a.strand = b.strand")
+
+
+def test_long_pinned_tables_are_uploaded_once(monkeypatch):
+    # execute._device_side keeps the device copy of a long table's (chrom id, start, end) for the next query over the
+    # same buffers -- for tables the caller has PINNED (giql_amd.pin: the promise that their memory does not change);
+    # another table of the same shape is another entry; unpin / clear_caches drop what was derived
+    import giql_amd
     from giql_amd import execute as X
     from giql_amd.engine import DeviceSide
 
-    rng = np.random.default_rng(3)
-    names = np.array(["chr1", "chr2", "chr3"])
-
-    def table(n, seed):
-        r = np.random.default_rng(seed)
-        s = r.integers(0, 50_000_000, n).astype(np.int32)
-        return pa.table({"chrom": pa.array(names[r.integers(0, 3, n)]), "start": s, "end": (s + r.integers(1, 300, n)).astype(np.int32),
-                         "name": pa.array(np.arange(n).astype(str)), "score": r.integers(0, 9, n).astype(np.int32),
-                         "strand": pa.array(np.array(["+", "-"])[r.integers(0, 2, n)])})
-
-    t = {"peaks": table(1_100_000, 1), "genes": table(1_050_000, 2)}
-    plan = transpile("SELECT a.start, a.score FROM peaks a SEMI JOIN genes b ON a.interval INTERSECTS b.interval AND a.strand = b.strand",
-                     tables=["peaks", "genes"], dialect="hip")
+    peaks, genes, genes2 = (giql_amd.pin(_long_table(n, seed)[0]) for n, seed in
+                            ((1_100_000, 1), (1_050_000, 2), (1_050_000, 5)))
+    t = {"peaks": peaks, "genes": genes}
+    plan = transpile(_SEMI_Q, tables=["peaks", "genes"], dialect="hip")
     uploads = []
     real = DeviceSide.from_numpy.__func__
     monkeypatch.setattr(DeviceSide, "from_numpy", classmethod(lambda cls, *a, **k: uploads.append(1) or real(cls, *a, **k)))
     monkeypatch.setattr(X, "_SIDES_CACHE", None)
     first = execute(plan, t)
     n1 = len(uploads)
-    second = execute(plan, t)
+    second = execute(plan, {"peaks": peaks.table, "genes": genes})   # (the table itself stands for its pin)
     assert n1 == 2 and len(uploads) == 2 and second.equals(first) and first.num_rows > 1000
-    other = dict(t, genes=table(1_050_000, 5))
-    third = execute(plan, other)
+    info = X.cache_info()
+    assert info["sides"] == 2 and info["hbm_bytes"] == 12 * (1_100_000 + 1_050_000)
+    third = execute(plan, dict(t, genes=genes2))
     # (both sides again: the chromosome ids belong to the PAIR's shared dictionary)
     assert len(uploads) == 4 and not third.equals(first)
-    monkeypatch.setattr(X, "_SIDES_CACHE_SLOTS", 0)
+    genes2.unpin()      # ... drops the entries derived from it (both sides of that pair: one key each)
+    assert X.cache_info()["sides"] == 3
+    held = X.clear_caches()
+    assert held["sides"] == 3 and X.cache_info()["sides"] == 0 and X.cache_info()["codes"] == 0
+    assert execute(plan, t).equals(first) and len(uploads) == 6     # derived again, still pinned
     assert execute(plan, t).equals(first) and len(uploads) == 6
+    monkeypatch.setattr(X, "_SIDES_CACHE_SLOTS", 0)
+    assert execute(plan, t).equals(first) and len(uploads) == 8
+    peaks.unpin(), genes.unpin()
+    assert X.cache_info()["pinned_chunks"] == 0
+
+
+@pytest.mark.parametrize("backing", ["pa.array(numpy)", "from_pandas"])
+def test_tables_changed_in_place_between_calls_give_the_new_rows(backing):
+    # an Arrow column built from numpy / pandas aliases that memory zero-copy; a device copy
+    # keyed by buffer addresses would serve the OLD coordinates after an in-place update.  Nothing is kept for such
+    # tables unless they are pinned.
+    import pandas as pd
+
+    from giql_amd import execute as X
+
+    X.clear_caches()
+    n = 1_200_000
+    _t, s, e = _long_table(n, 11)
+    g, gs, ge = _long_table(1_050_000, 12)
+    chrom = np.array(["chr1", "chr2", "chr3"])[np.random.default_rng(1).integers(0, 3, n)]
+    if backing == "from_pandas":
+        df = pd.DataFrame({"start": s, "end": e, "score": np.arange(n, dtype=np.int32) % 9})
+        peaks = pa.Table.from_pandas(df, preserve_index=False).append_column("chrom", pa.array(chrom))
+        s_mem, e_mem = df["start"].to_numpy(), df["end"].to_numpy()
+        assert peaks.column("start").chunk(0).buffers()[1].address == s_mem.ctypes.data     # zero-copy: the premise
+    else:
+        peaks = pa.table({"chrom": pa.array(chrom), "start": pa.array(s), "end": pa.array(e),
+                          "score": pa.array(np.arange(n, dtype=np.int32) % 9)})
+        s_mem, e_mem = s, e
+        assert peaks.column("start").chunk(0).buffers()[1].address == s.ctypes.data
+    q = "SELECT a.start, a.score FROM peaks a SEMI JOIN genes b ON a.interval INTERSECTS b.interval"
+    plan = transpile(q, tables=["peaks", "genes"], dialect="hip")
+    t = {"peaks": peaks, "genes": g}
+    first = execute(plan, t)
+    assert X.cache_info()["sides"] == 0          # nothing kept: the memory is not the caller's promise
+    # move every peak far away from every gene, in place
+    s_mem += 60_000_000
+    e_mem += 60_000_000
+    second = execute(plan, t)
+    assert first.num_rows > 1000 and second.num_rows == 0
+    s_mem -= 60_000_000
+    e_mem -= 60_000_000
+    assert execute(plan, t).equals(first)
+
+
+def test_pinned_table_refresh_after_an_in_place_change():
+    import giql_amd
+    from giql_amd import execute as X
+
+    X.clear_caches()
+    _t, s, e = _long_table(1_200_000, 21)
+    chrom = np.array(["chr1", "chr2", "chr3"])[np.random.default_rng(2).integers(0, 3, s.size)]
+    g = _long_table(1_050_000, 22)[0]
+    with giql_amd.pin(pa.table({"chrom": pa.array(chrom), "start": pa.array(s), "end": pa.array(e)})) as peaks, \
+            giql_amd.pin(g) as genes:
+        plan = transpile("SELECT a.start FROM peaks a SEMI JOIN genes b ON a.interval INTERSECTS b.interval",
+                         tables=["peaks", "genes"], dialect="hip")
+        t = {"peaks": peaks, "genes": genes}
+        first = execute(plan, t)
+        assert X.cache_info()["sides"] == 2
+        s += 60_000_000
+        e += 60_000_000
+        peaks.refresh()                      # the documented contract after an in-place change
+        assert X.cache_info()["sides"] == 1
+        assert execute(plan, t).num_rows == 0 and first.num_rows > 1000
+    assert X.cache_info()["sides"] == 0 and X.cache_info()["pinned_chunks"] == 0
+
+
+def test_immutable_buffers_are_kept_without_a_pin(monkeypatch, tmp_path):
+    # memory-mapped / IPC-read tables cannot be written behind Arrow's back: kept implicitly
+    import pyarrow.ipc as ipc
+
+    from giql_amd import execute as X
+    from giql_amd.engine import DeviceSide
+
+    X.clear_caches()
+    tabs = {}
+    for name, (n, seed) in {"peaks": (1_100_000, 31), "genes": (1_050_000, 32)}.items():
+        path = tmp_path / f"{name}.arrow"
+        with ipc.new_file(str(path), _long_table(n, seed)[0].schema) as w:
+            w.write_table(_long_table(n, seed)[0])
+        tabs[name] = ipc.open_file(pa.memory_map(str(path))).read_all()
+        assert not tabs[name].column("start").chunk(0).buffers()[1].is_mutable
+    uploads = []
+    real = DeviceSide.from_numpy.__func__
+    monkeypatch.setattr(DeviceSide, "from_numpy", classmethod(lambda cls, *a, **k: uploads.append(1) or real(cls, *a, **k)))
+    plan = transpile(_SEMI_Q, tables=["peaks", "genes"], dialect="hip")
+    first = execute(plan, tabs)
+    assert execute(plan, tabs).equals(first) and len(uploads) == 2 and X.cache_info()["sides"] == 2
+    X.clear_caches()

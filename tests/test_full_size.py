@@ -289,3 +289,82 @@ def test_join_past_2_pow_32_pairs_fused_count_and_chained_scan():
         assert st["join_form"] == "uniform_b" and st["sort_local"] and st["fused_fill"]
     finally:
         eng.close()
+
+
+# ---- the headline kernels at the headline size, on contexts of their own --------------------
+@pytest.fixture(scope="module")
+def cfg4():
+    """BASELINE config 4 (10M peaks x 100M reads, seeds 5 / 6) with the oracle's sweep: pair count, the 64-bit
+    multiset checksum in both argument orders and the per-row multiplicities (= count_overlaps)."""
+    a = ora.Side(*synth.make_table(10_000_000, 5, "peaks"))
+    b = ora.Side(*synth.make_table(100_000_000, 6, "reads"))
+    wa, wb = ora.c_inner(a, b, "sweep")
+    want = {"n": int(wa.shape[0]), "sum": ora.c_pairs_checksum(wa, wb), "sum_swapped": ora.c_pairs_checksum(wb, wa)}
+    del wa, wb
+    want["count"] = ora.c_count(a, b, "sweep")
+    assert want["n"] == 404_376_266 == int(want["count"].sum())
+    return a, b, want
+
+
+@pytest.mark.parametrize("env,form", [
+    ({}, "uniform_b"),                          # k_bucket_sort<1, 2>: the benchmarked kernel
+    ({"GIQL_HIP_NO_UNIFORM": "1"}, "general"),  # k_bucket_sort<3, 3>: rows of any length
+])
+def test_config4_join_in_the_bucket_stage_on_a_fresh_context(monkeypatch, cfg4, env, form):
+    """A context of its own (no guess inherited from an earlier, smaller test): the first join is plan + fill, the
+    second is the ONE-CALL form in which the bucket stage writes the pairs -- asserted, not assumed -- and must give
+    the oracle's pair count, multiset checksum and per-row multiplicities (bag semantics,
+    tests/test_duckdb_iejoin.py:4514-4555 of the reference); then the same with the larger table first."""
+    a, b, want = cfg4
+    e = _engine(monkeypatch, **env)
+    try:
+        da, db = dev(a), dev(b)
+        count = torch.from_numpy(want["count"]).to("cuda:0")
+        for it in range(3):
+            ra, rb = e.inner_join(da, db, 24)
+            st = e.stats()
+            assert st["join_form"] == form and st["sort_local"] and not st["sort_resorted"] and not st["swapped"], (it, st)
+            if it >= 1:
+                assert st["bucket_join"] and st["count_fused"], (it, st)
+            assert int(ra.shape[0]) == want["n"] and e.pairs_checksum(ra, rb) == want["sum"], it
+            assert bool((torch.bincount(ra, minlength=a.n) == count).all()), it
+            assert int(rb.min()) >= 0 and int(rb.max()) < b.n
+            del ra, rb
+        for it in range(2):
+            rb2, ra2 = e.inner_join(db, da, 24)       # the larger table first: planned with the sides exchanged
+            st = e.stats()
+            assert st["join_form"] == form and st["swapped"] and st["n_a"] == b.n, (it, st)
+            if it >= 1:
+                assert st["bucket_join"], (it, st)
+            assert int(ra2.shape[0]) == want["n"] and e.pairs_checksum(rb2, ra2) == want["sum_swapped"], it
+            assert bool((torch.bincount(ra2, minlength=a.n) == count).all()), it
+            del ra2, rb2
+    finally:
+        e.close()
+
+
+def test_config4_through_transpile_and_execute(monkeypatch, cfg4):
+    """The product API at the headline size: transpile(dialect="hip") + execute() on Arrow tables, twice on an engine
+    of its own -- the second call takes the one-call join -- with the returned index pairs checked on the host."""
+    pa = pytest.importorskip("pyarrow")
+    from giql_amd.execute import execute
+    from giql_amd.transpile import transpile
+
+    a, b, want = cfg4
+    t = {"peaks": pa.table({"chrom": pa.array(a.chrom), "start": pa.array(a.start), "end": pa.array(a.end)}),
+         "reads": pa.table({"chrom": pa.array(b.chrom), "start": pa.array(b.start), "end": pa.array(b.end)})}
+    plan = transpile("SELECT a.start, b.start AS s2 FROM peaks a JOIN reads b ON a.interval INTERSECTS b.interval",
+                     tables=["peaks", "reads"], dialect="hip")
+    e = _engine(monkeypatch)
+    try:
+        for it in range(2):
+            ra, rb = execute(plan, t, engine=e, return_indices=True)
+            assert ra.shape[0] == want["n"] and ora.c_pairs_checksum(ra, rb) == want["sum"], it
+            del ra, rb
+        assert e.stats()["bucket_join"]
+        out = execute(plan, t, engine=e)       # ... and once with the projected columns gathered on the device
+        assert out.num_rows == want["n"]
+        import pyarrow.compute as pc
+        assert pc.sum(out.column("start")).as_py() == int((a.start.astype(np.int64) * want["count"]).sum())
+    finally:
+        e.close()

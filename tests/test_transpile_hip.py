@@ -445,8 +445,15 @@ def test_codes_of_long_columns_are_kept_for_the_next_query():
     a = pa.chunked_array([pa.array(names[rng.integers(0, 3, 700_000)]), pa.array(names[rng.integers(0, 3, 400_000)])])
     b = pa.array(names[rng.integers(1, 3, 50_000)])
     old = (X._CODES_CACHE_SLOTS, X._CODES_CACHE)
+    pins = []
     try:
         X._CODES_CACHE_SLOTS, X._CODES_CACHE = 3, None
+        # nothing is kept for memory that is not the caller's promise (Arrow's own pool buffers are mutable too:
+        # giql_amd.pin is the contract) ...
+        u1, u2 = X.encode_chroms(a, b), X.encode_chroms(a, b)
+        assert u2[0] is not u1[0] and not X._CODES_CACHE
+        # ... and everything for pinned tables
+        pins = [X.pin(pa.table({"c": a})), X.pin(pa.table({"c": b})), X.pin(pa.table({"c": a.slice(5, 1_050_000)}))]
         r1 = X.encode_chroms(a, b)
         r2 = X.encode_chroms(a, b)
         assert r2[0] is r1[0] and r2[1] is r1[1] and r1[2] == ["chr1", "chr2", "chrX"] and not r1[0].flags.writeable
@@ -457,5 +464,13 @@ def test_codes_of_long_columns_are_kept_for_the_next_query():
         X._CODES_CACHE_SLOTS, X._CODES_CACHE = 0, None
         r4 = X.encode_chroms(a, b)
         assert X._CODES_CACHE is None and (r4[0] == r1[0]).all()
+        X._CODES_CACHE_SLOTS = 3
+        X.encode_chroms(a, b)
+        assert len(X._CODES_CACHE) == 2          # the long column and the pair's shared encoding (b is short)
+        pins[1].unpin()                          # the end of b's promise takes what was derived from b with it
+        assert len(X._CODES_CACHE) == 1
     finally:
+        for p in pins:
+            p.unpin()
         X._CODES_CACHE_SLOTS, X._CODES_CACHE = old
+    assert not X._PINNED
