@@ -57,10 +57,15 @@ WORKLOADS = {
     "cfg3_anti_1Mx10M_24chrom": ("anti", (1_000_000, "peaks", 3), (10_000_000, "reads", 4), HG38),
     "cfg3_count_1Mx10M_24chrom": ("count", (1_000_000, "peaks", 3), (10_000_000, "reads", 4), HG38),
     "cfg5_nearest_10Mx10M_24chrom": ("nearest", (10_000_000, "peaks", 7), (10_000_000, "peaks", 8), HG38),
+    # the headline tables with the 100M-row one INDEXED (giql_hip_index_create_dev: what the reference's users get from
+    # CREATE INDEX, docs/transpilation/performance.rst:111-130): per step only the small side's sort + the bucket stage.
+    # An extra line, never the headline -- the index build is outside the timed region and reported beside it
+    "cfg4_indexed_10Mx100M_24chrom": ("inner_indexed", (10_000_000, "peaks", 5), (100_000_000, "reads", 6), HG38),
 }
 DEFAULT_WORKLOAD = "cfg4_10Mx100M_24chrom"
 METRIC = {
     "inner": ("overlap-pairs/sec, {a}x{b} INTERSECTS inner join", "pairs/s"),
+    "inner_indexed": ("overlap-pairs/sec, {a}x{b} INTERSECTS inner join against a table index", "pairs/s"),
     "semi": ("input rows/sec, {a}x{b} INTERSECTS SEMI join", "rows/s"),
     "anti": ("input rows/sec, {a}x{b} INTERSECTS ANTI join", "rows/s"),
     "count": ("input rows/sec, {a}x{b} count_overlaps", "rows/s"),
@@ -525,6 +530,96 @@ def run_shard(args):
         "parity": parity,
         "gen_seconds": round(gen_s, 1),
     }
+    eng.close()
+    return line
+
+
+# ------------------------------------------------------- the join against a table index
+def run_indexed(args):
+    """``--workload cfg4_indexed_...``: table B indexed once (outside the timed region, its build time reported), a
+    step = ``giql_hip_inner_join_indexed_dev`` of table A against the index.  Full parity against the CPU leg."""
+    import torch
+
+    from giql_amd.engine import DeviceSide, HipEngine
+
+    wl = args.workload
+    op, (n_a, kind_a, seed_a), (n_b, kind_b, seed_b), genome = WORKLOADS[wl]
+    if args.gpus != 1:
+        raise SystemExit("the indexed workload runs on one GPU")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    t0 = time.time()
+    _op, ha, hb, n_chrom = make_inputs(wl)
+    gen_s = time.time() - t0
+    a, b = DeviceSide.from_numpy(*ha, device=dev), DeviceSide.from_numpy(*hb, device=dev)
+    eng = HipEngine(0)
+    build_ms = []
+    index = None
+    for _ in range(3):
+        if index is not None:
+            index.close()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        index = eng.index_create(b, n_chrom)
+        torch.cuda.synchronize(dev)
+        build_ms.append((time.perf_counter() - t1) * 1e3)
+    ra, rb = eng.inner_join_indexed(a, index)
+    n_pairs = int(ra.shape[0])
+    cap = (int(n_pairs * 1.05) + 1024 + (1 << 19) - 1) >> 19 << 19
+    del ra, rb
+    out = (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev))
+    eng.set_profiling(True)
+    for _ in range(max(args.warmup, 1)):
+        eng.inner_join_indexed_into(a, index, out[0], out[1])
+    warm = eng.stats()
+    eng.set_profiling("sort_local")
+    eng.inner_join_indexed_into(a, index, out[0], out[1])
+    torch.cuda.synchronize(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    dom_ms = 0.0
+    t1 = time.perf_counter()
+    ev[0].record()
+    for k in range(args.steps):
+        eng.inner_join_indexed_into(a, index, out[0], out[1])
+        dom_ms += eng.stats()["phase_ms"]["sort_local"]
+        ev[k + 1].record()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t1
+    st = eng.stats()
+    eng.set_profiling(False)
+    step_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
+    dom_ms /= args.steps
+    dom_bytes = float(st["phase_bytes"]["sort_local"])
+    join_bytes = op_bytes("inner", n_a, n_b, n_pairs)
+    phases = {k: round(v, 3) for k, v in warm["phase_ms"].items() if v > 0}
+    phases["sort_local"] = round(dom_ms, 3)
+    cpu_baseline = None
+    if not args.no_cpu_baseline:
+        cpu_baseline, ref = cpu_baseline_inner(args, "cfg4_10Mx100M_24chrom", n_chrom, None, whole=True)
+        gpu_sum = eng.pairs_checksum(out[0][:n_pairs], out[1][:n_pairs])
+        cpu_baseline["parity"] = {"pairs_equal": ref[0] == n_pairs, "multiset_checksum_equal": gpu_sum == ref[1],
+                                  "checked": "all %d pairs of the last timed step against the CPU leg" % n_pairs}
+    metric, unit = METRIC[op]
+    line = {
+        "metric": metric.format(a=short(n_a), b=short(n_b)), "value": round(n_pairs * args.steps / elapsed, 1), "unit": unit,
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "ms_per_step_median": round(statistics.median(step_ms), 3), "step_ms": [round(x, 3) for x in step_ms],
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": wl, "n_a": n_a, "n_b": n_b, "n_chrom": n_chrom, "pairs_per_step": n_pairs,
+                   "inputs": "resident in HBM before the timed region; table B indexed before the timed region",
+                   "join_form": st["join_form"], "index": {"rows": index.n, "hbm_bytes": index.nbytes,
+                                                           "form": "general" if index.general else "fixed_length",
+                                                           "build_ms": [round(x, 3) for x in build_ms]}},
+        "roofline": {"bound": "hbm", "kernel": DOMINANT_KERNEL["sort_local"], "launches_per_step": 1,
+                     "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": round(dom_bytes),
+                     "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1) if dom_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dom_ms > 0 else 0.0,
+                     "traffic": None, "phase_ms": phases,
+                     "whole_join": {"algorithmic_bytes": join_bytes,
+                                    "frac_of_wall_step": round(join_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}},
+        "cpu_baseline": cpu_baseline, "gen_seconds": round(gen_s, 1),
+    }
+    index.close()
     eng.close()
     return line
 
@@ -1076,7 +1171,11 @@ def run_rowop(args):
         base_a, base_b = (int(x) for x in all_sizes[:rank].sum(0).tolist()) if rank else (0, 0)
     root = 0 if (args.gather == "root" and distributed) else None
     local = {"semi": lambda: eng.semi_join(a, b, n_chrom), "anti": lambda: eng.anti_join(a, b, n_chrom),
-             "count": lambda: eng.count_overlaps(a, b, n_chrom), "nearest": lambda: eng.nearest(a, b, n_chrom)}[op]
+             "count": lambda: eng.count_overlaps(a, b, n_chrom),
+             # N = 1: the (int32 idx, int32 distance) output SURVEY.md section 8 a9 sizes -- one 8-byte record per row
+             # (giql_hip_nearest32_dev); the N > 1 exchange carries the int64 ABI's two arrays
+             "nearest": (lambda: eng.nearest(a, b, n_chrom)) if distributed
+             else (lambda: tuple(eng.nearest32(a, b, n_chrom).unbind(1)))}[op]
 
     last_local = [0]
 
@@ -1235,7 +1334,8 @@ def main() -> None:
     args = parse_args()
     self_launch(args)
     op = WORKLOADS[args.workload][0]
-    line = run_shard(args) if args.shard_of else (run_inner(args) if op == "inner" else run_rowop(args))
+    line = run_shard(args) if args.shard_of else (run_inner(args) if op == "inner" else
+                                                 run_indexed(args) if op == "inner_indexed" else run_rowop(args))
     if line is not None:
         print(json.dumps(line), flush=True)
         parity = ((line.get("cpu_baseline") or {}).get("parity") or {})

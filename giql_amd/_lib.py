@@ -39,6 +39,8 @@ SYMBOLS = [
     "giql_hip_group_rows_dev", "giql_hip_segment_sum_dev", "giql_hip_inner_join_dev",
     "giql_hip_inner_plan_export_dev", "giql_hip_fill_from_plan_dev", "giql_hip_copy_probe_dev",
     "giql_hip_nearest_k_dev", "giql_hip_stream_probe_dev", "giql_hip_host_pool_trim",
+    "giql_hip_nearest32_dev", "giql_hip_index_create_dev", "giql_hip_index_destroy", "giql_hip_index_info",
+    "giql_hip_inner_join_indexed_dev",
 ]
 
 
@@ -158,6 +160,11 @@ def load() -> ctypes.CDLL:
     L.giql_hip_semi_anti_dev.argtypes = [vp, P(CSide), P(CSide), i32, ctypes.c_int, vp, P(i64), vp]
     L.giql_hip_count_dev.argtypes = [vp, P(CSide), P(CSide), i32, vp, vp]
     L.giql_hip_nearest_dev.argtypes = [vp, P(CSide), P(CSide), i32, ctypes.c_int, i64, vp, vp, vp]
+    L.giql_hip_index_create_dev.argtypes = [vp, P(CSide), i32, vp, P(vp)]
+    L.giql_hip_index_destroy.argtypes = [vp]
+    L.giql_hip_index_info.argtypes = [vp, P(i64), P(i64), P(i32), P(i64)]
+    L.giql_hip_inner_join_indexed_dev.argtypes = [vp, vp, P(CSide), vp, vp, i64, vp, P(i64)]
+    L.giql_hip_nearest32_dev.argtypes = [vp, P(CSide), P(CSide), i32, ctypes.c_int, i64, vp, vp]
     L.giql_hip_nearest_k_dev.argtypes = [vp, P(CSide), P(CSide), i32, i32, ctypes.c_int, i64, vp, vp, vp]
     L.giql_hip_chrom_spans_dev.argtypes = [vp, P(CSide), P(CSide), i32, vp, vp]
     L.giql_hip_inner.argtypes = [vp, P(CSide), P(CSide), i32, P(i64), P(vp), P(vp)]

@@ -473,12 +473,21 @@ constexpr int NR_TQ = NR_NT * NR_ITEMS;  // A rows per block
 constexpr int NR_CAP = 4096;             // staged B rows (keys + prefix max: 32 KB)
 constexpr u32 NR_BACK = 128;             // rows staged below the bracket
 
-__global__ __launch_bounds__(NR_NT) void k_nearest(
+// OUT32 (round 4, giql_hip_nearest32_dev): the result of a row is ONE 8-byte {idx_b : int32, distance : int32}
+// record scattered straight to its final place out32[row id] -- SURVEY.md section 8 a9 sizes NEAREST's output as
+// (int32, int32) -- so there is no record array and no unpack pass (40 us of a 1.0 ms call at 10M x 10M).  A distance
+// past INT32_MAX (coordinates near the ends of the int32 range) is reported through DevMeta::aux1: the caller takes
+// the int64 entry point then.
+#ifndef GIQL_NR_MIN_WAVES
+#define GIQL_NR_MIN_WAVES 4   // (the 36 KB of LDS allow four blocks per CU = 4 waves per SIMD: up to 128 VGPRs cost nothing)
+#endif
+template <bool OUT32>
+__global__ __launch_bounds__(NR_NT, GIQL_NR_MIN_WAVES) void k_nearest(
     const u32* __restrict__ a_keys, const u32* __restrict__ a_ends, const u32* __restrict__ a_rids,
     u32 n_a, int n_chrom, const u32* __restrict__ chrom_first, const u32* __restrict__ chrom_lo,
     const u32* __restrict__ b_keys, const u32* __restrict__ b_pmax, const u32* __restrict__ b_rids,
     u32 n_b, int is_signed, i64 max_distance, NearestRec* __restrict__ rec_out,
-    DevMeta* __restrict__ meta) {
+    DevMeta* __restrict__ meta, int2* __restrict__ out32 = nullptr) {
   __shared__ u32 s_keys[NR_CAP], s_pmax[NR_CAP];
   __shared__ u32 s_min[NR_NT / WAVE], s_max[NR_NT / WAVE];
   __shared__ u32 s_w[2];
@@ -621,16 +630,28 @@ __global__ __launch_bounds__(NR_NT) void k_nearest(
     // ONE 16-byte scattered store per row (a partial-line write costs about the same
     // whatever its width); k_nearest_unpack then streams the records into the two
     // output arrays.  Two scattered stores (4 B + 8 B) took 0.39 of the kernel's 0.77 ms.
-    NearestRec rec;
-    rec.dist = best < 0 ? 0 : best_d;
-    rec.idx = best;
-    rec.pad = 0;
+    if constexpr (OUT32) {
+      const i64 d = best < 0 ? 0 : best_d;
+      if (d > 0x7FFFFFFFll || d < -0x7FFFFFFFll) meta->aux1 = 1u;  // does not fit: the int64 entry point's case
+      out32[rr[u]] = make_int2(best, (int)d);
+    } else {
+      NearestRec rec;
+      rec.dist = best < 0 ? 0 : best_d;
+      rec.idx = best;
+      rec.pad = 0;
 #if defined(GIQL_NEAREST_ABLATE) && GIQL_NEAREST_ABLATE == 1  // timing-only build: records in sorted order, no scatter
-    rec_out[i] = rec;
+      rec_out[i] = rec;
 #else
-    rec_out[rr[u]] = rec;
+      rec_out[rr[u]] = rec;
 #endif
+    }
   }
+}
+
+// giql_hip_nearest32_dev with no target row at all: every record is {-1, 0}
+__global__ __launch_bounds__(256) void k_nearest32_none(int2* __restrict__ out, u32 n) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = make_int2(-1, 0);
 }
 
 __global__ __launch_bounds__(256) void k_nearest_unpack(const NearestRec* __restrict__ rec, u32 n,

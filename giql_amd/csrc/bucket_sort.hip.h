@@ -282,12 +282,12 @@ constexpr u32 BJ_WCAP_CROWD = BJ_QR_CROWD * BS_NT;
 // window's keys are staged in LDS (in the bin table's place, once the ranks are done), every bucket row searches
 // them for its own range (a lower bound and a short walk: 0.3 matches per row at 10M x 100M) and writes its few
 // pairs itself, behind the class-2 runs.  Every pair (q, u) leaves from the block of u's bucket.
-template <int R, bool GENERAL, int QR>
+template <int R, bool GENERAL, int QR, bool OUTMAJOR = false>
 __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (&pay)[R], const u32 (&slot)[R], u32 cnt,
                                                  u32 v, const u32* __restrict__ ep, u32* s_buf, u64* s_cell,
                                                  u32* s_jtot, const BsFuse& fq, u32 qw0, u32 nw,
                                                  const u32 (&jq_key)[QR], const u32 (&jq_end)[QR],
-                                                 u32* s_bend = nullptr) {
+                                                 u32* s_bend = nullptr, u32* s_run = nullptr) {
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const u32 k0 = v << 16;
 #if defined(GIQL_BJ_ABLATE)  // timing-only builds (results invalid, tools/bj_ablate.sh): the tail stops after its k-th stage
@@ -334,22 +334,31 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
       if (q_cnt[i]) q_rid[i] = fq.qrid[qw0 + j];  // (flies under the scan and the staging below)
     }
     incl[i] = wave_incl_scan_add_u32(q_cnt[i]);
-    if (lane == WAVE - 1) s_jtot[i * BS_NW + w] = incl[i];
+    // a wave's pairs (< 2^18: 64 queries x at most 4096 rows each) and, above them, its RUNS (queries with a pair)
+    const u32 runs_w = OUTMAJOR ? (u32)__popcll(__ballot(q_cnt[i] != 0u)) : 0u;
+    if (lane == WAVE - 1) s_jtot[i * BS_NW + w] = incl[i] | (runs_w << 24);
   }
   bs_sync<2>();  // every rank has been read: s_buf and the cells are free; the wave totals are in
   GIQL_BJ_STOP(2);  // + ranks
-  // pairs of the block, and where each (slot, wave) group of queries starts among them
-  u32 total = 0, q_off[QR];
+  // pairs of the block, and where each (slot, wave) group of queries starts among them; the same for the runs
+  u32 total = 0, q_off[QR], n_runs = 0, run0[QR];
 #pragma unroll
   for (int i = 0; i < QR; i++) {
-    u32 mine = 0;
+    u32 mine = 0, mine_r = 0;
 #pragma unroll
     for (int k = 0; k < BS_NW; k++) {
-      if (k == (int)w) mine = total;
-      total += s_jtot[i * BS_NW + k];
+      if (k == (int)w) {
+        mine = total;
+        mine_r = n_runs;
+      }
+      const u32 t = s_jtot[i * BS_NW + k];
+      total += t & 0xFFFFFFu;
+      n_runs += t >> 24;
     }
     q_off[i] = mine + incl[i] - q_cnt[i];
+    run0[i] = mine_r;  // the first run of my wave in this round (my rank among them is added where the table is written)
   }
+  const u32 total2 = total;  // the class-2 pairs: the outputs [0, total2) of the block
   // class 1 (GENERAL): the bucket rows that COVER a query's start, q.start in [u.start, u.end).  Asked from the
   // query's side: such a row starts in (q.start - longest row of the bucket, q.start] -- a contiguous stretch of the
   // sorted bucket, both ends one bin-table read -- and is kept when its end key (staged above by final place) lies
@@ -408,6 +417,22 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
     const u32 r = i * BS_NT + tid;
     if (i < R - 1 || r < cnt) s_buf[slot[i]] = pay[i];
   }
+  // the run table of the output-major emission (below): {first output, first sorted row, query id} per run, in the
+  // order of the outputs, in the bin table's memory (every rank has been read)
+  constexpr u32 RC = QR * BS_NT;
+  if constexpr (OUTMAJOR) {
+#pragma unroll
+    for (int i = 0; i < QR; i++) {
+      const u64 mr = __ballot(q_cnt[i] != 0u);
+      if (q_cnt[i] != 0u) {
+        const u32 r = run0[i] + __builtin_amdgcn_mbcnt_hi((u32)(mr >> 32), __builtin_amdgcn_mbcnt_lo((u32)mr, 0u));
+        s_run[r] = q_off[i];
+        s_run[RC + 1 + r] = q_lo[i];
+        s_run[2 * RC + 1 + r] = q_rid[i];
+      }
+    }
+    if (tid == 0) s_run[n_runs] = total2;
+  }
   unsigned long long* s_jbase = reinterpret_cast<unsigned long long*>(s_jtot + QR * BS_NW);
   if (tid == 0) *s_jbase = base;
   bs_sync<2>();
@@ -416,7 +441,56 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
   if (base + total > fq.cap) return;  // the caller's buffers are too small: the count still adds up, nothing is written
   int32_t* const rq = fq.row_q + base;
   int32_t* const rs = fq.row_s + base;
-  // one query per wave iteration: its numbers come from the lane that ranked it
+  if constexpr (OUTMAJOR) {
+   if (total2 != 0u) {
+    // OUTPUT-MAJOR emission (round 4).  Every wave takes a contiguous stretch of the block's class-2 output in windows
+    // of 64 pairs ALIGNED to 256 bytes of the output arrays: a store instruction writes one full, aligned segment
+    // (the run-major loop below writes one run per iteration -- ~35 of 64 lanes at the headline's run lengths, two
+    // partial lines per store, four v_readlane per run).  The runs that START inside a window come from ONE coalesced
+    // LDS read of the (sorted) run table, folded into a 64-bit start mask by a scalar loop over just those runs; a
+    // lane's run = the run the window opens in + the starts at or below the lane's position.
+    const u32 shift = (u32)(base & 63ull);
+    const u32 n_win = (shift + total2 + 63u) >> 6;
+    const u32 per = (n_win + BS_NW - 1) / BS_NW;
+    u32 win = w * per;
+    const u32 win_end = win + per < n_win ? win + per : n_win;
+    if (win < win_end) {
+      int o_base = (int)(win * 64u) - (int)shift;   // block-local output of lane 0 (negative only in the first window)
+      const u32 o_first = o_base < 0 ? 0u : (u32)o_base;
+      u32 j0 = 0, hi_ = n_runs;   // s_run[j0] <= o_first < s_run[hi_]  (s_run[0] = 0, s_run[n_runs] = total2)
+      while (hi_ - j0 > 1u) {
+        const u32 mid = (j0 + hi_) >> 1;
+        if (s_run[mid] <= o_first)
+          j0 = mid;
+        else
+          hi_ = mid;
+      }
+      for (; win < win_end; win++, o_base += 64) {
+        const u32 cand = j0 + 1u + lane;
+        const u32 s_c = cand < n_runs ? s_run[cand] : 0x7FFFFFFFu;
+        const u64 mk = __ballot((int)s_c < o_base + 64);   // a prefix of the lanes: the table is sorted
+        const u32 nin = (u32)__popcll(mk);
+        u64 starts = 0;
+        for (u32 t = 0; t < nin; t++)
+          starts |= 1ull << (u32)(__builtin_amdgcn_readlane((int)s_c, (int)t) - o_base);
+        const u32 le = __builtin_amdgcn_mbcnt_hi((u32)(starts >> 32), __builtin_amdgcn_mbcnt_lo((u32)starts, 0u)) +
+                       (u32)((starts >> lane) & 1ull);
+        const int o = o_base + (int)lane;
+        if (o >= 0 && (u32)o < total2) {
+          const u32 j = j0 + le;
+          const u32 off = s_run[j], lo = s_run[RC + 1 + j];
+          rq[o] = (int32_t)s_run[2 * RC + 1 + j];
+          rs[o] = (int32_t)s_buf[lo + ((u32)o - off)];
+        }
+        j0 += (u32)__popcll(starts);
+      }
+    }
+   }
+  }
+  // one query per wave iteration: its numbers come from the lane that ranked it (the general form, whose registers
+  // are taken by its class-1 ranges, and the crowded windows of the queue kernel, whose run table would not fit
+  // the bin table's memory)
+  if constexpr (!OUTMAJOR)
 #pragma unroll
   for (int i = 0; i < QR; i++) {
     u64 m = __ballot(q_cnt[i] != 0u);
@@ -612,8 +686,16 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
     }
   }
   if constexpr (FUSE >= 2) {  // the pairs leave from here: no sorted array is stored
-    bucket_join_tail<R, FUSE == 3, QR>(pk, pay, slot, cnt, v, ep, s_buf, s_cell, s_jtot, fq, qw0, qw1 - qw0, jq_key, jq_end,
-                                       s_bend);
+    // (the run table of the output-major emission takes the bin table's place once the ranks are done -- when it fits)
+    // ... and in the fixed-length form: the general form's class-1 ranges take the registers (80 VGPRs; with the
+    // run table on top the compiler spilled 259 of them: 3.03 -> 3.67 ms)
+#if defined(GIQL_BJ_RUN_MAJOR)  // A/B aid: round 3's run-major emission
+    constexpr bool OUTMAJOR = false;
+#else
+    constexpr bool OUTMAJOR = FUSE == 2 && 3u * QR * BS_NT + 1u <= 2u * BS_NB;
+#endif
+    bucket_join_tail<R, FUSE == 3, QR, OUTMAJOR>(pk, pay, slot, cnt, v, ep, s_buf, s_cell, s_jtot, fq, qw0, qw1 - qw0, jq_key,
+                                                 jq_end, s_bend, OUTMAJOR ? reinterpret_cast<u32*>(s_cell) : nullptr);
     return;
   }
   bs_sync<FUSE>();  // every gathered bin has been read: s_buf and the cells are free

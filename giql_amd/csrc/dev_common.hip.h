@@ -55,6 +55,20 @@ __device__ __forceinline__ u32 xcd_tile_of_block(u32 b, u32 n_blocks) {
   return ((j / G) * XCD_GROUPS + x) * G + j % G;
 }
 
+// A load of bytes that are read ONCE (a column streamed through a kernel): non-temporal, so the line is not
+// kept in L2 / the Infinity Cache at the expense of what the kernel writes or re-reads.  Measured on MI355X with the
+// library's own probe (giql_hip_stream_probe_dev, profiles/r04a_stream_probe.log): a read-only sweep runs at
+// 6.2-6.4 TB/s with default-policy loads and 7.0-7.15 TB/s with nt loads; a copy at 5.3 vs 5.5-5.65.
+// -DGIQL_NO_NT_LOADS=1 builds the default-policy variant (A/B aid).
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+#if defined(GIQL_NO_NT_LOADS)
+  return *p;
+#else
+  return __builtin_nontemporal_load(p);
+#endif
+}
+
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }

@@ -169,6 +169,7 @@ struct giql_hip_ctx {
   bool no_coarse_b = false;    // GIQL_HIP_NO_COARSE_B=1: the fixed-length B of SEMI / ANTI / COUNT is sorted on every digit
   double coarse_max_group_rows = 8.0;  // ... and coarsely only while the rows sharing their upper 24 key bits are at most this many on average
   bool local_sort = true;
+  int force_local = 0;         // +1 while a table index is built (giql_hip_index_create_dev): the three-stage sort whatever the guesses say; -1: global passes only
   u64 local_min_rows = 1u << 21;  // (round 4: a floor only; the density bounds above decide)
   int local_resorts = 0;      // calls repeated with the four-pass sort
   bool last_sort_local = false;  // the call in flight sorted at least one side in three stages
@@ -525,6 +526,8 @@ static void launch_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, int
 // 16-23 and 24-31 only, then every 16-bit bucket sorted on its low bits inside LDS, in place
 // (bucket_sort.hip.h) -- three trips through HBM instead of four.
 static inline bool sort_is_local(const giql_hip_ctx* ctx, size_t n) {
+  if (ctx->force_local > 0 && ctx->bucket_bnd && ctx->os_variant == 0) return true;
+  if (ctx->force_local < 0) return false;
   if (!(ctx->local_sort && ctx->bucket_bnd && ctx->os_variant == 0 && n >= ctx->local_min_rows)) return false;
   // The in-LDS stage holds 4096 rows per bucket; larger buckets go through a slow queue (one block each, two
   // more passes: 30M x 300M reads, ~6000 rows per bucket, spent 10.4 of 21 ms there).  So the form is taken
@@ -1845,6 +1848,287 @@ int giql_hip_inner_join_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_si
   return giql_hip_inner_fill_dev(ctx, row_a, row_b, capacity, stream);
 }
 
+// ------------------------------------------------------------- table index
+// The reference tells its users to CREATE INDEX ... (chrom, start, "end") on both join sides
+// (docs/transpilation/performance.rst:111-130): what the engine keeps between queries.  Here: the properties of a
+// TABLE that every join over it recomputes -- span and chromosome bases, the fixed length, the (key, rid) rows
+// grouped by 65,536-key bucket and sorted -- kept in HBM as an explicit object.  A join against an index
+// (giql_hip_inner_join_indexed_dev) is the other side's span pass + sort + the bucket stage: the larger table's
+// span pass (1.2 GB read at 100M rows) and its two global sort passes (3.2 GB) are not repeated.  An extra, never
+// the headline: bench.py times it as its own workload beside the build time of the index.
+struct giql_hip_index {
+  int device = 0;
+  u32 n = 0;
+  int n_chrom = 0;
+  bool general = false;    // rows of any length: (key, end, rid); else fixed length: (key, rid)
+  i64 uni_len = 0;         // the fixed canonical length (0 in the general form)
+  int len_max = 0;         // the longest row
+  u64 span = 0;
+  u32 sentinel = 0;        // one past the largest key of the axis
+  u32 *key = nullptr, *end = nullptr, *rid = nullptr;   // [n] sorted by key (every bucket sorted in place)
+  u32* small = nullptr;    // the sort's digit offsets gbase[4][256] | first[n_chrom + 1]: chromosome c owns keys [first[c], first[c + 1])
+  size_t bytes = 0;
+};
+
+int giql_hip_index_destroy(giql_hip_index* idx) {
+  if (!idx) return GIQL_OK;
+  (void)hipSetDevice(idx->device);
+  if (idx->key) (void)hipFree(idx->key);
+  if (idx->end) (void)hipFree(idx->end);
+  if (idx->rid) (void)hipFree(idx->rid);
+  if (idx->small) (void)hipFree(idx->small);
+  delete idx;
+  return GIQL_OK;
+}
+
+int giql_hip_index_info(const giql_hip_index* idx, int64_t* n_rows, int64_t* bytes, int32_t* general, int64_t* span) {
+  if (!idx) return set_err(GIQL_ERR_INVALID, "index is NULL");
+  if (n_rows) *n_rows = idx->n;
+  if (bytes) *bytes = (int64_t)idx->bytes;
+  if (general) *general = idx->general ? 1 : 0;
+  if (span) *span = (int64_t)idx->span;
+  return GIQL_OK;
+}
+
+int giql_hip_index_create_dev(giql_hip_ctx* ctx, const giql_side* side, int32_t n_chrom, void* stream,
+                              giql_hip_index** out) {
+  if (!ctx || !out) return set_err(GIQL_ERR_INVALID, "ctx/out is NULL");
+  *out = nullptr;
+  GIQL_TRY(check_side(side, "side"));
+  if (n_chrom < 1 || n_chrom > MM_HIST_CHROMS)
+    return set_err(GIQL_ERR_STATE, "a table index takes 1..%d chromosomes (the 2^24-aligned axis), got %d", MM_HIST_CHROMS, n_chrom);
+  if (side->n < 1 || (size_t)side->n > OS_MAX_ROWS) return set_err(GIQL_ERR_STATE, "a table index takes 1..2^30-1 rows");
+  if (ctx->classic_sort || ctx->os_variant != 0 || !ctx->bucket_bnd)
+    return set_err(GIQL_ERR_STATE, "this context cannot run the three-stage sort (GIQL_HIP_SORT / GIQL_HIP_OS_VARIANT)");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  ctx->planned = false;
+  reset_stats(ctx);
+  const size_t n = (size_t)side->n;
+  LinBufs lb;
+  SortBufs scratch;  // buffer 1 of the sort (buffer 0 = the index's own arrays)
+  u32 *hist = nullptr, *gbase = nullptr, *status = nullptr;
+  size_t zero_off = 0, zero_end = 0;
+  auto carve = [&](char* base) {
+    Carver c{base};
+    common_sizes(c, n_chrom, lb);
+    scratch.key[1] = c.take<u32>(n);
+    scratch.end[1] = c.take<u32>(n);
+    scratch.rid[1] = c.take<u32>(n);
+    c.off = align_up(c.off, 256);
+    zero_off = c.off;
+    hist = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
+    lb.top_partial = c.take<u32>((size_t)LIN_HIST_REPLICAS * MM_TOP_WORDS);
+    gbase = c.take<u32>(1024);
+    lb.abase = c.take<u32>(MM_HIST_CHROMS);
+    status = c.take<u32>(2 * os_pass_words(n));
+    c.off = align_up(c.off, 256);
+    zero_end = c.off;
+    return c.off;
+  };
+  GIQL_TRY(ensure_arena(ctx, carve(nullptr), st));
+  carve(ctx->arena);
+  giql_hip_index* idx = new (std::nothrow) giql_hip_index();
+  if (!idx) return set_err(GIQL_ERR_NOMEM, "out of host memory");
+  struct Fail {  // released on every early way out
+    giql_hip_index* p;
+    giql_hip_ctx* c;
+    ~Fail() {
+      c->force_local = 0;
+      c->prezeroed = false;
+      if (p) giql_hip_index_destroy(p);
+    }
+  } guard{idx, ctx};
+  idx->device = ctx->device;
+  idx->n = (u32)n;
+  idx->n_chrom = n_chrom;
+  HIP_TRY(hipMemsetAsync(ctx->arena + zero_off, 0, zero_end - zero_off, st));
+  ctx->prezeroed = true;
+  ctx->force_local = 1;
+  ctx->span_hist_dirty[0] = ctx->span_hist_dirty[1] = nullptr;
+  giql_side none = *side;
+  none.n = 0;
+  none.chrom = none.start = none.end = nullptr;
+  // the span pass of the ordinary plan, this table as its side B: per-chromosome range, length range, the digits
+  // of the aligned keys (k_chrom_minmax<2>: the two high digits, the low ones are sorted in LDS)
+  GIQL_TRY(run_spans(ctx, st, none, *side, n_chrom, lb, 1, hist));
+  GIQL_TRY(read_meta(ctx, st));
+  const DevMeta& m = *ctx->h_meta;
+  if (!m.aligned_ok)
+    return set_err(GIQL_ERR_STATE, "the table does not take the aligned axis (a negative coordinate, or more than 255 2^24-position blocks)");
+  if (m.len_min_b <= 0) return set_err(GIQL_ERR_STATE, "the table holds irregular rows (canonical end <= start): not indexable");
+  if (m.len_max_b > (int)BS_FUSE_WCAP)
+    return set_err(GIQL_ERR_STATE, "a row of %d positions is longer than the bucket stage's windows allow (%u)", m.len_max_b, BS_FUSE_WCAP);
+  const double per_bucket = (double)n * 65536.0 / (double)(m.total_span ? m.total_span : 1);
+  if (per_bucket > ctx->local_max_bucket_rows)
+    return set_err(GIQL_ERR_STATE, "%.0f rows per 65,536-key bucket: too dense for the in-LDS bucket stage (at most %.0f)",
+                   per_bucket, ctx->local_max_bucket_rows);
+  idx->general = ctx->no_uniform || m.len_min_b != m.len_max_b;
+  idx->uni_len = idx->general ? 0 : m.len_max_b;
+  idx->len_max = m.len_max_b;
+  idx->span = m.total_span;
+  idx->sentinel = m.sentinel;
+  HIP_TRY(hipMalloc((void**)&idx->key, n * sizeof(u32)));
+  HIP_TRY(hipMalloc((void**)&idx->rid, n * sizeof(u32)));
+  if (idx->general) HIP_TRY(hipMalloc((void**)&idx->end, n * sizeof(u32)));
+  HIP_TRY(hipMalloc((void**)&idx->small, (1024 + (size_t)n_chrom + 1) * sizeof(u32)));
+  idx->bytes = n * sizeof(u32) * (idx->general ? 3 : 2) + (1024 + (size_t)n_chrom + 1) * sizeof(u32);
+  {
+    Phase ph(ctx, st, GIQL_PH_LINEARIZE, 2);
+    hipLaunchKernelGGL(k_fold_top, dim3(MM_HIST_CHROMS), dim3(256), 0, st, lb.top_partial, lb.abase, hist);
+    hipLaunchKernelGGL(k_digit_offsets, dim3(4), dim3(256), 0, st, hist, (u32)LIN_HIST_REPLICAS, gbase);
+    GIQL_TRY(post_launch("digit offsets (index)"));
+  }
+  SortBufs sb = scratch;
+  sb.key[0] = idx->key;
+  sb.rid[0] = idx->rid;
+  sb.end[0] = idx->general ? idx->end : nullptr;
+  if (!idx->general) sb.end[1] = nullptr;
+  // two global passes from the raw columns + every bucket sorted in LDS, in place: the result is in buffer 0
+  GIQL_TRY(run_sort_onesweep(ctx, st, sb, (u32)n, gbase, status, false, side, lb.abase, 0, nullptr, false));
+  if (sb.key[0] != idx->key) return set_err(GIQL_ERR_HIP, "internal: the sort did not end in the index's buffers");
+  HIP_TRY(hipMemcpyAsync(idx->small, gbase, 1024 * sizeof(u32), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(idx->small + 1024, lb.chrom_first, ((size_t)n_chrom + 1) * sizeof(u32), hipMemcpyDeviceToDevice, st));
+  {
+    const int rc = read_meta(ctx, st);
+    if (rc == GIQL_STATUS_RESORT)
+      return set_err(GIQL_ERR_STATE, "a 65,536-key bucket of the table holds more rows than the bucket stage sorts (%u)", BS_BIG_MAX);
+    if (rc != GIQL_OK) return rc;
+  }
+  collect_spans(ctx);
+  ctx->stats.n_b = side->n;
+  ctx->stats.span = (int64_t)idx->span;
+  guard.p = nullptr;
+  *out = idx;
+  return GIQL_OK;
+}
+
+// INNER join of `a` against an indexed table: pairs (row of a, row of the indexed table).  Per call: a's span pass
+// (lengths only), its keys on the index's axis, its sort (grouped by bucket: two passes) and the bucket stage over
+// the index's rows -- the one-call join's last stage, reading the index instead of a freshly sorted side.
+// GIQL_ERR_STATE: `a` holds irregular rows or rows too long for the windows (the ordinary join answers those);
+// GIQL_ERR_CAPACITY with *n_pairs set when the buffers are short.
+int giql_hip_inner_join_indexed_dev(giql_hip_ctx* ctx, const giql_hip_index* idx, const giql_side* a,
+                                    int32_t* row_a, int32_t* row_idx, int64_t capacity, void* stream,
+                                    int64_t* n_pairs) {
+  if (!ctx || !idx || !n_pairs) return set_err(GIQL_ERR_INVALID, "ctx/index/n_pairs is NULL");
+  GIQL_TRY(check_side(a, "a"));
+  if (idx->device != ctx->device) return set_err(GIQL_ERR_INVALID, "the index lives on device %d, the context on %d", idx->device, ctx->device);
+  if (capacity < 0 || (capacity > 0 && (!row_a || !row_idx))) return set_err(GIQL_ERR_INVALID, "bad output buffers");
+  *n_pairs = 0;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  ctx->planned = false;
+  ctx->fuse_done = false;
+  reset_stats(ctx);
+  ctx->stats.n_a = a->n;
+  ctx->stats.n_b = idx->n;
+  if (a->n == 0) return GIQL_OK;
+  const size_t na = (size_t)a->n, nb = (size_t)idx->n;
+  if (na > OS_MAX_ROWS) return set_err(GIQL_ERR_INVALID, "side larger than 2^30 rows");
+  SortBufs sa, sq;  // a's sort; buffer 1 of the index side (only a queued bucket's block ever touches it)
+  u32 *hist = nullptr, *gbase = nullptr, *status = nullptr, *flags = nullptr;
+  size_t zero_off = 0, zero_end = 0;
+  auto carve = [&](char* base) {
+    Carver c{base};
+    sort_sizes(c, na, sa, true);
+    sq.key[1] = c.take<u32>(nb);
+    sq.rid[1] = c.take<u32>(nb);
+    sq.end[1] = idx->general ? c.take<u32>(nb) : nullptr;
+    c.off = align_up(c.off, 256);
+    zero_off = c.off;
+    hist = c.take<u32>((size_t)LIN_HIST_REPLICAS * 1024);
+    gbase = c.take<u32>(1024);
+    flags = c.take<u32>(64);
+    status = c.take<u32>(4 * os_pass_words(na));
+    c.off = align_up(c.off, 256);
+    zero_end = c.off;
+    return c.off;
+  };
+  GIQL_TRY(ensure_arena(ctx, carve(nullptr), st));
+  carve(ctx->arena);
+  struct Guard {
+    giql_hip_ctx* c;
+    ~Guard() { c->prezeroed = false; }
+  } guard{ctx};
+  HIP_TRY(hipMemsetAsync(ctx->arena + zero_off, 0, zero_end - zero_off, st));
+  ctx->prezeroed = true;
+  const u32* first = idx->small + 1024;
+  u32* const dead = flags;           // rows of a that cannot match (sorted last, skipped by the windows)
+  u32* const irregular = flags + 1;
+  int* const len_max_q = reinterpret_cast<int*>(flags + 2);
+  int* const len_max_u = reinterpret_cast<int*>(flags + 3);
+  {
+    Phase ph(ctx, st, GIQL_PH_LINEARIZE, 3);
+    hipLaunchKernelGGL(k_init_minmax, dim3(1), dim3(256), 0, st, (int*)nullptr, (int*)nullptr, 0, ctx->d_meta);
+    u32 grid = cdiv((u64)na, LIN_NT);
+    if (grid > (u32)LIN_MAX_BLOCKS) grid = LIN_MAX_BLOCKS;
+    hipLaunchKernelGGL(k_index_query_keys, dim3(grid), dim3(LIN_NT), 0, st, a->chrom, a->start, a->end, (u32)na,
+                       a->start_off, a->end_off, idx->n_chrom, first, idx->sentinel, sa.key[0], sa.end[0], dead, irregular,
+                       len_max_q, hist);
+    hipLaunchKernelGGL(k_digit_offsets, dim3(4), dim3(256), 0, st, hist, (u32)LIN_HIST_REPLICAS, gbase);
+    GIQL_TRY(post_launch("query keys (index)"));
+  }
+  HIP_TRY(hipMemcpyAsync(len_max_u, &idx->len_max, sizeof(int), hipMemcpyHostToDevice, st));
+  // grouped by bucket only (two passes): the windows are computed under the same mask.  The general form ranks a
+  // window's keys against the bucket rows and wants them fully sorted.
+  const int q_skip = idx->general ? 0 : 2;
+  const u32 q_mask = q_skip == 2 ? 0xFFFF0000u : 0xFFFFFFFFu;
+  ctx->force_local = -1;  // a's own sort: global passes only (its bucket stage would reuse the context's boundary arrays)
+  const int rc_sort = run_sort_onesweep(ctx, st, sa, (u32)na, gbase, status, false, nullptr, nullptr, q_skip, nullptr, false);
+  ctx->force_local = 0;
+  GIQL_TRY(rc_sort);
+  FuseCount fc;
+  fc.join = true;
+  fc.general = idx->general;
+  fc.zero_ptr = flags + 8;
+  fc.zero_words = 0;
+  fc.dev.qkey = sa.key[0];
+  fc.dev.qend = sa.end[0];
+  fc.dev.qrid = sa.rid[0];
+  fc.dev.qwin = ctx->bucket_qwin;
+  fc.dev.lo_out = fc.dev.hi_out = nullptr;
+  fc.dev.lo_off = idx->general ? 1 : 1 - idx->uni_len;
+  fc.dev.row_q = row_a;
+  fc.dev.row_s = row_idx;
+  fc.dev.cap = (u64)capacity;
+  fc.dev.cursor = reinterpret_cast<unsigned long long*>(&ctx->d_meta->n_out);  // zeroed by k_init_minmax
+  fc.nq_total = (u32)na;
+  fc.irr_q = dead;
+  fc.gbq3 = gbase + 3 * OS_BINS;
+  fc.key_mask = q_mask;
+  fc.len_max_q = len_max_q;
+  fc.len_max_u = idx->general ? len_max_u : nullptr;
+  SortBufs sb = sq;
+  sb.key[0] = idx->key;
+  sb.rid[0] = idx->rid;
+  sb.end[0] = idx->end;
+  ctx->last_sort_local = true;
+  launch_bucket_stage_fused(ctx, st, sb, (u32)nb, idx->small, fc);
+  GIQL_TRY(post_launch("bucket stage (index)"));
+  u32 h_flags[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, st));
+  {
+    const int rc = read_meta(ctx, st);   // (synchronises the stream: h_flags has arrived too)
+    if (rc == GIQL_STATUS_RESORT) return set_err(GIQL_ERR_STATE, "a bucket of the index is too large for the bucket stage");
+    if (rc != GIQL_OK) return rc;
+  }
+  collect_spans(ctx);
+  if (h_flags[1]) return set_err(GIQL_ERR_STATE, "the query table holds irregular rows (canonical end <= start): use the ordinary join");
+  if ((int)h_flags[2] > (int)BS_FUSE_WCAP)
+    return set_err(GIQL_ERR_STATE, "a query row of %d positions is longer than the bucket stage's windows allow (%u): use the ordinary join",
+                   (int)h_flags[2], BS_FUSE_WCAP);
+  const u64 total = ctx->h_meta->n_out;
+  *n_pairs = (int64_t)total;
+  ctx->stats.n_out = (int64_t)total;
+  ctx->stats.span = (int64_t)idx->span;
+  ctx->stats.reserved = idx->general ? 0 : 1;
+  ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += (int64_t)8 * (int64_t)total;
+  if (total > (u64)capacity)
+    return set_err(GIQL_ERR_CAPACITY, "capacity %lld < %llu pairs", (long long)capacity, (unsigned long long)total);
+  return GIQL_OK;
+}
+
 // Scratch shared by the single-output operators: histogram replicas, digit bases,
 // onesweep status words (+ tile-claim state) for one side at a time.
 struct OsScratch {
@@ -2106,9 +2390,10 @@ int giql_hip_count_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b
 }
 
 // ----------------------------------------------------------------- NEAREST
+// out32 (giql_hip_nearest32_dev): [n_a] {idx_b, distance} int32 records instead of the two arrays
 static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
                          int is_signed, int64_t max_distance, int32_t* idx_b_out, int64_t* dist_out,
-                         void* stream) {
+                         void* stream, int32_t* out32 = nullptr) {
   if (!ctx) return set_err(GIQL_ERR_INVALID, "ctx is NULL");
   GIQL_TRY(check_side(a, "a"));
   GIQL_TRY(check_side(b, "b"));
@@ -2121,10 +2406,15 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
   ctx->stats.n_a = a->n;
   ctx->stats.n_b = b->n;
   if (a->n == 0) return GIQL_OK;
-  if (!idx_b_out || !dist_out) return set_err(GIQL_ERR_INVALID, "idx_b_out/dist_out is NULL");
+  if (!out32 && (!idx_b_out || !dist_out)) return set_err(GIQL_ERR_INVALID, "idx_b_out/dist_out is NULL");
+  if (out32 && ((uintptr_t)out32 & 7)) return set_err(GIQL_ERR_INVALID, "idx_dist_out must be 8-byte aligned");
   const size_t na = (size_t)a->n, nb = (size_t)b->n;
   if (na > OS_MAX_ROWS || nb > OS_MAX_ROWS) return set_err(GIQL_ERR_INVALID, "side larger than 2^30 rows");
   if (nb == 0 || n_chrom == 0) {
+    if (out32) {
+      hipLaunchKernelGGL(k_nearest32_none, dim3(cdiv(na, 256)), dim3(256), 0, st, reinterpret_cast<int2*>(out32), (u32)na);
+      return post_launch("nearest32 (no target)");
+    }
     HIP_TRY(hipMemsetAsync(idx_b_out, 0xFF, na * sizeof(int32_t), st));
     HIP_TRY(hipMemsetAsync(dist_out, 0, na * sizeof(int64_t), st));
     return GIQL_OK;
@@ -2144,7 +2434,7 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
     lb.top_partial2 = c.take<u32>((size_t)LIN_HIST_REPLICAS * MM_TOP_WORDS);
     lb.abase = c.take<u32>(MM_HIST_CHROMS);
     os_scratch_sizes(c, nb, os);     // (right behind A's: prezero_row_scratch)
-    recs = c.take<NearestRec>(na);
+    recs = c.take<NearestRec>(out32 ? 0 : na);   // (the 32-bit form scatters its records straight into the output)
     pmax = c.take<u32>(nb);
     bmax = c.take<u32>(cdiv(nb, PM_TILE) + 1);
     chrom_lo = c.take<u32>((size_t)n_chrom + 2);
@@ -2210,11 +2500,17 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
     Phase ph(ctx, st, GIQL_PH_COUNT, 3);
     hipLaunchKernelGGL(k_chrom_bounds, dim3(cdiv((u64)n_chrom + 1, 256)), dim3(256), 0, st,
                        lb.chrom_first, n_chrom, sbb.key[0], (u32)nb, chrom_lo);
-    hipLaunchKernelGGL(k_nearest, dim3(cdiv(na, NR_TQ)), dim3(NR_NT), 0, st, sa.key[0], sa.end[0], sa.rid[0],
-                       (u32)na, n_chrom, lb.chrom_first, chrom_lo, sbb.key[0], pmax, sbb.rid[0], (u32)nb,
-                       is_signed, (i64)max_distance, recs, ctx->d_meta);
-    hipLaunchKernelGGL(k_nearest_unpack, dim3(cdiv(na, 256)), dim3(256), 0, st, recs, (u32)na, idx_b_out,
-                       (i64*)dist_out);
+    if (out32) {
+      hipLaunchKernelGGL(k_nearest<true>, dim3(cdiv(na, NR_TQ)), dim3(NR_NT), 0, st, sa.key[0], sa.end[0], sa.rid[0],
+                         (u32)na, n_chrom, lb.chrom_first, chrom_lo, sbb.key[0], pmax, sbb.rid[0], (u32)nb,
+                         is_signed, (i64)max_distance, (NearestRec*)nullptr, ctx->d_meta, reinterpret_cast<int2*>(out32));
+    } else {
+      hipLaunchKernelGGL(k_nearest<false>, dim3(cdiv(na, NR_TQ)), dim3(NR_NT), 0, st, sa.key[0], sa.end[0], sa.rid[0],
+                         (u32)na, n_chrom, lb.chrom_first, chrom_lo, sbb.key[0], pmax, sbb.rid[0], (u32)nb,
+                         is_signed, (i64)max_distance, recs, ctx->d_meta, (int2*)nullptr);
+      hipLaunchKernelGGL(k_nearest_unpack, dim3(cdiv(na, 256)), dim3(256), 0, st, recs, (u32)na, idx_b_out,
+                         (i64*)dist_out);
+    }
     GIQL_TRY(post_launch("nearest"));
   }
   GIQL_TRY(read_meta(ctx, st));
@@ -2222,14 +2518,16 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
     const bool aligned_now = ctx->h_meta->aligned_ok != 0;
     ctx->nearest_aligned = aligned_now ? 1 : 0;
     if (keygen && !aligned_now)  // the layout did not hold for this data: its keys were built on bases that overlap
-      return giql_hip_nearest_dev_impl(ctx, a, b, n_chrom, is_signed, max_distance, idx_b_out, dist_out, stream);
+      return giql_hip_nearest_dev_impl(ctx, a, b, n_chrom, is_signed, max_distance, idx_b_out, dist_out, stream, out32);
   }
   if (ctx->h_meta->inverted_b) return set_err(GIQL_ERR_INVALID, "NEAREST: a target row has end < start");
   if (!two_sorts && ctx->h_meta->aux0 != 0) {
     // a long run of equal starts (pile-ups): this table wants the two-sort plan
     ctx->nearest_two_sorts = true;
-    return giql_hip_nearest_dev_impl(ctx, a, b, n_chrom, is_signed, max_distance, idx_b_out, dist_out, stream);
+    return giql_hip_nearest_dev_impl(ctx, a, b, n_chrom, is_signed, max_distance, idx_b_out, dist_out, stream, out32);
   }
+  if (out32 && ctx->h_meta->aux1 != 0)
+    return set_err(GIQL_ERR_INVALID, "NEAREST: a distance does not fit int32; use giql_hip_nearest_dev (int64 distances)");
   collect_spans(ctx);
   ctx->stats.n_out = a->n;
   ctx->stats.span = (int64_t)ctx->h_meta->total_span;
@@ -2243,6 +2541,12 @@ int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side*
   return with_order_fallback(ctx, [&] { return giql_hip_nearest_dev_impl(ctx, a, b, n_chrom, is_signed, max_distance, idx_b_out, dist_out, stream); });
 }
 
+
+int giql_hip_nearest32_dev(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom, int is_signed,
+                           int64_t max_distance, int32_t* idx_dist_out, void* stream) {
+  if (!idx_dist_out && a && a->n > 0) return set_err(GIQL_ERR_INVALID, "idx_dist_out is NULL");
+  return with_order_fallback(ctx, [&] { return giql_hip_nearest_dev_impl(ctx, a, b, n_chrom, is_signed, max_distance, nullptr, nullptr, stream, idx_dist_out); });
+}
 
 // ------------------------------------------------------------ NEAREST k > 1
 static int giql_hip_nearest_k_dev_impl(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,

@@ -181,7 +181,11 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
         mx = hi > mx ? hi : mx;
       }
     }
+#if defined(GIQL_MM_ABLATE_HIST)  // timing-only build: (almost) no histogram atomics -- what the loads alone cost
+    if (HIST && (s & 0x3FF) == 0) {
+#else
     if (HIST) {
+#endif
       // n_chrom <= MM_HIST_CHROMS here (host); a bad id (flagged above) is masked into range
       const u32 pos = (u32)(s + start_off);
       const u32 tb = ((u32)c & (MM_HIST_CHROMS - 1)) * 256u + (pos >> 24);
@@ -212,34 +216,66 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
       }
     }
   };
-  // Tiles of 4 * NT consecutive rows, grid-stride: row u * NT + tid of a tile is item u of thread
-  // tid.  Every tile but the last is full, so its twelve loads are issued back to back with no
-  // bounds predicate (the predicated form branched around every single load).
+  // Tiles of 4 * NT consecutive rows, grid-stride.  Round 4: 16-byte loads -- thread tid holds rows 4 tid .. 4 tid + 3
+  // of the tile (one dwordx4 per column) and, where the columns are 16-byte aligned, loads them non-temporally: the
+  // box reads 7.0-7.1 TB/s that way against 6.2-6.4 with default-policy and ~4.6 with 4-byte loads (stream probe,
+  // profiles/r04a_stream_probe.log; nt on 4-byte loads is SLOWER than plain ones: 0.33 -> 0.39 ms here).  Two tiles
+  // are in flight per iteration (six 16-byte loads per thread).  A row's predecessor is the thread's previous
+  // element, for element 0 the previous lane's element 3 (a DPP shift), for lane 0 a load of its own.
   constexpr u32 TILE = 4u * NT;
   const u64 n_full = (u64)n / TILE;
-  for (u64 t = blockIdx.x; t < n_full; t += gridDim.x) {
-    const int* cp = chrom + t * TILE + threadIdx.x;
-    const int* sp = start + t * TILE + threadIdx.x;
-    const int* ep = end + t * TILE + threadIdx.x;
-    int cv[4], sv[4], ev[4], pc0[4], ps0[4];
+  const bool vec_ok = ((((uintptr_t)chrom) | ((uintptr_t)start) | ((uintptr_t)end)) & 15u) == 0;
+  typedef int mm_i4 __attribute__((ext_vector_type(4)));
+  auto tile4 = [&](const u64 t, mm_i4& c4, mm_i4& s4, mm_i4& e4, int& pc, int& ps) {
+    const u64 r0 = t * TILE + 4u * threadIdx.x;
+    if (vec_ok) {
+      c4 = ld_stream(reinterpret_cast<const mm_i4*>(chrom + r0));
+      s4 = ld_stream(reinterpret_cast<const mm_i4*>(start + r0));
+      e4 = ld_stream(reinterpret_cast<const mm_i4*>(end + r0));
+    } else {
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      cv[u] = cp[u * NT];
-      sv[u] = sp[u * NT];
-      ev[u] = ep[u * NT];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      pc0[u] = ps0[u] = INT_MIN;
-      if (lane_id() == 0 && (t | (u64)u | (u64)threadIdx.x) != 0) {  // row 0 of the table has no predecessor
-        pc0[u] = cp[u * NT - 1];
-        ps0[u] = sp[u * NT - 1];
+      for (int u = 0; u < 4; u++) {
+        c4[u] = chrom[r0 + u];
+        s4[u] = start[r0 + u];
+        e4[u] = end[r0 + u];
       }
     }
+    pc = ps = INT_MIN;
+    if (lane_id() == 0 && r0 != 0) {  // row 0 of the table has no predecessor
+      pc = chrom[r0 - 1];
+      ps = start[r0 - 1];
+    }
+  };
+  auto rows4 = [&](const mm_i4& c4, const mm_i4& s4, const mm_i4& e4, const int pc0, const int ps0) {
+    // element 0 against the previous lane's element 3 (lane 0: the loaded predecessor), 1..3 inside the thread
+    int pc = __builtin_amdgcn_update_dpp(0, c4[3], 0x138, 0xF, 0xF, false);   // wave_shr:1
+    int ps = __builtin_amdgcn_update_dpp(0, s4[3], 0x138, 0xF, 0xF, false);
+    if (lane_id() == 0) {
+      pc = pc0;
+      ps = ps0;
+    }
+    if (pc > c4[0] || (pc == c4[0] && ps > s4[0])) inv = true;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      order(cv[u], sv[u], pc0[u], ps0[u], true);
-      row(cv[u], sv[u], ev[u], true);
+    for (int u = 1; u < 4; u++)
+      if (c4[u - 1] > c4[u] || (c4[u - 1] == c4[u] && s4[u - 1] > s4[u])) inv = true;
+#pragma unroll
+    for (int u = 0; u < 4; u++) row(c4[u], s4[u], e4[u], true);
+  };
+  {
+    u64 t = blockIdx.x;
+    for (; t + gridDim.x < n_full; t += 2ull * gridDim.x) {   // two tiles in flight
+      mm_i4 c4a, s4a, e4a, c4b, s4b, e4b;
+      int pca, psa, pcb, psb;
+      tile4(t, c4a, s4a, e4a, pca, psa);
+      tile4(t + gridDim.x, c4b, s4b, e4b, pcb, psb);
+      rows4(c4a, s4a, e4a, pca, psa);
+      rows4(c4b, s4b, e4b, pcb, psb);
+    }
+    if (t < n_full) {
+      mm_i4 c4a, s4a, e4a;
+      int pca, psa;
+      tile4(t, c4a, s4a, e4a, pca, psa);
+      rows4(c4a, s4a, e4a, pca, psa);
     }
   }
   if (blockIdx.x == (u32)(n_full % gridDim.x)) {  // the ragged tail: one block
@@ -597,6 +633,68 @@ __global__ __launch_bounds__(LIN_NT) void k_linearize(
         if (ve) atomicAdd(&hist_partial_end[(size_t)(blockIdx.x % LIN_HIST_REPLICAS) * 1024 + k], ve);
       }
     }
+  }
+}
+
+// ---- query keys against a table INDEX (giql_hip_index_create_dev, round 4) ----
+// The index fixed the linear axis when it was built: chromosome c of the indexed table owns keys
+// [first[c], first[c + 1]) (2^24-aligned bases; every indexed row starts AND ends inside).  A query row is placed
+// on that axis: key = first[c] + start, end key = first[c] + end CLAMPED to the chromosome's range (no indexed row
+// starts beyond it, and an unclamped end would reach into the next chromosome's keys).  A row that cannot match --
+// its chromosome is not in the index, its end lies at or below 0, its start at or beyond the range -- gets the
+// sentinel key: it sorts behind every live row and is counted in *dead (the windows of the bucket stage skip that
+// many rows at the end of the sorted order, as they skip irregular rows in the ordinary plan).  An IRREGULAR row
+// (canonical end <= start) that is otherwise live cannot be answered by range queries: flagged in *irregular, the
+// host declines the call.  The 4 x 256 digit histogram of the keys for the sort, as in k_linearize.
+__global__ __launch_bounds__(LIN_NT) void k_index_query_keys(
+    const int* __restrict__ chrom, const int* __restrict__ start, const int* __restrict__ end, u32 n, int start_off,
+    int end_off, int n_chrom_idx, const u32* __restrict__ first, u32 sentinel, u32* __restrict__ keys,
+    u32* __restrict__ ends, u32* __restrict__ dead, u32* __restrict__ irregular, int* __restrict__ len_max,
+    u32* __restrict__ hist_partial) {
+  __shared__ u32 s_hist[4 * 256];
+  __shared__ u32 s_first[MM_HIST_CHROMS + 1];
+  for (int k = threadIdx.x; k < 4 * 256; k += LIN_NT) s_hist[k] = 0;
+  for (int k = threadIdx.x; k <= n_chrom_idx && k <= MM_HIST_CHROMS; k += LIN_NT) s_first[k] = first[k];
+  __syncthreads();
+  const u32 stride = gridDim.x * LIN_NT;
+  u32 n_dead = 0;
+  int lmax = 0;
+  bool irr = false;
+  for (u32 i = blockIdx.x * LIN_NT + threadIdx.x; i < n; i += stride) {
+    const int c = chrom[i];
+    const i64 cs = (i64)start[i] + start_off, ce = (i64)end[i] + end_off;
+    u32 k = sentinel, ke = sentinel;
+    if (c >= 0 && c < n_chrom_idx) {
+      const i64 lo = (i64)s_first[c], hi = (i64)s_first[c + 1];
+      if (ce <= cs) {
+        irr = true;  // (an irregular row on an indexed chromosome: the literal predicate may still hold for it)
+      } else if (ce > 0 && lo + cs < hi) {
+        const i64 s_ = cs < 0 ? 0 : cs;     // (no indexed row starts below 0: the range query loses nothing)
+        k = (u32)(lo + s_);
+        const i64 e_ = lo + ce;
+        ke = (u32)(e_ > hi ? hi : e_);
+        const i64 len = (i64)ke - (i64)k;
+        lmax = len > lmax ? (int)len : lmax;
+      }
+    }
+    keys[i] = k;
+    ends[i] = ke;
+    if (k == sentinel) n_dead++;
+#pragma unroll
+    for (int p = 0; p < 4; p++) atomicAdd(&s_hist[p * 256 + ((k >> (8 * p)) & 0xFFu)], 1u);
+  }
+  n_dead = wave_reduce_sum(n_dead);
+  lmax = (int)wave_reduce_max_u32((u32)lmax);
+  if (lane_id() == 0) {
+    if (n_dead) atomicAdd(dead, n_dead);
+    if (lmax) atomicMax(len_max, lmax);
+  }
+  if (__ballot(irr) != 0ull && lane_id() == 0) *irregular = 1u;
+  __syncthreads();
+  u32* g = hist_partial + (size_t)(blockIdx.x % LIN_HIST_REPLICAS) * 1024;
+  for (int k = threadIdx.x; k < 4 * 256; k += LIN_NT) {
+    const u32 v = s_hist[k];
+    if (v) atomicAdd(&g[k], v);
   }
 }
 

@@ -94,6 +94,29 @@ class DeviceSide:
             n, self.start_off, self.end_off)
 
 
+class DeviceIndex:
+    """A table index in HBM (``giql_hip_index``): what the reference's users get from ``CREATE INDEX ... (chrom,
+    start, "end")`` (``docs/transpilation/performance.rst:111-130``).  Built by :meth:`HipEngine.index_create`,
+    used by :meth:`HipEngine.inner_join_indexed`; released by :meth:`close` / garbage collection."""
+
+    def __init__(self, engine: "HipEngine", handle, n_chrom: int):
+        self.engine, self._h, self.n_chrom, self.last_pairs = engine, handle, n_chrom, 0
+        n, b, g, sp = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int64(0)
+        _lib.check(engine._L.giql_hip_index_info(handle, ctypes.byref(n), ctypes.byref(b), ctypes.byref(g), ctypes.byref(sp)))
+        self.n, self.nbytes, self.general, self.span = int(n.value), int(b.value), bool(g.value), int(sp.value)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.engine._L.giql_hip_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipEngine:
     """One context (device arena + bookkeeping) on one GPU.  Not thread-safe."""
 
@@ -273,6 +296,56 @@ class HipEngine:
         self.inner_fill(row_a, row_b)
         return row_a, row_b
 
+    # ------------------------------------------------------------- table index
+    def index_create(self, side: DeviceSide, n_chrom: int) -> "DeviceIndex":
+        """Build a :class:`DeviceIndex` over a table (``giql_hip_index_create_dev``): its rows keyed on the linear
+        axis, grouped by 65,536-key bucket and sorted, kept in HBM (8 B per row; 12 for variable lengths).  Raises
+        ``GiqlHipError`` with ``GIQL_ERR_STATE`` when the table does not take the indexed form."""
+        h = ctypes.c_void_p()
+        cs = side.c_struct()
+        _lib.check(self._L.giql_hip_index_create_dev(self._h, ctypes.byref(cs), int(n_chrom), self._stream(),
+                                                     ctypes.byref(h)))
+        return DeviceIndex(self, h, int(n_chrom))
+
+    def inner_join_indexed(self, a: DeviceSide, index: "DeviceIndex", cap: int | None = None):
+        """``(row_a, row_of_indexed_table)`` int32 device tensors of ``a INTERSECTS indexed table``
+        (``giql_hip_inner_join_indexed_dev``).  ``a.chrom`` speaks the indexed table's dictionary.  The buffers
+        are sized from the index's previous result (``cap`` overrides); a short buffer costs one more call."""
+        torch = _torch()
+        if index.engine is not self:
+            raise ValueError("the index was built on another engine")
+        if a.n and a.device != self.device:
+            raise ValueError(f"side lives on {a.device}, engine on {self.device}")
+        cap = int(cap) if cap is not None else (int(index.last_pairs * 1.05) + 4096 if index.last_pairs else max(a.n, 1 << 20))
+        for _attempt in range(3):
+            row_a = torch.empty(cap, dtype=torch.int32, device=self.device)
+            row_b = torch.empty(cap, dtype=torch.int32, device=self.device)
+            try:
+                n = self.inner_join_indexed_into(a, index, row_a, row_b)
+            except _lib.GiqlHipError as exc:
+                if exc.code != _lib.GIQL_ERR_CAPACITY:
+                    raise
+                del row_a, row_b
+                cap = int(self.last_pairs) + 4096
+                continue
+            return row_a[:n], row_b[:n]
+        raise _lib.GiqlHipError(_lib.GIQL_ERR_CAPACITY, "the pair count kept changing between calls")
+
+    def inner_join_indexed_into(self, a: DeviceSide, index: "DeviceIndex", row_a, row_b) -> int:
+        """The same into caller-owned int32 tensors; returns the pair count (``GIQL_ERR_CAPACITY`` with
+        ``self.last_pairs`` set when they are too small)."""
+        torch = _torch()
+        cap = min(int(row_a.shape[0]), int(row_b.shape[0]))
+        n = ctypes.c_int64(0)
+        ca = a.c_struct()
+        rc = self._L.giql_hip_inner_join_indexed_dev(
+            self._h, index._h, ctypes.byref(ca), self._dev_ptr(row_a, "row_a", torch.int32),
+            self._dev_ptr(row_b, "row_b", torch.int32), cap, self._stream(), ctypes.byref(n))
+        self.last_pairs = int(n.value)
+        _lib.check(rc)
+        index.last_pairs = int(n.value)
+        return int(n.value)
+
     # ------------------------------------------------ genomes longer than 2^32
     def chrom_spans(self, a: DeviceSide, b: DeviceSide, n_chrom: int):
         """Per-chromosome coordinate span (host list of ints)."""
@@ -412,6 +485,20 @@ class HipEngine:
             self._h, a.c_struct(), b.c_struct(), int(n_chrom), int(bool(signed)), md,
             idx.data_ptr() if a.n else None, dist.data_ptr() if a.n else None, self._stream()))
         return idx, dist
+
+    def nearest32(self, a: DeviceSide, b: DeviceSide, n_chrom: int, signed: bool = False, max_distance=None):
+        """NEAREST k=1 with the 8-byte-per-row output: an ``[n_a, 2]`` int32 tensor of ``{idx_b, distance}``
+        records (``giql_hip_nearest32_dev``; idx_b = -1: none).  Raises ``GiqlHipError`` (GIQL_ERR_INVALID) when a
+        distance does not fit int32 -- :meth:`nearest` is the entry for such data; a genome wider than 32 bits
+        (GIQL_ERR_SPAN) also belongs there."""
+        torch = _torch()
+        self._check_sides(a, b)
+        out = torch.empty((a.n, 2), dtype=torch.int32, device=self.device)
+        md = -1 if max_distance is None else int(max_distance)
+        _lib.check(self._L.giql_hip_nearest32_dev(
+            self._h, a.c_struct(), b.c_struct(), int(n_chrom), int(bool(signed)), md,
+            out.data_ptr() if a.n else None, self._stream()))
+        return out
 
     def nearest_k(self, a: DeviceSide, b: DeviceSide, n_chrom: int, k: int, signed: bool = False, max_distance=None):
         """NEAREST k >= 1: ``(idx_b [n_a, k] int32, distance [n_a, k] int64)`` per A row in the reference's

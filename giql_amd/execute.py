@@ -139,7 +139,7 @@ class PinnedTable:
     the table in place: ``refresh()``.  The reference's counterpart is the engine's own table + ``CREATE INDEX
     ... (chrom, start, "end")`` (``docs/transpilation/performance.rst:111-130``)."""
 
-    def __init__(self, table):
+    def __init__(self, table, index: bool = False):
         import pyarrow as pa
 
         if isinstance(table, PinnedTable):
@@ -147,6 +147,8 @@ class PinnedTable:
         if not isinstance(table, pa.Table):
             table = pa.table(table) if isinstance(table, dict) else pa.Table.from_pandas(table)
         self.table = table
+        self.index = bool(index)
+        self._indexes: dict = {}    # (device, chrom / start / end columns, encoding) -> (DeviceIndex | None, dictionary)
         self._idents = [i for name in table.column_names for i in _col_idents(table.column(name))]
         self._live = True
         with _CODES_LOCK:
@@ -171,6 +173,18 @@ class PinnedTable:
     def refresh(self) -> None:
         """The table was changed in place: drop what was derived from it (the next call derives it again)."""
         _drop_derived(set(self._idents))
+        self._drop_indexes()
+
+    def _drop_indexes(self) -> None:
+        for idx, _d in self._indexes.values():
+            if idx is not None:
+                idx.close()
+        self._indexes.clear()
+
+    def index_info(self) -> list:
+        """``[{"device", "rows", "hbm_bytes", "form"}]`` of the indexes built so far (one per device / column set)."""
+        return [{"device": k[0], "rows": i.n, "hbm_bytes": i.nbytes, "form": "general" if i.general else "fixed_length"}
+                for k, (i, _d) in self._indexes.items() if i is not None]
 
     def unpin(self) -> None:
         if not self._live:
@@ -186,6 +200,7 @@ class PinnedTable:
                 else:
                     _PINNED[i] = n
         _drop_derived(gone)
+        self._drop_indexes()
 
     def __enter__(self):
         return self
@@ -200,9 +215,11 @@ class PinnedTable:
             pass
 
 
-def pin(table) -> PinnedTable:
-    """See :class:`PinnedTable`."""
-    return PinnedTable(table)
+def pin(table, index: bool = False) -> PinnedTable:
+    """See :class:`PinnedTable`.  ``index=True``: INNER joins against this table go through a table index in HBM,
+    built on first use (``giql_hip_index_create_dev``: the table's span pass and global sort passes are then not
+    repeated per query) -- the counterpart of ``CREATE INDEX ... (chrom, start, "end")``."""
+    return PinnedTable(table, index=index)
 
 
 def _unwrap(table):
@@ -937,6 +954,64 @@ def _nearest_rows(plan: JoinPlan, a: DeviceSide, b: DeviceSide, n_chrom: int, en
             dist_k[hit[:, 0], hit[:, 1]].cpu().numpy())
 
 
+def _chrom_values(col):
+    """A chrom column as ``(int32 codes, values)`` in the column's OWN dictionary (sorted values)."""
+    fast = _arrow_codes(col, "chrom column")
+    if fast is not None:
+        (codes,), dictionary = _sorted_union_codes([fast])
+        return codes, list(dictionary)
+    x = _to_numpy(col, "chrom column")
+    if x.dtype.kind in "iu":
+        dictionary, inverse = np.unique(x, return_inverse=True)
+        return np.ascontiguousarray(inverse.astype(np.int32)), dictionary.tolist()
+    dictionary, inverse = np.unique(x.astype(str), return_inverse=True)
+    return np.ascontiguousarray(inverse.astype(np.int32)), dictionary.tolist()
+
+
+def _indexed_inner(plan: JoinPlan, lt, rt, pins, eng: HipEngine):
+    """INNER join through a pinned table's index, or None when no side offers one / the tables do not take the
+    indexed form (the ordinary join follows).  The index speaks its OWN chromosome dictionary (it outlives the
+    pairing of this query): the other table's chrom values are looked up in it, unknown ones match nothing."""
+    from . import _lib
+
+    for which in ("r", "l"):       # the right table first: the usual place of the large one
+        pin_ = pins.get(which)
+        if pin_ is None or not pin_.index:
+            continue
+        it, iside = (rt, plan.right) if which == "r" else (lt, plan.left)
+        qt, qside = (lt, plan.left) if which == "r" else (rt, plan.right)
+        key = (str(eng.device), iside.chrom_col, iside.start_col, iside.end_col, iside.encoding)
+        if key not in pin_._indexes:
+            codes, dictionary = _chrom_values(_column(it, iside.chrom_col))
+            try:
+                dev = DeviceSide.from_numpy(codes, _int32_column(_column(it, iside.start_col), iside.start_col),
+                                            _int32_column(_column(it, iside.end_col), iside.end_col), iside.encoding,
+                                            device=eng.device)
+                pin_._indexes[key] = (eng.index_create(dev, len(dictionary)), dictionary)
+                del dev            # (the index holds its own arrays: the columns' device copy is not kept)
+            except _lib.GiqlHipError as exc:
+                if exc.code != _lib.GIQL_ERR_STATE:
+                    raise
+                pin_._indexes[key] = (None, dictionary)    # this table does not take the indexed form
+        index, dictionary = pin_._indexes[key]
+        if index is None:
+            continue
+        qcodes, qvalues = _chrom_values(_column(qt, qside.chrom_col))
+        pos = {v: i for i, v in enumerate(dictionary)}
+        lut = np.fromiter((pos.get(v, len(dictionary)) for v in qvalues), dtype=np.int32, count=len(qvalues))
+        q = DeviceSide.from_numpy(lut[qcodes] if len(qvalues) else qcodes,
+                                  _int32_column(_column(qt, qside.start_col), qside.start_col),
+                                  _int32_column(_column(qt, qside.end_col), qside.end_col), qside.encoding, device=eng.device)
+        try:
+            rq, ri = eng.inner_join_indexed(q, index)
+        except _lib.GiqlHipError as exc:
+            if exc.code != _lib.GIQL_ERR_STATE:
+                raise
+            continue               # e.g. irregular query rows: the ordinary join answers them
+        return (rq, ri) if which == "r" else (ri, rq)
+    return None
+
+
 def _join_piece(plan: JoinPlan, lt, rt, ia: np.ndarray, ib: np.ndarray, n_chrom: int, eng: HipEngine,
                 return_indices: bool, device_projection: bool, sides_out: dict | None = None):
     """The join of ``lt`` x ``rt`` (chrom ids ``ia`` / ``ib`` from one shared dictionary) on ONE engine,
@@ -1197,6 +1272,7 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
     if engine is not None and devices is not None and len(devices) > 1:
         raise ValueError("pass either an engine or several devices, not both")
     eng = engine or default_engine(devices[0] if devices else 0)
+    pinned = {name: t for name, t in tables.items() if isinstance(t, PinnedTable)}
     tables = {name: _unwrap(t) for name, t in tables.items()}   # (a pinned table stands for its Arrow table)
     if plan.kind in ("CLUSTER", "MERGE"):
         return _execute_cluster_merge(plan, tables, eng, return_indices)
@@ -1206,6 +1282,16 @@ def execute(plan, tables, engine: HipEngine | None = None, *, giql_tables=None, 
         if side.table not in tables:
             raise ValueError(f"table {side.table!r} was not provided")
     lt, rt = tables[plan.left.table], tables[plan.right.table]
+    pins = {"l": pinned.get(plan.left.table), "r": pinned.get(plan.right.table)}
+    if (plan.kind == "INNER" and not plan.residuals and not (devices and len(devices) > 1)
+            and any(p is not None and p.index for p in pins.values())):
+        # a pinned table offers an index: the join reads it instead of spanning and sorting that table again
+        got = _indexed_inner(plan, lt, rt, pins, eng)
+        if got is not None:
+            ra, rb = got
+            if return_indices:
+                return ra.cpu().numpy(), rb.cpu().numpy()
+            return _finish_outer(_project(plan, lt, rt, {"l": ra, "r": rb}, {}, eng, device_projection), plan)
     ia, ib, dictionary = encode_chroms(_column(lt, plan.left.chrom_col), _column(rt, plan.right.chrom_col))
     n_chrom = len(dictionary)
     dev_sides: dict = {}

@@ -200,6 +200,18 @@ int giql_hip_nearest_dev(giql_hip_ctx* ctx, const giql_side* a,
                          int64_t max_distance, int32_t* idx_b_out,
                          int64_t* dist_out, void* stream);
 
+/* The same with the output SURVEY.md section 8 (a9) sizes: one {idx_b, distance}
+ * int32 record per A row, idx_dist_out[2 * i] = nearest B row (-1: none),
+ * idx_dist_out[2 * i + 1] = distance -- 8 bytes per row, written straight to
+ * their place (no second pass over the result).  GIQL_ERR_INVALID when a distance
+ * does not fit int32 (coordinates near the ends of the int32 range): the int64
+ * entry point above is the one for such data.  8-byte aligned.  Replaces the
+ * same reference lines (src/giql/expanders/nearest.py:336-397). */
+int giql_hip_nearest32_dev(giql_hip_ctx* ctx, const giql_side* a,
+                           const giql_side* b, int32_t n_chrom, int is_signed,
+                           int64_t max_distance, int32_t* idx_dist_out,
+                           void* stream);
+
 /* Per-chromosome coordinate span (max - min + 1 over both sides' canonical
  * coordinates, 0 for an absent chromosome) into the HOST array spans_out[n_chrom].
  * The join entry points place all chromosomes on one 32-bit axis and return
@@ -433,6 +445,38 @@ int giql_hip_fill_from_plan_dev(giql_hip_ctx* ctx, const int32_t* q_rid,
 int giql_hip_copy_probe_dev(giql_hip_ctx* ctx, const void* src, void* dst,
                             int64_t bytes, int32_t reps, void* stream,
                             double* gbytes_per_s);
+
+/* ---- table index (round 4) -------------------------------------------------
+ * The reference tells its users to CREATE INDEX ... (chrom, start, "end") on both
+ * join sides (docs/transpilation/performance.rst:111-130): what the engine keeps
+ * between queries.  Here the properties of a TABLE that every join over it would
+ * recompute -- chromosome bases on the linear axis, the fixed length, the
+ * (key, row id) rows grouped by 65,536-key bucket and sorted -- live in HBM as an
+ * explicit object (8 bytes per row, 12 for tables of variable length).  The
+ * table's columns are read once, at creation; the index keeps no pointer to them.
+ * GIQL_ERR_STATE when the table does not take the indexed form (more than 32
+ * chromosomes, a negative coordinate, irregular rows, more than ~2800 rows per
+ * 65,536 positions): the ordinary join serves such tables. */
+typedef struct giql_hip_index giql_hip_index;
+int giql_hip_index_create_dev(giql_hip_ctx* ctx, const giql_side* side,
+                              int32_t n_chrom, void* stream, giql_hip_index** out);
+int giql_hip_index_destroy(giql_hip_index* idx);
+int giql_hip_index_info(const giql_hip_index* idx, int64_t* n_rows, int64_t* bytes,
+                        int32_t* general, int64_t* span);
+/* INNER join of `a` against an indexed table (per-chromosome INNER plan,
+ * src/giql/expanders/intersects_duckdb.py:1283-1330, with one side indexed as
+ * performance.rst advises): pair k = (row_a[k] of a, row_idx[k] of the indexed
+ * table), same bag semantics and unspecified order as giql_hip_inner_join_dev.
+ * `a`'s chrom ids speak the INDEXED table's dictionary (ids >= its n_chrom
+ * match nothing).  Per call: a's keys on the index's axis, its sort, and the
+ * bucket stage over the index -- the indexed table's span pass and global sort
+ * passes are not repeated.  GIQL_ERR_STATE: `a` holds irregular rows or rows
+ * longer than 32768 positions (use the ordinary join); GIQL_ERR_CAPACITY with
+ * *n_pairs set when the buffers are short (nothing useful was written). */
+int giql_hip_inner_join_indexed_dev(giql_hip_ctx* ctx, const giql_hip_index* idx,
+                                    const giql_side* a, int32_t* row_a,
+                                    int32_t* row_idx, int64_t capacity,
+                                    void* stream, int64_t* n_pairs);
 
 /* What this device reads / writes / copies per second, by access shape (round 4:
  * the measured ceiling the kernels are held against; SURVEY.md section 8d "verify

@@ -86,6 +86,12 @@ def test_config5_nearest_10m_x_10m(monkeypatch, n_b, env):
         idx2, dist2 = e.nearest(dev(a), dev(b), 24, signed=True, max_distance=500)
         wi2, wd2 = ora.c_nearest_k1(a, b, signed=True, max_distance=500, method="sweep")
         assert np.array_equal(dist2.cpu().numpy(), wd2) and np.array_equal(idx2.cpu().numpy() >= 0, wi2 >= 0)
+        # the 8-byte-record output (giql_hip_nearest32_dev: what bench.py times for config 5)
+        rec = e.nearest32(dev(a), dev(b), 24).cpu().numpy()
+        assert np.array_equal(rec[:, 1], wd) and np.array_equal(b.start[rec[:, 0]], b.start[wi]) \
+            and np.array_equal(b.end[rec[:, 0]], b.end[wi])
+        rec2 = e.nearest32(dev(a), dev(b), 24, signed=True, max_distance=500).cpu().numpy()
+        assert np.array_equal(rec2[:, 1], wd2) and np.array_equal(rec2[:, 0] >= 0, wi2 >= 0)
         assert e.stats()["sort_local"] == bool(env)
     finally:
         e.close()
@@ -333,7 +339,8 @@ def test_config4_join_in_the_bucket_stage_on_a_fresh_context(monkeypatch, cfg4, 
         for it in range(2):
             rb2, ra2 = e.inner_join(db, da, 24)       # the larger table first: planned with the sides exchanged
             st = e.stats()
-            assert st["join_form"] == form and st["swapped"] and st["n_a"] == b.n, (it, st)
+            # (the stats speak in the caller's labels: the fixed-length table is now side A)
+            assert st["join_form"] == {"uniform_b": "uniform_a"}.get(form, form) and st["swapped"] and st["n_a"] == b.n, (it, st)
             if it >= 1:
                 assert st["bucket_join"], (it, st)
             assert int(ra2.shape[0]) == want["n"] and e.pairs_checksum(rb2, ra2) == want["sum_swapped"], it

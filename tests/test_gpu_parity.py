@@ -81,11 +81,21 @@ def test_semi_anti_known_answers(eng, case):
     assert G.rows_of_left(case, rows) == sorted(tuple(r) for r in case["expected"])
 
 
+def _nearest(eng, a, b, n_chrom, out32, **kw):
+    """NEAREST k = 1 through the int64 ABI (two arrays) or the 8-byte-record one (giql_hip_nearest32_dev)."""
+    if not out32:
+        return eng.nearest(a, b, n_chrom, **kw)
+    rec = eng.nearest32(a, b, n_chrom, **kw)
+    assert rec.dtype == torch.int32 and tuple(rec.shape) == (a.n, 2)
+    return rec[:, 0].contiguous(), rec[:, 1].to(torch.int64)
+
+
+@pytest.mark.parametrize("out32", [False, True], ids=["i64", "rec32"])
 @pytest.mark.parametrize("case", [c for c in KNOWN if c["kind"] == "nearest"], ids=lambda c: c["name"])
-def test_nearest_known_answers(eng, case):
+def test_nearest_known_answers(eng, case, out32):
     a, b = G.sides_of(case)
-    idx, dist = eng.nearest(dev(a), dev(b), n_chrom_of(a, b), signed=case["signed"],
-                            max_distance=case["max_distance"])
+    idx, dist = _nearest(eng, dev(a), dev(b), n_chrom_of(a, b), out32, signed=case["signed"],
+                         max_distance=case["max_distance"])
     with_d = len(case["expected"][0]) == 4
     got = G.nearest_rows(case, idx.cpu().numpy(), dist.cpu().numpy(), with_d)
     assert got == sorted(tuple(r) for r in case["expected"])
@@ -104,11 +114,12 @@ def test_join_fuzz_vs_sqlite(eng, case):
                           np.asarray(case["anti"], np.int64))
 
 
+@pytest.mark.parametrize("out32", [False, True], ids=["i64", "rec32"])
 @pytest.mark.parametrize("case", [c for c in FUZZ if c["kind"] == "nearest"], ids=lambda c: c["name"])
-def test_nearest_fuzz_vs_sqlite(eng, case):
+def test_nearest_fuzz_vs_sqlite(eng, case, out32):
     a, b = G.sides_of(case)
-    idx, dist = eng.nearest(dev(a), dev(b), max(n_chrom_of(a, b), 1), signed=case["signed"],
-                            max_distance=case["max_distance"])
+    idx, dist = _nearest(eng, dev(a), dev(b), max(n_chrom_of(a, b), 1), out32, signed=case["signed"],
+                         max_distance=case["max_distance"])
     idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
     for i, exp in enumerate(case["expected"]):
         if not exp:
@@ -271,17 +282,40 @@ def test_semi_anti_count_random_vs_oracle(eng, na, nb, nch):
     assert np.array_equal(eng.count_overlaps(da, db, nch).cpu().numpy(), ora.c_count(a, b, "sweep"))
 
 
+@pytest.mark.parametrize("out32", [False, True], ids=["i64", "rec32"])
 @pytest.mark.parametrize("signed,md", [(False, None), (True, None), (False, 500), (True, 2000)])
-def test_nearest_random_vs_oracle(eng, signed, md):
+def test_nearest_random_vs_oracle(eng, signed, md, out32):
     a = rand_side(41, 60_000, 6, 5_000_000, 800)
     b = rand_side(42, 50_000, 5, 5_000_000, 800)
-    idx, dist = eng.nearest(dev(a), dev(b), 6, signed=signed, max_distance=md)
+    idx, dist = _nearest(eng, dev(a), dev(b), 6, out32, signed=signed, max_distance=md)
     oi, od = ora.c_nearest_k1(a, b, signed=signed, max_distance=md, method="sweep")
     idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
     assert np.array_equal(idx >= 0, oi >= 0)
     assert np.array_equal(dist, od)
     m = oi >= 0
     assert np.array_equal(b.start[idx[m]], b.start[oi[m]]) and np.array_equal(b.end[idx[m]], b.end[oi[m]])
+
+
+def test_nearest32_edges(eng):
+    """The 8-byte-record form: no target rows -> {-1, 0} everywhere; a distance past INT32_MAX is refused (the
+    int64 entry point answers it); an empty reference table is fine."""
+    from giql_amd import _lib
+    from giql_amd.engine import DeviceSide
+
+    a = ora.Side(np.zeros(3, np.int32), np.array([10, 50, 70], np.int32), np.array([20, 60, 80], np.int32))
+    none = DeviceSide.from_numpy(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    rec = eng.nearest32(dev(a), none, 1).cpu().numpy()
+    assert rec.tolist() == [[-1, 0]] * 3
+    assert tuple(eng.nearest32(none, dev(a), 1).shape) == (0, 2)
+    # a on chromosome 1 only: no target there
+    b_other = ora.Side(np.ones(2, np.int32), np.array([5, 9], np.int32), np.array([8, 12], np.int32))
+    assert eng.nearest32(dev(a), dev(b_other), 2).cpu().numpy().tolist() == [[-1, 0]] * 3
+    far_a = ora.Side(np.zeros(1, np.int32), np.array([-2_000_000_000], np.int32), np.array([-1_999_999_990], np.int32))
+    far_b = ora.Side(np.zeros(1, np.int32), np.array([2_000_000_000], np.int32), np.array([2_000_000_010], np.int32))
+    i64 = eng.nearest(dev(far_a), dev(far_b), 1)
+    assert int(i64[1][0]) == 2_000_000_000 + 1_999_999_990 + 1
+    with pytest.raises(_lib.GiqlHipError, match="int32"):
+        eng.nearest32(dev(far_a), dev(far_b), 1)
 
 
 def test_nearest_rejects_inverted_rows(eng):
