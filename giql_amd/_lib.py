@@ -114,7 +114,7 @@ class CPred(ctypes.Structure):
     _fields_ = [("lhs", COperand), ("rhs", COperand), ("op", ctypes.c_int32), ("group", ctypes.c_int32)]
 
 
-OPS = {"=": 0, "==": 0, "!=": 1, "<>": 1, "<": 2, "<=": 3, ">": 4, ">=": 5, "isnull": 6, "notnull": 7}
+OPS = {"=": 0, "==": 0, "!=": 1, "<>": 1, "<": 2, "<=": 3, ">": 4, ">=": 5, "isnull": 6, "notnull": 7, "istrue": 8}
 SIDE_A, SIDE_B, SIDE_LIT, SIDE_EXPR = 0, 1, 2, 3
 T_I32, T_I64, T_F32, T_F64, T_U8 = range(5)
 

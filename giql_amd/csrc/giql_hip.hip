@@ -2817,9 +2817,11 @@ static int check_program(const giql_operand* nodes, int32_t n_nodes, int first, 
       GIQL_TRY(check_operand(nd, k, which));
       if (uses && nd.side != GIQL_SIDE_LIT) uses[nd.side] = true;
       if (++sp > SEL_X_STACK) return set_err(GIQL_ERR_INVALID, "predicate %d %s: expression deeper than %d", k, which, SEL_X_STACK);
-    } else if (nd.side == GIQL_X_NEG || nd.side == GIQL_X_ABS) {
+    } else if (nd.side == GIQL_X_NEG || nd.side == GIQL_X_ABS || nd.side == GIQL_X_ISNULL || nd.side == GIQL_X_NOTNULL ||
+               nd.side == GIQL_X_NOT) {
       if (sp < 1) return set_err(GIQL_ERR_INVALID, "predicate %d %s: malformed expression", k, which);
-    } else if (nd.side >= GIQL_X_ADD && nd.side <= GIQL_X_GREATEST) {
+    } else if ((nd.side >= GIQL_X_ADD && nd.side <= GIQL_X_GREATEST) || (nd.side >= GIQL_X_EQ && nd.side <= GIQL_X_GE) ||
+               nd.side == GIQL_X_AND || nd.side == GIQL_X_OR) {
       if (sp < 2) return set_err(GIQL_ERR_INVALID, "predicate %d %s: malformed expression", k, which);
       sp--;
     } else {
@@ -2837,8 +2839,8 @@ static int convert_preds(const giql_pred* preds, int32_t n_preds, DevPreds& ps, 
   memset(&ps, 0, sizeof(ps));
   ps.n = n_preds;
   for (int k = 0; k < n_preds; k++) {
-    const bool unary = preds[k].op == GIQL_OP_IS_NULL || preds[k].op == GIQL_OP_NOT_NULL;
-    if (preds[k].op < GIQL_OP_EQ || preds[k].op > GIQL_OP_NOT_NULL)
+    const bool unary = preds[k].op == GIQL_OP_IS_NULL || preds[k].op == GIQL_OP_NOT_NULL || preds[k].op == GIQL_OP_IS_TRUE;
+    if (preds[k].op < GIQL_OP_EQ || preds[k].op > GIQL_OP_IS_TRUE)
       return set_err(GIQL_ERR_INVALID, "predicate %d: operator %d", k, preds[k].op);
     if (preds[k].group < 0) return set_err(GIQL_ERR_INVALID, "predicate %d: group %d", k, preds[k].group);
     for (int w = 0; w < (unary ? 1 : 2); w++) {

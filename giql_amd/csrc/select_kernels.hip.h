@@ -34,7 +34,7 @@ struct DevOperand {
 };
 struct DevPred {
   DevOperand lhs, rhs;
-  int op;     // 0 ==, 1 !=, 2 <, 3 <=, 4 >, 5 >=, 6 IS NULL, 7 IS NOT NULL (lhs only)
+  int op;     // 0 ==, 1 !=, 2 <, 3 <=, 4 >, 5 >=, 6 IS NULL, 7 IS NOT NULL, 8 IS TRUE (lhs only)
   int group;  // != 0 and equal to the predecessor's: OR-ed with it; otherwise a new AND-ed clause
 };
 struct DevPreds {
@@ -96,8 +96,15 @@ __device__ __forceinline__ bool sel_cmp(T a, T b, int op) {
 constexpr int SEL_SIDE_EXPR = 3;
 constexpr int SEL_X_ADD = 16, SEL_X_SUB = 17, SEL_X_MUL = 18, SEL_X_DIV = 19, SEL_X_NEG = 20, SEL_X_ABS = 21,
               SEL_X_LEAST = 22, SEL_X_GREATEST = 23;
-constexpr int SEL_X_STACK = 8;
-constexpr int SEL_MAX_NODES = 64;
+// Boolean nodes (round 4): a whole condition as ONE program -- comparisons, IS [NOT] NULL, AND / OR / NOT over
+// three-valued results (a boolean is {i = 0 / 1, null}: Kleene logic, as SQL's) -- so that a condition needs no normal
+// form: the reference inlines any boolean combination as text (intersects_duckdb.py:889-957), and a conjunctive
+// normal form of an OR of ANDs outgrows every cap.  The predicate that holds such a program has op SEL_OP_IS_TRUE.
+constexpr int SEL_X_EQ = 24, SEL_X_NE = 25, SEL_X_LT = 26, SEL_X_LE = 27, SEL_X_GT = 28, SEL_X_GE = 29,
+              SEL_X_ISNULL = 30, SEL_X_NOTNULL = 31, SEL_X_AND = 32, SEL_X_OR = 33, SEL_X_NOT = 34;
+constexpr int SEL_OP_IS_TRUE = 8;
+constexpr int SEL_X_STACK = 12;
+constexpr int SEL_MAX_NODES = 256;
 
 __device__ __forceinline__ double sel_as_f(const SelValue& v) { return v.is_float ? v.f : (double)v.i; }
 
@@ -122,9 +129,38 @@ __device__ __noinline__ SelValue sel_eval_prog(const DevOperand* __restrict__ pr
       }
       continue;
     }
+    if (nd.side == SEL_X_ISNULL || nd.side == SEL_X_NOTNULL || nd.side == SEL_X_NOT) {
+      SelValue& v = st[sp - 1];
+      if (nd.side == SEL_X_NOT) {
+        v.i = (v.is_float ? v.f != 0.0 : v.i != 0) ? 0 : 1;   // NULL stays NULL
+      } else {
+        v.i = (nd.side == SEL_X_ISNULL) == v.null ? 1 : 0;
+        v.null = false;
+      }
+      v.is_float = false;
+      continue;
+    }
     const SelValue b = st[--sp];
     SelValue& a = st[sp - 1];
     const bool fl = a.is_float || b.is_float;
+    if (nd.side >= SEL_X_EQ && nd.side <= SEL_X_GE) {
+      const int op = nd.side - SEL_X_EQ;
+      const bool t = fl ? sel_cmp<double>(sel_as_f(a), sel_as_f(b), op) : sel_cmp<i64>(a.i, b.i, op);
+      a.i = t ? 1 : 0;
+      a.null = a.null || b.null;
+      a.is_float = false;
+      continue;
+    }
+    if (nd.side == SEL_X_AND || nd.side == SEL_X_OR) {
+      // Kleene: AND is FALSE as soon as one side is FALSE, NULL when a NULL is left, else TRUE; OR the dual
+      const bool ta = a.is_float ? a.f != 0.0 : a.i != 0, tb = b.is_float ? b.f != 0.0 : b.i != 0;
+      const bool dom = nd.side == SEL_X_OR;   // the value that decides on its own
+      const bool decided = (!a.null && ta == dom) || (!b.null && tb == dom);
+      a.null = !decided && (a.null || b.null);
+      a.i = decided ? (dom ? 1 : 0) : (dom ? 0 : 1);
+      a.is_float = false;
+      continue;
+    }
     if (nd.side == SEL_X_LEAST || nd.side == SEL_X_GREATEST) {
       if (a.null) {
         a = b;
@@ -177,7 +213,9 @@ __device__ __forceinline__ bool sel_eval(const DevPreds& ps, int ia, int ib, con
     const int op = ps.p[k].op;
     const SelValue a = sel_operand<EXPR>(ps.p[k].lhs, prog, ia, ib);
     bool t;
-    if (op >= 6) {
+    if (op == SEL_OP_IS_TRUE) {
+      t = !a.null && (a.is_float ? a.f != 0.0 : a.i != 0);
+    } else if (op >= 6) {
       t = (op == 6) == a.null;
     } else {
       const SelValue b = sel_operand<EXPR>(ps.p[k].rhs, prog, ia, ib);

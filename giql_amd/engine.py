@@ -695,7 +695,12 @@ class HipEngine:
         return out_off, out
 
     # ----------------------------------------------------- residual predicates
-    _XOPS = {"+": 16, "-": 17, "*": 18, "/": 19, "neg": 20, "abs": 21, "least": 22, "greatest": 23}
+    _XOPS = {"+": 16, "-": 17, "*": 18, "/": 19, "neg": 20, "abs": 21, "least": 22, "greatest": 23,
+             # boolean nodes (three-valued): a whole condition as one program, GIQL_X_EQ .. GIQL_X_NOT
+             "=": 24, "!=": 25, "<": 26, "<=": 27, ">": 28, ">=": 29, "isnull": 30, "notnull": 31,
+             "and": 32, "or": 33, "not": 34}
+    _UNARY = ("neg", "abs", "isnull", "notnull", "not")
+    _NARY = ("least", "greatest", "and", "or")
 
     def _flatten_expr(self, tree, nodes, keep_alive) -> None:
         """Append the postfix form of ``tree`` -- ``("a" | "b", column[, valid])``, ``("lit", v)`` or
@@ -709,14 +714,14 @@ class HipEngine:
         if kind not in self._XOPS:
             raise ValueError(f"expression operator {kind!r}")
         args = tree[1:]
-        arity_ok = (len(args) == 1) if kind in ("neg", "abs") else (len(args) >= 1 if kind in ("least", "greatest")
-                                                                    else len(args) == 2)
+        arity_ok = (len(args) == 1) if kind in self._UNARY else (len(args) >= 1 if kind in self._NARY
+                                                                  else len(args) == 2)
         if not arity_ok:
             raise ValueError(f"{kind!r} with {len(args)} argument(s)")
         self._flatten_expr(args[0], nodes, keep_alive)
         op = _lib.COperand()
         op.side = self._XOPS[kind]
-        if kind in ("neg", "abs"):
+        if kind in self._UNARY:
             nodes.append(op)
             return
         for child in args[1:]:
@@ -751,12 +756,12 @@ class HipEngine:
                 raise ValueError(f"operator {op!r}")
             c_preds[j].lhs, ka = operand(lhs)
             keep_alive.append(ka)
-            c_preds[j].rhs, ka = operand(rhs if op not in ("isnull", "notnull") else ("lit", 0))
+            c_preds[j].rhs, ka = operand(rhs if op not in ("isnull", "notnull", "istrue") else ("lit", 0))
             keep_alive.append(ka)
             c_preds[j].op = _lib.OPS[op]
             c_preds[j].group = int(p[3]) if len(p) > 3 else 0
-        if len(nodes) > 64:
-            raise ValueError("at most 64 expression nodes per call")
+        if len(nodes) > 256:
+            raise ValueError("at most 256 expression nodes per call")
         c_nodes = (_lib.COperand * max(len(nodes), 1))(*nodes)
         return c_preds, k, keep_alive, c_nodes, len(nodes)
 

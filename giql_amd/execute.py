@@ -521,14 +521,17 @@ class _Residuals:
         self._cache[key] = out
         return out
 
-    def _is_string(self, o) -> bool:
+    def _is_string_column(self, side: str, column: str) -> bool:
         import pyarrow as pa
 
+        t = self._arrow(side, column).type
+        return pa.types.is_string(t) or pa.types.is_large_string(t)
+
+    def _is_string(self, o) -> bool:
         if o.kind == "str":
             return True
         if o.kind in ("l", "r"):
-            t = self._arrow(o.kind, o.value).type
-            return pa.types.is_string(t) or pa.types.is_large_string(t)
+            return self._is_string_column(o.kind, o.value)
         return False
 
     def pred(self, res):
@@ -537,6 +540,8 @@ class _Residuals:
 
         ops = (res.lhs, res.rhs)
         eside = {"l": "a", "r": "b"}
+        if res.op == "istrue":                # a whole boolean condition as one program
+            return self._spec(res.lhs), "istrue", ("lit", 0), res.group
         if res.op in ("isnull", "notnull"):   # reads the validity of lhs only, whatever the column's type
             if res.lhs.kind == "expr":        # (a.score + 1) IS NULL: the kernel tells the expression's own NULL
                 return self._spec(res.lhs), res.op, ("lit", 0), res.group
@@ -546,30 +551,45 @@ class _Residuals:
         if any(o.kind == "expr" for o in ops) and not any(self._is_string(o) for o in ops):
             return self._spec(ops[0]), res.op, self._spec(ops[1]), res.group
         if any(self._is_string(o) for o in ops):
-            if not all(self._is_string(o) for o in ops):
-                raise ValueError(f"cannot compare a string with a number in {res.lhs.value!r} {res.op} {res.rhs.value!r}")
-            parts = []
-            for o in ops:
-                if o.kind == "str":
-                    parts.append((np.zeros(1, np.int32), [o.value]))
-                else:   # (the raw column first: its buffers are the cache's key; _arrow() may build a new array)
-                    coded = _arrow_codes(_column(self.tables[o.kind], o.value), o.value, nulls_as="")
-                    parts.append(coded if coded is not None else _arrow_codes(self._arrow(o.kind, o.value), o.value, nulls_as=""))
-            coded, _dictionary = _sorted_union_codes(parts)   # ONE sorted dictionary: = / < on the codes is = / < on the strings
-            specs = []
-            for o, codes in zip(ops, coded):
-                if o.kind == "str":
-                    specs.append(("lit", int(codes[0])))
-                else:
-                    col = self._arrow(o.kind, o.value)
-                    specs.append((eside[o.kind], torch.from_numpy(np.ascontiguousarray(codes, dtype=np.int32)).to(self.eng.device),
-                                  self._valid(col)))
+            specs = self._string_pair(ops, res.op)
             return specs[0], res.op, specs[1], res.group
         return self._spec(ops[0]), res.op, self._spec(ops[1]), res.group
 
+    def _string_pair(self, ops, op):
+        """Two string operands (columns / literals) of ONE comparison as int32 codes of one sorted dictionary
+        shared by both: ``=`` / ``<`` on the codes is ``=`` / ``<`` on the strings (binary collation)."""
+        import torch
+
+        from .plan import Operand
+
+        eside = {"l": "a", "r": "b"}
+        ops = [o if isinstance(o, Operand) else Operand(o[0], o[1]) for o in ops]
+        if not all(self._is_string(o) for o in ops):
+            raise ValueError(f"cannot compare a string with a number in {ops[0].value!r} {op} {ops[1].value!r}")
+        parts = []
+        for o in ops:
+            if o.kind == "str":
+                parts.append((np.zeros(1, np.int32), [o.value]))
+            else:   # (the raw column first: its buffers are the cache's key; _arrow() may build a new array)
+                coded = _arrow_codes(_column(self.tables[o.kind], o.value), o.value, nulls_as="")
+                parts.append(coded if coded is not None else _arrow_codes(self._arrow(o.kind, o.value), o.value, nulls_as=""))
+        coded, _dictionary = _sorted_union_codes(parts)
+        specs = []
+        for o, codes in zip(ops, coded):
+            if o.kind == "str":
+                specs.append(("lit", int(codes[0])))
+            else:
+                col = self._arrow(o.kind, o.value)
+                specs.append((eside[o.kind], torch.from_numpy(np.ascontiguousarray(codes, dtype=np.int32)).to(self.eng.device),
+                              self._valid(col)))
+        return specs
+
     def _spec(self, o):
-        """A numeric operand as :meth:`HipEngine.select` takes it: a column, a literal, or ``("expr", tree)`` for
-        arithmetic (``giql_hip_select_expr_dev``)."""
+        """An operand as :meth:`HipEngine.select` takes it: a column, a literal, or ``("expr", tree)`` -- arithmetic,
+        or (round 4) a whole boolean condition: comparisons, IS [NOT] NULL, AND / OR / NOT
+        (``giql_hip_select_expr_dev``)."""
+        import torch
+
         eside = {"l": "a", "r": "b"}
 
         def leaf(kind, value):
@@ -581,10 +601,26 @@ class _Residuals:
                                  "in a dialect='hip' predicate" + (" expression" if o.kind == "expr" else ""))
             return (eside[kind], nv[0], nv[1])
 
+        def is_str(t):
+            return t[0] == "str" or (t[0] in ("l", "r") and self._is_string_column(t[0], t[1]))
+
         def tree(t):
-            if t[0] == "fn":
-                return (t[1], *[tree(c) for c in t[2]])
-            return leaf(t[0], t[1])
+            if t[0] != "fn":
+                return leaf(t[0], t[1])
+            op, kids = t[1], t[2]
+            if op in ("isnull", "notnull") and kids[0][0] in ("l", "r"):
+                # the validity of a column, whatever its type
+                col = self._arrow(kids[0][0], kids[0][1])
+                key = (kids[0][0], kids[0][1], "valid")
+                if key not in self._cache:
+                    self._cache[key] = (torch.zeros(len(col), dtype=torch.uint8, device=self.eng.device), self._valid(col))
+                data, valid = self._cache[key]
+                return (op, (eside[kids[0][0]], data, valid))
+            if op in ("=", "!=", "<", "<=", ">", ">=") and any(is_str(c) for c in kids):
+                if any(c[0] == "fn" for c in kids):
+                    raise ValueError("cannot compare a string with an arithmetic expression")
+                return (op, *self._string_pair(kids, op))
+            return (op, *[tree(c) for c in kids])
 
         return ("expr", tree(o.value)) if o.kind == "expr" else leaf(o.kind, o.value)
 

@@ -247,7 +247,7 @@ def _cond_tree(n, operand=None):
 
 
 def _terms(cond):
-    return condition_terms(_cond_tree(cond)) if cond is not None else []
+    return condition_terms(_cond_tree(cond), trees=True) if cond is not None else []
 
 
 def _select_item(n) -> SelItem:

@@ -87,12 +87,51 @@ def _cnf(node) -> list:
     return acc
 
 
-def condition_terms(tree) -> list:
+def _bool_term(node):
+    """A (NOT-free) condition node as an operand term ``("fn", op, [args])`` for the select kernel's boolean
+    programs: comparisons, IS [NOT] NULL, AND / OR (``giql_hip_select_expr_dev``, GIQL_X_EQ .. GIQL_X_OR)."""
+    k = node[0]
+    if k == "leaf":
+        t = node[1]
+        if t[0] != "cmp":
+            raise decline("spatial predicate under OR")
+        if t[2] in ("isnull", "notnull"):
+            return ("fn", t[2], [t[1]])
+        return ("fn", t[2], [t[1], t[3]])
+    return ("fn", k, [_bool_term(c) for c in node[1]])
+
+
+def condition_terms(tree, trees: bool = False) -> list:
     """The condition's CNF as terms: a one-leaf clause is the leaf itself, a longer one
     ``("or", [cmp, ...])``.  A spatial predicate must be a conjunct of its own (under OR / NOT
-    the reference falls back too: ``_classify_extras``)."""
+    the reference falls back too: ``_classify_extras``).
+
+    ``trees`` (the join's residuals, round 4): a condition whose normal form outgrows the cap is not declined --
+    its top-level conjuncts stay as they are, a plain comparison a term as before, anything nested ONE term
+    ``("tree", ("fn", op, [...]))`` that the select kernel evaluates as a boolean program under three-valued
+    logic (the reference inlines such a condition as text, intersects_duckdb.py:889-957).  Small conditions keep
+    their normal form: its clauses are what places a one-table condition BEFORE the join."""
+    nnf = _nnf(tree)
+    if trees:
+        try:
+            return condition_terms(tree)
+        except HipDeclined as exc:
+            if "too large" not in str(exc):
+                raise
+        out = []
+        stack = [nnf]
+        conjuncts = []
+        while stack:                      # the top-level ANDs, in order
+            n = stack.pop()
+            if n[0] == "and":
+                stack.extend(reversed(n[1]))
+            else:
+                conjuncts.append(n)
+        for n in conjuncts:
+            out.append(n[1] if n[0] == "leaf" else ("tree", _bool_term(n)))
+        return out
     out, leaves = [], 0
-    for clause in _cnf(_nnf(tree)):
+    for clause in _cnf(nnf):
         uniq = []
         for t in clause:
             if t not in uniq:
@@ -160,7 +199,7 @@ class JoinShape:
     join_ref: TableRef
     kind: str = "INNER"                      # INNER (also CROSS / comma) | SEMI | ANTI | LEFT
     on_seen: bool = False
-    # ("intersects", ColRef, ColRef) | ("cmp", lhs, op, rhs) | ("or", [cmp, ...]): see condition_terms
+    # ("intersects", ColRef, ColRef) | ("cmp", lhs, op, rhs) | ("or", [cmp, ...]) | ("tree", boolean program): see condition_terms
     on_terms: list = field(default_factory=list)
     where_terms: list = field(default_factory=list)
     using: list[str] = field(default_factory=list)
@@ -231,6 +270,9 @@ def resolve_projection(items, left: PlanSide, right: PlanSide, left_only: bool,
     return tuple(out)
 
 
+COMPARISONS = ("=", "!=", "<", "<=", ">", ">=", "isnull", "notnull")
+
+
 def bind_expression(o, bind_leaf) -> Operand:
     """An operand term -- ``("lit", v)`` / a column term / ``("fn", op, [terms])`` -- as a plan operand; columns and
     literals through ``bind_leaf``.  Arithmetic becomes ``Operand("expr", ["fn", op, [children]])`` whose leaves
@@ -238,11 +280,12 @@ def bind_expression(o, bind_leaf) -> Operand:
     if o[0] != "fn":
         return bind_leaf(o)
 
-    def tree(t):
+    def tree(t, strings_ok=False):
         if t[0] == "fn":
-            return ["fn", t[1], [tree(c) for c in t[2]]]
+            cmp = t[1] in COMPARISONS       # (strings compare and can be NULL; they take no part in arithmetic)
+            return ["fn", t[1], [tree(c, cmp) for c in t[2]]]
         leaf = bind_leaf(t)
-        if leaf.kind == "str":
+        if leaf.kind == "str" and not strings_ok:
             raise ValueError(f"a string ({leaf.value!r}) cannot take part in arithmetic")
         return [leaf.kind, leaf.value]
 
@@ -266,8 +309,8 @@ def operand_sides(o: Operand) -> set:
 
 #: what one call of the select kernel takes (``check_program`` in ``csrc/giql_hip.hip``: ``SEL_X_STACK`` values
 #: live, 64 postfix nodes per call): the gate declines what the target cannot run instead of failing at run time
-MAX_EXPR_DEPTH = 8
-MAX_EXPR_NODES = 64
+MAX_EXPR_DEPTH = 12
+MAX_EXPR_NODES = 256
 
 
 def expression_cost(o: Operand) -> tuple:
@@ -318,6 +361,8 @@ def resolve_residuals(clause_terms, left: PlanSide, right: PlanSide, kind: str) 
         if t[0] == "or":
             group += 1
             out.extend(resolve_residual(clause, leaf, left, right, kind, group) for leaf in t[1])
+        elif t[0] == "tree":    # a nested condition as one boolean program: kept when it IS TRUE
+            out.append(resolve_residual(clause, ("cmp", t[1], "istrue", ("lit", 0)), left, right, kind))
         else:
             out.append(resolve_residual(clause, t, left, right, kind))
     check_expression_sizes(out, kind)
@@ -597,8 +642,8 @@ def lower_join_shape(shape: JoinShape, tables: Tables) -> JoinPlan:
     if kind in ("SEMI", "ANTI") and not any(t[0] == "intersects" for t in on_terms):
         raise decline("SEMI/ANTI join with its INTERSECTS outside ON")  # #201
     _, lhs, rhs = [t for t in on_terms + where_terms if t[0] == "intersects"][0]
-    cmp_terms = ([("on", t) for t in on_terms if t[0] in ("cmp", "or")]
-                 + [("where", t) for t in where_terms if t[0] in ("cmp", "or")])
+    cmp_terms = ([("on", t) for t in on_terms if t[0] in ("cmp", "or", "tree")]
+                 + [("where", t) for t in where_terms if t[0] in ("cmp", "or", "tree")])
     if kind == "COUNT" and (cmp_terms or where_terms):
         raise decline("count_overlaps with predicates beside the INTERSECTS")  # bare ON only (:432-548)
     if kind == "COUNT" and not shape.group_by:

@@ -392,14 +392,14 @@ def _parse_bool(p: _Parser, allow_literal: bool, level: int = 0, operand=None):
     return _parse_predicate(p, allow_literal, operand)
 
 
-def _parse_conjunction(p: _Parser, allow_literal: bool = False):
+def _parse_conjunction(p: _Parser, allow_literal: bool = False, trees: bool = False):
     """A boolean condition -> the terms of its conjunctive normal form: ``("intersects", ...)``,
     ``("cmp", lhs, op, rhs)`` and ``("or", [cmp, ...])`` (``shape.condition_terms``).  The
     reference inlines any such extra beside the INTERSECTS as SQL text (``_classify_extras``,
     intersects_duckdb.py:889-912); arithmetic, functions, LIKE and sub-queries have no
     evaluator here and decline, as does a spatial predicate under OR / NOT (where the
     reference falls back too)."""
-    return _condition_terms(_parse_bool(p, allow_literal))
+    return _condition_terms(_parse_bool(p, allow_literal), trees=trees)
 
 
 def _own_table_residuals(terms, own) -> list:
@@ -1051,10 +1051,10 @@ def _lower(giql: str, tables, want_sql: bool):
         if p.peek().kind not in ("id", "num", "str") and not p.at_punct("-") and not p.at_punct("(") \
                 and not p.at_kw("NOT"):
             raise _decline("join condition other than INTERSECTS / simple comparisons")
-        shape.on_terms = _parse_conjunction(p)
+        shape.on_terms = _parse_conjunction(p, trees=True)   # (a join's residuals may be boolean programs)
     if p.at_kw("WHERE"):
         p.next()
-        shape.where_terms = _parse_conjunction(p)
+        shape.where_terms = _parse_conjunction(p, trees=True)
     # the clauses the reference lets ride on its outer SELECT wrapper (intersects_duckdb.py:1336-1400)
     if p.at_kw("GROUP"):
         p.next()

@@ -308,13 +308,18 @@ int giql_hip_take_utf8_fill_dev(giql_hip_ctx* ctx, const int32_t* offsets,
  * row id) or a literal.  Integers compare as int64, anything involving a float
  * as double; a NULL operand (valid[row] == 0) makes the predicate not true. */
 enum { GIQL_OP_EQ = 0, GIQL_OP_NE = 1, GIQL_OP_LT = 2, GIQL_OP_LE = 3, GIQL_OP_GT = 4, GIQL_OP_GE = 5,
-       GIQL_OP_IS_NULL = 6, GIQL_OP_NOT_NULL = 7 /* unary: lhs only, rhs ignored */ };
+       GIQL_OP_IS_NULL = 6, GIQL_OP_NOT_NULL = 7 /* unary: lhs only, rhs ignored */,
+       GIQL_OP_IS_TRUE = 8 /* unary: lhs is a boolean program (GIQL_X_EQ .. GIQL_X_NOT nodes), kept when TRUE */ };
 enum { GIQL_T_I32 = 0, GIQL_T_I64 = 1, GIQL_T_F32 = 2, GIQL_T_F64 = 3, GIQL_T_U8 = 4 };
 enum { GIQL_SIDE_A = 0, GIQL_SIDE_B = 1, GIQL_SIDE_LIT = 2,
        GIQL_SIDE_EXPR = 3 /* an arithmetic expression: giql_hip_select_expr_dev */ };
 /* node kinds of an expression program (giql_operand.side of a node): 0 / 1 / 2 push a column value / a literal */
 enum { GIQL_X_ADD = 16, GIQL_X_SUB = 17, GIQL_X_MUL = 18, GIQL_X_DIV = 19, GIQL_X_NEG = 20, GIQL_X_ABS = 21,
-       GIQL_X_LEAST = 22, GIQL_X_GREATEST = 23 };
+       GIQL_X_LEAST = 22, GIQL_X_GREATEST = 23,
+       /* boolean nodes over three-valued results (round 4): a whole condition as one program, the way the
+        * reference inlines it as text (src/giql/expanders/intersects_duckdb.py:889-957) -- no normal form */
+       GIQL_X_EQ = 24, GIQL_X_NE = 25, GIQL_X_LT = 26, GIQL_X_LE = 27, GIQL_X_GT = 28, GIQL_X_GE = 29,
+       GIQL_X_ISNULL = 30, GIQL_X_NOTNULL = 31, GIQL_X_AND = 32, GIQL_X_OR = 33, GIQL_X_NOT = 34 };
 
 typedef struct giql_operand {
   int32_t side;          /* GIQL_SIDE_*                                          */
@@ -357,12 +362,13 @@ int giql_hip_select_dev(giql_hip_ctx* ctx, const giql_pred* preds, int32_t n_pre
 /* The same with ARITHMETIC operands -- the overlap-fraction recipes of docs/recipes/intersect.rst:144-190
  * ("(LEAST(a.end, b.end) - GREATEST(a.start, b.start)) >= 0.5 * (a.end - a.start)"), which the reference
  * inlines into its join's ON clause as text (intersects_duckdb.py:889-912, 1239-1243).  An operand of side
- * GIQL_SIDE_EXPR is a postfix program over `nodes` (a HOST array of n_nodes <= 64 giql_operand-shaped
+ * GIQL_SIDE_EXPR is a postfix program over `nodes` (a HOST array of n_nodes <= 256 giql_operand-shaped
  * nodes): lit_i = its first node, type = its node count.  A node of side A / B / LIT pushes that value, a node
- * of side GIQL_X_* pops its one (NEG, ABS) or two arguments and pushes the result; at most 8 values are
- * live.  Semantics are those of the reference's execution target (DuckDB): integer + - * stay 64-bit
- * integers, `/` is a floating division and NULL on a zero divisor, NULL propagates through arithmetic,
- * LEAST / GREATEST skip NULL arguments. */
+ * of side GIQL_X_* pops its one (NEG, ABS, ISNULL, NOTNULL, NOT) or two arguments and pushes the result; at
+ * most 12 values are live.  Semantics are those of the reference's execution target (DuckDB): integer + - *
+ * stay 64-bit integers, `/` is a floating division and NULL on a zero divisor, NULL propagates through
+ * arithmetic, LEAST / GREATEST skip NULL arguments; comparisons and AND / OR / NOT are three-valued (a boolean
+ * program is the lhs of a predicate with op GIQL_OP_IS_TRUE: the candidate is kept when it is TRUE). */
 int giql_hip_select_expr_dev(giql_hip_ctx* ctx, const giql_pred* preds, int32_t n_preds,
                              const giql_operand* nodes, int32_t n_nodes,
                              const int32_t* idx_a, int64_t n_rows_a,

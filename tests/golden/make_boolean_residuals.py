@@ -73,6 +73,35 @@ ARITH = [
 ]
 
 
+def random_condition(rng, depth):
+    """A random nested condition over scores, names and strands (SQL text valid in GIQL and in sqlite)."""
+    if depth == 0 or rng.random() < 0.2:
+        kind = rng.random()
+        col = rng.choice(["a.score", "b.score"])
+        if kind < 0.12:
+            return f"{rng.choice(['a.score', 'b.score', 'a.name', 'b.name'])} IS {'NOT ' if rng.random() < 0.5 else ''}NULL"
+        if kind < 0.24:
+            return f"{col} {'NOT ' if rng.random() < 0.5 else ''}BETWEEN {rng.randrange(0, 4)} AND {rng.randrange(2, 6)}"
+        if kind < 0.36:
+            vals = sorted({rng.randrange(0, 6) for _ in range(rng.randrange(1, 4))})
+            return f"{col} {'NOT ' if rng.random() < 0.5 else ''}IN ({', '.join(map(str, vals))})"
+        if kind < 0.48:
+            return f"a.strand {rng.choice(['=', '<>'])} b.strand"
+        if kind < 0.58:
+            return f"{rng.choice(['a.name', 'b.name'])} {rng.choice(['=', '<>', '<', '>='])} '{rng.choice('pg')}{rng.randrange(0, 7)}'"
+        if kind < 0.66:
+            return f"a.score + b.score {rng.choice(['<', '>=', '='])} {rng.randrange(2, 9)}"
+        op = rng.choice(["=", "<>", "<", "<=", ">", ">="])
+        if rng.random() < 0.4:
+            return f"a.score {op} b.score"
+        return f"{col} {op} {rng.randrange(0, 6)}"
+    kind = rng.random()
+    if kind < 0.2:
+        return f"NOT ({random_condition(rng, depth - 1)})"
+    kids = [random_condition(rng, depth - 1) for _ in range(rng.randrange(2, 4))]
+    return "(" + (" AND " if kind < 0.55 else " OR ").join(kids) + ")"
+
+
 def giql_query(kind: str, on: str, where: str) -> str:
     join = {"INNER": "JOIN", "SEMI": "SEMI JOIN", "ANTI": "ANTI JOIN"}[kind]
     cols = "a.name AS an, a.start AS s, b.name AS bn, b.end AS e" if kind == "INNER" else "a.name, a.start, a.score"
@@ -158,14 +187,35 @@ def main() -> None:
             arith.append({"kind": kind, "query": giql_query(kind, on, where), "peaks": [list(r) for r in peaks],
                           "genes": [list(r) for r in genes], "rows": [list(r) for r in sorted(got, key=key)]})
     assert sum(1 for c in arith if c["rows"]) >= len(arith) * 2 // 3
+    # nested conditions (round 4): random three-level combinations, most of them past what a conjunctive normal form
+    # of 12 comparisons holds -- the hip target runs those as boolean programs.  A generator of its own: the cases
+    # above stay what they were.
+    rng2 = random.Random(20261104)
+    nested = []
+    for i in range(72):
+        kind = ("INNER", "INNER", "INNER", "SEMI", "ANTI")[i % 5]
+        cond = random_condition(rng2, 3)
+        on, where = (cond, "") if i % 2 == 0 else ("", cond)
+        if kind != "INNER" and where and "b." in where:      # (a SEMI / ANTI WHERE reads the left table only)
+            on, where = where, ""
+        peaks, genes = rand_rows(rng2, 40, "p"), rand_rows(rng2, 35, "g")
+        conn = sqlite3.connect(":memory:")
+        for t, rows in (("peaks", peaks), ("genes", genes)):
+            conn.execute(f'CREATE TABLE {t} (chrom TEXT, "start" INTEGER, "end" INTEGER, name TEXT, score INTEGER, strand TEXT)')
+            conn.executemany(f"INSERT INTO {t} VALUES (?, ?, ?, ?, ?, ?)", rows)
+        got = sqlite_rows(conn, kind, on, where)
+        conn.close()
+        key = lambda r: tuple((x is None, x) for x in r)
+        nested.append({"kind": kind, "query": giql_query(kind, on, where), "peaks": [list(r) for r in peaks],
+                       "genes": [list(r) for r in genes], "rows": [list(r) for r in sorted(got, key=key)]})
     doc = {"_source": "tests/golden/make_boolean_residuals.py: sqlite3 evaluates the overlap join AND the condition "
                       "text the reference would inline (intersects_duckdb.py:889-912, 1239-1243); rows sorted with NULLs last "
                       "per column; table rows are (chrom, start, end, name, score, strand)",
-           "cases": cases, "having": having, "arith": arith}
+           "cases": cases, "having": having, "arith": arith, "nested": nested}
     with open(os.path.join(HERE, "boolean_residuals.json"), "w") as f:
         json.dump(doc, f, separators=(",", ":"))
     print(len(cases), "cases,", sum(len(c["rows"]) for c in cases), "rows;", len(having), "HAVING cases,",
-          sum(len(c["rows"]) for c in having), "rows;", len(arith), "arithmetic cases,", sum(len(c["rows"]) for c in arith), "rows")
+          sum(len(c["rows"]) for c in having), "rows;", len(arith), "arithmetic cases,", sum(len(c["rows"]) for c in arith), "rows;", len(nested), "nested cases,", sum(len(c["rows"]) for c in nested), "rows")
 
 
 if __name__ == "__main__":

@@ -36,6 +36,20 @@ def _arith(t, p, g):
     if t[0] != "fn":
         return (p if t[0] == "l" else g)[COLS.index(t[1])] if t[0] in ("l", "r") else t[1]
     args = [_arith(c, p, g) for c in t[2]]
+    # boolean nodes (round 4: a nested condition travels as one program): three-valued, True / False / None
+    if t[1] in ("isnull", "notnull"):
+        return (args[0] is None) == (t[1] == "isnull")
+    if t[1] == "not":
+        return None if args[0] is None else not args[0]
+    if t[1] == "and":
+        return False if any(a is False for a in args) else (None if any(a is None for a in args) else True)
+    if t[1] == "or":
+        return True if any(a is True for a in args) else (None if any(a is None for a in args) else False)
+    if t[1] in ("=", "!=", "<", "<=", ">", ">="):
+        a, b = args
+        if a is None or b is None:
+            return None
+        return {"=": a == b, "!=": a != b, "<": a < b, "<=": a <= b, ">": a > b, ">=": a >= b}[t[1]]
     if t[1] in ("least", "greatest"):
         vals = [a for a in args if a is not None]
         return None if not vals else (min(vals) if t[1] == "least" else max(vals))
@@ -53,6 +67,8 @@ def _arith(t, p, g):
 
 def _leaf(res, p, g) -> bool:
     a = _value(res.lhs, p, g)
+    if res.op == "istrue":
+        return a is True
     if res.op in ("isnull", "notnull"):
         return (a is None) == (res.op == "isnull")
     b = _value(res.rhs, p, g)
@@ -249,11 +265,8 @@ def test_random_conditions_normalise_to_what_three_valued_logic_gives(seed):
     rng = random.Random(seed)
     text, truth = _random_condition(rng, 3)
     q = f"SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND {text}"
-    try:
-        plan = build_plan(q, ["peaks", "genes"])
-    except HipDeclined as exc:
-        assert "too large" in str(exc)        # (more than 12 comparisons once normalised)
-        return
+    plan = build_plan(q, ["peaks", "genes"])   # (round 4: never declined -- what outgrows the normal form is a program)
+    assert HipDeclined is not None
     rows = [("c", 0, 1, "n", v, "+") for v in (None, 0, 1, 2, 3, 4, 5)]
     for p in rows:
         for g in rows:
@@ -280,20 +293,77 @@ def test_expression_depth_and_size_limits_are_declined_at_plan_time():
     with pytest.raises(HipDeclined, match="too deep"):
         build_plan(base + _nested_sum(MAX_EXPR_DEPTH) + " > 3", ["peaks", "genes"])
     # a LEFT-nested sum of any length keeps two values live: only the node count bounds it
-    flat = " + ".join(["a.score"] * 32)                      # 32 leaves + 31 operators = 63 nodes
+    half = MAX_EXPR_NODES // 2
+    flat = " + ".join(["a.score"] * half)                      # n leaves + (n - 1) operators = 2 n - 1 nodes
     p = build_plan(base + flat + " > b.score", ["peaks", "genes"])
-    assert expression_cost(p.residuals[0].lhs) == (63, 2)
+    assert expression_cost(p.residuals[0].lhs) == (MAX_EXPR_NODES - 1, 2)
     with pytest.raises(HipDeclined, match="too large"):
-        build_plan(base + " + ".join(["a.score"] * 33) + " > b.score", ["peaks", "genes"])   # 65 nodes
+        build_plan(base + " + ".join(["a.score"] * (half + 1)) + " > b.score", ["peaks", "genes"])   # one node too many
     # the nodes of ONE select call add up over its comparisons (here: all two-sided, AND-ed) ...
     recipe = "(LEAST(a.end, b.end) - GREATEST(a.start, b.start)) >= 0.5 * (b.end - b.start)"   # 12 nodes
-    assert sum(expression_cost(o)[0] for o in (build_plan(base + recipe, ["peaks", "genes"]).residuals[0].lhs,
-                                               build_plan(base + recipe, ["peaks", "genes"]).residuals[0].rhs)) == 12
-    build_plan(base + " AND ".join(recipe.replace("0.5", f"0.{k}") for k in range(1, 6)), ["peaks", "genes"])      # 60 nodes
+    one = build_plan(base + recipe, ["peaks", "genes"]).residuals[0]
+    assert expression_cost(one.lhs)[0] + expression_cost(one.rhs)[0] == 12
+    variants = [recipe.replace("0.5", f"0.{k:02d}") for k in range(1, 40)]
+    build_plan(base + " AND ".join(variants[:21]), ["peaks", "genes"])                        # 252 nodes
     with pytest.raises(HipDeclined, match="too large"):
-        build_plan(base + " OR ".join(recipe.replace("0.5", f"0.{k}") for k in range(1, 7)), ["peaks", "genes"])   # 72 nodes
+        build_plan(base + " AND ".join(variants[:22]), ["peaks", "genes"])                    # 264 nodes in one call
+    # an OR of many recipes outgrows the normal form and travels as ONE boolean program: 13 nodes per comparison
+    # + the ORs between them
+    prog = build_plan(base + " OR ".join(variants[:15]), ["peaks", "genes"]).residuals
+    assert len(prog) == 1 and prog[0].op == "istrue" and expression_cost(prog[0].lhs)[0] == 15 * 13 + 14
+    with pytest.raises(HipDeclined, match="too large"):
+        build_plan(base + " OR ".join(variants[:20]), ["peaks", "genes"])                     # 279 nodes
     # ... but one-sided conditions run in calls of their own
-    left = " + ".join(["a.score"] * 30) + " > 0"                                             # 59 nodes, left only
-    right = " + ".join(["b.score"] * 30) + " > 0"                                            # 59 nodes, right only
+    left = " + ".join(["a.score"] * (half - 2)) + " > 0"
+    right = " + ".join(["b.score"] * (half - 2)) + " > 0"
     assert len(build_plan(base + left + " AND " + right, ["peaks", "genes"]).residuals) == 2
-    assert MAX_EXPR_NODES == 64
+    assert (MAX_EXPR_DEPTH, MAX_EXPR_NODES) == (12, 256)
+
+
+# ---- conditions past the normal form's cap: boolean programs (round 4) -------------------------
+NESTED = _DOC.get("nested", [])
+
+
+@pytest.mark.parametrize("case", NESTED, ids=[f"nested{i}:{c['kind']}" for i, c in enumerate(NESTED)])
+def test_nested_conditions_as_programs_give_sqlites_rows_on_the_cpu(case):
+    plan = build_plan(case["query"], ["peaks", "genes"])
+    peaks, genes = case["peaks"], case["genes"]
+    if plan.kind == "INNER":
+        got = [[p[3], p[1], g[3], g[2]] for p in peaks for g in genes if _overlap(p, g) and _holds(plan.residuals, p, g)]
+    else:
+        on = [r for r in plan.residuals if r.clause == "on"]
+        where = [r for r in plan.residuals if r.clause == "where"]
+        got = [[p[3], p[1], p[4]] for p in peaks
+               if _holds(where, p, None) and (any(_overlap(p, g) and _holds(on, p, g) for g in genes) != (plan.kind == "ANTI"))]
+    assert sorted(got, key=_key) == case["rows"]
+
+
+def test_the_nested_golden_cases_are_the_ones_the_normal_form_could_not_take():
+    # a good third of them carry a boolean program (op "istrue": the normal form would have been declined in round 3,
+    # the others still fit it); the plan's string form round-trips
+    from giql_amd.plan import JoinPlan
+
+    n_prog = 0
+    for case in NESTED:
+        plan = build_plan(case["query"], ["peaks", "genes"])
+        n_prog += any(r.op == "istrue" for r in plan.residuals)
+        assert JoinPlan.from_string(plan.to_string()) == plan
+    assert len(NESTED) >= 60 and n_prog >= 24
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", NESTED, ids=[f"nested{i}:{c['kind']}" for i, c in enumerate(NESTED)])
+def test_nested_conditions_run_on_the_gpu_path(case):
+    import pyarrow as pa
+
+    from giql_amd.execute import execute
+
+    def table(rows):
+        cols = list(zip(*rows)) if rows else [[]] * 6
+        types = [pa.string(), pa.int32(), pa.int32(), pa.string(), pa.int32(), pa.string()]
+        return pa.table({c: pa.array(list(v), t) for c, v, t in zip(COLS, cols, types)})
+
+    t = {"peaks": table(case["peaks"]), "genes": table(case["genes"])}
+    out = execute(transpile(case["query"], tables=["peaks", "genes"], dialect="hip"), t)
+    got = sorted(([*d.values()] for d in out.to_pylist()), key=_key)
+    assert got == case["rows"]

@@ -129,11 +129,22 @@ def test_tables_outside_the_indexed_form_are_declined_with_state(eng):
     with pytest.raises(_lib.GiqlHipError) as ei:
         eng.index_create(dev(neg), 24)
     assert ei.value.code == _lib.GIQL_ERR_STATE
-    s = np.random.default_rng(1).integers(0, 1_000_000, 400_000).astype(np.int32)
-    dense = ora.Side(np.zeros(400_000, np.int32), s, (s + 100).astype(np.int32))
+    # more rows in ONE 65,536-key bucket than the bucket stage sorts (2^18): declined ...
+    s = np.random.default_rng(1).integers(0, 60_000, 400_000).astype(np.int32)
+    piled = ora.Side(np.zeros(400_000, np.int32), s, (s + 100).astype(np.int32))
     with pytest.raises(_lib.GiqlHipError) as ei:
-        eng.index_create(dev(dense), 1)
+        eng.index_create(dev(piled), 1)
     assert ei.value.code == _lib.GIQL_ERR_STATE
+    # ... while buckets past what LDS holds (4096 rows) but below that go through the queue kernel: slow, exact
+    s = np.random.default_rng(2).integers(0, 1_000_000, 400_000).astype(np.int32)
+    dense = ora.Side(np.zeros(400_000, np.int32), s, (s + 100).astype(np.int32))
+    index = eng.index_create(dev(dense), 1)
+    try:
+        qs = np.random.default_rng(3).integers(0, 1_000_000, 3_000).astype(np.int32)
+        q = ora.Side(np.zeros(3_000, np.int32), qs, (qs + np.random.default_rng(4).integers(1, 400, 3_000)).astype(np.int32))
+        assert np.array_equal(pairs_of(*eng.inner_join_indexed(dev(q), index)), want_pairs(q, dense))
+    finally:
+        index.close()
     # an irregular QUERY row: declined per call (the literal predicate may hold for it: the ordinary join's case)
     index = eng.index_create(dev(ok), 24)
     try:

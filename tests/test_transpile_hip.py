@@ -99,9 +99,8 @@ def test_case_insensitive_aliases():
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score IN (1, b.score)",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score % 2 = 1",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND 1 + 1 = 2",
-    # 13 comparisons once in conjunctive normal form: the select kernel takes 12 beside a filter's own three
-    "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score IN "
-    "(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)",
+    # (13 comparisons once in conjunctive normal form were declined until round 4; a join's residual past the cap now
+    # travels as one boolean program: test_an_in_list_past_the_normal_forms_cap_is_a_boolean_program)
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND SQRT(a.score) > 5",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND 1 = 1",
     "SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.interval INTERSECTS b.interval",
@@ -121,6 +120,17 @@ def test_case_insensitive_aliases():
 def test_valid_but_unsupported_shapes_decline(query):
     with pytest.raises(HipDeclined):
         build_plan(query, ["peaks", "genes"])
+
+
+def test_an_in_list_past_the_normal_forms_cap_is_a_boolean_program():
+    q = ("SELECT a.start FROM peaks a JOIN genes b ON a.interval INTERSECTS b.interval AND a.score IN "
+         "(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)")
+    (r,) = build_plan(q, ["peaks", "genes"]).residuals
+    assert r.op == "istrue" and r.lhs.kind == "expr" and r.lhs.value[1] == "or" and len(r.lhs.value[2]) == 13
+    # ... while the literal-range filter and CLUSTER / MERGE predicates keep the normal form and its cap
+    with pytest.raises(HipDeclined, match="too large"):
+        build_plan("SELECT * FROM peaks WHERE interval INTERSECTS 'chr1:1-10' AND score IN "
+                   "(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)", ["peaks"])
 
 
 def test_boolean_having_arrives_in_conjunctive_normal_form():
