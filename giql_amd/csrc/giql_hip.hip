@@ -166,6 +166,7 @@ struct giql_hip_ctx {
   double local_max_bucket_rows = 2800.0;  // three-stage sort only while a 16-bit bucket holds at most this many rows on average
   double local_min_bucket_rows = 300.0;   // ... and at least this many (below: a block per bucket is mostly overhead)
   bool no_skip_digit = false;  // GIQL_HIP_NO_SKIP_DIGIT=1: query sides are sorted on every digit
+  bool no_dual_span = false;   // GIQL_HIP_NO_DUAL_SPAN=1: one span launch per side (round 3)
   bool no_coarse_b = false;    // GIQL_HIP_NO_COARSE_B=1: the fixed-length B of SEMI / ANTI / COUNT is sorted on every digit
   double coarse_max_group_rows = 8.0;  // ... and coarsely only while the rows sharing their upper 24 key bits are at most this many on average
   bool local_sort = true;
@@ -410,6 +411,34 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
   const size_t lds = n_chrom <= MM_LDS_CHROMS ? (size_t)n_chrom * 2 * sizeof(int) : 0;
   const giql_side* sides[2] = {&a, &b};
   int nblk[2] = {0, 0};
+  if (a.n > 0 && b.n > 0 && !ctx->no_dual_span) {
+    // both sides in ONE launch: the grid (one resident wave of 512-thread blocks) is shared in proportion to the rows
+    MmSide ms[2];
+    const double tot = (double)a.n + (double)b.n;
+    for (int k = 0; k < 2; k++) {
+      const giql_side& s = *sides[k];
+      const bool with_hist = hist && (k == hist_side || hist2);
+      u32* const hp = k == hist_side ? hist_partial : lb.hist_partial2;
+      if (with_hist) ctx->span_hist_dirty[k] = hp;
+      u32 grid = (u32)((double)MM_MAX_BLOCKS * (double)s.n / tot + 0.5);
+      const u32 need = cdiv((u64)s.n, (u64)MM_NT_HIST * 4);   // a block per tile at most
+      if (grid > need) grid = need;
+      if (grid < 1) grid = 1;
+      nblk[k] = (int)grid;
+      ms[k].chrom = s.chrom;
+      ms[k].start = s.start;
+      ms[k].end = s.end;
+      ms[k].n = (i64)s.n;
+      ms[k].len_bias = s.end_off - s.start_off;
+      ms[k].start_off = with_hist ? s.start_off : 0;
+      ms[k].hist = !with_hist ? 0 : (sort_is_local(ctx, (size_t)s.n) ? 2 : 1);
+      ms[k].nblk = grid;
+      ms[k].hist_partial = with_hist ? hp : nullptr;
+      ms[k].top_partial = with_hist ? (k == hist_side ? lb.top_partial : lb.top_partial2) : nullptr;
+    }
+    hipLaunchKernelGGL((k_chrom_minmax2<MM_NT_HIST>), dim3(ms[0].nblk + ms[1].nblk), dim3(MM_NT_HIST), lds, st, ms[0], ms[1],
+                       n_chrom, lb.gmin, lb.gmax, ctx->d_meta, lb.len_part);
+  } else
   for (int k = 0; k < 2; k++) {
     const giql_side& s = *sides[k];
     if (s.n == 0) continue;
@@ -985,6 +1014,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->no_span_hist = nh && atoi(nh) != 0;
     const char* nsd = getenv("GIQL_HIP_NO_SKIP_DIGIT");
     ctx->no_skip_digit = nsd && atoi(nsd) != 0;
+    const char* nds = getenv("GIQL_HIP_NO_DUAL_SPAN");
+    ctx->no_dual_span = nds && atoi(nds) != 0;
     const char* ncb = getenv("GIQL_HIP_NO_COARSE_B");
     ctx->no_coarse_b = ncb && atoi(ncb) != 0;
     const char* cmb = getenv("GIQL_HIP_COARSE_MAX_GROUP_ROWS");

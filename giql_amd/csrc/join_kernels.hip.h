@@ -87,19 +87,17 @@ constexpr int MM_TOP_WORDS = MM_HIST_CHROMS * 256;
 // HIST: 0 = min/max and lengths only; 1 = also the four digit histograms; 2 = only the two high
 // digits (the three-stage sort scatters on bits 16-31 only: its low bits are sorted in LDS, and the
 // two per-row LDS atomics of the low digits are what bounds this pass).
-template <int HIST, int NT>
-__global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chrom,
-                                                         const int* __restrict__ start,
-                                                         const int* __restrict__ end, i64 n,
-                                                         int n_chrom, int* __restrict__ gmin,
-                                                         int* __restrict__ gmax,
-                                                         DevMeta* __restrict__ meta, int len_bias,
-                                                         int which, int* __restrict__ len_part,
-                                                         int start_off, u32* __restrict__ hist_partial,
-                                                         u32* __restrict__ top_partial) {
+// The body: block `bid` of `nblk` over one side.  HIST is a compile-time constant in k_chrom_minmax (the body is
+// inlined: the branches fold) and a per-side run-time value in k_chrom_minmax2 (both sides in ONE launch).
+template <int NT>
+__device__ __forceinline__ void chrom_minmax_body(const int HIST, const int* __restrict__ chrom,
+                                                  const int* __restrict__ start, const int* __restrict__ end, i64 n,
+                                                  int n_chrom, int* __restrict__ gmin, int* __restrict__ gmax,
+                                                  DevMeta* __restrict__ meta, int len_bias, int which,
+                                                  int* __restrict__ len_part, int start_off,
+                                                  u32* __restrict__ hist_partial, u32* __restrict__ top_partial,
+                                                  const u32 bid, const u32 nblk, u32* s_hist, u32* s_top) {
   extern __shared__ int mm_lds[];
-  __shared__ u32 s_hist[HIST ? 3 * 256 : 1];
-  __shared__ u32 s_top[HIST ? MM_TOP_WORDS : 1];
   if (HIST) {
     for (int k = threadIdx.x; k < 3 * 256; k += NT) s_hist[k] = 0;
     for (int k = threadIdx.x; k < MM_TOP_WORDS; k += NT) s_top[k] = 0;
@@ -262,12 +260,12 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
     for (int u = 0; u < 4; u++) row(c4[u], s4[u], e4[u], true);
   };
   {
-    u64 t = blockIdx.x;
-    for (; t + gridDim.x < n_full; t += 2ull * gridDim.x) {   // two tiles in flight
+    u64 t = bid;
+    for (; t + nblk < n_full; t += 2ull * nblk) {   // two tiles in flight
       mm_i4 c4a, s4a, e4a, c4b, s4b, e4b;
       int pca, psa, pcb, psb;
       tile4(t, c4a, s4a, e4a, pca, psa);
-      tile4(t + gridDim.x, c4b, s4b, e4b, pcb, psb);
+      tile4(t + nblk, c4b, s4b, e4b, pcb, psb);
       rows4(c4a, s4a, e4a, pca, psa);
       rows4(c4b, s4b, e4b, pcb, psb);
     }
@@ -278,7 +276,7 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
       rows4(c4a, s4a, e4a, pca, psa);
     }
   }
-  if (blockIdx.x == (u32)(n_full % gridDim.x)) {  // the ragged tail: one block
+  if (bid == (u32)(n_full % nblk)) {  // the ragged tail: one block
     const u64 base = n_full * TILE;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -292,7 +290,7 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
   }
   if (HIST) {
     __syncthreads();
-    const size_t rep = blockIdx.x % LIN_HIST_REPLICAS;
+    const size_t rep = bid % LIN_HIST_REPLICAS;
     u32* g = hist_partial + rep * 1024;
     for (int k = threadIdx.x; k < 3 * 256; k += NT) {
       const u32 v = s_hist[k];
@@ -338,8 +336,8 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
         a = s_len[0][k] < a ? s_len[0][k] : a;
         b = s_len[1][k] > b ? s_len[1][k] : b;
       }
-      len_part[(which * MM_MAX_BLOCKS + blockIdx.x) * 2 + 0] = a;
-      len_part[(which * MM_MAX_BLOCKS + blockIdx.x) * 2 + 1] = b;
+      len_part[(which * MM_MAX_BLOCKS + bid) * 2 + 0] = a;
+      len_part[(which * MM_MAX_BLOCKS + bid) * 2 + 1] = b;
     }
   }
   if (use_lds) {
@@ -351,6 +349,49 @@ __global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chr
       }
     }
   }
+}
+
+template <int HIST, int NT>
+__global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chrom,
+                                                         const int* __restrict__ start,
+                                                         const int* __restrict__ end, i64 n,
+                                                         int n_chrom, int* __restrict__ gmin,
+                                                         int* __restrict__ gmax,
+                                                         DevMeta* __restrict__ meta, int len_bias,
+                                                         int which, int* __restrict__ len_part,
+                                                         int start_off, u32* __restrict__ hist_partial,
+                                                         u32* __restrict__ top_partial) {
+  __shared__ u32 s_hist[HIST ? 3 * 256 : 1];
+  __shared__ u32 s_top[HIST ? MM_TOP_WORDS : 1];
+  chrom_minmax_body<NT>(HIST, chrom, start, end, n, n_chrom, gmin, gmax, meta, len_bias, which, len_part, start_off,
+                        hist_partial, top_partial, blockIdx.x, gridDim.x, s_hist, s_top);
+}
+
+// Both sides in ONE launch (round 4): the smaller side's span pass is a latency-bound 20-50 us kernel of its own
+// in front of the larger side's; its blocks -- a share of the grid in proportion to its rows -- run beside the
+// larger side's instead.  Blocks [0, a.nblk) take side A, the rest side B.
+struct MmSide {
+  const int* chrom;
+  const int* start;
+  const int* end;
+  i64 n;
+  int len_bias, start_off, hist;
+  u32 nblk;
+  u32* hist_partial;
+  u32* top_partial;
+};
+template <int NT>
+__global__ __launch_bounds__(NT) void k_chrom_minmax2(MmSide a, MmSide b, int n_chrom, int* __restrict__ gmin,
+                                                      int* __restrict__ gmax, DevMeta* __restrict__ meta,
+                                                      int* __restrict__ len_part) {
+  __shared__ u32 s_hist[3 * 256];
+  __shared__ u32 s_top[MM_TOP_WORDS];
+  if (blockIdx.x < a.nblk)
+    chrom_minmax_body<NT>(a.hist, a.chrom, a.start, a.end, a.n, n_chrom, gmin, gmax, meta, a.len_bias, 0, len_part,
+                          a.start_off, a.hist_partial, a.top_partial, blockIdx.x, a.nblk, s_hist, s_top);
+  else
+    chrom_minmax_body<NT>(b.hist, b.chrom, b.start, b.end, b.n, n_chrom, gmin, gmax, meta, b.len_bias, 1, len_part,
+                          b.start_off, b.hist_partial, b.top_partial, blockIdx.x - a.nblk, b.nblk, s_hist, s_top);
 }
 
 // Single block: chrom_base[c] = (exclusive prefix of spans) - (lowest canonical

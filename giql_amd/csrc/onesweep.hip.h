@@ -204,6 +204,9 @@ __device__ __forceinline__ u32 onesweep_tile(
   // microseconds waiting for its predecessors (the 64 tiles of a dispatch group start together;
   // tools/os_timeline.py), and the staging needs none of what the walk returns.
   u32 lb_count = 0;
+#if defined(GIQL_OS_FAKE_SEG)
+  u32 lb_fake = 0;
+#endif
   if (tid < OS_BINS) {
     u32 run = 0;
 #pragma unroll
@@ -219,8 +222,25 @@ __device__ __forceinline__ u32 onesweep_tile(
     const u32 incl = wave_incl_scan(count);
     if (lane == WAVE - 1) s_scan[w] = incl;
 #if !(defined(GIQL_ABLATE) && GIQL_ABLATE == 1)
+#if defined(GIQL_OS_FAKE_SEG)  // timing-only build (results WRONG): the look-back chain restarts every GIQL_OS_FAKE_SEG tiles,
+                               // as it would with per-segment digit bases known up front -- what would that buy?
+    // (a segment's first tile starts from the EXPECTED prefix of a shuffled input -- its bin's size x the share of the
+    // tiles before it -- so that the destinations spread as the real ones do: without it the segments overwrite each
+    // other's lines in L2 and the build flatters itself)
+    {
+      const u32 n_tiles_ = (n_total + (u32)(OS_NT * OS_ITEMS) - 1u) / (u32)(OS_NT * OS_ITEMS);
+      const u32 bin_ = (tid == OS_BINS - 1 ? n_total : gbase[tid + 1]) - gbase[tid];
+      const u32 fake_ = (u32)((u64)bin_ * tile / n_tiles_);
+      const bool head_ = (tile % GIQL_OS_FAKE_SEG) == 0;
+      lb_fake = head_ ? fake_ : 0u;
+      __hip_atomic_store(status + (size_t)tile * OS_BINS + tid,
+                         (head_ ? OS_FLAG_PREFIX : OS_FLAG_AGG) | ((count + lb_fake) & OS_VALUE_MASK), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+#else
     __hip_atomic_store(status + (size_t)tile * OS_BINS + tid, (tile == 0 ? OS_FLAG_PREFIX : OS_FLAG_AGG) | count,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 #endif
     s_dstart[tid] = incl - count;  // wave-local exclusive; wave base added below
   }
@@ -294,10 +314,17 @@ __device__ __forceinline__ u32 onesweep_tile(
   GIQL_TL(tile, 8);  // every LDS round done (one-payload sorts)
   if (tid < OS_BINS) {
     u32 excl = 0;
+#if defined(GIQL_OS_FAKE_SEG)
+    excl = lb_fake;
+#endif
 #if defined(GIQL_ABLATE) && GIQL_ABLATE == 1  // timing-only build: no look-back
     excl = tile * 32;
 #else
+#if defined(GIQL_OS_FAKE_SEG)
+    if ((tile % GIQL_OS_FAKE_SEG) != 0) {
+#else
     if (tile != 0) {
+#endif
       // look back: the OS_LB_WIDTH nearest predecessors are polled together (independent loads
       // in flight).  The 64 tiles of a dispatch group start together, so a walk crosses ~25
       // aggregate-only tiles (its distance from the group's first tile) before it meets a prefix.

@@ -892,12 +892,50 @@ def test_select_arithmetic_operands_match_numpy(eng):
     for preds, want in cases:
         ga, gb = eng.select(preds, idx_a=d(ia), idx_b=d(ib), n_rows_a=na, n_rows_b=nb)
         assert np.array_equal(ga.cpu().numpy(), ia[want]) and np.array_equal(gb.cpu().numpy(), ib[want])
+    # boolean programs (round 4): comparisons, IS [NOT] NULL, AND / OR / NOT under three-valued logic, kept when TRUE
+    def k3(t, known):        # (value, known) pairs -> Kleene
+        return t, known
+    def k_and(x, y):
+        val = x[0] & y[0]
+        known = (x[1] & y[1]) | (x[1] & ~x[0]) | (y[1] & ~y[0])
+        return val & known, known
+    def k_or(x, y):
+        known = (x[1] & y[1]) | (x[1] & x[0]) | (y[1] & y[0])
+        val = ((x[0] & x[1]) | (y[0] & y[1]))
+        return val, known
+    def k_not(x):
+        return ~x[0] & x[1], x[1]
+    c1 = k3(sc < 2, ok_a)                               # a.score < 2
+    c2 = k3(f > 0.3, ok_b)                              # b.f > 0.3
+    c3 = k3((e_a - s_a) > 250, np.ones(n, bool))        # a.end - a.start > 250
+    c4 = k3(sc * 1.0 >= f, ok_a & ok_b)                 # a.score >= b.f
+    isnull_b = k3(~ok_b, np.ones(n, bool))
+    prog_cases = [
+        (("or", ("and", ("<", A_sc, ("lit", 2)), (">", B_f, ("lit", 0.3))), ("not", (">", ("-", A_e, A_s), ("lit", 250)))),
+         k_or(k_and(c1, c2), k_not(c3))),
+        (("not", ("or", (">=", A_sc, B_f), ("isnull", B_f))), k_not(k_or(c4, isnull_b))),
+        (("and", ("or", ("<", A_sc, ("lit", 2)), ("notnull", B_f), (">=", A_sc, B_f)), ("not", ("and", (">", B_f, ("lit", 0.3)), ("<", A_sc, ("lit", 2))))),
+         k_and(k_or(k_or(c1, k_not(isnull_b)), c4), k_not(k_and(c2, c1)))),
+    ]
+    for tree, (val, known) in prog_cases:
+        want = val & known
+        ga, gb = eng.select([(("expr", tree), "istrue", ("lit", 0))], idx_a=d(ia), idx_b=d(ib), n_rows_a=na, n_rows_b=nb)
+        assert np.array_equal(ga.cpu().numpy(), ia[want]) and np.array_equal(gb.cpu().numpy(), ib[want])
+        # ... and beside a plain conjunct
+        ga, gb = eng.select([(("expr", tree), "istrue", ("lit", 0)), (A_sc, ">=", ("lit", 0))], idx_a=d(ia), idx_b=d(ib),
+                            n_rows_a=na, n_rows_b=nb)
+        w2 = want & (sc >= 0) & ok_a
+        assert np.array_equal(ga.cpu().numpy(), ia[w2]) and np.array_equal(gb.cpu().numpy(), ib[w2])
     from giql_amd._lib import GiqlHipError
     deep = ("lit", 1)
-    for _ in range(9):
-        deep = ("+", ("lit", 1), deep)                      # right-nested: nine values live at once
+    for _ in range(13):
+        deep = ("+", ("lit", 1), deep)                      # right-nested: thirteen values live at once (twelve fit)
     with pytest.raises(GiqlHipError):
         eng.select([(("expr", deep), ">", ("lit", 0))], n=10, n_rows_a=10, want=("a",))
+    deep = ("lit", 1)
+    for _ in range(11):
+        deep = ("+", ("lit", 1), deep)
+    assert int(eng.select([(("expr", deep), ">", ("lit", 0))], n=10, n_rows_a=10, want=("a",))[0].shape[0]) == 10
 
 
 def test_select_rejects_bad_ids_and_mark_flags(eng):
