@@ -444,18 +444,21 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
   if constexpr (OUTMAJOR) {
    if (total2 != 0u) {
     // OUTPUT-MAJOR emission (round 4).  Every wave takes a contiguous stretch of the block's class-2 output in windows
-    // of 64 pairs ALIGNED to 256 bytes of the output arrays: a store instruction writes one full, aligned segment
-    // (the run-major loop below writes one run per iteration -- ~35 of 64 lanes at the headline's run lengths, two
-    // partial lines per store, four v_readlane per run).  The runs that START inside a window come from ONE coalesced
-    // LDS read of the (sorted) run table, folded into a 64-bit start mask by a scalar loop over just those runs; a
-    // lane's run = the run the window opens in + the starts at or below the lane's position.
-    const u32 shift = (u32)(base & 63ull);
-    const u32 n_win = (shift + total2 + 63u) >> 6;
+    // of 256 pairs ALIGNED to 1 KB of the output arrays; a lane owns FOUR consecutive pairs of a window and writes them
+    // with one 16-byte store per array (the run-major loop below writes one run per iteration -- ~35 of 64 lanes at the
+    // headline's run lengths, two partial lines per store, four v_readlane per run; the first output-major version
+    // wrote one pair per lane and window: the kernel is bound by its instruction count, and the per-window work --
+    // which run does my position belong to -- is shared by four pairs now).  The run of a lane's first pair comes from
+    // a binary search of the (sorted) run table between the run the window opens in and the last run that starts
+    // inside it (one coalesced LDS read tells how many do: 2-8 at the headline's sizes); its other three pairs walk on.
+    const bool vec_ok = ((((uintptr_t)fq.row_q) | ((uintptr_t)fq.row_s)) & 15u) == 0;   // block-uniform
+    const u32 shift = (u32)(base & 255ull);
+    const u32 n_win = (shift + total2 + 255u) >> 8;
     const u32 per = (n_win + BS_NW - 1) / BS_NW;
     u32 win = w * per;
     const u32 win_end = win + per < n_win ? win + per : n_win;
     if (win < win_end) {
-      int o_base = (int)(win * 64u) - (int)shift;   // block-local output of lane 0 (negative only in the first window)
+      int o_base = (int)(win * 256u) - (int)shift;   // block-local output of lane 0's first pair (negative only in the first window)
       const u32 o_first = o_base < 0 ? 0u : (u32)o_base;
       u32 j0 = 0, hi_ = n_runs;   // s_run[j0] <= o_first < s_run[hi_]  (s_run[0] = 0, s_run[n_runs] = total2)
       while (hi_ - j0 > 1u) {
@@ -465,24 +468,58 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
         else
           hi_ = mid;
       }
-      for (; win < win_end; win++, o_base += 64) {
+      typedef int bj_i4 __attribute__((ext_vector_type(4)));
+      for (; win < win_end; win++, o_base += 256) {
+        // how many runs start inside the window (64 or more: the search below takes the whole table)
         const u32 cand = j0 + 1u + lane;
         const u32 s_c = cand < n_runs ? s_run[cand] : 0x7FFFFFFFu;
-        const u64 mk = __ballot((int)s_c < o_base + 64);   // a prefix of the lanes: the table is sorted
-        const u32 nin = (u32)__popcll(mk);
-        u64 starts = 0;
-        for (u32 t = 0; t < nin; t++)
-          starts |= 1ull << (u32)(__builtin_amdgcn_readlane((int)s_c, (int)t) - o_base);
-        const u32 le = __builtin_amdgcn_mbcnt_hi((u32)(starts >> 32), __builtin_amdgcn_mbcnt_lo((u32)starts, 0u)) +
-                       (u32)((starts >> lane) & 1ull);
-        const int o = o_base + (int)lane;
-        if (o >= 0 && (u32)o < total2) {
-          const u32 j = j0 + le;
-          const u32 off = s_run[j], lo = s_run[RC + 1 + j];
-          rq[o] = (int32_t)s_run[2 * RC + 1 + j];
-          rs[o] = (int32_t)s_buf[lo + ((u32)o - off)];
+        const u32 nin = (u32)__popcll(__ballot((int)s_c < o_base + 256));   // a prefix of the lanes: the table is sorted
+        const int o0 = o_base + 4 * (int)lane;
+        const u32 oc = o0 < 0 ? 0u : (u32)o0;
+        u32 j = j0, hj = nin == 64u ? n_runs : j0 + nin + 1u;   // s_run[j] <= oc < s_run[hj] (or oc past the block's output)
+        if (hj > n_runs) hj = n_runs;
+        while (hj - j > 1u) {
+          const u32 mid = (j + hj) >> 1;
+          if (s_run[mid] <= oc)
+            j = mid;
+          else
+            hj = mid;
         }
-        j0 += (u32)__popcll(starts);
+        u32 off = s_run[j], nxt = s_run[j + 1u], lo = s_run[RC + 1 + j];
+        int rid = (int)s_run[2 * RC + 1 + j];
+        bj_i4 q4, s4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int o = o0 + k;
+          int sv = 0;
+          if (o >= 0 && (u32)o < total2) {
+            while ((u32)o >= nxt) {   // the next run (short runs: more than one step)
+              j++;
+              off = nxt;
+              nxt = s_run[j + 1u];
+              lo = s_run[RC + 1 + j];
+              rid = (int)s_run[2 * RC + 1 + j];
+            }
+            sv = (int)s_buf[lo + ((u32)o - off)];
+          }
+          q4[k] = rid;
+          s4[k] = sv;
+        }
+        if (vec_ok && o0 >= 0 && (u32)o0 + 3u < total2) {
+          *reinterpret_cast<bj_i4*>(rq + o0) = q4;
+          *reinterpret_cast<bj_i4*>(rs + o0) = s4;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int o = o0 + k;
+            if (o >= 0 && (u32)o < total2) {
+              rq[o] = q4[k];
+              rs[o] = s4[k];
+            }
+          }
+        }
+        // the run the next window opens in: the last valid lane's last run
+        j0 = (u32)__builtin_amdgcn_readlane((int)j, 63);
       }
     }
    }

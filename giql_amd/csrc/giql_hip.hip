@@ -166,6 +166,10 @@ struct giql_hip_ctx {
   double local_max_bucket_rows = 2800.0;  // three-stage sort only while a 16-bit bucket holds at most this many rows on average
   double local_min_bucket_rows = 300.0;   // ... and at least this many (below: a block per bucket is mostly overhead)
   bool no_skip_digit = false;  // GIQL_HIP_NO_SKIP_DIGIT=1: query sides are sorted on every digit
+  // a sort's FIRST pass may rank its rows with LDS atomics (unstable: rows of equal digits in any order) when the caller
+  // does not need equal keys in input order -- the INNER join's sides (onesweep.hip.h); GIQL_HIP_NO_UNSTABLE_FIRST=1: never
+  bool first_unstable = false;
+  bool no_unstable_first = false;
   bool no_dual_span = false;   // GIQL_HIP_NO_DUAL_SPAN=1: one span launch per side (round 3)
   bool no_coarse_b = false;    // GIQL_HIP_NO_COARSE_B=1: the fixed-length B of SEMI / ANTI / COUNT is sorted on every digit
   double coarse_max_group_rows = 8.0;  // ... and coarsely only while the rows sharing their upper 24 key bits are at most this many on average
@@ -527,7 +531,7 @@ static inline size_t os_pass_stride(const giql_hip_ctx* ctx, size_t n) {
 
 template <int NT, int ITEMS>
 static void launch_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, int src, int dst, bool first,
-                            u32 n, int shift, const u32* gbase, u32* status, DevMeta* meta) {
+                            u32 n, int shift, const u32* gbase, u32* status, DevMeta* meta, int unstable = 0) {
   const u32 grid = cdiv(n, NT * ITEMS);  // one block per tile
   u32* claim = status + os_pass_stride(ctx, n) - 16;  // the pass's ticket word
   const u32* rin = (first || !sb.rid[0]) ? (const u32*)nullptr : sb.rid[src];
@@ -536,7 +540,8 @@ static void launch_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, int
   hipLaunchKernelGGL((k_onesweep<M, NT, ITEMS>), dim3(grid), dim3(NT), 0, st, sb.key[src],           \
                      sb.end[0] ? sb.end[src] : (const u32*)nullptr, rin, sb.key[dst],                 \
                      sb.end[0] ? sb.end[dst] : (u32*)nullptr, sb.rid[0] ? sb.rid[dst] : (u32*)nullptr, \
-                     n, shift, gbase, status, claim, meta, ctx->os_order, ctx->os_help_after)
+                     n, shift, gbase, status, claim, meta, ctx->os_order, ctx->os_help_after, (const u32*)nullptr, 0u, 0u,  \
+                     unstable)
   switch (mode) {
     case 0: GIQL_OS_LAUNCH(0); break;
     case 1: GIQL_OS_LAUNCH(1); break;
@@ -704,6 +709,7 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
                                                : 1 + ((sb.rid[0] && !first) ? 1 : 0) + (sb.end[0] ? 1 : 0);
         ctx->stats.phase_bytes[GIQL_PH_SORT_SCATTER] += (int64_t)4 * (w_in + w_out) * n;
       }
+      const int unstable = (pass == 0 && !keep_rids && ctx->first_unstable && !ctx->no_unstable_first) ? 1 : 0;
       if (pass == 0 && keygen) {
         const u32 grid = cdiv(n, 1024 * 8);
         u32* claim = stat + per_pass - 16;
@@ -712,21 +718,21 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
                              reinterpret_cast<const u32*>(keygen->start), reinterpret_cast<const u32*>(keygen->end),
                              reinterpret_cast<const u32*>(keygen->chrom), sb.key[dst], sb.end[dst], sb.rid[dst], n,
                              digit * 8, gb, stat, claim, ctx->d_meta, ctx->os_order, ctx->os_help_after, abase,
-                             (u32)keygen->start_off, (u32)keygen->end_off);
+                             (u32)keygen->start_off, (u32)keygen->end_off, unstable);
         else
           hipLaunchKernelGGL((k_onesweep<1, 1024, 8, true>), dim3(grid), dim3(1024), 0, st,
                              reinterpret_cast<const u32*>(keygen->start), reinterpret_cast<const u32*>(keygen->chrom),
                              (const u32*)nullptr, sb.key[dst], (u32*)nullptr, sb.rid[dst], n, digit * 8, gb, stat, claim,
-                             ctx->d_meta, ctx->os_order, ctx->os_help_after, abase, (u32)keygen->start_off);
+                             ctx->d_meta, ctx->os_order, ctx->os_help_after, abase, (u32)keygen->start_off, 0u, unstable);
         continue;
       }
       switch (ctx->os_variant) {  // block-shape sweep (tools/os_variants.py); default 1024 x 8
-        case 1: launch_onesweep<512, 8>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
-        case 2: launch_onesweep<512, 16>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
-        case 3: launch_onesweep<256, 16>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
-        case 4: launch_onesweep<1024, 4>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
-        case 5: case 7: launch_onesweep<1024, 12>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
-        default: launch_onesweep<1024, 8>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta); break;
+        case 1: launch_onesweep<512, 8>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta, unstable); break;
+        case 2: launch_onesweep<512, 16>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta, unstable); break;
+        case 3: launch_onesweep<256, 16>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta, unstable); break;
+        case 4: launch_onesweep<1024, 4>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta, unstable); break;
+        case 5: case 7: launch_onesweep<1024, 12>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta, unstable); break;
+        default: launch_onesweep<1024, 8>(ctx, st, sb, src, dst, first, n, digit * 8, gb, stat, ctx->d_meta, unstable); break;
       }
     }
   }
@@ -1014,6 +1020,8 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     ctx->no_span_hist = nh && atoi(nh) != 0;
     const char* nsd = getenv("GIQL_HIP_NO_SKIP_DIGIT");
     ctx->no_skip_digit = nsd && atoi(nsd) != 0;
+    const char* nuf = getenv("GIQL_HIP_NO_UNSTABLE_FIRST");
+    ctx->no_unstable_first = nuf && atoi(nuf) != 0;
     const char* nds = getenv("GIQL_HIP_NO_DUAL_SPAN");
     ctx->no_dual_span = nds && atoi(nds) != 0;
     const char* ncb = getenv("GIQL_HIP_NO_COARSE_B");
@@ -1233,8 +1241,12 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   SortBufs& sbb = S.sb;
   struct Prezero {  // the helpers skip their own memsets while this plan runs
     giql_hip_ctx* c;
-    ~Prezero() { c->prezeroed = false; }
+    ~Prezero() {
+      c->prezeroed = false;
+      c->first_unstable = false;
+    }
   } prezero_guard{ctx};
+  ctx->first_unstable = true;  // an INNER join needs no order among rows of equal keys: first passes rank by LDS atomics
   ctx->prezeroed = false;
   ctx->span_hist_dirty[0] = ctx->span_hist_dirty[1] = nullptr;
   int big_passes_zeroed = 0;

@@ -132,28 +132,34 @@ __device__ __forceinline__ void chrom_minmax_body(const int HIST, const int* __r
     }
     if (ok && (pc > c || (pc == c && ps > s))) inv = true;
   };
+  // This pass is bound by its INSTRUCTIONS, not by its loads or its LDS atomics (round 4: ~190 instructions per row in
+  // the ISA, half of them scalar; a wave64 VALU op occupies its SIMD for 4 cycles: 0.24 ms of pure issue time at 100M
+  // rows, and timing-only builds without any atomic run no faster).  So the per-row work is kept branch-free where it
+  // can be, and what only pays on SORTED input -- the per-thread run cache of the chromosome range, the wave-uniform
+  // shortcut of the histogram -- is tried only while the wave has seen no row out of order (`sorted_so_far`, wave-
+  // uniform: refreshed once per tile from the order check's own flag).
+  bool sorted_so_far = true;
   // One row: length range, per-chromosome min/max through the run cache, digit counts.
   auto row = [&](const int c, const int s, const int e, const bool ok) {
     if (ok) {
-      // canonical length, saturated to int range; rows with len <= 0 are irregular
-      if (e > s) {
-        const u32 d = (u32)e - (u32)s;  // exact for e > s
-        const int len = (int)(d > 0x7FFFFFF0u ? 0x7FFFFFF0u : d) + len_bias;
-        if (len > 0) {
-          lmn = len < lmn ? len : lmn;
-          lmx = len > lmx ? len : lmx;
-        }
-      } else if (e - s + len_bias > 0) {  // e in {s, s-1} with a positive offset
-        const int len = e - s + len_bias;
-        lmn = len < lmn ? len : lmn;
-        lmx = len > lmx ? len : lmx;
-      } else {
-        lmn = 0;  // an irregular row (canonical end <= start): this side is not uniform
-        inv = true;
-        if ((i64)e - (i64)s + len_bias < 0) neg = true;
-      }
+      // canonical length (end - start + the encodings' offset), saturated to int range; <= 0: an irregular row --
+      // this side is not uniform (lmn = 0) and not "sorted"
+      const i64 len64 = (i64)e - (i64)s + (i64)len_bias;
+      const bool regular = len64 > 0;
+      const int len = (int)(len64 > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : len64);
+      lmn = regular ? (len < lmn ? len : lmn) : 0;
+      lmx = (regular && len > lmx) ? len : lmx;
+      inv = inv || !regular;
+      neg = neg || len64 < 0;
       if (c < 0 || c >= n_chrom) {
         bad = true;
+      } else if (!sorted_so_far && use_lds) {
+        // unsorted input: the chromosome changes from row to row and the run cache would flush every time
+        const int lo = s < e ? s : e, hi = s < e ? e : s;
+#if !defined(GIQL_MM_ABLATE)
+        atomicMin(&mm_lds[c], lo);
+        atomicMax(&mm_lds[n_chrom + c], hi);
+#endif
       } else {
         if (c != cur) {
 #if defined(GIQL_MM_ABLATE)  // timing-only build: (almost) no LDS atomics
@@ -193,6 +199,13 @@ __device__ __forceinline__ void chrom_minmax_body(const int HIST, const int* __r
       }
       // chromosome- and position-sorted input makes the two high digits wave-uniform:
       // one add per wave instead of 64 serialised ones on the same LDS word
+      if (!sorted_so_far) {   // (wave-uniform) shuffled input: the test would fail for every row
+        if (ok) {
+          atomicAdd(&s_hist[512 + ((pos >> 16) & 0xFFu)], 1u);
+          atomicAdd(&s_top[tb], 1u);
+        }
+        return;
+      }
       const u64 act = __ballot(ok);
       if (act != 0) {
         const u32 d2 = (pos >> 16) & 0xFFu;
@@ -258,6 +271,7 @@ __device__ __forceinline__ void chrom_minmax_body(const int HIST, const int* __r
       if (c4[u - 1] > c4[u] || (c4[u - 1] == c4[u] && s4[u - 1] > s4[u])) inv = true;
 #pragma unroll
     for (int u = 0; u < 4; u++) row(c4[u], s4[u], e4[u], true);
+    if (sorted_so_far) sorted_so_far = __ballot(inv) == 0ull;
   };
   {
     u64 t = bid;

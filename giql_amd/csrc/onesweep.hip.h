@@ -120,7 +120,7 @@ __device__ __forceinline__ u32 onesweep_tile(
     u32 tile, u32 tile_base, int shift, const u32* __restrict__ gbase, u32* __restrict__ status,
     DevMeta* __restrict__ meta, u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff,
     u32* s_scan, u32* s_help, u32 help_after, u32 n_total, const u32* s_abase = nullptr, u32 start_off = 0,
-    u32 end_off = 0) {
+    u32 end_off = 0, const bool unstable = false) {
   constexpr int OS_NW = OS_NT / WAVE;
   const u32 tid = threadIdx.x;
   const u32 lane = lane_id();
@@ -170,7 +170,19 @@ __device__ __forceinline__ u32 onesweep_tile(
 #endif
   // stable rank inside the wave (peers = lanes with the same digit)
   u32 rank[OS_ITEMS];
-  {
+  if (unstable) {
+    // UNSTABLE ranking (round 4; a FIRST pass whose caller does not need the rows of equal keys in input order --
+    // the INNER join's sides): one returning LDS atomic on the wave's own counter is a row's rank among the wave's
+    // rows of its digit.  The ballot ranking below costs ~45 VALU operations per row, and these passes are bound by
+    // their instruction count (a wave64 VALU op holds its SIMD for 4 cycles), not by HBM.
+    u32* wcnt = s_wcnt[w];
+#pragma unroll
+    for (int i = 0; i < OS_ITEMS; i++) {
+      const u32 r = wbase + i * WAVE + lane;
+      const bool ok = FULL || r < n_valid;
+      rank[i] = ok ? atomicAdd(&wcnt[(key[i] >> shift) & 0xFFu], 1u) : 0u;
+    }
+  } else {
     u32* wcnt = s_wcnt[w];
 #pragma unroll
     for (int i = 0; i < OS_ITEMS; i++) {
@@ -503,7 +515,7 @@ __device__ __forceinline__ u32 os_run_tile(
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n, u32 tile,
     int shift, const u32* __restrict__ gbase, u32* __restrict__ status, DevMeta* __restrict__ meta,
     u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff, u32* s_scan, u32* s_help,
-    u32 help_after, const u32* s_abase = nullptr, u32 start_off = 0, u32 end_off = 0) {
+    u32 help_after, const u32* s_abase = nullptr, u32 start_off = 0, u32 end_off = 0, const bool unstable = false) {
   constexpr int OS_TILE = OS_NT * OS_ITEMS;
   const u32 tile_base = tile * OS_TILE;
   const u32 n_valid = (n - tile_base) < (u32)OS_TILE ? (n - tile_base) : (u32)OS_TILE;
@@ -511,11 +523,13 @@ __device__ __forceinline__ u32 os_run_tile(
     return onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, true, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
                                                                  rids_out, n_valid, tile, tile_base, shift, gbase,
                                                                  status, meta, s_buf, s_wcnt, s_dstart, s_goff,
-                                                                 s_scan, s_help, help_after, n, s_abase, start_off, end_off);
+                                                                 s_scan, s_help, help_after, n, s_abase, start_off, end_off,
+                                                                 unstable);
   return onesweep_tile<PAYLOAD, OS_NT, OS_ITEMS, false, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
                                                                 rids_out, n_valid, tile, tile_base, shift, gbase,
                                                                 status, meta, s_buf, s_wcnt, s_dstart, s_goff,
-                                                                s_scan, s_help, help_after, n, s_abase, start_off, end_off);
+                                                                s_scan, s_help, help_after, n, s_abase, start_off, end_off,
+                                                                unstable);
 }
 
 // The cold path: compute the silent predecessor `need` (recursively the earliest silent
@@ -527,7 +541,8 @@ __device__ __noinline__ void os_help_loop(
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n, u32 own,
     u32 need, int shift, const u32* __restrict__ gbase, u32* __restrict__ status,
     DevMeta* __restrict__ meta, u32* s_buf, u32 (*s_wcnt)[OS_BINS], u32* s_dstart, u32* s_goff,
-    u32* s_scan, u32* s_help, u32 help_after, const u32* s_abase = nullptr, u32 start_off = 0, u32 end_off = 0) {
+    u32* s_scan, u32* s_help, u32 help_after, const u32* s_abase = nullptr, u32 start_off = 0, u32 end_off = 0,
+    const bool unstable = false) {
   constexpr int OS_NW = OS_NT / WAVE;
   const u32 tid = threadIdx.x;
   u32 cur = need;
@@ -540,7 +555,7 @@ __device__ __noinline__ void os_help_loop(
     const u32 r = os_run_tile<PAYLOAD, OS_NT, OS_ITEMS, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
                                                                rids_out, n, cur, shift, gbase, status, meta, s_buf,
                                                                s_wcnt, s_dstart, s_goff, s_scan, s_help, help_after,
-                                                               s_abase, start_off, end_off);
+                                                               s_abase, start_off, end_off, unstable);
     if (r == OS_NO_TILE) {
       if (cur == own) return;
       cur = own;  // the helped tile is done: start over on this block's own tile
@@ -571,7 +586,7 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
     u32* __restrict__ keys_out, u32* __restrict__ ends_out, u32* __restrict__ rids_out, u32 n,
     int shift, const u32* __restrict__ gbase, u32* __restrict__ status, u32* __restrict__ ticket,
     DevMeta* __restrict__ meta, int order, u32 help_after, const u32* __restrict__ abase = nullptr,
-    u32 start_off = 0, u32 end_off = 0) {
+    u32 start_off = 0, u32 end_off = 0, int unstable = 0) {
   constexpr int OS_TILE = OS_NT * OS_ITEMS;
   constexpr int OS_NW = OS_NT / WAVE;
   __shared__ u32 s_buf[OS_TILE];          // staging, reused for key / end / rid
@@ -601,11 +616,12 @@ __global__ __launch_bounds__(OS_NT, (OS_NT == 1024 && (PAYLOAD != 3 || OS_ITEMS 
   const u32 need = os_run_tile<PAYLOAD, OS_NT, OS_ITEMS, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out,
                                                                 rids_out, n, own, shift, gbase, status, meta, s_buf,
                                                                 s_wcnt, s_dstart, s_goff, s_scan, &s_help, help_after,
-                                                                s_abase, start_off, end_off);
+                                                                s_abase, start_off, end_off, unstable != 0);
   if (need != OS_NO_TILE)
     os_help_loop<PAYLOAD, OS_NT, OS_ITEMS, KEYGEN>(keys_in, ends_in, rids_in, keys_out, ends_out, rids_out, n, own,
                                                    need, shift, gbase, status, meta, s_buf, s_wcnt, s_dstart,
-                                                   s_goff, s_scan, &s_help, help_after, s_abase, start_off, end_off);
+                                                   s_goff, s_scan, &s_help, help_after, s_abase, start_off, end_off,
+                                                   unstable != 0);
 }
 
 // A side that arrives SORTED on the linear axis (coordinate-sorted BED / BAM-derived tables; the span pass
