@@ -61,6 +61,11 @@ WORKLOADS = {
     # CREATE INDEX, docs/transpilation/performance.rst:111-130): per step only the small side's sort + the bucket stage.
     # An extra line, never the headline -- the index build is outside the timed region and reported beside it
     "cfg4_indexed_10Mx100M_24chrom": ("inner_indexed", (10_000_000, "peaks", 5), (100_000_000, "reads", 6), HG38),
+    # 4x the headline tables on the same genome (~8,450 reads per 65,536 positions: whole-genome read sets are this
+    # dense and denser): the 400M-row side keeps the three-stage sort with buckets of 2^14 keys (round 4).  6.5e9
+    # pairs, 52 GB of output; run it with --no-cpu-baseline (parity at this density: tests/test_full_size.py,
+    # tests/test_bucket_width.py).  An extra line, never the headline
+    "dense_40Mx400M_24chrom": ("inner", (40_000_000, "peaks", 5), (400_000_000, "reads", 6), HG38),
 }
 DEFAULT_WORKLOAD = "cfg4_10Mx100M_24chrom"
 METRIC = {
@@ -1006,8 +1011,10 @@ def run_inner(args):
                 "join_form": form,
                 "presorted_side_skipped_its_sort": bool(st.get("presorted", False)),
                 "span_hist": span_hist,
-                "sort": ("two global passes + in-LDS bucket sort for sides of 300-2800 rows per 16-bit bucket" if st.get("sort_local")
-                         else "four global passes"),
+                "sort": (("two global passes + in-LDS bucket sort for sides of 300-2800 rows per 16-bit bucket"
+                          if st.get("bucket_bits", 16) == 16 else
+                          f"three global passes + in-LDS bucket sort, buckets of 2^{st.get('bucket_bits')} keys (dense table)")
+                         if st.get("sort_local") else "four global passes"),
                 "pairs_written_by": ("the bucket stage of the sort (k_bucket_sort<1, 2>: no count / scan / fill kernel)"
                                      if st.get("bucket_join") else "k_fill"),
             },
@@ -1114,6 +1121,29 @@ def inner_extras(eng, dev_index, a, b, ha, hb, n_chrom, n_pairs, alloc_out, join
     except Exception as exc:
         out["t_e2e_ms"] = None
         out["t_e2e_error"] = str(exc)[:200]
+    # the same call with the COMPACT-PLAN download (GIQL_HIP_E2E_COMPACT=1: 0.52 GB over the link instead of 3.2, expanded
+    # by host threads while the sorted ids are still arriving); its pairs checked against the timed step's checksum
+    try:
+        seen = {}
+
+        def inspect(va, vb):
+            ta = torch.from_numpy(va).to(eng.device)
+            tb = torch.from_numpy(vb).to(eng.device)
+            seen["sum"] = eng.pairs_checksum(ta, tb)
+            seen["n"] = int(va.shape[0])
+
+        os.environ["GIQL_HIP_E2E_COMPACT"] = "1"
+        eng.inner_join_host_timed(ha, hb, n_chrom)
+        ms_c, n_c = eng.inner_join_host_timed(ha, hb, n_chrom)
+        eng.inner_join_host_timed(ha, hb, n_chrom, inspect=inspect)
+        out["t_e2e_compact_ms"] = round(ms_c, 1)
+        out["t_e2e_compact_parity"] = {"pairs_equal": n_c == n_pairs and seen.get("n") == n_pairs,
+                                       "multiset_checksum_equal": seen.get("sum") == uniform_sum}
+    except Exception as exc:
+        out["t_e2e_compact_ms"] = None
+        out["t_e2e_compact_error"] = str(exc)[:200]
+    finally:
+        os.environ.pop("GIQL_HIP_E2E_COMPACT", None)
     return out
 
 

@@ -27,6 +27,15 @@
 namespace giql {
 
 constexpr u32 BS_BUCKETS = 1u << 16;
+// Bucket width by density (round 4): a bucket is the rows sharing key >> W.  W = 16 for tables of up to ~2,800 rows
+// per 65,536 keys; denser tables (0.13-1 G rows on a human-genome axis) take W = 15 / 14 / 13, so that the average
+// bucket stays within what the LDS stage holds -- after THREE global passes (bits 8-15, 16-23, 24-31: the rows come
+// grouped by key >> 8, which groups them by key >> W for every W >= 8) instead of two.  Inside the kernels the low W
+// key bits are scaled up to 16 (key << (16 - W)), so the bin table, the ranks and the packed words of the body are
+// the same for every width; W travels in BsFuse::wbits.
+constexpr int BS_MIN_WBITS = 13;
+constexpr u32 BS_MAX_BUCKETS = 1u << (32 - BS_MIN_WBITS);
+__host__ __device__ __forceinline__ constexpr u32 bs_n_buckets(u32 wbits) { return 1u << (32u - wbits); }
 constexpr int BS_NT = 512;
 constexpr int BS_ITEMS = 8;
 constexpr int BS_NW = BS_NT / WAVE;
@@ -42,17 +51,18 @@ constexpr u32 BS_BIG_MAX = GIQL_BS_BIG_MAX;  // rows of one bucket the in-block 
 // exclusive offsets of the bits 24-31 digit).
 __global__ __launch_bounds__(256) void k_bucket_bounds(const u32* __restrict__ keys, u32 n,
                                                         const u32* __restrict__ gb3,
-                                                        u32* __restrict__ bnd) {
+                                                        u32* __restrict__ bnd, u32 wbits) {
   const u32 v = blockIdx.x * 256 + threadIdx.x;
-  if (v > BS_BUCKETS) return;
-  if (v == BS_BUCKETS) {
+  const u32 nbk = bs_n_buckets(wbits);
+  if (v > nbk) return;
+  if (v == nbk) {
     bnd[v] = n;
     return;
   }
-  const u32 d3 = v >> 8;
+  const u32 d3 = v >> (24u - wbits);
   const u32 lo = gb3[d3];
   const u32 hi = d3 == 255u ? n : gb3[d3 + 1];
-  bnd[v] = lower_bound_u32(keys, lo < n ? lo : n, hi < n ? hi : n, v << 16);
+  bnd[v] = lower_bound_u32(keys, lo < n ? lo : n, hi < n ? hi : n, v << wbits);
 }
 
 // ---- the range count of the fixed-length INNER form, fused into the bucket sort (round 3) ----
@@ -79,6 +89,7 @@ struct BsFuse {
   int32_t* row_s;    // ... and the sorted side's
   u64 cap;           // pairs the outputs hold
   unsigned long long* cursor;  // pairs handed out so far (DevMeta::n_out): a block takes its output range with ONE atomic add
+  u32 wbits = 16;    // key bits of a bucket (BS_MIN_WBITS .. 16)
 };
 
 __device__ __forceinline__ u32 bs_shift_key(u32 k, i64 off) {  // = shift_key of join_kernels.hip.h
@@ -103,23 +114,24 @@ __global__ __launch_bounds__(256) void k_bucket_bounds_fused(const u32* __restri
   if (t == 0) big_list[0] = 0;  // the queue of buckets too large for LDS starts empty
   // the status words + ticket of the chained scan that follows the bucket sort (scan.hip.h) start at zero
   for (u32 i = t; i < zero_words; i += gridDim.x * 256) zero_ptr[i] = 0u;
-  if (t <= BS_BUCKETS) {
-    if (t == BS_BUCKETS) {
+  const u32 wbits = fq.wbits, nbk = bs_n_buckets(wbits);
+  if (t <= nbk) {
+    if (t == nbk) {
       bnd[t] = n;
       return;
     }
-    const u32 d3 = t >> 8;
+    const u32 d3 = t >> (24u - wbits);
     const u32 lo = gb3[d3];
     const u32 hi = d3 == 255u ? n : gb3[d3 + 1];
-    bnd[t] = lower_bound_u32(keys, lo < n ? lo : n, hi < n ? hi : n, t << 16);
+    bnd[t] = lower_bound_u32(keys, lo < n ? lo : n, hi < n ? hi : n, t << wbits);
     return;
   }
-  const u32 u = t - (BS_BUCKETS + 1);
-  if (u >= 2 * BS_BUCKETS) return;
-  const u32 v = u & (BS_BUCKETS - 1);
-  const bool upper = u >= BS_BUCKETS;
+  const u32 u = t - (nbk + 1);
+  if (u >= 2 * nbk) return;
+  const u32 v = u & (nbk - 1);
+  const bool upper = u >= nbk;
   const u32 nq = nq_total - *irr_q;  // the regular rows: a sorted prefix
-  const u32 k0 = v << 16;
+  const u32 k0 = v << wbits;
   u32 target;  // lower: first row with masked key >= target; upper: first row with masked key > target
   if (!upper) {
     int lm = *len_max_q;
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(256) void k_bucket_bounds_fused(const u32* __restri
       const int lu = *len_max_u;
       reach = lu < 0 ? 0ull : ((u32)lu > BS_FUSE_WCAP ? (u64)BS_FUSE_WCAP : (u64)lu);
     }
-    const u64 tmax = (u64)k0 + 65535ull + reach;
+    const u64 tmax = (u64)k0 + (u64)((1u << wbits) - 1u) + reach;
     if (tmax >= (u64)U32_MAX) {
       fq.qwin[2 * v + 1] = nq;
       return;
@@ -220,6 +232,11 @@ __device__ __forceinline__ u32 bs_rank16(u32 x16, const u64* s_cell, const u32* 
   return start + c;
 }
 
+// ... of a full key x that lies in the block's bucket (sh = 16 - W: the bucket's low key bits scaled up to 16)
+__device__ __forceinline__ u32 bs_rank_key(u32 x, u32 sh, const u64* s_cell, const u32* s_buf) {
+  return bs_rank16((x << sh) & 0xFFFFu, s_cell, s_buf);
+}
+
 // Barrier of the bucket sort's body.  __syncthreads() also drains the wave's outstanding GLOBAL loads and stores
 // (s_waitcnt vmcnt(0)); the fused form has the query bounds' stores in flight in the middle of the kernel, and
 // every block would stand still for their acknowledgement: its barriers wait for the wave's LDS operations only.
@@ -282,14 +299,15 @@ constexpr u32 BJ_WCAP_CROWD = BJ_QR_CROWD * BS_NT;
 // window's keys are staged in LDS (in the bin table's place, once the ranks are done), every bucket row searches
 // them for its own range (a lower bound and a short walk: 0.3 matches per row at 10M x 100M) and writes its few
 // pairs itself, behind the class-2 runs.  Every pair (q, u) leaves from the block of u's bucket.
-template <int R, bool GENERAL, int QR, bool OUTMAJOR = false>
+template <int R, bool GENERAL, int QR, bool OUTMAJOR = false, bool W16 = false>
 __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (&pay)[R], const u32 (&slot)[R], u32 cnt,
                                                  u32 v, const u32* __restrict__ ep, u32* s_buf, u64* s_cell,
                                                  u32* s_jtot, const BsFuse& fq, u32 qw0, u32 nw,
                                                  const u32 (&jq_key)[QR], const u32 (&jq_end)[QR],
                                                  u32* s_bend = nullptr, u32* s_run = nullptr) {
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
-  const u32 k0 = v << 16;
+  const u32 wb = W16 ? 16u : fq.wbits, sh = 16u - wb;  // (W16: the 65,536-key bucket's shifts and masks fold to constants)
+  const u32 k0 = v << wb;
 #if defined(GIQL_BJ_ABLATE)  // timing-only builds (results invalid, tools/bj_ablate.sh): the tail stops after its k-th stage
 #define GIQL_BJ_STOP(k) do { if (GIQL_BJ_ABLATE == (k)) { if (pay[0] == 0x12345u && slot[0] == 77u) s_buf[0] = 1; return; } } while (0)
 #else
@@ -310,7 +328,7 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
     for (int i = 0; i < R; i++) {
       const u32 r = i * BS_NT + tid;
       if (i < R - 1 || r < cnt) {
-        const u32 key = k0 | (pk[i] >> 12);
+        const u32 key = k0 | (pk[i] >> (12u + sh));
         s_bend[slot[i]] = pe[i];
         const u32 len = pe[i] > key ? pe[i] - key : 0u;
         lmax = len > lmax ? len : lmax;
@@ -327,8 +345,8 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
     q_lo[i] = q_cnt[i] = q_rid[i] = 0;
     if (j < nw) {
       const u32 xlo = bs_shift_key(jq_key[i], fq.lo_off), xhi = jq_end[i];
-      const u32 lo_l = xlo < k0 ? 0u : ((xlo >> 16) != v ? cnt : bs_rank16(xlo & 0xFFFFu, s_cell, s_buf));
-      const u32 hi_l = xhi <= k0 ? 0u : ((xhi >> 16) != v ? cnt : bs_rank16(xhi & 0xFFFFu, s_cell, s_buf));
+      const u32 lo_l = xlo < k0 ? 0u : ((xlo >> wb) != v ? cnt : bs_rank_key(xlo, sh, s_cell, s_buf));
+      const u32 hi_l = xhi <= k0 ? 0u : ((xhi >> wb) != v ? cnt : bs_rank_key(xhi, sh, s_cell, s_buf));
       q_lo[i] = lo_l;
       q_cnt[i] = hi_l > lo_l ? hi_l - lo_l : 0u;
       if (q_cnt[i]) q_rid[i] = fq.qrid[qw0 + j];  // (flies under the scan and the staging below)
@@ -377,11 +395,11 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
       if (j < nw && jq_key[i] >= k0) {
         const u32 x = jq_key[i];
         // rows with key <= x, and rows with key <= x - lmax (those end at or before x)
-        const u32 hi_p = (x >> 16) != v ? cnt : ((x & 0xFFFFu) == 0xFFFFu ? cnt : bs_rank16((x & 0xFFFFu) + 1u, s_cell, s_buf));
+        const u32 hi_p = ((x >> wb) != v || ((x + 1u) >> wb) != v) ? cnt : bs_rank_key(x + 1u, sh, s_cell, s_buf);
         u32 lo_p = 0;
         if (x - k0 >= lmax) {  // y = x - lmax >= K0
           const u32 y = x - lmax;
-          lo_p = (y >> 16) != v ? cnt : ((y & 0xFFFFu) == 0xFFFFu ? cnt : bs_rank16((y & 0xFFFFu) + 1u, s_cell, s_buf));
+          lo_p = ((y >> wb) != v || ((y + 1u) >> wb) != v) ? cnt : bs_rank_key(y + 1u, sh, s_cell, s_buf);
         }
         u32 c = 0;
         for (u32 p = lo_p; p < hi_p; p++) c += (u32)(s_bend[p] > x);
@@ -563,7 +581,7 @@ __device__ __forceinline__ void bucket_join_tail(const u32 (&pk)[R], const u32 (
 }
 
 
-template <int PAYLOAD, int R, int FUSE = 0, int QR = BJ_QR>
+template <int PAYLOAD, int R, int FUSE = 0, int QR = BJ_QR, bool W16 = false>
 __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __restrict__ pp,
                                                  u32* __restrict__ ep, u32 cnt, u32 v, u32* s_buf,
                                                  u64* s_cell, u32* s_scan, const BsFuse& fq,
@@ -572,6 +590,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
   constexpr int BIN_SHIFT = 12 + BS_SUB_BITS;
   constexpr int PER = BS_NB / BS_NT;  // cells scanned per thread
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const u32 wb = W16 ? 16u : fq.wbits, sh = 16u - wb;  // block-uniform (SGPRs); constants in the W16 instances
 #define GIQL_BS_OK(i, r) ((i) < R - 1 || (r) < cnt)
   u32 pk[R], pay[R], slot[R];
 #pragma unroll
@@ -627,7 +646,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
   for (int i = 0; i < R; i++) {
     const u32 r = i * BS_NT + tid;
     if (GIQL_BS_OK(i, r)) {
-      pk[i] = ((pk[i] & 0xFFFFu) << 12) | r;
+      pk[i] = ((pk[i] << (12u + sh)) & 0x0FFFF000u) | r;
       const u32 sub = (pk[i] >> 12) & 31u;
       const u64 add = ((u64)(1u << sub) << 32) | 1ull;
       slot[i] = (u32)atomicAdd((unsigned long long*)&s_cell[pk[i] >> BIN_SHIFT], (unsigned long long)add);
@@ -696,14 +715,14 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
       const u32 i = tid + k * BS_NT;
       if (i < n_probe) {
         const u32 x = (tid & 1u) ? q_val[k] : bs_shift_key(q_val[k], fq.lo_off);
-        if ((x >> 16) == v) q_dst[qw0 + (i >> 1)] = b0 + bs_rank16(x & 0xFFFFu, s_cell, s_buf);
+        if ((x >> wb) == v) q_dst[qw0 + (i >> 1)] = b0 + bs_rank_key(x, sh, s_cell, s_buf);
       }
     }
     for (u32 i = tid + BS_QPRE * BS_NT; i < n_probe; i += BS_NT) {  // wider windows (dense query tables)
       const u32 q = qw0 + (i >> 1);
       const u32 qv = q_src[q];
       const u32 x = (tid & 1u) ? qv : bs_shift_key(qv, fq.lo_off);
-      if ((x >> 16) == v) q_dst[q] = b0 + bs_rank16(x & 0xFFFFu, s_cell, s_buf);
+      if ((x >> wb) == v) q_dst[q] = b0 + bs_rank_key(x, sh, s_cell, s_buf);
     }
   }
   if (any_dup) {
@@ -731,7 +750,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
 #else
     constexpr bool OUTMAJOR = FUSE == 2 && 3u * QR * BS_NT + 1u <= 2u * BS_NB;
 #endif
-    bucket_join_tail<R, FUSE == 3, QR, OUTMAJOR>(pk, pay, slot, cnt, v, ep, s_buf, s_cell, s_jtot, fq, qw0, qw1 - qw0, jq_key,
+    bucket_join_tail<R, FUSE == 3, QR, OUTMAJOR, W16>(pk, pay, slot, cnt, v, ep, s_buf, s_cell, s_jtot, fq, qw0, qw1 - qw0, jq_key,
                                                  jq_end, s_bend, OUTMAJOR ? reinterpret_cast<u32*>(s_cell) : nullptr);
     return;
   }
@@ -754,7 +773,7 @@ __device__ __forceinline__ void bucket_sort_body(u32* __restrict__ kp, u32* __re
   for (int i = 0; i < R; i++) {
     const u32 r = i * BS_NT + tid;
     if (GIQL_BS_OK(i, r)) {
-      if (!FUSE) kp[r] = (v << 16) | (u32)s_key16[r];
+      if (!FUSE) kp[r] = (v << wb) | ((u32)s_key16[r] >> sh);
       if (PAYLOAD) pp[r] = s_buf[r];
     }
   }
@@ -871,7 +890,9 @@ __device__ __forceinline__ void bucket_sort_big(u32* __restrict__ k0, u32* __res
   }
 }
 
-template <int PAYLOAD, int FUSE = 0>
+// W16: the instance for buckets of 65,536 keys (the headline's): W is a compile-time constant there -- carried at run
+// time it cost the join form 1.3 % (0.786 -> 0.797 ms); the narrow widths share ONE generic instance.
+template <int PAYLOAD, int FUSE = 0, bool W16 = false>
 __global__ __launch_bounds__(BS_NT, FUSE == 3 ? GIQL_BJG_MIN_WAVES : (FUSE == 2 ? GIQL_BJ_MIN_WAVES : GIQL_BS_MIN_WAVES)) void k_bucket_sort(u32* __restrict__ keys, u32* __restrict__ ends,
                                                            u32* __restrict__ rids,
                                                            const u32* __restrict__ bnd,
@@ -916,7 +937,7 @@ __global__ __launch_bounds__(BS_NT, FUSE == 3 ? GIQL_BJG_MIN_WAVES : (FUSE == 2 
   // the payload that rides along in registers: rid when there is one, else end
   u32* pp = (PAYLOAD & 1) ? rids + b0 : ((PAYLOAD & 2) ? ends + b0 : nullptr);
   u32* ep = (PAYLOAD == 3) ? ends + b0 : nullptr;  // a second payload array takes a round of its own
-#define GIQL_BS_BODY(RR) bucket_sort_body<PAYLOAD, RR, FUSE>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan, fq, b0, qw0, qw1, s_jtot, s_bend)
+#define GIQL_BS_BODY(RR) bucket_sort_body<PAYLOAD, RR, FUSE, BJ_QR, W16>(kp, pp, ep, cnt, v, s_buf, s_cell, s_scan, fq, b0, qw0, qw1, s_jtot, s_bend)
   switch ((cnt + BS_NT - 1) / BS_NT) {  // rows per thread: 1..BS_ITEMS, block-uniform
     case 0: case 1: GIQL_BS_BODY(1); break;  // (0: an empty bucket with bounds to answer)
     case 2: GIQL_BS_BODY(2); break;
@@ -948,7 +969,7 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ key
   const u32 n_big = big_list[0];
   for (u32 i = blockIdx.x; i < n_big; i += gridDim.x) {
     const u32 entry = big_list[1 + i];
-    const u32 v = entry & 0xFFFFu;
+    const u32 v = entry & 0x7FFFFFFFu;
     const u32 b0 = bnd[v];
     const u32 cnt = bnd[v + 1] - b0;
     if constexpr (FUSE >= 2) {
@@ -985,15 +1006,16 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ key
       __shared__ unsigned long long s_jbase;
       const u32* kb = keys + b0;
       const u32* rb = rids + b0;
-      const u32 k0 = v << 16, qw0 = fq.qwin[2 * v], qw1 = fq.qwin[2 * v + 1];
+      const u32 wb = fq.wbits;
+      const u32 k0 = v << wb, qw0 = fq.qwin[2 * v], qw1 = fq.qwin[2 * v + 1];
       const u32 lane = lane_id(), w = wave_id();
       for (u32 c0 = qw0; c0 < qw1; c0 += BS_NT) {  // block-uniform
         const u32 q = c0 + threadIdx.x;
         u32 q_lo = 0, q_cnt = 0, q_rid = 0;
         if (q < qw1) {
           const u32 xlo = bs_shift_key(fq.qkey[q], fq.lo_off), xhi = fq.qend[q];
-          const u32 lo_l = xlo < k0 ? 0u : ((xlo >> 16) != v ? cnt : lower_bound_u32(kb, 0, cnt, xlo));
-          const u32 hi_l = xhi <= k0 ? 0u : ((xhi >> 16) != v ? cnt : lower_bound_u32(kb, 0, cnt, xhi));
+          const u32 lo_l = xlo < k0 ? 0u : ((xlo >> wb) != v ? cnt : lower_bound_u32(kb, 0, cnt, xlo));
+          const u32 hi_l = xhi <= k0 ? 0u : ((xhi >> wb) != v ? cnt : lower_bound_u32(kb, 0, cnt, xhi));
           q_lo = lo_l;
           q_cnt = hi_l > lo_l ? hi_l - lo_l : 0u;
           if (q_cnt) q_rid = fq.qrid[q];
@@ -1073,8 +1095,8 @@ __global__ __launch_bounds__(BS_NT) void k_bucket_sort_big(u32* __restrict__ key
       const u32* kb = keys + b0;
       for (u32 q = fq.qwin[2 * v] + threadIdx.x; q < fq.qwin[2 * v + 1]; q += BS_NT) {
         const u32 xs = bs_shift_key(fq.qkey[q], fq.lo_off), xe = fq.qend[q];
-        if ((xs >> 16) == v) fq.lo_out[q] = b0 + lower_bound_u32(kb, 0, cnt, xs);
-        if ((xe >> 16) == v) fq.hi_out[q] = b0 + lower_bound_u32(kb, 0, cnt, xe);
+        if ((xs >> fq.wbits) == v) fq.lo_out[q] = b0 + lower_bound_u32(kb, 0, cnt, xs);
+        if ((xe >> fq.wbits) == v) fq.hi_out[q] = b0 + lower_bound_u32(kb, 0, cnt, xe);
       }
     }
   }

@@ -6,7 +6,12 @@
 // HIP device every entry point fails with GIQL_ERR_HIP.
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <atomic>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <mutex>
+#include <thread>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -165,6 +170,10 @@ struct giql_hip_ctx {
   u64 last_span = 0;           // linearised span of the context's last call: the density guess of row_skip() / sort_is_local()
   double local_max_bucket_rows = 2800.0;  // three-stage sort only while a 16-bit bucket holds at most this many rows on average
   double local_min_bucket_rows = 300.0;   // ... and at least this many (below: a block per bucket is mostly overhead)
+  // denser tables keep the form with NARROWER buckets (15 / 14 / 13 key bits, three global passes): sort_local_bits().
+  // GIQL_HIP_NO_NARROW_BUCKETS=1: 16 bits or nothing (round 3); GIQL_HIP_LOCAL_BITS=w: every three-stage sort takes w (tests)
+  bool no_narrow = false;
+  int force_bits = 0;
   bool no_skip_digit = false;  // GIQL_HIP_NO_SKIP_DIGIT=1: query sides are sorted on every digit
   // a sort's FIRST pass may rank its rows with LDS atomics (unstable: rows of equal digits in any order) when the caller
   // does not need equal keys in input order -- the INNER join's sides (onesweep.hip.h); GIQL_HIP_NO_UNSTABLE_FIRST=1: never
@@ -178,6 +187,7 @@ struct giql_hip_ctx {
   u64 local_min_rows = 1u << 21;  // (round 4: a floor only; the density bounds above decide)
   int local_resorts = 0;      // calls repeated with the four-pass sort
   bool last_sort_local = false;  // the call in flight sorted at least one side in three stages
+  int last_local_bits = 16;      // ... the key bits of its buckets (the last bucket stage launched)
   // fused range count (fixed-length INNER form whose sorted side takes the three-stage sort): the bucket
   // sort answers the queries' bounds from LDS, the sorted keys never return to HBM (bucket_sort.hip.h)
   // sorted inputs: a side the span pass found in (chrom id, start) order is not sorted again.  The answer of the
@@ -197,9 +207,9 @@ struct giql_hip_ctx {
   bool no_bucket_join = false;  // GIQL_HIP_NO_BUCKET_JOIN=1: bounds from the bucket sort, then scan + fill as before
   bool bucket_join = false;     // the call in flight emitted its pairs from the bucket stage
   bool plan_is_join = false;    // ... and so left no plan arrays behind (fill / export need a plan of their own)
-  u32* bucket_qwin = nullptr;   // [2 * BS_BUCKETS] query window per bucket
-  u32* bucket_bnd = nullptr;  // [BS_BUCKETS + 1] bucket boundaries of the sort in flight
-  u32* bucket_big = nullptr;  // [1 + BS_BUCKETS] buckets too large for LDS, queued for k_bucket_sort_big ([0] = count)
+  u32* bucket_qwin = nullptr;   // [2 * BS_MAX_BUCKETS] query window per bucket
+  u32* bucket_bnd = nullptr;  // [BS_MAX_BUCKETS + 1] bucket boundaries of the sort in flight
+  u32* bucket_big = nullptr;  // [1 + BS_MAX_BUCKETS] buckets too large for LDS, queued for k_bucket_sort_big ([0] = count)
   char* xplan = nullptr;      // scratch of giql_hip_fill_from_plan_dev (offsets + scan partials), grown on demand
   size_t xplan_cap = 0;
 
@@ -284,6 +294,7 @@ struct Phase {
 static void reset_stats(giql_hip_ctx* ctx) {
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   ctx->last_sort_local = false;
+  ctx->last_local_bits = 16;
   ctx->count_fused = false;
   ctx->bucket_join = false;
   ctx->used_sorted[0] = ctx->used_sorted[1] = false;
@@ -394,7 +405,8 @@ struct LinBufs {
   u32* hist_partial2 = nullptr;
 };
 
-static inline bool sort_is_local(const giql_hip_ctx* ctx, size_t n);
+static inline int sort_local_bits(const giql_hip_ctx* ctx, size_t n);
+static inline bool sort_is_local(const giql_hip_ctx* ctx, size_t n) { return sort_local_bits(ctx, n) != 0; }
 
 // hist_side = 0 / 1 (with hist_partial and lb.abase / lb.top_partial): that side's span pass
 // also counts the digits of its aligned keys (k_chrom_minmax<true>) and the chromosome bases
@@ -435,7 +447,8 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
       ms[k].n = (i64)s.n;
       ms[k].len_bias = s.end_off - s.start_off;
       ms[k].start_off = with_hist ? s.start_off : 0;
-      ms[k].hist = !with_hist ? 0 : (sort_is_local(ctx, (size_t)s.n) ? 2 : 1);
+      // (16-bit buckets: the low digits are sorted in LDS and not counted; narrower ones need the bits 8-15 digit)
+      ms[k].hist = !with_hist ? 0 : (sort_local_bits(ctx, (size_t)s.n) == 16 ? 2 : 1);
       ms[k].nblk = grid;
       ms[k].hist_partial = with_hist ? hp : nullptr;
       ms[k].top_partial = with_hist ? (k == hist_side ? lb.top_partial : lb.top_partial2) : nullptr;
@@ -453,7 +466,7 @@ static int run_spans(giql_hip_ctx* ctx, hipStream_t st, const giql_side& a, cons
     u32 grid = cdiv((u64)s.n, (u64)(with_hist ? MM_NT_HIST : MM_NT) * MM_ITEMS);
     if (grid > (u32)MM_MAX_BLOCKS) grid = MM_MAX_BLOCKS;
     nblk[k] = (int)grid;
-    if (with_hist && sort_is_local(ctx, (size_t)s.n))  // the low digits are sorted in LDS: not counted
+    if (with_hist && sort_local_bits(ctx, (size_t)s.n) == 16)  // the low digits are sorted in LDS: not counted
       hipLaunchKernelGGL((k_chrom_minmax<2, MM_NT_HIST>), dim3(grid), dim3(MM_NT_HIST), lds, st, s.chrom, s.start, s.end,
                          (i64)s.n, n_chrom, lb.gmin, lb.gmax, ctx->d_meta, s.end_off - s.start_off, k,
                          lb.len_part, s.start_off, hp, tp);
@@ -559,10 +572,12 @@ static void launch_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, int
 // Sides of ctx->local_min_rows rows and more take the three-stage form: global passes on bits
 // 16-23 and 24-31 only, then every 16-bit bucket sorted on its low bits inside LDS, in place
 // (bucket_sort.hip.h) -- three trips through HBM instead of four.
-static inline bool sort_is_local(const giql_hip_ctx* ctx, size_t n) {
-  if (ctx->force_local > 0 && ctx->bucket_bnd && ctx->os_variant == 0) return true;
-  if (ctx->force_local < 0) return false;
-  if (!(ctx->local_sort && ctx->bucket_bnd && ctx->os_variant == 0 && n >= ctx->local_min_rows)) return false;
+// Returns 0 (four global passes) or the key bits of a bucket: 16 (two global passes), or 15 / 14 / 13 for denser
+// tables (three global passes -- bits 8-15, 16-23, 24-31 -- and buckets of 2^W keys: bucket_sort.hip.h).
+static inline int sort_local_bits(const giql_hip_ctx* ctx, size_t n) {
+  if (ctx->force_local > 0 && ctx->bucket_bnd && ctx->os_variant == 0) return 16;
+  if (ctx->force_local < 0) return 0;
+  if (!(ctx->local_sort && ctx->bucket_bnd && ctx->os_variant == 0 && n >= ctx->local_min_rows)) return 0;
   // The in-LDS stage holds 4096 rows per bucket; larger buckets go through a slow queue (one block each, two
   // more passes: 30M x 300M reads, ~6000 rows per bucket, spent 10.4 of 21 ms there).  So the form is taken
   // only while the AVERAGE bucket is comfortably below that -- by the span of the context's previous call
@@ -572,10 +587,20 @@ static inline bool sort_is_local(const giql_hip_ctx* ctx, size_t n) {
   // ~2,100 rows per bucket on an eighth of the axis and takes the same path (fused count, join in the bucket stage);
   // a 10M-row table over the whole genome (212 rows per bucket) does not: a block per bucket is mostly overhead there
   // (0.135 ms against 0.106 for the two passes it replaces).
+  // Round 4, bucket width by density: past 2,800 rows per 65,536 keys (132M rows on a human-genome axis) the bucket
+  // narrows -- 2^15, 2^14, 2^13 keys, up to ~1G rows -- instead of the form being given up.
   const double span = ctx->last_span ? (double)ctx->last_span : 3.2e9;
-  const double per_bucket = (double)n * 65536.0 / span;
-  return per_bucket <= ctx->local_max_bucket_rows && per_bucket >= ctx->local_min_bucket_rows;
+  double per_bucket = (double)n * 65536.0 / span;
+  if (per_bucket < ctx->local_min_bucket_rows) return 0;
+  if (ctx->force_bits) return ctx->force_bits;
+  int w = 16;
+  while (per_bucket > ctx->local_max_bucket_rows && w > BS_MIN_WBITS && !ctx->no_narrow) {
+    per_bucket *= 0.5;
+    w--;
+  }
+  return per_bucket <= ctx->local_max_bucket_rows ? w : 0;
 }
+static inline int local_passes(int wbits) { return wbits == 16 ? 2 : 3; }  // global passes before the bucket stage
 
 // skip_digits = 1 (four-pass form only): the lowest digit is left unsorted -- rows come out ordered
 // by key >> 8 and the result is left in buffer 0 by swapping the ping-pong pointers.  For QUERY
@@ -603,21 +628,29 @@ static int64_t bucket_stage_fused_bytes(u32 n, const FuseCount& fuse);
 // windows (COUNT), the bucket kernel (SORT_LOCAL), the queue of buckets it could not take (AUX; almost always an
 // empty launch).
 static void launch_bucket_stage_fused(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n, const u32* gbase,
-                                      const FuseCount& fuse) {
+                                      const FuseCount& fuse_in, int wbits = 16) {
+  FuseCount fuse = fuse_in;
+  fuse.dev.wbits = (u32)wbits;
+  const u32 BS_BUCKETS = bs_n_buckets((u32)wbits);  // (shadows the 16-bit constant: every launch below is per bucket)
   ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] += bucket_stage_fused_bytes(n, fuse);
   ctx->count_fused = true;
   ctx->bucket_join = fuse.join;
+  ctx->last_local_bits = wbits;
   {
     Phase ph(ctx, st, GIQL_PH_COUNT, 1);
     hipLaunchKernelGGL(k_bucket_bounds_fused, dim3(cdiv((u64)3 * BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
                        gbase + 3 * OS_BINS, ctx->bucket_bnd, ctx->bucket_big, fuse.dev, fuse.nq_total, fuse.irr_q,
                        fuse.gbq3, fuse.key_mask, fuse.len_max_q, fuse.zero_ptr, fuse.zero_words, fuse.len_max_u);
   }
+  const bool w16 = wbits == 16;
+#define GIQL_BSF_LAUNCH(P, F, W)                                                                                    \
+  hipLaunchKernelGGL((k_bucket_sort<P, F, W>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0],                      \
+                     (P) == 3 ? sb.end[0] : (u32*)nullptr, sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, \
+                     fuse.dev)
   if (fuse.general) {
     {
       Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 1);
-      hipLaunchKernelGGL((k_bucket_sort<3, 3>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], sb.end[0], sb.rid[0],
-                         ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse.dev);
+      if (w16) GIQL_BSF_LAUNCH(3, 3, true); else GIQL_BSF_LAUNCH(3, 3, false);
     }
     Phase ph(ctx, st, GIQL_PH_AUX, 1);
     hipLaunchKernelGGL((k_bucket_sort_big<3, 3>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0], sb.end[0], sb.rid[0],
@@ -626,13 +659,13 @@ static void launch_bucket_stage_fused(giql_hip_ctx* ctx, hipStream_t st, SortBuf
   }
   {
     Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 1);
-    if (fuse.join)
-      hipLaunchKernelGGL((k_bucket_sort<1, 2>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
-                         sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse.dev);
-    else
-      hipLaunchKernelGGL((k_bucket_sort<1, 1>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0], (u32*)nullptr,
-                         sb.rid[0], ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, fuse.dev);
+    if (fuse.join) {
+      if (w16) GIQL_BSF_LAUNCH(1, 2, true); else GIQL_BSF_LAUNCH(1, 2, false);
+    } else {
+      if (w16) GIQL_BSF_LAUNCH(1, 1, true); else GIQL_BSF_LAUNCH(1, 1, false);
+    }
   }
+#undef GIQL_BSF_LAUNCH
   {
     Phase ph(ctx, st, GIQL_PH_AUX, 1);
     if (fuse.join)
@@ -659,7 +692,8 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
   if (presorted) {
     // the side arrives sorted: no scatter pass, one streaming pass for what a sort would have left in buffer 0
     const int mode = (sb.rid[0] ? 1 : 0) | (sb.end[0] ? 2 : 0);
-    const bool local_fused = fuse && mode == (fuse->general ? 3 : 1) && sort_is_local(ctx, n);
+    const int wbits_pre = sort_local_bits(ctx, n);
+    const bool local_fused = fuse && mode == (fuse->general ? 3 : 1) && wbits_pre != 0;
     {
       Phase ph(ctx, st, GIQL_PH_SORT_SCATTER, 1);
       u32 grid = cdiv(n, 256 * 8);
@@ -681,14 +715,15 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
     }
     if (!local_fused) return GIQL_OK;   // sorted already: the bucket stage only runs as the carrier of the fused count
     ctx->last_sort_local = true;
-    launch_bucket_stage_fused(ctx, st, sb, n, gbase, *fuse);
+    launch_bucket_stage_fused(ctx, st, sb, n, gbase, *fuse, wbits_pre);
     return post_launch("bucket stage (sorted input, fused count)");
   }
-  const bool local = sort_is_local(ctx, n);
+  const int wbits = sort_local_bits(ctx, n);
+  const bool local = wbits != 0;
   if (local) ctx->last_sort_local = true;
   if (local || ctx->no_skip_digit) skip_digits = 0;
-  const int n_pass = local ? 2 : 4 - skip_digits;
-  const int first_digit = local ? 2 : skip_digits;
+  const int n_pass = local ? local_passes(wbits) : 4 - skip_digits;
+  const int first_digit = local ? 4 - n_pass : skip_digits;
   const size_t per_pass = os_pass_stride(ctx, n);
   if (!ctx->prezeroed) HIP_TRY(hipMemsetAsync(status, 0, n_pass * per_pass * sizeof(u32), st));
   {
@@ -748,23 +783,32 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
     if (fuse && mode == (fuse->general ? 3 : 1)) {
       // (key, rid) rows + the query side's bounds: keys and rids read, rids written, the query rows' keys
       // and ends read and their two bounds written -- the sorted keys never leave the CU
-      launch_bucket_stage_fused(ctx, st, sb, n, gbase, *fuse);
+      launch_bucket_stage_fused(ctx, st, sb, n, gbase, *fuse, wbits);
       return post_launch("onesweep sort (fused count)");
     }
+    BsFuse bw;  // the plain sort: only the bucket width travels
+    bw.wbits = (u32)wbits;
+    ctx->last_local_bits = wbits;
+    const u32 BS_BUCKETS = bs_n_buckets((u32)wbits);
     HIP_TRY(hipMemsetAsync(ctx->bucket_big, 0, sizeof(u32), st));
     Phase ph(ctx, st, GIQL_PH_SORT_LOCAL, 3);
     ctx->stats.phase_bytes[GIQL_PH_SORT_LOCAL] +=
         (int64_t)8 * (1 + (sb.rid[0] ? 1 : 0) + (sb.end[0] ? 1 : 0)) * n;  // every array read once, written once
     hipLaunchKernelGGL(k_bucket_bounds, dim3(cdiv((u64)BS_BUCKETS + 1, 256)), dim3(256), 0, st, sb.key[0], n,
-                       gbase + 3 * OS_BINS, ctx->bucket_bnd);
+                       gbase + 3 * OS_BINS, ctx->bucket_bnd, (u32)wbits);
 #define GIQL_BS_LAUNCH(M)                                                                              \
+  if (wbits == 16)                                                                                     \
+    hipLaunchKernelGGL((k_bucket_sort<M, 0, true>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0],   \
+                       sb.end[0] ? sb.end[0] : (u32*)nullptr, sb.rid[0] ? sb.rid[0] : (u32*)nullptr,    \
+                       ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, bw);                             \
+  else                                                                                                 \
   hipLaunchKernelGGL((k_bucket_sort<M>), dim3(BS_BUCKETS), dim3(BS_NT), 0, st, sb.key[0],              \
                      sb.end[0] ? sb.end[0] : (u32*)nullptr, sb.rid[0] ? sb.rid[0] : (u32*)nullptr,      \
-                     ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big);                                   \
+                     ctx->bucket_bnd, ctx->d_meta, ctx->bucket_big, bw);                               \
   hipLaunchKernelGGL((k_bucket_sort_big<M>), dim3(ctx->n_cu), dim3(BS_NT), 0, st, sb.key[0],           \
                      sb.end[0] ? sb.end[0] : (u32*)nullptr, sb.rid[0] ? sb.rid[0] : (u32*)nullptr,      \
                      sb.key[1], sb.end[0] ? sb.end[1] : (u32*)nullptr, sb.rid[0] ? sb.rid[1] : (u32*)nullptr, \
-                     ctx->bucket_bnd, ctx->bucket_big)
+                     ctx->bucket_bnd, ctx->bucket_big, bw)
     switch (mode) {
       case 0: GIQL_BS_LAUNCH(0); break;
       case 1: GIQL_BS_LAUNCH(1); break;
@@ -1052,6 +1096,10 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
     if (lnb && atof(lnb) >= 0) ctx->local_min_bucket_rows = atof(lnb);
     const char* lmb = getenv("GIQL_HIP_LOCAL_MAX_BUCKET_ROWS");
     if (lmb && atof(lmb) > 0) ctx->local_max_bucket_rows = atof(lmb);
+    const char* nnb = getenv("GIQL_HIP_NO_NARROW_BUCKETS");
+    ctx->no_narrow = nnb && atoi(nnb) != 0;
+    const char* lbw = getenv("GIQL_HIP_LOCAL_BITS");
+    if (lbw && atoi(lbw) >= BS_MIN_WBITS && atoi(lbw) <= 16) ctx->force_bits = atoi(lbw);
   }
   memset(&ctx->stats, 0, sizeof(ctx->stats));
   {
@@ -1077,9 +1125,9 @@ int giql_hip_create(int device, giql_hip_ctx** out) {
         ctx->side_stream = nullptr;  // no second stream: everything stays on the caller's
     }
   }
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_bnd, ((size_t)BS_BUCKETS + 16) * sizeof(u32));
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_big, ((size_t)BS_BUCKETS + 16) * sizeof(u32));
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_qwin, ((size_t)2 * BS_BUCKETS + 16) * sizeof(u32));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_bnd, ((size_t)BS_MAX_BUCKETS + 16) * sizeof(u32));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_big, ((size_t)BS_MAX_BUCKETS + 16) * sizeof(u32));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->bucket_qwin, ((size_t)2 * BS_MAX_BUCKETS + 16) * sizeof(u32));
   if (e != hipSuccess) {
     giql_hip_destroy(ctx);
     return set_err(GIQL_ERR_HIP, "context allocation failed: %s", hipGetErrorString(e));
@@ -1138,11 +1186,13 @@ int giql_hip_get_stats(giql_hip_ctx* ctx, giql_hip_stats* out) {
   ctx->stats.workspace_bytes = (int64_t)ctx->arena_cap;
   *out = ctx->stats;
   // byte 0: join form (+ bit 5: a side was sorted in three stages, bit 6: this context fell back to
-  // the four-pass sort for good); byte 1: sort tile order in force; bytes 2-3: order fallbacks so far
+  // the four-pass sort for good); byte 1: sort tile order in force; bits 16-26: order fallbacks so far; bits 27-28:
+  // 16 - the key bits of the last bucket stage's buckets (0: 65,536-key buckets)
   out->reserved = (ctx->stats.reserved & 0x1F) | (ctx->last_sort_local ? 0x20 : 0) |
                   (ctx->local_resorts ? 0x40 : 0) | (ctx->swapped ? 0x80 : 0) | ((ctx->os_order & 0x7F) << 8) |
                   (ctx->count_fused ? 0x8000 : 0) | ((ctx->used_sorted[0] || ctx->used_sorted[1]) ? (int32_t)0x80000000u : 0) |
-                  ((ctx->order_fallbacks & 0x1FFF) << 16) | (ctx->bucket_join ? (1 << 29) : 0) |
+                  ((ctx->order_fallbacks & 0x7FF) << 16) | (((16 - ctx->last_local_bits) & 3) << 27) |
+                  (ctx->bucket_join ? (1 << 29) : 0) |
                   (ctx->fuse_done ? (1 << 30) : 0);
   return GIQL_OK;
 }
@@ -1252,7 +1302,7 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
   int big_passes_zeroed = 0;
   if (onesweep) {
     // the larger side takes at most 4 passes (2 in the three-stage form)
-    big_passes_zeroed = sort_is_local(ctx, n_max) ? 2 : 4;
+    big_passes_zeroed = sort_is_local(ctx, n_max) ? local_passes(sort_local_bits(ctx, n_max)) : 4;
     const size_t big_words = (size_t)big_passes_zeroed * os_pass_stride(ctx, n_max);
     HIP_TRY(hipMemsetAsync(ctx->arena + zero_off, 0, (zero_end - zero_off) + big_words * sizeof(u32), st));
     ctx->prezeroed = true;
@@ -1323,15 +1373,17 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
       // larger side leaves the three-stage sort, its high-digits-only histogram is of no use and that side
       // is linearized (which counts all four digits)
       const size_t n_big = big_side ? nb : na;
-      const bool expected_local = sort_is_local(ctx, n_big);
+      const int expected_bits = sort_local_bits(ctx, n_big);
       ctx->last_span = ctx->h_meta->total_span;
-      if (expected_local && !sort_is_local(ctx, n_big)) aligned = false;
-      if (big_passes_zeroed < 4 && !sort_is_local(ctx, n_max)) {
-        // the larger side leaves the three-stage sort after all: its third and fourth pass need zeroed status words too
+      // (the high-digits-only histogram serves 16-bit buckets alone: narrower ones sort on bits 8-15 too)
+      if (expected_bits == 16 && sort_local_bits(ctx, n_big) != 16) aligned = false;
+      const int passes_now = sort_is_local(ctx, n_max) ? local_passes(sort_local_bits(ctx, n_max)) : 4;
+      if (big_passes_zeroed < passes_now) {
+        // the larger side takes more global passes than expected: those need zeroed status words too
         const size_t stride = os_pass_stride(ctx, n_max);
         HIP_TRY(hipMemsetAsync(os_status + (size_t)big_passes_zeroed * stride, 0,
-                               (size_t)(4 - big_passes_zeroed) * stride * sizeof(u32), st));
-        big_passes_zeroed = 4;
+                               (size_t)(passes_now - big_passes_zeroed) * stride * sizeof(u32), st));
+        big_passes_zeroed = passes_now;
       }
     }
   }
@@ -1411,7 +1463,9 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     // of k_bucket_bounds_fused are computed under the same mask and then cover whole query buckets): TWO digits
     // unsorted, two passes (GIQL_HIP_Q_SKIP_DIGITS=1 keeps three).
     int q_skip = (speculated && ctx->last_no_irr && !ctx->no_skip_digit && !sort_is_local(ctx, nqr)) ? 1 : 0;
-    if (q_skip && fuse_cnt && ctx->fuse_q_skip > 1) q_skip = ctx->fuse_q_skip;
+    // (narrower buckets: the queries stay grouped by key >> 8 -- a window under the 16-bit mask would span 2-8 buckets)
+    const int wb_u = sort_local_bits(ctx, nu);
+    if (q_skip && fuse_cnt && ctx->fuse_q_skip > 1 && wb_u == 16) q_skip = ctx->fuse_q_skip;
     coarse_q = q_skip != 0;
     const u32 q_mask = q_skip == 2 ? 0xFFFF0000u : (q_skip == 1 ? 0xFFFFFF00u : 0xFFFFFFFFu);
     // (the smaller side's passes use the smaller status buffer: both were zeroed up front, neither is reused)
@@ -1433,7 +1487,9 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
     // (bucket_sort.hip.h, FUSE == 2) -- as long as the query windows stay well inside what a block holds in
     // registers: a window covers the query buckets (coarsely grouped: whole 65536-key buckets) that a bucket's
     // reach -- its own 65536 keys, the fixed length above it, the longest query below it -- touches
-    const double win_keys = 3.0 * 65536.0 + (double)uni_len;
+    const double win_keys = q_skip == 2 ? 3.0 * 65536.0 + (double)uni_len
+                                        : (double)(1u << (wb_u ? wb_u : 16)) + 512.0 + (double)uni_len +
+                                              (double)(q_len_max > 0 ? q_len_max : 0);
     const bool join_in_buckets = fuse_cnt && !ctx->no_bucket_join && ctx->fuse_a && speculated && ctx->last_no_irr &&
                                  ctx->fuse_cap > 0 && ctx->last_span > 0 &&
                                  (double)nqr * win_keys / (double)ctx->last_span <= 0.75 * (double)BJ_WCAP;
@@ -1532,7 +1588,8 @@ static int inner_plan_core(giql_hip_ctx* ctx, const giql_side* a, const giql_sid
                             ctx->last_span > 0 &&
                             // (a window = the A rows within the bucket's 65536 keys + the longest rows of either side: the
                             // previous plan's maxima, like the guess they validate)
-                            (double)na * (65536.0 + (double)ctx->h_meta->len_max_a + (double)ctx->h_meta->len_max_b) /
+                            (double)na * ((double)(1u << (sort_local_bits(ctx, nb) ? sort_local_bits(ctx, nb) : 16)) +
+                                          (double)ctx->h_meta->len_max_a + (double)ctx->h_meta->len_max_b) /
                                     (double)ctx->last_span <= 0.5 * (double)BJ_WCAP;
   // the smaller side's chain (linearize + sort) beside the larger side's when it is small (not in the form above:
   // B's last stage reads the sorted A)
@@ -3862,6 +3919,229 @@ static int inner_host_pipelined(giql_hip_ctx* ctx, const giql_side* a, const giq
   return GIQL_OK;
 }
 
+// ---- the host-buffer INNER join with a COMPACT-PLAN download (round 4; GIQL_HIP_E2E_COMPACT=1) ----
+// 3.2 GB of pairs take 57 ms on the PCIe link; the plan they are made of -- per query row {row id, first match,
+// count} + the other side's row ids in sorted order, giql_hip_inner_plan_export_dev -- is 0.52 GB at the headline
+// sizes (9 ms), and host threads expand it at the host's memory rate (tools/probes/host_expand_probe.cpp: 150 GB/s
+// of pairs with 16 threads on the GPU box = 21 ms for 3.2 GB).  So: columns up, plan, export, the three per-query
+// arrays down, then the sorted ids in chunks while the threads already expand the queries whose ranges have arrived
+// (blocks of 65,536 queries handed out in order; a block waits for the chunk that holds its last id).  The pairs
+// come out in the plan's query order.  Only the single-range form (fixed-length side, no irregular rows) has a compact
+// plan: any other plan is filled and downloaded as before.  GIQL_HIP_E2E_THREADS: expansion threads (default 16).
+struct CompactHost {  // page-locked staging of the plan, back to the pool on every path out
+  int32_t* q_rid = nullptr;
+  u32 *lo = nullptr, *cnt = nullptr;
+  int32_t* s_rid = nullptr;
+  ~CompactHost() {
+    giql_hip_free_host(q_rid);
+    giql_hip_free_host(lo);
+    giql_hip_free_host(cnt);
+    giql_hip_free_host(s_rid);
+  }
+};
+
+// returns GIQL_OK with *done = false when the plan has no compact form (the caller fills and downloads)
+static int inner_host_compact_tail(giql_hip_ctx* ctx, int64_t n, int32_t* ha, int32_t* hb, bool* done) {
+  *done = false;
+  InnerState& S = ctx->inner;
+  if (n <= 0 || S.uniform == 0 || ctx->n_irr != 0 || ctx->n_c1 != 0 || ctx->plan_is_join) return GIQL_OK;
+  const bool q_is_a_plan = S.uniform != 2;
+  const size_t nq = (size_t)(q_is_a_plan ? ctx->n_a : ctx->n_b), ns = (size_t)(q_is_a_plan ? ctx->n_b : ctx->n_a);
+  if (nq == 0 || ns == 0) return GIQL_OK;
+  // device staging: the context's output staging buffer (3 nq + ns words)
+  const size_t need = (3 * nq + ns + 64) * sizeof(u32);
+  if (need > ctx->stage_out_cap) {
+    if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+    ctx->stage_out = nullptr;
+    ctx->stage_out_cap = 0;
+    if (hipMalloc(&ctx->stage_out, need + need / 16) != hipSuccess)
+      return set_err(GIQL_ERR_NOMEM, "hipMalloc for the compact plan (%zu bytes) failed", need);
+    ctx->stage_out_cap = need + need / 16;
+  }
+  int32_t* d_qrid = (int32_t*)ctx->stage_out;
+  u32* d_lo = (u32*)d_qrid + nq;
+  u32* d_cnt = d_lo + nq;
+  int32_t* d_srid = (int32_t*)(d_cnt + nq);
+  int32_t query_is_a = 0;
+  int64_t xq = 0, xs = 0;
+  const int rc_x = giql_hip_inner_plan_export_dev(ctx, d_qrid, d_lo, d_cnt, d_srid, (int64_t)nq, (int64_t)ns, 0, 0,
+                                                  &query_is_a, &xq, &xs, nullptr);
+  if (rc_x == GIQL_ERR_STATE) return GIQL_OK;
+  GIQL_TRY(rc_x);
+  if ((size_t)xq != nq || (size_t)xs != ns) return set_err(GIQL_ERR_STATE, "plan export sizes changed under the call");
+  CompactHost H;
+  H.q_rid = (int32_t*)host_alloc(nq * 4);
+  H.lo = (u32*)host_alloc(nq * 4);
+  H.cnt = (u32*)host_alloc(nq * 4);
+  H.s_rid = (int32_t*)host_alloc(ns * 4);
+  if (!H.q_rid || !H.lo || !H.cnt || !H.s_rid) return set_err(GIQL_ERR_NOMEM, "out of host memory for the compact plan");
+  constexpr size_t CHUNK = (size_t)16 << 20;   // sorted ids per download chunk (64 MB: ~1.1 ms on the link)
+  constexpr size_t QBLK = (size_t)1 << 16;     // queries per expansion block
+  const size_t n_chunks = (ns + CHUNK - 1) / CHUNK, n_blk = (nq + QBLK - 1) / QBLK;
+  std::vector<hipEvent_t> ev(n_chunks + 1, nullptr);
+  struct EvGuard {
+    std::vector<hipEvent_t>& e;
+    ~EvGuard() {
+      for (hipEvent_t x : e)
+        if (x) (void)hipEventDestroy(x);
+    }
+  } ev_guard{ev};
+  for (auto& e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipStream_t st = nullptr;  // the export kernel ran on the null stream: the copies follow it there
+  HIP_TRY(hipMemcpyAsync(H.cnt, d_cnt, nq * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(H.lo, d_lo, nq * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(H.q_rid, d_qrid, nq * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipEventRecord(ev[0], st));
+  for (size_t c = 0; c < n_chunks; c++) {
+    const size_t c0 = c * CHUNK, cn = ns - c0 < CHUNK ? ns - c0 : CHUNK;
+    HIP_TRY(hipMemcpyAsync(H.s_rid + c0, d_srid + c0, cn * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(ev[c + 1], st));
+  }
+  HIP_TRY(hipEventSynchronize(ev[0]));  // the per-query arrays are here
+  int n_thr = 16;
+  if (const char* e = getenv("GIQL_HIP_E2E_THREADS")) n_thr = atoi(e);
+  const int hw = (int)std::thread::hardware_concurrency();
+  if (hw > 0 && n_thr > hw) n_thr = hw;
+  if (n_thr < 1) n_thr = 1;
+  if ((size_t)n_thr > n_blk) n_thr = (int)n_blk;
+  bool stream_stores = true;  // GIQL_HIP_E2E_NT=0: plain stores
+  if (const char* e = getenv("GIQL_HIP_E2E_NT")) stream_stores = atoi(e) != 0;
+  (void)stream_stores;
+  // block offsets: per-block sums in parallel, a serial scan over the (few hundred) blocks
+  std::vector<u64> blk_off(n_blk + 1, 0);
+  std::vector<u32> blk_need(n_blk, 0);  // one past the last sorted id a block reads
+  std::atomic<size_t> next{0};
+  std::atomic<size_t> chunks_here{0};
+  std::atomic<int> bad{0};
+  const u32* const lo = H.lo;
+  const u32* const cnt = H.cnt;
+  auto sums = [&] {
+    for (;;) {
+      const size_t bk = next.fetch_add(1);
+      if (bk >= n_blk) return;
+      const size_t q0 = bk * QBLK, q1 = q0 + QBLK < nq ? q0 + QBLK : nq;
+      u64 t = 0;
+      u32 need_s = 0;
+      for (size_t q = q0; q < q1; q++) {
+        t += cnt[q];
+        const u64 e = (u64)lo[q] + cnt[q];
+        if (cnt[q] && e > need_s) need_s = e > (u64)ns ? 0xFFFFFFFFu : (u32)e;
+      }
+      blk_off[bk + 1] = t;
+      blk_need[bk] = need_s;
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_thr; t++) th.emplace_back(sums);
+    sums();
+    for (auto& t : th) t.join();
+  }
+  for (size_t bk = 0; bk < n_blk; bk++) {
+    if (blk_need[bk] == 0xFFFFFFFFu) return set_err(GIQL_ERR_STATE, "compact plan: a range past the sorted ids");
+    blk_off[bk + 1] += blk_off[bk];
+  }
+  if (blk_off[n_blk] != (u64)n) return set_err(GIQL_ERR_STATE, "compact plan: %llu pairs, the plan counted %lld",
+                                               (unsigned long long)blk_off[n_blk], (long long)n);
+  int32_t* const out_q = query_is_a ? ha : hb;
+  int32_t* const out_s = query_is_a ? hb : ha;
+  const int32_t* const q_rid = H.q_rid;
+  const int32_t* const s_rid = H.s_rid;
+  next.store(0);
+  auto expand = [&] {
+    for (;;) {
+      const size_t bk = next.fetch_add(1);
+      if (bk >= n_blk) return;
+      const size_t want = ((size_t)blk_need[bk] + CHUNK - 1) / CHUNK;  // chunks that must have arrived
+      while (chunks_here.load(std::memory_order_acquire) < want) {
+        if (bad.load()) return;
+        std::this_thread::yield();
+      }
+      const size_t q0 = bk * QBLK, q1 = q0 + QBLK < nq ? q0 + QBLK : nq;
+      u64 o = blk_off[bk];
+#if defined(__SSE2__)
+      if (stream_stores) {
+        // The pairs are staged in two 4 KB buffers (L1) and leave in aligned 16-byte NON-TEMPORAL stores: a plain store
+        // makes the core read every output line before writing it, i.e. 6.4 GB of memory traffic for 3.2 GB of pairs.
+        // Both arrays come page-aligned from the pool and share the offset, so one alignment serves both.
+        constexpr u32 BUF = 1024;
+        alignas(64) int32_t bq[BUF], bs[BUF];
+        const u64 o_end = blk_off[bk + 1];
+        size_t q = q0;
+        u32 k = 0;  // next pair of query q
+        auto next_pair = [&](int32_t& vq, int32_t& vs) {  // (the block holds o_end - o more pairs: never runs past q1)
+          while (k >= cnt[q]) {
+            q++;
+            k = 0;
+          }
+          vq = q_rid[q];
+          vs = s_rid[lo[q] + k];
+          k++;
+        };
+        while (o < o_end && (o & 15u)) {  // up to the first 64-byte boundary: plain stores
+          next_pair(out_q[o], out_s[o]);
+          o++;
+        }
+        while (o_end - o >= BUF) {
+          u32 f = 0;
+          while (f < BUF) {  // whole runs of one query at a time
+            while (k >= cnt[q]) {
+              q++;
+              k = 0;
+            }
+            const u32 c = cnt[q] - k < BUF - f ? cnt[q] - k : BUF - f;
+            const int32_t id = q_rid[q];
+            const int32_t* src = s_rid + lo[q] + k;
+            for (u32 j = 0; j < c; j++) {
+              bq[f + j] = id;
+              bs[f + j] = src[j];
+            }
+            f += c;
+            k += c;
+          }
+          for (u32 j = 0; j < BUF; j += 4) {
+            _mm_stream_si128(reinterpret_cast<__m128i*>(out_q + o + j), _mm_load_si128(reinterpret_cast<const __m128i*>(bq + j)));
+            _mm_stream_si128(reinterpret_cast<__m128i*>(out_s + o + j), _mm_load_si128(reinterpret_cast<const __m128i*>(bs + j)));
+          }
+          o += BUF;
+        }
+        while (o < o_end) {
+          next_pair(out_q[o], out_s[o]);
+          o++;
+        }
+        _mm_sfence();
+        continue;
+      }
+#endif
+      for (size_t q = q0; q < q1; q++) {
+        const u32 c = cnt[q];
+        const int32_t id = q_rid[q];
+        const int32_t* src = s_rid + lo[q];
+        for (u32 k = 0; k < c; k++) {
+          out_q[o + k] = id;
+          out_s[o + k] = src[k];
+        }
+        o += c;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_thr; t++) th.emplace_back(expand);
+  int rc = GIQL_OK;
+  for (size_t c = 0; c < n_chunks; c++) {  // this thread follows the link and publishes what has arrived
+    if (hipEventSynchronize(ev[c + 1]) != hipSuccess) {
+      rc = set_err(GIQL_ERR_HIP, "D2H copy of the compact plan failed");
+      bad.store(1);
+      break;
+    }
+    chunks_here.store(c + 1, std::memory_order_release);
+  }
+  for (auto& t : th) t.join();
+  GIQL_TRY(rc);
+  *done = true;
+  return GIQL_OK;
+}
+
 int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, int32_t n_chrom,
                    int64_t* n_pairs, int32_t** row_a, int32_t** row_b) {
   if (!ctx || !n_pairs || !row_a || !row_b) return set_err(GIQL_ERR_INVALID, "NULL argument");
@@ -3869,7 +4149,9 @@ int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, in
   GIQL_TRY(check_side(b, "b"));
   HIP_TRY(hipSetDevice(ctx->device));
   *row_a = *row_b = nullptr;
-  {
+  const char* e_compact = getenv("GIQL_HIP_E2E_COMPACT");
+  const bool compact = e_compact && atoi(e_compact) != 0;
+  if (!compact) {
     const char* e = getenv("GIQL_HIP_E2E_BLOCK_ROWS");
     const size_t block_rows = e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)4 << 20);
     const size_t n_big = (size_t)(a->n > b->n ? a->n : b->n);
@@ -3905,7 +4187,16 @@ int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, in
   const double ms_pin = ms_since(t0);
   t0 = now();
   double ms_fill = 0, ms_d2h = 0;
-  if (n > 0) {
+  bool compact_done = false;
+  if (compact && n > 0) {
+    const int rc = inner_host_compact_tail(ctx, n, ha, hb, &compact_done);
+    if (rc != GIQL_OK) {
+      giql_hip_free_host(ha);
+      giql_hip_free_host(hb);
+      return rc;
+    }
+  }
+  if (n > 0 && !compact_done) {
     // row_b starts on a 2 MiB boundary of its own: a row that begins in the middle of a cache
     // line makes every 256-byte wave store of the fill touch three lines instead of two
     const size_t stride = align_up((size_t)n, (size_t)1 << 19);
@@ -3942,8 +4233,8 @@ int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, in
   }
   ms_d2h = ms_since(t0);
   if (dbg)
-    fprintf(stderr, "[giql_hip_inner] H2D %.1f ms, plan %.1f, pinned alloc %.1f, output alloc + fill %.1f, D2H %.1f (%lld pairs)\n",
-            ms_h2d, ms_plan, ms_pin, ms_fill, ms_d2h, (long long)n);
+    fprintf(stderr, "[giql_hip_inner] H2D %.1f ms, plan %.1f, pinned alloc %.1f, output alloc + fill %.1f, %s %.1f (%lld pairs)\n",
+            ms_h2d, ms_plan, ms_pin, ms_fill, compact_done ? "compact plan D2H + host expansion" : "D2H", ms_d2h, (long long)n);
   *row_a = ha;
   *row_b = hb;
   return GIQL_OK;

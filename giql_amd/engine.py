@@ -172,7 +172,8 @@ class HipEngine:
         out["swapped"] = bool(int(st.reserved) & 0x80)  # the INNER plan ran with the sides exchanged (larger side as B)
         out["sort_tile_order"] = (int(st.reserved) >> 8) & 0x7F
         out["count_fused"] = bool(int(st.reserved) & 0x8000)  # the bucket sort answered the range bounds (no count kernel)
-        out["sort_order_fallbacks"] = (int(st.reserved) >> 16) & 0x1FFF
+        out["sort_order_fallbacks"] = (int(st.reserved) >> 16) & 0x7FF
+        out["bucket_bits"] = 16 - ((int(st.reserved) >> 27) & 3)  # key bits of a bucket of the last three-stage sort
         out["bucket_join"] = bool((int(st.reserved) >> 29) & 1)  # the bucket stage wrote the pairs itself (one-call form)
         out["fused_fill"] = bool((int(st.reserved) >> 30) & 1)  # the last plan launched its own fill
         out["presorted"] = bool(int(st.reserved) & 0x80000000)  # a side arrived sorted and skipped its sort
@@ -917,9 +918,10 @@ class HipEngine:
         del keep_a, keep_b
         return ra, rb
 
-    def inner_join_host_timed(self, a_cols, b_cols, n_chrom: int):
+    def inner_join_host_timed(self, a_cols, b_cols, n_chrom: int, inspect=None):
         """Wall time (ms) and pair count of one ``giql_hip_inner`` call; the pinned results are
-        released without being copied (bench.py's t_e2e)."""
+        released without being copied (bench.py's t_e2e).  ``inspect(row_a, row_b)``: called with numpy views
+        of the library-owned arrays before they are released (parity checks)."""
         import time
 
         import numpy as np
@@ -936,8 +938,15 @@ class HipEngine:
         rc = self._L.giql_hip_inner(self._h, ctypes.byref(ca), ctypes.byref(cb), int(n_chrom), ctypes.byref(n),
                                     ctypes.byref(pa), ctypes.byref(pb))
         ms = (time.perf_counter() - t0) * 1e3
-        self._L.giql_hip_free_host(pa)
-        self._L.giql_hip_free_host(pb)
+        try:
+            if rc == 0 and inspect is not None and n.value > 0:
+                va = np.ctypeslib.as_array(ctypes.cast(pa, ctypes.POINTER(ctypes.c_int32)), shape=(int(n.value),))
+                vb = np.ctypeslib.as_array(ctypes.cast(pb, ctypes.POINTER(ctypes.c_int32)), shape=(int(n.value),))
+                inspect(va, vb)
+                del va, vb
+        finally:
+            self._L.giql_hip_free_host(pa)
+            self._L.giql_hip_free_host(pb)
         _lib.check(rc)
         del keep_a, keep_b
         return ms, int(n.value)

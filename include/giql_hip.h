@@ -132,8 +132,11 @@ typedef struct giql_hip_stats {
                                bits 8-14: sort tile order in force (2 =
                                blockIdx order, 0 = ticket order); bit 15: the range count of the
                                fixed-length form ran inside the bucket sort (no count kernel, the
-                               sorted keys never stored); bits 16-28: calls
-                               repeated in ticket order after a look-back timeout; bit 29: the
+                               sorted keys never stored); bits 16-26: calls
+                               repeated in ticket order after a look-back timeout; bits 27-28:
+                               16 - the key bits of a bucket of the last three-stage sort (0: buckets
+                               of 65,536 keys; 1-3: 2^15 / 2^14 / 2^13 keys after THREE global
+                               passes -- tables past ~2,800 rows per 65,536 positions); bit 29: the
                                bucket stage wrote the pairs itself (one-call form: no sorted id,
                                bound or offset array was stored, no scan and no fill kernel ran);
                                bit 30: the last plan launched its own fill

@@ -261,14 +261,34 @@ def _check_big_join(eng, A, B, n_chrom, expect_fused):
     return n, st
 
 
-def test_join_past_2_pow_32_pairs_dense_tables_four_pass_sort():
-    """35M peaks x 350M reads (3.5x the headline sizes): 4.95e9 pairs, 40 GB of output.  ~7,400 rows per
-    65536-wide bucket: the tables leave the three-stage sort, the count kernel and the 64-bit scan run."""
+def test_join_past_2_pow_32_pairs_dense_tables_narrow_buckets():
+    """35M peaks x 350M reads (3.5x the headline sizes): 4.95e9 pairs, 40 GB of output.  ~7,400 rows per 65,536
+    positions: since round 4 the 350M-row side keeps the three-stage sort with buckets of 2^14 keys (~1,850 rows,
+    three global passes), the fused count and -- in the one-call form -- the join in the bucket stage
+    (VERDICT r03 "Next round" 5)."""
     from giql_amd.engine import HipEngine
 
     A = synth.make_table(35_000_000, 5, "peaks")
     B = synth.make_table(350_000_000, 6, "reads")
     eng = HipEngine(0)
+    try:
+        n, st = _check_big_join(eng, A, B, 24, expect_fused=True)
+        assert n == 4_952_361_736 and st["join_form"] == "uniform_b"
+        assert st["sort_local"] and st["bucket_bits"] == 14 and st["bucket_join"] and not st["sort_resorted"], st
+    finally:
+        eng.close()
+
+
+def test_join_past_2_pow_32_pairs_dense_tables_four_pass_sort(monkeypatch):
+    """The same tables with GIQL_HIP_NO_NARROW_BUCKETS=1 (round 3's behaviour): the 350M-row side leaves the
+    three-stage sort, the count kernel and the 64-bit scan run."""
+    from giql_amd.engine import HipEngine
+
+    A = synth.make_table(35_000_000, 5, "peaks")
+    B = synth.make_table(350_000_000, 6, "reads")
+    monkeypatch.setenv("GIQL_HIP_NO_NARROW_BUCKETS", "1")
+    eng = HipEngine(0)
+    monkeypatch.delenv("GIQL_HIP_NO_NARROW_BUCKETS")
     try:
         n, st = _check_big_join(eng, A, B, 24, expect_fused=False)
         # (the 35M-row QUERY side is sparse enough for the three-stage sort; the 350M-row side is not, so the

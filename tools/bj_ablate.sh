@@ -12,7 +12,7 @@ for n in "$@"; do
   python3 - "$f" "$n" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if "k_bucket_sort<1, 2>" in r["Name"]:
+    if "k_bucket_sort<1, 2" in r["Name"]:
         print("%-10s k_bucket_sort<1,2>: calls %s avg %.1f us" % (sys.argv[2], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done
