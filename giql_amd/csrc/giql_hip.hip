@@ -174,6 +174,7 @@ struct giql_hip_ctx {
   // GIQL_HIP_NO_NARROW_BUCKETS=1: 16 bits or nothing (round 3); GIQL_HIP_LOCAL_BITS=w: every three-stage sort takes w (tests)
   bool no_narrow = false;
   int force_bits = 0;
+  int index_bits = 16;  // the width of the index being built (force_local > 0)
   bool no_skip_digit = false;  // GIQL_HIP_NO_SKIP_DIGIT=1: query sides are sorted on every digit
   // a sort's FIRST pass may rank its rows with LDS atomics (unstable: rows of equal digits in any order) when the caller
   // does not need equal keys in input order -- the INNER join's sides (onesweep.hip.h); GIQL_HIP_NO_UNSTABLE_FIRST=1: never
@@ -572,10 +573,20 @@ static void launch_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, int
 // Sides of ctx->local_min_rows rows and more take the three-stage form: global passes on bits
 // 16-23 and 24-31 only, then every 16-bit bucket sorted on its low bits inside LDS, in place
 // (bucket_sort.hip.h) -- three trips through HBM instead of four.
+// the narrowest-needed bucket for a table of per_bucket rows per 65,536 keys on average (0: too dense for any)
+static inline int density_bits(const giql_hip_ctx* ctx, double per_bucket) {
+  int w = 16;
+  while (per_bucket > ctx->local_max_bucket_rows && w > BS_MIN_WBITS && !ctx->no_narrow) {
+    per_bucket *= 0.5;
+    w--;
+  }
+  return per_bucket <= ctx->local_max_bucket_rows ? w : 0;
+}
+
 // Returns 0 (four global passes) or the key bits of a bucket: 16 (two global passes), or 15 / 14 / 13 for denser
 // tables (three global passes -- bits 8-15, 16-23, 24-31 -- and buckets of 2^W keys: bucket_sort.hip.h).
 static inline int sort_local_bits(const giql_hip_ctx* ctx, size_t n) {
-  if (ctx->force_local > 0 && ctx->bucket_bnd && ctx->os_variant == 0) return 16;
+  if (ctx->force_local > 0 && ctx->bucket_bnd && ctx->os_variant == 0) return ctx->index_bits;
   if (ctx->force_local < 0) return 0;
   if (!(ctx->local_sort && ctx->bucket_bnd && ctx->os_variant == 0 && n >= ctx->local_min_rows)) return 0;
   // The in-LDS stage holds 4096 rows per bucket; larger buckets go through a slow queue (one block each, two
@@ -593,12 +604,7 @@ static inline int sort_local_bits(const giql_hip_ctx* ctx, size_t n) {
   double per_bucket = (double)n * 65536.0 / span;
   if (per_bucket < ctx->local_min_bucket_rows) return 0;
   if (ctx->force_bits) return ctx->force_bits;
-  int w = 16;
-  while (per_bucket > ctx->local_max_bucket_rows && w > BS_MIN_WBITS && !ctx->no_narrow) {
-    per_bucket *= 0.5;
-    w--;
-  }
-  return per_bucket <= ctx->local_max_bucket_rows ? w : 0;
+  return density_bits(ctx, per_bucket);
 }
 static inline int local_passes(int wbits) { return wbits == 16 ? 2 : 3; }  // global passes before the bucket stage
 
@@ -1965,6 +1971,7 @@ struct giql_hip_index {
   int len_max = 0;         // the longest row
   u64 span = 0;
   u32 sentinel = 0;        // one past the largest key of the axis
+  int wbits = 16;          // key bits of a bucket (16; 15 / 14 / 13 for tables past ~2,800 rows per 65,536 positions)
   u32 *key = nullptr, *end = nullptr, *rid = nullptr;   // [n] sorted by key (every bucket sorted in place)
   u32* small = nullptr;    // the sort's digit offsets gbase[4][256] | first[n_chrom + 1]: chromosome c owns keys [first[c], first[c + 1])
   size_t bytes = 0;
@@ -2021,7 +2028,7 @@ int giql_hip_index_create_dev(giql_hip_ctx* ctx, const giql_side* side, int32_t 
     lb.top_partial = c.take<u32>((size_t)LIN_HIST_REPLICAS * MM_TOP_WORDS);
     gbase = c.take<u32>(1024);
     lb.abase = c.take<u32>(MM_HIST_CHROMS);
-    status = c.take<u32>(2 * os_pass_words(n));
+    status = c.take<u32>(3 * os_pass_words(n));
     c.off = align_up(c.off, 256);
     zero_end = c.off;
     return c.off;
@@ -2035,6 +2042,7 @@ int giql_hip_index_create_dev(giql_hip_ctx* ctx, const giql_side* side, int32_t 
     giql_hip_ctx* c;
     ~Fail() {
       c->force_local = 0;
+      c->index_bits = 16;
       c->prezeroed = false;
       if (p) giql_hip_index_destroy(p);
     }
@@ -2045,12 +2053,13 @@ int giql_hip_index_create_dev(giql_hip_ctx* ctx, const giql_side* side, int32_t 
   HIP_TRY(hipMemsetAsync(ctx->arena + zero_off, 0, zero_end - zero_off, st));
   ctx->prezeroed = true;
   ctx->force_local = 1;
+  ctx->index_bits = 15;  // (not 16: the span pass counts the bits 8-15 digit too -- the density is not known yet)
   ctx->span_hist_dirty[0] = ctx->span_hist_dirty[1] = nullptr;
   giql_side none = *side;
   none.n = 0;
   none.chrom = none.start = none.end = nullptr;
   // the span pass of the ordinary plan, this table as its side B: per-chromosome range, length range, the digits
-  // of the aligned keys (k_chrom_minmax<2>: the two high digits, the low ones are sorted in LDS)
+  // of the aligned keys (all but the lowest matter: buckets narrower than 2^16 keys sort on bits 8-15 as well)
   GIQL_TRY(run_spans(ctx, st, none, *side, n_chrom, lb, 1, hist));
   GIQL_TRY(read_meta(ctx, st));
   const DevMeta& m = *ctx->h_meta;
@@ -2060,9 +2069,11 @@ int giql_hip_index_create_dev(giql_hip_ctx* ctx, const giql_side* side, int32_t 
   if (m.len_max_b > (int)BS_FUSE_WCAP)
     return set_err(GIQL_ERR_STATE, "a row of %d positions is longer than the bucket stage's windows allow (%u)", m.len_max_b, BS_FUSE_WCAP);
   const double per_bucket = (double)n * 65536.0 / (double)(m.total_span ? m.total_span : 1);
-  if (per_bucket > ctx->local_max_bucket_rows)
-    return set_err(GIQL_ERR_STATE, "%.0f rows per 65,536-key bucket: too dense for the in-LDS bucket stage (at most %.0f)",
-                   per_bucket, ctx->local_max_bucket_rows);
+  idx->wbits = ctx->force_bits ? ctx->force_bits : density_bits(ctx, per_bucket);
+  if (idx->wbits == 0)
+    return set_err(GIQL_ERR_STATE, "%.0f rows per 65,536 positions: too dense for the in-LDS bucket stage (at most %.0f per %d)",
+                   per_bucket, ctx->local_max_bucket_rows, 1 << BS_MIN_WBITS);
+  ctx->index_bits = idx->wbits;
   idx->general = ctx->no_uniform || m.len_min_b != m.len_max_b;
   idx->uni_len = idx->general ? 0 : m.len_max_b;
   idx->len_max = m.len_max_b;
@@ -2084,7 +2095,15 @@ int giql_hip_index_create_dev(giql_hip_ctx* ctx, const giql_side* side, int32_t 
   sb.rid[0] = idx->rid;
   sb.end[0] = idx->general ? idx->end : nullptr;
   if (!idx->general) sb.end[1] = nullptr;
-  // two global passes from the raw columns + every bucket sorted in LDS, in place: the result is in buffer 0
+  if (local_passes(idx->wbits) & 1) {
+    // three global passes end in the buffer they did not start from (run_sort_onesweep then calls THAT "buffer 0"):
+    // the index's own arrays start as buffer 1
+    u32* t;
+    t = sb.key[0], sb.key[0] = sb.key[1], sb.key[1] = t;
+    t = sb.rid[0], sb.rid[0] = sb.rid[1], sb.rid[1] = t;
+    t = sb.end[0], sb.end[0] = sb.end[1], sb.end[1] = t;
+  }
+  // two (three) global passes from the raw columns + every bucket sorted in LDS, in place: the result is in buffer 0
   GIQL_TRY(run_sort_onesweep(ctx, st, sb, (u32)n, gbase, status, false, side, lb.abase, 0, nullptr, false));
   if (sb.key[0] != idx->key) return set_err(GIQL_ERR_HIP, "internal: the sort did not end in the index's buffers");
   HIP_TRY(hipMemcpyAsync(idx->small, gbase, 1024 * sizeof(u32), hipMemcpyDeviceToDevice, st));
@@ -2092,7 +2111,7 @@ int giql_hip_index_create_dev(giql_hip_ctx* ctx, const giql_side* side, int32_t 
   {
     const int rc = read_meta(ctx, st);
     if (rc == GIQL_STATUS_RESORT)
-      return set_err(GIQL_ERR_STATE, "a 65,536-key bucket of the table holds more rows than the bucket stage sorts (%u)", BS_BIG_MAX);
+      return set_err(GIQL_ERR_STATE, "a %d-key bucket of the table holds more rows than the bucket stage sorts (%u)", 1 << idx->wbits, BS_BIG_MAX);
     if (rc != GIQL_OK) return rc;
   }
   collect_spans(ctx);
@@ -2172,8 +2191,9 @@ int giql_hip_inner_join_indexed_dev(giql_hip_ctx* ctx, const giql_hip_index* idx
   HIP_TRY(hipMemcpyAsync(len_max_u, &idx->len_max, sizeof(int), hipMemcpyHostToDevice, st));
   // grouped by bucket only (two passes): the windows are computed under the same mask.  The general form ranks a
   // window's keys against the bucket rows and wants them fully sorted.
-  const int q_skip = idx->general ? 0 : 2;
-  const u32 q_mask = q_skip == 2 ? 0xFFFF0000u : 0xFFFFFFFFu;
+  // (narrower buckets: grouped by key >> 8, three passes)
+  const int q_skip = idx->general ? 0 : (idx->wbits == 16 ? 2 : 1);
+  const u32 q_mask = q_skip == 2 ? 0xFFFF0000u : (q_skip == 1 ? 0xFFFFFF00u : 0xFFFFFFFFu);
   ctx->force_local = -1;  // a's own sort: global passes only (its bucket stage would reuse the context's boundary arrays)
   const int rc_sort = run_sort_onesweep(ctx, st, sa, (u32)na, gbase, status, false, nullptr, nullptr, q_skip, nullptr, false);
   ctx->force_local = 0;
@@ -2204,7 +2224,7 @@ int giql_hip_inner_join_indexed_dev(giql_hip_ctx* ctx, const giql_hip_index* idx
   sb.rid[0] = idx->rid;
   sb.end[0] = idx->end;
   ctx->last_sort_local = true;
-  launch_bucket_stage_fused(ctx, st, sb, (u32)nb, idx->small, fc);
+  launch_bucket_stage_fused(ctx, st, sb, (u32)nb, idx->small, fc, idx->wbits);
   GIQL_TRY(post_launch("bucket stage (index)"));
   u32 h_flags[4] = {0, 0, 0, 0};
   HIP_TRY(hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, st));

@@ -200,3 +200,58 @@ def test_execute_uses_the_index_of_a_pinned_table(monkeypatch):
         key = [("start", "ascending"), ("score", "ascending"), ("bs", "ascending")]
         assert got.sort_by(key).equals(want.sort_by(key)) and len(built) == 1
     assert pinned.index_info() == []
+
+
+# ---- an index over a DENSE table: narrower buckets (round 4, VERDICT r03 "Next round" 5 + 6) --------------------------
+def test_index_of_a_dense_table_takes_narrower_buckets():
+    """6M fixed-length rows on 60M positions (~5,900 rows per 65,536): round 3's index declined this table
+    (GIQL_ERR_STATE), now it is indexed with buckets of 2^14 keys and serves the same pairs as the oracle."""
+    from giql_amd.engine import HipEngine
+
+    r = np.random.default_rng(611)
+    s = r.integers(0, 60_000_000, 6_000_000).astype(np.int32)
+    b = ora.Side(np.zeros(s.size, np.int32), s, s + np.int32(100))
+    e = HipEngine(0)
+    try:
+        index = e.index_create(dev(b), 1)
+        try:
+            for seed, nq in ((612, 200_000), (613, 3_000)):
+                qs = np.random.default_rng(seed).integers(0, 60_000_000, nq).astype(np.int32)
+                q = ora.Side(np.zeros(nq, np.int32), qs, (qs + np.random.default_rng(seed + 9).integers(1, 900, nq)).astype(np.int32))
+                for _ in range(2):
+                    ra, rb = e.inner_join_indexed(dev(q), index)
+                    st = e.stats()
+                    assert st["bucket_join"] and st["bucket_bits"] == 14, st
+                    assert np.array_equal(pairs_of(ra, rb), want_pairs(q, b))
+        finally:
+            index.close()
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("bits", [13, 15])
+@pytest.mark.parametrize("kind_b", ["reads", "peaks"])
+def test_index_with_a_forced_bucket_width(monkeypatch, bits, kind_b):
+    from giql_amd.engine import HipEngine
+
+    monkeypatch.setenv("GIQL_HIP_LOCAL_BITS", str(bits))
+    e = HipEngine(0)
+    monkeypatch.delenv("GIQL_HIP_LOCAL_BITS")
+    try:
+        b = table(1_500_000, 31, kind_b)
+        index = e.index_create(dev(b), 24)
+        try:
+            assert index.general == (kind_b == "peaks")
+            for seed, n_a, kind_a in ((32, 200_000, "peaks"), (33, 90_000, "reads")):
+                a = table(n_a, seed, kind_a)
+                ra, rb = e.inner_join_indexed(dev(a), index)
+                st = e.stats()
+                assert st["bucket_join"] and st["bucket_bits"] == bits, st
+                assert np.array_equal(pairs_of(ra, rb), want_pairs(a, b))
+            # the ordinary join on the same context afterwards
+            a = table(50_000, 34, "peaks")
+            assert np.array_equal(pairs_of(*e.inner_join(dev(a), dev(b), 24)), want_pairs(a, b))
+        finally:
+            index.close()
+    finally:
+        e.close()
