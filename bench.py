@@ -1108,21 +1108,10 @@ def inner_extras(eng, dev_index, a, b, ha, hb, n_chrom, n_pairs, alloc_out, join
         del buf
     finally:
         g.close()
-    # host Arrow buffers in, host index pairs out (H2D of 12 B/row, join, D2H of 8 B/pair into pinned memory)
-    try:
-        first_ms, n = eng.inner_join_host_timed(ha, hb, n_chrom)
-        ms, n = eng.inner_join_host_timed(ha, hb, n_chrom)
-        out["t_e2e_ms"] = round(ms, 1)
-        out["t_e2e_first_call_ms"] = round(first_ms, 1)
-        out["t_e2e_note"] = ("giql_hip_inner: pageable host columns -> device, join, pairs -> pinned host memory, the "
-                             "larger table uploaded in blocks of 4M rows so that a block's pairs travel out while the "
-                             "next block travels in; the first call also page-locks the output arrays, later calls "
-                             "reuse them (the library's pool); never the headline value")
-    except Exception as exc:
-        out["t_e2e_ms"] = None
-        out["t_e2e_error"] = str(exc)[:200]
-    # the same call with the COMPACT-PLAN download (GIQL_HIP_E2E_COMPACT=1: 0.52 GB over the link instead of 3.2, expanded
-    # by host threads while the sorted ids are still arriving); its pairs checked against the timed step's checksum
+    # host columns in, host index pairs out (giql_hip_inner).  Default since round 4: the columns go up, the COMPACT PLAN
+    # comes down (0.52 GB instead of 3.2 GB of pairs) and host threads expand it into plain memory while the sorted ids
+    # are still arriving; GIQL_HIP_E2E_COMPACT=0 is round 3's path (pairs downloaded into page-locked arrays, the larger
+    # table uploaded block by block).  The default path's pairs are checked against the timed step's checksum.
     try:
         seen = {}
 
@@ -1132,16 +1121,28 @@ def inner_extras(eng, dev_index, a, b, ha, hb, n_chrom, n_pairs, alloc_out, join
             seen["sum"] = eng.pairs_checksum(ta, tb)
             seen["n"] = int(va.shape[0])
 
-        os.environ["GIQL_HIP_E2E_COMPACT"] = "1"
-        eng.inner_join_host_timed(ha, hb, n_chrom)
-        ms_c, n_c = eng.inner_join_host_timed(ha, hb, n_chrom)
+        first_ms, n = eng.inner_join_host_timed(ha, hb, n_chrom)
+        ms, n = eng.inner_join_host_timed(ha, hb, n_chrom)
         eng.inner_join_host_timed(ha, hb, n_chrom, inspect=inspect)
-        out["t_e2e_compact_ms"] = round(ms_c, 1)
-        out["t_e2e_compact_parity"] = {"pairs_equal": n_c == n_pairs and seen.get("n") == n_pairs,
-                                       "multiset_checksum_equal": seen.get("sum") == uniform_sum}
+        out["t_e2e_ms"] = round(ms, 1)
+        out["t_e2e_first_call_ms"] = round(first_ms, 1)
+        out["t_e2e_parity"] = {"pairs_equal": n == n_pairs and seen.get("n") == n_pairs,
+                               "multiset_checksum_equal": seen.get("sum") == uniform_sum}
+        out["t_e2e_note"] = ("giql_hip_inner: pageable host columns -> device, join, the compact plan (per-query {id, first "
+                             "match, count} + the sorted ids) -> host, expanded by 32 host threads into plain host memory; "
+                             "never the headline value")
     except Exception as exc:
-        out["t_e2e_compact_ms"] = None
-        out["t_e2e_compact_error"] = str(exc)[:200]
+        out["t_e2e_ms"] = None
+        out["t_e2e_error"] = str(exc)[:200]
+    try:
+        os.environ["GIQL_HIP_E2E_COMPACT"] = "0"
+        first_ms, n = eng.inner_join_host_timed(ha, hb, n_chrom)
+        ms, n = eng.inner_join_host_timed(ha, hb, n_chrom)
+        out["t_e2e_pairs_download_ms"] = round(ms, 1)
+        out["t_e2e_pairs_download_first_call_ms"] = round(first_ms, 1)
+    except Exception as exc:
+        out["t_e2e_pairs_download_ms"] = None
+        out["t_e2e_pairs_download_error"] = str(exc)[:200]
     finally:
         os.environ.pop("GIQL_HIP_E2E_COMPACT", None)
     return out

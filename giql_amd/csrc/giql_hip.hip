@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <atomic>
+#include <sys/mman.h>
+#include <utility>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
@@ -3706,7 +3708,14 @@ struct HostPool {
     void* p;
     size_t bytes;
     bool idle;
+    bool pinned;  // page-locked (hipHostMalloc) or plain memory (the compact-plan path's outputs: written by host threads)
   };
+  static void release(void* p, bool pinned) {
+    if (pinned)
+      (void)hipHostFree(p);
+    else
+      free(p);
+  }
   std::mutex mu;
   std::vector<Buf> bufs;
   size_t idle_limit;
@@ -3714,26 +3723,37 @@ struct HostPool {
     const char* e = getenv("GIQL_HIP_HOST_POOL_MB");
     idle_limit = (size_t)(e ? strtoull(e, nullptr, 10) : 8192ull) << 20;
   }
-  void* get(size_t bytes) {
+  void* get(size_t bytes, bool pinned = true) {
     {
       std::lock_guard<std::mutex> g(mu);
       Buf* best = nullptr;
-      for (auto& b : bufs)
-        if (b.idle && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+      for (auto& b : bufs)  // (a page-locked buffer serves a plain request as well)
+        if (b.idle && b.bytes >= bytes && (b.pinned || !pinned) && (!best || b.bytes < best->bytes)) best = &b;
       if (best && best->bytes <= 2 * bytes + (1u << 20)) {  // not a 3 GB buffer for a 4-byte result
         best->idle = false;
         return best->p;
       }
     }
     void* p = nullptr;
-    const size_t cap = bytes + bytes / 16;  // a little head-room: the next result of a similar call fits too
-    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    size_t cap = bytes + bytes / 16;  // a little head-room: the next result of a similar call fits too
+    if (pinned) {
+      if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    } else {
+      // plain memory on 2 MiB boundaries, huge pages asked for: the expansion threads touch it for the first time
+      // (4 KB pages: ~800,000 faults for 3.2 GB of pairs)
+      cap = align_up(cap, (size_t)2 << 20);
+      p = aligned_alloc((size_t)2 << 20, cap);
+      if (!p) return nullptr;
+#if defined(MADV_HUGEPAGE)
+      (void)madvise(p, cap, MADV_HUGEPAGE);
+#endif
+    }
     std::lock_guard<std::mutex> g(mu);
-    bufs.push_back({p, cap, false});
+    bufs.push_back({p, cap, false, pinned});
     return p;
   }
   void put(void* p) {
-    std::vector<void*> drop;
+    std::vector<std::pair<void*, bool>> drop;
     {
       std::lock_guard<std::mutex> g(mu);
       bool known = false;
@@ -3742,7 +3762,7 @@ struct HostPool {
           b.idle = true;
           known = true;
         }
-      if (!known) drop.push_back(p);
+      if (!known) drop.push_back({p, true});
       // over the limit: release the smallest idle buffers first (the big ones are the ones worth keeping)
       size_t idle = 0;
       for (auto& b : bufs)
@@ -3753,11 +3773,11 @@ struct HostPool {
           if (bufs[i].idle && (k == bufs.size() || bufs[i].bytes < bufs[k].bytes)) k = i;
         if (k == bufs.size()) break;
         idle -= bufs[k].bytes;
-        drop.push_back(bufs[k].p);
+        drop.push_back({bufs[k].p, bufs[k].pinned});
         bufs.erase(bufs.begin() + (long)k);
       }
     }
-    for (void* d : drop) (void)hipHostFree(d);
+    for (auto& d : drop) release(d.first, d.second);
   }
 };
 static HostPool& host_pool() {
@@ -3765,11 +3785,12 @@ static HostPool& host_pool() {
   return *pool;
 }
 static void* host_alloc(size_t bytes) { return host_pool().get(bytes ? bytes : 1); }
+static void* host_alloc_plain(size_t bytes) { return host_pool().get(bytes ? bytes : 1, false); }
 
 int giql_hip_host_pool_trim(int64_t keep_bytes, int64_t* released) {
   if (keep_bytes < 0) return set_err(GIQL_ERR_INVALID, "keep_bytes < 0");
   HostPool& hp = host_pool();
-  std::vector<void*> drop;
+  std::vector<std::pair<void*, bool>> drop;
   size_t freed = 0;
   {
     std::lock_guard<std::mutex> g(hp.mu);
@@ -3783,11 +3804,11 @@ int giql_hip_host_pool_trim(int64_t keep_bytes, int64_t* released) {
       if (k == hp.bufs.size()) break;
       idle -= hp.bufs[k].bytes;
       freed += hp.bufs[k].bytes;
-      drop.push_back(hp.bufs[k].p);
+      drop.push_back({hp.bufs[k].p, hp.bufs[k].pinned});
       hp.bufs.erase(hp.bufs.begin() + (long)k);
     }
   }
-  for (void* d : drop) (void)hipHostFree(d);
+  for (auto& d : drop) HostPool::release(d.first, d.second);
   if (released) *released = (int64_t)freed;
   return GIQL_OK;
 }
@@ -3947,7 +3968,7 @@ static int inner_host_pipelined(giql_hip_ctx* ctx, const giql_side* a, const giq
 // arrays down, then the sorted ids in chunks while the threads already expand the queries whose ranges have arrived
 // (blocks of 65,536 queries handed out in order; a block waits for the chunk that holds its last id).  The pairs
 // come out in the plan's query order.  Only the single-range form (fixed-length side, no irregular rows) has a compact
-// plan: any other plan is filled and downloaded as before.  GIQL_HIP_E2E_THREADS: expansion threads (default 16).
+// plan: any other plan is filled and downloaded as before.  GIQL_HIP_E2E_THREADS: expansion threads (default 32: tools/e2e_threads.py -- 16: 45.8 ms, 32: 39.9, 64: 40.0 at the headline sizes).
 struct CompactHost {  // page-locked staging of the plan, back to the pool on every path out
   int32_t* q_rid = nullptr;
   u32 *lo = nullptr, *cnt = nullptr;
@@ -4018,7 +4039,7 @@ static int inner_host_compact_tail(giql_hip_ctx* ctx, int64_t n, int32_t* ha, in
     HIP_TRY(hipEventRecord(ev[c + 1], st));
   }
   HIP_TRY(hipEventSynchronize(ev[0]));  // the per-query arrays are here
-  int n_thr = 16;
+  int n_thr = 32;
   if (const char* e = getenv("GIQL_HIP_E2E_THREADS")) n_thr = atoi(e);
   const int hw = (int)std::thread::hardware_concurrency();
   if (hw > 0 && n_thr > hw) n_thr = hw;
@@ -4169,9 +4190,14 @@ int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, in
   GIQL_TRY(check_side(b, "b"));
   HIP_TRY(hipSetDevice(ctx->device));
   *row_a = *row_b = nullptr;
+  // GIQL_HIP_E2E_COMPACT: 1 = compact-plan download whenever the plan has that form, 0 = never (round 3: pairs
+  // downloaded, the larger table uploaded block by block); unset = compact unless this context's last plan says the
+  // tables do not take the single-range form (then the block pipeline, which hides most of the upload, is the better bet)
   const char* e_compact = getenv("GIQL_HIP_E2E_COMPACT");
-  const bool compact = e_compact && atoi(e_compact) != 0;
-  if (!compact) {
+  const int compact_mode = e_compact ? (atoi(e_compact) != 0 ? 1 : 0) : -1;
+  const bool try_compact = compact_mode == 1 ||
+                           (compact_mode < 0 && !(ctx->spec_valid && (ctx->spec_form == 0 || !ctx->last_no_irr)));
+  if (!try_compact) {
     const char* e = getenv("GIQL_HIP_E2E_BLOCK_ROWS");
     const size_t block_rows = e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)4 << 20);
     const size_t n_big = (size_t)(a->n > b->n ? a->n : b->n);
@@ -4195,10 +4221,19 @@ int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, in
   const double ms_plan = ms_since(t0);
   t0 = now();
   *n_pairs = n;
-  // library-owned host outputs are PINNED (the D2H copy of the pairs runs at link speed, not
-  // through a pageable bounce buffer); giql_hip_free_host releases them
-  int32_t* ha = (int32_t*)host_alloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
-  int32_t* hb = (int32_t*)host_alloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
+  // The compact plan pays when it is smaller than the pairs (and the result is worth a team of threads)
+  bool compact = false;
+  if (try_compact && n > 0 && ctx->inner.uniform != 0 && ctx->n_irr == 0 && ctx->n_c1 == 0 && !ctx->plan_is_join) {
+    const bool q_is_a_plan = ctx->inner.uniform != 2;
+    const int64_t nq = q_is_a_plan ? ctx->n_a : ctx->n_b, ns = q_is_a_plan ? ctx->n_b : ctx->n_a;
+    compact = compact_mode == 1 || (n >= (4ll << 20) && 8 * n >= 12 * nq + 4 * ns);
+  }
+  // library-owned host outputs are PINNED (the D2H copy of the pairs runs at link speed, not through a pageable
+  // bounce buffer) -- unless host threads write them (compact plan): plain memory then, nothing to page-lock (3.2 GB:
+  // ~200 ms on a first call); giql_hip_free_host releases either kind
+  const size_t out_bytes = (size_t)(n > 0 ? n : 1) * sizeof(int32_t);
+  int32_t* ha = (int32_t*)(compact ? host_alloc_plain(out_bytes) : host_alloc(out_bytes));
+  int32_t* hb = (int32_t*)(compact ? host_alloc_plain(out_bytes) : host_alloc(out_bytes));
   if (!ha || !hb) {
     giql_hip_free_host(ha);
     giql_hip_free_host(hb);

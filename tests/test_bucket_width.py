@@ -221,14 +221,18 @@ def test_no_narrow_buckets_switch_keeps_the_round_3_behaviour(monkeypatch):
 
 
 # ---- the host-buffer entry point with the compact-plan download (VERDICT r03 "Next round" 8) -------------------------
-def test_host_join_with_the_compact_plan_download(monkeypatch):
-    """GIQL_HIP_E2E_COMPACT=1: ``giql_hip_inner`` downloads the plan (per-query {id, first match, count} + the sorted
+@pytest.mark.parametrize("mode", ["1", None])
+def test_host_join_with_the_compact_plan_download(monkeypatch, mode):
+    """``giql_hip_inner`` downloads the plan (per-query {id, first match, count} + the sorted
     ids) and expands it with host threads instead of downloading the pairs.  Same pairs as the oracle in both argument
     orders and with every encoding; plans without a compact form (rows of variable length on both sides, irregular
     rows, no pair at all) are filled and downloaded as before.  Reference semantics: intersects_duckdb.py:1283-1330."""
     from giql_amd.engine import HipEngine
 
-    monkeypatch.setenv("GIQL_HIP_E2E_COMPACT", "1")
+    # mode "1": whenever the plan has the compact form; None (the default): when that form is also the smaller download
+    # and the result is large -- the last case below; the small ones take the pairs download
+    if mode:
+        monkeypatch.setenv("GIQL_HIP_E2E_COMPACT", mode)
     monkeypatch.setenv("GIQL_HIP_E2E_THREADS", "5")
     e = HipEngine(0)
     try:
