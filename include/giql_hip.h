@@ -385,10 +385,19 @@ int giql_hip_mark_dev(giql_hip_ctx* ctx, const int32_t* idx, int64_t n,
                       uint8_t* flags, int64_t n_rows, void* stream);
 
 /* ---- host-buffer entry points (Arrow buffers in host memory) ------------
- * giql_hip_inner: columns of both tables in host memory in, the pairs out in pinned host arrays the
- * library owns (giql_hip_free_host).  A table of 8M rows and more is uploaded in blocks of 4M rows
+ * giql_hip_inner: columns of both tables in host memory in, the pairs out in host arrays the library
+ * owns (giql_hip_free_host; the order of the pairs is unspecified, as an INNER join's always is).
+ * Since round 4 a large result whose plan has the compact form (one table of fixed length, no
+ * irregular row) comes down as that PLAN -- per query row {row id, first match, count} + the other
+ * side's row ids in sorted order, 0.52 GB instead of 3.2 GB at 10M x 100M -- and is expanded into
+ * plain (not page-locked) memory by host threads while the ids still arrive: 71 -> 40-47 ms, first
+ * call 230-345 -> 78 ms.  GIQL_HIP_E2E_COMPACT=0 / 1: never / whenever the form allows;
+ * GIQL_HIP_E2E_THREADS (default 32).  Otherwise the pairs themselves are downloaded into page-locked
+ * arrays, and a table of 8M rows and more is uploaded in blocks of 4M rows
  * (GIQL_HIP_E2E_BLOCK_ROWS; 0 = one shot): an INNER join is the union of the joins of its row
- * blocks, so block j's pairs travel to the host while block j + 1 travels to the device. */
+ * blocks, so block j's pairs travel to the host while block j + 1 travels to the device.
+ * Reference counterpart: conn.execute(sql).arrow() around the per-chromosome plan of
+ * src/giql/expanders/intersects_duckdb.py:1283-1330 (host tables in, host result out). */
 int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b,
                    int32_t n_chrom, int64_t* n_pairs, int32_t** row_a,
                    int32_t** row_b);
@@ -465,7 +474,8 @@ int giql_hip_copy_probe_dev(giql_hip_ctx* ctx, const void* src, void* dst,
  * table's columns are read once, at creation; the index keeps no pointer to them.
  * GIQL_ERR_STATE when the table does not take the indexed form (more than 32
  * chromosomes, a negative coordinate, irregular rows, more than ~2800 rows per
- * 65,536 positions): the ordinary join serves such tables. */
+ * 8,192 positions -- denser tables than 2800 per 65,536 are indexed with buckets
+ * of 2^15 / 2^14 / 2^13 keys): the ordinary join serves such tables. */
 typedef struct giql_hip_index giql_hip_index;
 int giql_hip_index_create_dev(giql_hip_ctx* ctx, const giql_side* side,
                               int32_t n_chrom, void* stream, giql_hip_index** out);
@@ -499,8 +509,8 @@ int giql_hip_stream_probe_dev(giql_hip_ctx* ctx, const void* src, void* dst,
                               int32_t nontemporal, int32_t blocks_per_cu,
                               int32_t reps, void* stream, double* gbytes_per_s);
 
-/* The host-buffer entry points (giql_hip_inner & co.) keep released page-locked
- * output buffers for the next call (up to GIQL_HIP_HOST_POOL_MB, default 8192).
+/* The host-buffer entry points (giql_hip_inner & co.) keep released output
+ * buffers (page-locked ones, and the plain ones of the compact-plan path) for the next call (up to GIQL_HIP_HOST_POOL_MB, default 8192).
  * This returns every idle one beyond keep_bytes to the OS; *released (optional)
  * = bytes freed.  Buffers a caller still owns are untouched.  There is no
  * reference counterpart: DuckDB owns its buffers (conn.execute(sql)). */
