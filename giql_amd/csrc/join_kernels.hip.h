@@ -62,6 +62,15 @@ __global__ void k_init_minmax(int* __restrict__ gmin, int* __restrict__ gmax, in
 #ifndef GIQL_MM_BLOCKS
 #define GIQL_MM_BLOCKS 1024
 #endif
+// waves per SIMD the span kernels' register allocation must allow (0: whatever the compiler takes)
+#ifndef GIQL_MM_MIN_WAVES
+#define GIQL_MM_MIN_WAVES 0
+#endif
+#if GIQL_MM_MIN_WAVES > 0
+#define GIQL_MM_LAUNCH_BOUNDS(NT) __launch_bounds__(NT, GIQL_MM_MIN_WAVES)
+#else
+#define GIQL_MM_LAUNCH_BOUNDS(NT) __launch_bounds__(NT)
+#endif
 constexpr int MM_NT = GIQL_MM_NT;            // threads of the plain min/max pass
 constexpr int MM_NT_HIST = 2 * GIQL_MM_NT;   // ... and of the one that also counts digits (0.343 -> 0.331 ms)
 constexpr int MM_ITEMS = 8;
@@ -132,12 +141,13 @@ __device__ __forceinline__ void chrom_minmax_body(const int HIST, const int* __r
     }
     if (ok && (pc > c || (pc == c && ps > s))) inv = true;
   };
-  // This pass is bound by its INSTRUCTIONS, not by its loads or its LDS atomics (round 4: ~190 instructions per row in
-  // the ISA, half of them scalar; a wave64 VALU op occupies its SIMD for 4 cycles: 0.24 ms of pure issue time at 100M
-  // rows, and timing-only builds without any atomic run no faster).  So the per-row work is kept branch-free where it
-  // can be, and what only pays on SORTED input -- the per-thread run cache of the chromosome range, the wave-uniform
-  // shortcut of the histogram -- is tried only while the wave has seen no row out of order (`sorted_so_far`, wave-
-  // uniform: refreshed once per tile from the order check's own flag).
+  // This pass is instruction-heavy (round 4: ~150 instructions per row in the ISA, more than half of them scalar), and
+  // timing-only builds without any LDS atomic run no faster.  The per-row work is kept branch-free where that paid,
+  // and what only pays on SORTED input -- the per-thread run cache of the chromosome range, the wave-uniform shortcut of
+  // the histogram -- is tried only while the wave has seen no row out of order (`sorted_so_far`, wave-uniform:
+  // refreshed once per tile from the order check's own flag): 0.30-0.32 -> 0.285-0.29 ms.  (A fully straight-line loop
+  // for shuffled input -- a third fewer vector, six times fewer scalar instructions -- was SLOWER, 0.32 ms: the pass is
+  // not bound by instruction issue; DESIGN.md section 7, profiles/r04y_span_branch_free_rows_ab.log.)
   bool sorted_so_far = true;
   // One row: length range, per-chromosome min/max through the run cache, digit counts.
   auto row = [&](const int c, const int s, const int e, const bool ok) {
@@ -366,7 +376,7 @@ __device__ __forceinline__ void chrom_minmax_body(const int HIST, const int* __r
 }
 
 template <int HIST, int NT>
-__global__ __launch_bounds__(NT) void k_chrom_minmax(const int* __restrict__ chrom,
+__global__ GIQL_MM_LAUNCH_BOUNDS(NT) void k_chrom_minmax(const int* __restrict__ chrom,
                                                          const int* __restrict__ start,
                                                          const int* __restrict__ end, i64 n,
                                                          int n_chrom, int* __restrict__ gmin,
@@ -395,7 +405,7 @@ struct MmSide {
   u32* top_partial;
 };
 template <int NT>
-__global__ __launch_bounds__(NT) void k_chrom_minmax2(MmSide a, MmSide b, int n_chrom, int* __restrict__ gmin,
+__global__ GIQL_MM_LAUNCH_BOUNDS(NT) void k_chrom_minmax2(MmSide a, MmSide b, int n_chrom, int* __restrict__ gmin,
                                                       int* __restrict__ gmax, DevMeta* __restrict__ meta,
                                                       int* __restrict__ len_part) {
   __shared__ u32 s_hist[3 * 256];

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-@pytest.fixture(params=[13, 14, 15])
+@pytest.fixture(params=[13, 15])   # (14: the density tests below, tests/test_full_size.py, tests/test_index_gpu.py)
 def eng_narrow(request, monkeypatch):
     from giql_amd.engine import HipEngine
 
@@ -152,7 +152,7 @@ def test_narrow_buckets_general_join_both_orders_and_queued_buckets(eng_narrow):
     _join_into(eng_narrow, q, dense, 1, expect_join=None)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(5))
 def test_narrow_buckets_randomized_sweep(eng_narrow, seed):
     r = np.random.default_rng(8800 + seed)
     n_chrom = int(r.choice([1, 3, 24, 40]))

@@ -16,7 +16,9 @@ rng = np.random.default_rng(seed)
 eng_default = HipEngine(0)
 os.environ["GIQL_HIP_LOCAL_MIN_ROWS"] = "1"   # a second context that takes the three-stage sort at every size
 eng_local = HipEngine(0)
-del os.environ["GIQL_HIP_LOCAL_MIN_ROWS"]
+os.environ["GIQL_HIP_LOCAL_BITS"] = "13"       # a third one with the narrowest buckets (dense tables' form, round 4)
+eng_narrow = HipEngine(0)
+del os.environ["GIQL_HIP_LOCAL_MIN_ROWS"], os.environ["GIQL_HIP_LOCAL_BITS"]
 ENC = list(ora.ENCODING_OFFSETS.values())
 
 
@@ -52,7 +54,8 @@ while time.time() - t0 < budget:
     a = side(na, nch, span, fixed_a, rng.random() < 0.25)
     b = side(nb, nch, span, fixed_b, rng.random() < 0.15)
     da, db = dev(a), dev(b)
-    eng = eng_local if rng.random() < 0.3 else eng_default
+    pick = rng.random()
+    eng = eng_local if pick < 0.25 else (eng_narrow if pick < 0.45 else eng_default)
     try:
         ra, rb = eng.inner_join(da, db, nch)
     except Exception as exc:
