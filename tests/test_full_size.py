@@ -189,11 +189,12 @@ def test_config4_sized_join_with_variable_length_reads_both_argument_orders(monk
         e.close()
 
 
-def test_dense_table_leaves_the_three_stage_sort_once_its_span_is_known(monkeypatch):
-    """40M rows on a 2e8-position axis = ~13,000 rows per 16-bit bucket, three times what the in-LDS stage
+def test_dense_table_takes_narrow_buckets_once_its_span_is_known(monkeypatch):
+    """40M rows on a 2e8-position axis = ~13,000 rows per 65,536 positions, three times what the in-LDS stage
     holds: the span is read back before anything is sorted on a context's first call, so already that call
-    takes the four global passes (as does every later one, on the remembered span).  A context forced
-    into the three-stage sort goes through the big-bucket queue instead.  Same rows out of all of them."""
+    takes buckets of 2^13 keys (as does every later one, on the remembered span; round 3 -- and
+    GIQL_HIP_NO_NARROW_BUCKETS=1 -- left the three-stage sort for four global passes instead).  A context forced
+    into 65,536-key buckets goes through the big-bucket queue.  Same rows out of all of them."""
     r = np.random.default_rng(99)
     nb, na = 40_000_000, 200_000
     sb = r.integers(0, 200_000_000, nb).astype(np.int32)
@@ -204,21 +205,36 @@ def test_dense_table_leaves_the_three_stage_sort_once_its_span_is_known(monkeypa
     e = _engine(monkeypatch)
     try:
         da, db = dev(a), dev(b)
-        got1 = e.count_overlaps(da, db, 1).cpu().numpy()
-        first_local = e.stats()["sort_local"]
-        got2 = e.count_overlaps(da, db, 1).cpu().numpy()
-        assert not first_local and not e.stats()["sort_local"] and not e.stats()["sort_resorted"]
-        assert np.array_equal(got1, want) and np.array_equal(got2, want)
-        # the INNER plan: first call (span read back mid-plan, the span pass's histogram dropped), then speculated
+        for it in range(2):
+            got = e.count_overlaps(da, db, 1).cpu().numpy()
+            st = e.stats()
+            assert st["sort_local"] and st["bucket_bits"] == 13 and not st["sort_resorted"], (it, st)
+            assert np.array_equal(got, want), it
+        # the INNER plan: first call (span read back mid-plan, the digits recounted for the narrow form), then speculated
         for it in range(2):
             n = e.inner_plan(da, db, 1)
-            assert n == int(want.sum()) and not e.stats()["sort_local"], it
+            st = e.stats()
+            assert n == int(want.sum()) and st["sort_local"] and st["count_fused"] and st["bucket_bits"] == 13, (it, st)
     finally:
         e.close()
+    g = _engine(monkeypatch, GIQL_HIP_NO_NARROW_BUCKETS="1")
+    try:
+        da, db = dev(a), dev(b)
+        got1 = g.count_overlaps(da, db, 1).cpu().numpy()
+        first_local = g.stats()["sort_local"]
+        got2 = g.count_overlaps(da, db, 1).cpu().numpy()
+        assert not first_local and not g.stats()["sort_local"] and not g.stats()["sort_resorted"]
+        assert np.array_equal(got1, want) and np.array_equal(got2, want)
+        for it in range(2):
+            n = g.inner_plan(da, db, 1)
+            assert n == int(want.sum()) and not g.stats()["sort_local"], it
+    finally:
+        g.close()
     f = _engine(monkeypatch, GIQL_HIP_LOCAL_MAX_BUCKET_ROWS="1e9")
     try:
         got3 = f.count_overlaps(dev(a), dev(b), 1).cpu().numpy()
-        assert f.stats()["sort_local"] and np.array_equal(got3, want)
+        st = f.stats()
+        assert st["sort_local"] and st["bucket_bits"] == 16 and np.array_equal(got3, want)
     finally:
         f.close()
 
@@ -279,21 +295,20 @@ def test_join_past_2_pow_32_pairs_dense_tables_narrow_buckets():
         eng.close()
 
 
-def test_join_past_2_pow_32_pairs_dense_tables_four_pass_sort(monkeypatch):
-    """The same tables with GIQL_HIP_NO_NARROW_BUCKETS=1 (round 3's behaviour): the 350M-row side leaves the
-    three-stage sort, the count kernel and the 64-bit scan run."""
-    from giql_amd.engine import HipEngine
-
-    A = synth.make_table(35_000_000, 5, "peaks")
-    B = synth.make_table(350_000_000, 6, "reads")
-    monkeypatch.setenv("GIQL_HIP_NO_NARROW_BUCKETS", "1")
-    eng = HipEngine(0)
-    monkeypatch.delenv("GIQL_HIP_NO_NARROW_BUCKETS")
+def test_join_past_2_pow_32_pairs_four_pass_sort_count_kernel_and_fill(monkeypatch):
+    """Past 2^32 pairs WITHOUT the three-stage sort (GIQL_HIP_NO_LOCAL_SORT=1: what tables beyond every bucket width,
+    and round 1's pipeline, run): four global passes, the count kernel, the 64-bit scan, the partition and `k_fill`.
+    6M long peaks (20-32 kb) x 100M reads, ~850 reads per peak."""
+    r = np.random.default_rng(1606)
+    ch, st_, _en = synth.make_table(6_000_000, 15, "peaks")
+    ln = r.integers(20_000, 32_000, ch.shape[0]).astype(np.int32)
+    st_ = np.maximum(st_ - 32_000, 0).astype(np.int32)
+    A = (ch, st_, st_ + ln)
+    B = synth.make_table(100_000_000, 6, "reads")
+    eng = _engine(monkeypatch, GIQL_HIP_NO_LOCAL_SORT="1")
     try:
         n, st = _check_big_join(eng, A, B, 24, expect_fused=False)
-        # (the 35M-row QUERY side is sparse enough for the three-stage sort; the 350M-row side is not, so the
-        # bounds come from the count kernel: expect_fused=False above)
-        assert n == 4_952_361_736 and st["join_form"] == "uniform_b"
+        assert st["join_form"] == "uniform_b" and not st["sort_local"] and not st["bucket_join"]
     finally:
         eng.close()
 
