@@ -4074,7 +4074,10 @@ static int inner_host_compact_tail(giql_hip_ctx* ctx, int64_t n, int32_t* ha, in
   };
   {
     std::vector<std::thread> th;
-    for (int t = 1; t < n_thr; t++) th.emplace_back(sums);
+    try {
+      for (int t = 1; t < n_thr; t++) th.emplace_back(sums);
+    } catch (...) {  // no more threads to be had: the ones that started (and this one) do the work
+    }
     sums();
     for (auto& t : th) t.join();
   }
@@ -4167,7 +4170,10 @@ static int inner_host_compact_tail(giql_hip_ctx* ctx, int64_t n, int32_t* ha, in
     }
   };
   std::vector<std::thread> th;
-  for (int t = 0; t < n_thr; t++) th.emplace_back(expand);
+  try {
+    for (int t = 0; t < n_thr; t++) th.emplace_back(expand);
+  } catch (...) {  // (as above; this thread expands too once every chunk has arrived)
+  }
   int rc = GIQL_OK;
   for (size_t c = 0; c < n_chunks; c++) {  // this thread follows the link and publishes what has arrived
     if (hipEventSynchronize(ev[c + 1]) != hipSuccess) {
@@ -4177,6 +4183,7 @@ static int inner_host_compact_tail(giql_hip_ctx* ctx, int64_t n, int32_t* ha, in
     }
     chunks_here.store(c + 1, std::memory_order_release);
   }
+  if (rc == GIQL_OK) expand();  // whatever blocks are left (all of them when no helper thread could be started)
   for (auto& t : th) t.join();
   GIQL_TRY(rc);
   *done = true;
