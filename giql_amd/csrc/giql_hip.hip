@@ -4233,7 +4233,9 @@ int giql_hip_inner(giql_hip_ctx* ctx, const giql_side* a, const giql_side* b, in
   if (try_compact && n > 0 && ctx->inner.uniform != 0 && ctx->n_irr == 0 && ctx->n_c1 == 0 && !ctx->plan_is_join) {
     const bool q_is_a_plan = ctx->inner.uniform != 2;
     const int64_t nq = q_is_a_plan ? ctx->n_a : ctx->n_b, ns = q_is_a_plan ? ctx->n_b : ctx->n_a;
-    compact = compact_mode == 1 || (n >= (4ll << 20) && 8 * n >= 12 * nq + 4 * ns);
+    // ... on a host with the cores to expand it: 16 threads write ~150 GB/s of pairs, 4 would lose against the link
+    const unsigned hw = std::thread::hardware_concurrency();
+    compact = compact_mode == 1 || (n >= (4ll << 20) && 8 * n >= 12 * nq + 4 * ns && hw >= 16);
   }
   // library-owned host outputs are PINNED (the D2H copy of the pairs runs at link speed, not through a pageable
   // bounce buffer) -- unless host threads write them (compact plan): plain memory then, nothing to page-lock (3.2 GB:

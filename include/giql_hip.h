@@ -391,7 +391,8 @@ int giql_hip_mark_dev(giql_hip_ctx* ctx, const int32_t* idx, int64_t n,
  * irregular row) comes down as that PLAN -- per query row {row id, first match, count} + the other
  * side's row ids in sorted order, 0.52 GB instead of 3.2 GB at 10M x 100M -- and is expanded into
  * plain (not page-locked) memory by host threads while the ids still arrive: 71 -> 40-47 ms, first
- * call 230-345 -> 78 ms.  GIQL_HIP_E2E_COMPACT=0 / 1: never / whenever the form allows;
+ * call 230-345 -> 78 ms (taken on hosts with 16 hardware threads and more).  GIQL_HIP_E2E_COMPACT=0 / 1:
+ * never / whenever the form allows;
  * GIQL_HIP_E2E_THREADS (default 32).  Otherwise the pairs themselves are downloaded into page-locked
  * arrays, and a table of 8M rows and more is uploaded in blocks of 4M rows
  * (GIQL_HIP_E2E_BLOCK_ROWS; 0 = one shot): an INNER join is the union of the joins of its row
