@@ -828,6 +828,19 @@ static int run_sort_onesweep(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u3
   return post_launch("onesweep sort");
 }
 
+// A two-key sort's FIRST sort runs on a view of the buffers with key and end exchanged.  run_sort_onesweep leaves its
+// result in what it then CALLS buffer 0 -- after an odd number of passes (three: a query side sorted without its lowest
+// digit, a side with buckets narrower than 2^16 keys) that is the other physical buffer, and it says so by exchanging the
+// view's pointers.  The owner of the buffers has to follow, or its second sort starts from the unsorted copy (round 4:
+// found by the soak on a context forced to 8,192-key buckets -- ties among equal starts came out in input order).
+static inline void adopt_by_end(SortBufs& owner, const SortBufs& by_end) {
+  for (int k = 0; k < 2; k++) {
+    owner.end[k] = by_end.key[k];
+    owner.key[k] = by_end.end[k];
+    owner.rid[k] = by_end.rid[k];
+  }
+}
+
 // Stable LSD radix sort; input in buffer 0, result in buffer 0 (4 passes).
 // rids: identity on the first pass.  Payload-less when bufs.end[0] == nullptr.
 static int run_sort(giql_hip_ctx* ctx, hipStream_t st, SortBufs& sb, u32 n, u32* tile_hist,
@@ -2608,6 +2621,7 @@ static int giql_hip_nearest_dev_impl(giql_hip_ctx* ctx, const giql_side* a, cons
       by_end.end[k] = sbb.key[k];
     }
     GIQL_TRY(run_sort_onesweep(ctx, st, by_end, (u32)nb, os.gbase_e, os.status));
+    adopt_by_end(sbb, by_end);
     GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, /*keep_rids=*/true));
   } else {
     // one sort by start; the (short) runs of equal starts are ordered by end in place
@@ -2734,6 +2748,7 @@ static int giql_hip_nearest_k_dev_impl(giql_hip_ctx* ctx, const giql_side* a, co
         by_end.end[i] = sbb.key[i];
       }
       GIQL_TRY(run_sort_onesweep(ctx, st, by_end, (u32)nb, os.gbase_e, os.status));
+      adopt_by_end(sbb, by_end);
       GIQL_TRY(run_sort_onesweep(ctx, st, sbb, (u32)nb, os.gbase, os.status, /*keep_rids=*/true));
     }
     HIP_TRY(hipMemcpyAsync(se.key[0], sbb.end[0], nb * sizeof(u32), hipMemcpyDeviceToDevice, st));
@@ -3110,6 +3125,7 @@ static int giql_hip_group_rows_dev_impl(giql_hip_ctx* ctx, const giql_side* s, i
       by_end.end[k] = sb.key[k];
     }
     GIQL_TRY(run_sort_onesweep(ctx, st, by_end, (u32)n, os.gbase_e, os.status));
+    adopt_by_end(sb, by_end);
     GIQL_TRY(run_sort_onesweep(ctx, st, sb, (u32)n, os.gbase, os.status, /*keep_rids=*/true));
   } else {
     GIQL_TRY(run_sort_onesweep(ctx, st, sb, (u32)n, os.gbase, os.status));

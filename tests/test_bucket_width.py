@@ -273,3 +273,49 @@ def test_host_join_with_the_compact_plan_download(monkeypatch, mode):
         assert np.array_equal(got, ora.sort_pairs(*ora.c_inner(qs, big, "sweep")))
     finally:
         e.close()
+
+
+def test_narrow_buckets_keep_the_two_key_sorts_stable(eng_narrow):
+    """Pile-ups (long runs of equal starts) put NEAREST and group_rows on their two-sort plan: sort by end, then STABLY by
+    start.  With three global passes the first sort ends in the OTHER ping-pong buffer, and the owner of the buffers has
+    to follow its view (the soak found ties among equal starts in input order on a context forced to 8,192-key buckets
+    that had met pile-ups before: `adopt_by_end`)."""
+    rng = np.random.default_rng(77)
+    n = 120_000
+    st = (rng.integers(0, 400, n) * 50_000).astype(np.int32)        # 400 distinct starts, ~300 rows each
+    b = ora.Side(np.zeros(n, np.int32), st, st + rng.integers(1, 3000, n).astype(np.int32))
+    qs = rng.integers(0, 20_000_000, 50_000).astype(np.int32)
+    a = ora.Side(np.zeros(50_000, np.int32), qs, qs + rng.integers(1, 500, 50_000).astype(np.int32))
+    for _ in range(2):  # the first call discovers the pile-ups and switches plans
+        idx, dist = eng_narrow.nearest(dev(a), dev(b), 1)
+        oi, od = ora.c_nearest_k1(a, b, method="sweep")
+        assert np.array_equal(dist.cpu().numpy(), od)
+        j = idx.cpu().numpy()
+        assert np.array_equal(b.start[j], b.start[oi]) and np.array_equal(b.end[j], b.end[oi])
+    gid, rep = eng_narrow.group_rows(dev(b), 1)
+    assert rep.shape[0] == len({(int(x), int(y)) for x, y in zip(b.start, b.end)})
+    assert eng_narrow.stats()["sort_local"]
+    # the context stays on the two-sort plan: a table WITHOUT long runs (many rows per start all the same: ~4 rows on each
+    # of 66,000 positions, 33 chromosomes -- the soak's case), every overlapping tie decided by the end
+    r = np.random.default_rng(154)
+    nb2 = 300_000
+    b2 = ora.Side(r.integers(0, 33, nb2).astype(np.int32), r.integers(0, 2_000, nb2).astype(np.int32), np.zeros(nb2, np.int32))
+    b2.end[:] = b2.start + r.integers(1, 2_600, nb2).astype(np.int32)
+    a2s = r.integers(0, 2_000, 500).astype(np.int32)
+    a2 = ora.Side(r.integers(0, 33, 500).astype(np.int32), a2s, a2s + r.integers(1, 100, 500).astype(np.int32))
+    for signed in (False, True):
+        idx, dist = eng_narrow.nearest(dev(a2), dev(b2), 33, signed=signed)
+        oi, od = ora.c_nearest_k1(a2, b2, signed=signed)
+        assert np.array_equal(dist.cpu().numpy(), od)
+        j = idx.cpu().numpy()
+        hit = j >= 0
+        assert np.array_equal(hit, oi >= 0)
+        assert np.array_equal(b2.start[j[hit]], b2.start[oi[hit]]) and np.array_equal(b2.end[j[hit]], b2.end[oi[hit]])
+    # NEAREST k = 3 on the same context (its (end, start) view is a third stable sort)
+    k_idx, k_dist = eng_narrow.nearest_k(dev(a2), dev(b2), 33, 3)
+    want_i, want_d = ora.c_nearest_k(a2, b2, 3)
+    assert np.array_equal(k_dist.cpu().numpy(), want_d)
+    ki = k_idx.cpu().numpy()
+    ok = want_i >= 0
+    assert np.array_equal(ki >= 0, ok)
+    assert np.array_equal(b2.start[ki[ok]], b2.start[want_i[ok]]) and np.array_equal(b2.end[ki[ok]], b2.end[want_i[ok]])

@@ -16,7 +16,7 @@ rng = np.random.default_rng(seed)
 eng_default = HipEngine(0)
 os.environ["GIQL_HIP_LOCAL_MIN_ROWS"] = "1"   # a second context that takes the three-stage sort at every size
 eng_local = HipEngine(0)
-os.environ["GIQL_HIP_LOCAL_BITS"] = "13"       # a third one with the narrowest buckets (dense tables' form, round 4)
+os.environ["GIQL_HIP_LOCAL_BITS"] = os.environ.get("SOAK_NARROW_BITS", "13")   # a third one with the narrowest buckets (dense tables' form, round 4)
 eng_narrow = HipEngine(0)
 del os.environ["GIQL_HIP_LOCAL_MIN_ROWS"], os.environ["GIQL_HIP_LOCAL_BITS"]
 ENC = list(ora.ENCODING_OFFSETS.values())
@@ -90,7 +90,18 @@ while time.time() - t0 < budget:
         gi, gd = gi.cpu().numpy(), gd.cpu().numpy()
         assert np.array_equal(gd, wd) and np.array_equal(gi >= 0, wi >= 0), ("nearest", it, nch, na, nb, span)
         hit = gi >= 0
-        assert np.array_equal(b.start[gi[hit]], b.start[wi[hit]]) and np.array_equal(b.end[gi[hit]], b.end[wi[hit]]), ("nearest rows", it)
+        if not (np.array_equal(b.start[gi[hit]], b.start[wi[hit]]) and np.array_equal(b.end[gi[hit]], b.end[wi[hit]])):
+            bad = np.nonzero(hit)[0][(b.start[gi[hit]] != b.start[wi[hit]]) | (b.end[gi[hit]] != b.end[wi[hit]])]
+            name = "narrow" if eng is eng_narrow else ("local" if eng is eng_local else "default")
+            rows = [(int(i), int(gd[i]), (int(a.chrom[i]), int(a.start[i]), int(a.end[i])),
+                     "got", (int(gi[i]), int(b.start[gi[i]]), int(b.end[gi[i]])),
+                     "want", (int(wi[i]), int(b.start[wi[i]]), int(b.end[wi[i]]))) for i in bad[:6]]
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            np.savez_compressed(os.path.join(ROOT, "gpurun_out", "soak_fail.npz"), ac=a.chrom, as_=a.start, ae=a.end,
+                                bc=b.chrom, bs=b.start, be=b.end, offs=np.array([a.start_off, a.end_off, b.start_off, b.end_off]),
+                                nch=nch, signed=signed)
+            raise AssertionError(("nearest rows", it, name, signed, nch, na, nb, span, fixed_a, fixed_b,
+                                  (a.start_off, a.end_off), (b.start_off, b.end_off), len(bad), rows, eng.stats()))
     assert np.array_equal(eng.semi_join(da, db, nch).cpu().numpy(), ora.c_semi_anti(a, b, False)), ("semi", it)
     if eng.stats()["coarse_b"]:
         forms[("coarse_b", True)] = forms.get(("coarse_b", True), 0) + 1
